@@ -1,0 +1,226 @@
+"""ctypes front-end of oracle/hhx_oracle.c — CPU restatement of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg, never by haphic_amd/.  See the header of hhx_oracle.c for the reference citations and how the
+oracle is pinned (tests/golden/, generated from the reference's own Python functions).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, '_build', 'libhhx_oracle.so')
+
+_i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
+_i64p = np.ctypeslib.ndpointer(np.int64, flags='C_CONTIGUOUS')
+_f32p = np.ctypeslib.ndpointer(np.float32, flags='C_CONTIGUOUS')
+_f64p = np.ctypeslib.ndpointer(np.float64, flags='C_CONTIGUOUS')
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags='C_CONTIGUOUS')
+
+
+def build(force=False):
+    src = os.path.join(_HERE, 'hhx_oracle.c')
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-s'] + (['-B'] if force else []))
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_normalize_l1.argtypes = [C.c_int32, _i32p, _f32p]
+        L.orc_normalize_l1.restype = None
+        L.orc_power.argtypes = [C.c_int64, _f32p, C.c_double]
+        L.orc_power.restype = None
+        L.orc_spgemm.argtypes = [C.c_int32, C.c_int32, _i32p, _i32p, _f32p, _i32p, _i32p, _f32p, _i32p,
+                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_spgemm.restype = C.c_int64
+        L.orc_prune.argtypes = [C.c_int32, _i32p, _i32p, _f32p, C.c_double, _i32p, _i32p, _f32p]
+        L.orc_prune.restype = C.c_int64
+        L.orc_convergence_stat.argtypes = [C.c_int32, _i32p, _i32p, _f32p, _i32p, _i32p, _f32p]
+        L.orc_convergence_stat.restype = C.c_float
+        L.orc_mcl.argtypes = [C.c_int32, _i32p, _i32p, _f32p, C.c_int, C.c_double, C.c_int, C.c_double,
+                              C.c_int, C.c_int, C.c_int64, _i32p, _i32p, _f32p, C.POINTER(C.c_int),
+                              C.POINTER(C.c_int), C.c_void_p]
+        L.orc_mcl.restype = C.c_int64
+        L.orc_interpret.argtypes = [C.c_int32, _i32p, _i32p, _f32p, _i32p, _i32p, _i32p]
+        L.orc_interpret.restype = C.c_int32
+        L.orc_ingest_new.argtypes = [C.c_int32, C.c_int, C.c_int]
+        L.orc_ingest_new.restype = C.c_void_p
+        L.orc_ingest_push.argtypes = [C.c_void_p, C.c_int64, _i32p, _i64p, _i32p, _i64p, C.c_int, C.c_int32,
+                                      _i32p, _i64p, _i32p, _u8p, C.c_int64, _i32p, _i64p, _u8p, C.c_int64]
+        L.orc_ingest_push.restype = None
+        L.orc_ingest_sizes.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 4
+        L.orc_ingest_sizes.restype = None
+        L.orc_ingest_fetch.argtypes = [C.c_void_p, _i32p, _i32p, _i64p, _i64p, _i32p, _i32p, _i64p, _i64p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ingest_fetch.restype = None
+        L.orc_ingest_free.argtypes = [C.c_void_p]
+        L.orc_ingest_free.restype = None
+        L.orc_dict_to_matrix.argtypes = [C.c_int64, _i32p, _i32p, _f64p, C.c_int32, _u8p, C.c_int32, C.c_int,
+                                         _i32p, C.POINTER(C.c_int32), _i32p, C.c_void_p, C.c_void_p]
+        L.orc_dict_to_matrix.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def _csr(indptr, indices, data):
+    return (np.ascontiguousarray(indptr, np.int32), np.ascontiguousarray(indices, np.int32),
+            np.ascontiguousarray(data, np.float32))
+
+
+# ---------------------------------------------------------------- MCL pieces (CSR(T) == CSC(M) triples)
+def normalize_l1(indptr, data):
+    indptr = np.ascontiguousarray(indptr, np.int32)
+    out = np.array(data, np.float32, copy=True)
+    lib().orc_normalize_l1(len(indptr) - 1, indptr, out)
+    return out
+
+
+def power(data, r):
+    out = np.array(data, np.float32, copy=True)
+    lib().orc_power(out.size, out, float(r))
+    return out
+
+
+def spgemm(A, B, n_cols=None, mode=0, fx_shift=62):
+    ap, aj, ax = _csr(*A)
+    bp, bj, bx = _csr(*B)
+    n_rows = len(ap) - 1
+    n_cols = n_cols if n_cols is not None else len(bp) - 1
+    cp = np.zeros(n_rows + 1, np.int32)
+    nnz = lib().orc_spgemm(n_rows, n_cols, ap, aj, ax, bp, bj, bx, cp, None, None, mode, fx_shift)
+    cj = np.zeros(max(nnz, 1), np.int32)
+    cx = np.zeros(max(nnz, 1), np.float32)
+    lib().orc_spgemm(n_rows, n_cols, ap, aj, ax, bp, bj, bx, cp, cj.ctypes.data, cx.ctypes.data, mode, fx_shift)
+    return cp, cj[:nnz], cx[:nnz]
+
+
+def prune(A, pruning):
+    ap, aj, ax = _csr(*A)
+    n = len(ap) - 1
+    op = np.zeros(n + 1, np.int32)
+    oj = np.zeros(max(ax.size, 1), np.int32)
+    ox = np.zeros(max(ax.size, 1), np.float32)
+    nnz = lib().orc_prune(n, ap, aj, ax, float(pruning), op, oj, ox)
+    return op, oj[:nnz], ox[:nnz]
+
+
+def convergence_stat(A, B):
+    ap, aj, ax = _csr(*A)
+    bp, bj, bx = _csr(*B)
+    return float(lib().orc_convergence_stat(len(ap) - 1, ap, aj, ax, bp, bj, bx))
+
+
+def mcl(A, expansion, inflation, iters, pruning, spgemm_mode=0, fx_shift=62, want_stats=False):
+    """mcl() :2026-2062 on the pre-expanded matrix.  Returns (indptr, indices, data, n_iter, converged[, stats])."""
+    ap, aj, ax = _csr(*A)
+    n = len(ap) - 1
+    cap = max(int(ax.size), 1)
+    op = np.zeros(n + 1, np.int32)
+    oj = np.zeros(cap, np.int32)
+    ox = np.zeros(cap, np.float32)
+    n_iter, conv = C.c_int(0), C.c_int(0)
+    stats = np.zeros((max(iters, 1), 4), np.int64)
+    nnz = lib().orc_mcl(n, ap, aj, ax, int(expansion), float(inflation), int(iters), float(pruning),
+                        int(spgemm_mode), int(fx_shift), cap, op, oj, ox, C.byref(n_iter), C.byref(conv),
+                        stats.ctypes.data)
+    if nnz < 0:
+        raise RuntimeError('oracle mcl: output larger than input (unexpected)')
+    res = (op, oj[:nnz], ox[:nnz], n_iter.value, bool(conv.value))
+    return res + (stats[:n_iter.value],) if want_stats else res
+
+
+def interpret(A):
+    """Array half of interpret_result(): (attractors, att_ptr, members), all ascending."""
+    ap, aj, ax = _csr(*A)
+    n = len(ap) - 1
+    att = np.zeros(max(n, 1), np.int32)
+    ptr = np.zeros(n + 1, np.int32)
+    mem = np.zeros(max(ax.size, 1), np.int32)
+    na = lib().orc_interpret(n, ap, aj, ax, att, ptr, mem)
+    return att[:na], ptr[:na + 1], mem[:ptr[na]]
+
+
+# ---------------------------------------------------------------- ingest
+class FragTable:
+    """Integer view of fa_dict / stat_fragments() outputs that the id-based ingest needs.
+
+    ctg_rank / frag_rank are ranks under Python string ordering of the names."""
+
+    def __init__(self, ctg_rank, ctg_len, ctg_frag0, ctg_split, bin_size, frag_rank, frag_len, frag_nx):
+        self.ctg_rank = np.ascontiguousarray(ctg_rank, np.int32)
+        self.ctg_len = np.ascontiguousarray(ctg_len, np.int64)
+        self.ctg_frag0 = np.ascontiguousarray(ctg_frag0, np.int32)
+        self.ctg_split = np.ascontiguousarray(ctg_split, np.uint8)
+        self.bin_size = int(bin_size)
+        self.frag_rank = np.ascontiguousarray(frag_rank, np.int32)
+        self.frag_len = np.ascontiguousarray(frag_len, np.int64)
+        self.frag_nx = np.ascontiguousarray(frag_nx, np.uint8)
+        self.n_ctg = len(self.ctg_rank)
+        self.n_frag = len(self.frag_rank)
+
+
+def ingest(table, id1, pos1, id2, pos2, flank, bins=False, want_clm=False, max_read_pairs=0, chunk=None):
+    """parse_alignments_for_ctgs (bins=False) / parse_alignments (bins=True) on integer ids."""
+    L = lib()
+    h = L.orc_ingest_new(table.n_frag, int(want_clm), int(max_read_pairs))
+    id1 = np.ascontiguousarray(id1, np.int32)
+    id2 = np.ascontiguousarray(id2, np.int32)
+    pos1 = np.ascontiguousarray(pos1, np.int64)
+    pos2 = np.ascontiguousarray(pos2, np.int64)
+    n = id1.size
+    step = chunk or max(n, 1)
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        L.orc_ingest_push(h, e - s, id1[s:e], pos1[s:e], id2[s:e], pos2[s:e], int(bins), table.n_ctg,
+                          table.ctg_rank, table.ctg_len, table.ctg_frag0, table.ctg_split, table.bin_size,
+                          table.frag_rank, table.frag_len, table.frag_nx, int(flank))
+    sz = [C.c_int64(0) for _ in range(4)]
+    L.orc_ingest_sizes(h, *[C.byref(s) for s in sz])
+    nf, nk, nclm, ncrd = [s.value for s in sz]
+    out = dict(full_i=np.zeros(nf, np.int32), full_j=np.zeros(nf, np.int32), full_cnt=np.zeros(nf, np.int64),
+               ht_cnt=np.zeros((nf, 4), np.int64), flank_i=np.zeros(nk, np.int32), flank_j=np.zeros(nk, np.int32),
+               flank_cnt=np.zeros(nk, np.int64), frag_links=np.zeros(max(table.n_frag, 1), np.int64))
+    extra = want_clm or max_read_pairs
+    if extra:
+        out.update(clm_ptr=np.zeros(nf + 1, np.int64), clm=np.zeros(max(nclm, 1), np.int64),
+                   crd_ptr=np.zeros(nf + 1, np.int64), crd=np.zeros(max(ncrd, 1), np.int64))
+    L.orc_ingest_fetch(h, out['full_i'], out['full_j'], out['full_cnt'], out['ht_cnt'].reshape(-1),
+                       out['flank_i'], out['flank_j'], out['flank_cnt'], out['frag_links'],
+                       out['clm_ptr'].ctypes.data if extra else None, out['clm'].ctypes.data if extra else None,
+                       out['crd_ptr'].ctypes.data if extra else None, out['crd'].ctypes.data if extra else None)
+    L.orc_ingest_free(h)
+    out['frag_links'] = out['frag_links'][:table.n_frag]
+    if extra:
+        out['clm'] = out['clm'][:nclm]
+        out['crd'] = out['crd'][:ncrd]
+    return out
+
+
+def dict_to_matrix(fi, fj, val, n_frag, in_set, n_rest, add_self_loops=True):
+    """Array half of dict_to_matrix() :310-373.  Returns (indptr, indices, data, frag_index, n_linked)."""
+    L = lib()
+    fi = np.ascontiguousarray(fi, np.int32)
+    fj = np.ascontiguousarray(fj, np.int32)
+    val = np.ascontiguousarray(val, np.float64)
+    in_set = np.ascontiguousarray(in_set, np.uint8)
+    frag_index = np.zeros(max(n_frag, 1), np.int32)
+    n_linked = C.c_int32(0)
+    # counting call needs indptr sized by the (yet unknown) shape: upper bound n_frag + n_rest
+    indptr = np.zeros(n_frag + n_rest + 2, np.int32)
+    nnz = L.orc_dict_to_matrix(fi.size, fi, fj, val, n_frag, in_set, n_rest, int(add_self_loops), frag_index,
+                               C.byref(n_linked), indptr, None, None)
+    shape = n_linked.value + n_rest
+    indices = np.zeros(max(nnz, 1), np.int32)
+    data = np.zeros(max(nnz, 1), np.float32)
+    L.orc_dict_to_matrix(fi.size, fi, fj, val, n_frag, in_set, n_rest, int(add_self_loops), frag_index,
+                         C.byref(n_linked), indptr, indices.ctypes.data, data.ctypes.data)
+    return indptr[:shape + 1].copy(), indices[:nnz], data[:nnz], frag_index[:n_frag], n_linked.value

@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own functions (HapHiC_cluster.py).
+
+Run in the dev container only (needs /root/reference):
+    PYTHONHASHSEED=0 python tests/golden/make_golden.py
+The reference has no tests / golden vectors of its own, so these fixtures are what pins
+the oracle (oracle/hhx_oracle.c) and, through it, the HIP kernels.  Only the two import stubs of
+SURVEY Appendix B are applied (pysam / portion are absent here); MKL is absent too, so the sparse
+code path runs with scipy's `@` standing in for sparse_dot_mkl.dot_product_mkl.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.sparse as sp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+for name, attrs in (('pysam', {'set_verbosity': lambda *a, **k: None, 'AlignmentFile': None}),
+                    ('portion', {'closed': None, 'empty': None})):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+sys.path.insert(0, '/root/reference/scripts')
+import HapHiC_cluster as H  # noqa: E402
+
+H.dot_product_mkl = lambda a, b: (a @ b).tocsc()
+H.INTEL_MKL = True
+H.logger.setLevel('WARNING')
+
+from haphic_amd import synth  # noqa: E402
+
+
+def canon(m):
+    m = m.tocsc().copy()
+    m.sum_duplicates()
+    m.sort_indices()
+    return m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32)
+
+
+def planted_matrix(n, ngroups, seed, p_in=0.5, p_out=0.02, max_cnt=40):
+    rng = np.random.default_rng(seed)
+    grp = rng.integers(0, ngroups, n)
+    iu, ju = np.triu_indices(n, 1)
+    p = np.where(grp[iu] == grp[ju], p_in, p_out)
+    keep = rng.random(iu.size) < p
+    iu, ju = iu[keep], ju[keep]
+    cnt = np.where(grp[iu] == grp[ju], rng.integers(1, max_cnt, iu.size), rng.integers(1, 4, iu.size)).astype(np.float32)
+    rows = np.concatenate([iu, ju, np.arange(n)])
+    cols = np.concatenate([ju, iu, np.arange(n)])
+    data = np.concatenate([cnt, cnt, np.ones(n, np.float32)])
+    return sp.coo_matrix((data, (rows, cols)), shape=(n, n), dtype=np.float32).tocsc()
+
+
+def gen_mcl(path):
+    out = {}
+    cases = [('a', 150, 4, 1, 2.0), ('b', 320, 6, 2, 2.0), ('c', 200, 5, 3, 1.7), ('d', 90, 3, 4, 3.0)]
+    out['cases'] = np.array([c[0] for c in cases])
+    for tag, n, ng, seed, infl in cases:
+        link = planted_matrix(n, ng, seed)
+        norm = H.normalize(link, norm='l1', axis=0)
+        m2 = H.mkl_matrix_power(norm, 2)
+        # record the matrix at the end of every iteration = every return value of prune()
+        per_iter = []
+        orig_prune = H.prune
+
+        def rec_prune(matrix, pruning, dense_matrix, _o=orig_prune, _l=per_iter):
+            r = _o(matrix, pruning, dense_matrix)
+            _l.append(canon(r))
+            return r
+        H.prune = rec_prune
+        try:
+            res = H.mcl(m2, 2, infl, 200, 1e-4, False)
+        finally:
+            H.prune = orig_prune
+        clusters = H.interpret_result(res, False)
+        for k, v in zip(('p', 'j', 'x'), canon(link)):
+            out['%s_link_%s' % (tag, k)] = v
+        for k, v in zip(('p', 'j', 'x'), canon(norm)):
+            out['%s_norm_%s' % (tag, k)] = v
+        for k, v in zip(('p', 'j', 'x'), canon(m2)):
+            out['%s_m2_%s' % (tag, k)] = v
+        out[tag + '_inflation'] = np.float64(infl)
+        out[tag + '_niter'] = np.int32(len(per_iter))
+        for it, (p, j, x) in enumerate(per_iter):
+            out['%s_it%d_p' % (tag, it)] = p
+            out['%s_it%d_j' % (tag, it)] = j
+            out['%s_it%d_x' % (tag, it)] = x
+        assert clusters is not None
+        out[tag + '_clusters_ptr'] = np.cumsum([0] + [len(c) for c in clusters]).astype(np.int32)
+        out[tag + '_clusters'] = np.concatenate([np.asarray(c, np.int32) for c in clusters])
+        print('mcl case', tag, 'n', n, 'iters', len(per_iter), 'clusters', len(clusters))
+    np.savez_compressed(path, **out)
+
+
+class Args:
+    pass
+
+
+def ingest_case(nchrs, chr_len, mean_len, npairs, flank_kb, Nx, bin_size_kb, seed, max_read_pairs):
+    g = synth.make_genome(nchrs, chr_len, mean_len, cv=0.5, min_len=2000, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    fa_dict = {}
+    for nm, ln in zip(g.names, g.length):
+        seq = ''.join(rng.choice(list('ACGT'), int(ln)))
+        fa_dict[nm] = [seq, int(ln), H.count_RE_sites(seq, 'GATC') + 1]
+    _, bin_set, bin_size, frag_len_dict, Nx_frag_set, RE_site_dict, split_ctg_set = H.stat_fragments(
+        fa_dict, 'GATC', {}, set(), nchrs=nchrs, flank=flank_kb, Nx=Nx, bin_size=bin_size_kb)
+    id1, p1, id2, p2 = [t.numpy() for t in synth.sample_pairs(g, npairs, seed=seed + 2, cis=0.8)]
+    # sprinkle alignments to names that are not in the FASTA, and exact duplicates
+    id1 = id1.copy(); id2 = id2.copy()
+    bad = rng.random(npairs) < 0.01
+    id1[bad & (rng.random(npairs) < 0.5)] = -1
+    id2[bad & (id1 >= 0)] = -1
+    names = list(g.names)
+
+    def nm(i):
+        return names[i] if i >= 0 else 'unplaced_scaffold'
+
+    if not split_ctg_set:   # run() feeds the inter-contig generator in that case (:2865)
+        keep = id1 != id2
+        id1, p1, id2, p2 = id1[keep], p1[keep], id2[keep], p2[keep]
+    aln = [(nm(a), nm(b), int(x), int(y)) for a, x, b, y in zip(id1, p1, id2, p2)]
+    args = Args()
+    args.flank = flank_kb
+    args.remove_allelic_links = 4 if max_read_pairs else 0
+    args.remove_concentrated_links = False
+    args.max_read_pairs = max_read_pairs
+    args.nwindows = 50
+    captured = {}
+    orig_ccr = H.cal_concordance_ratio
+    H.cal_concordance_ratio = lambda coord_list, shorter_len, nwindows: tuple(coord_list)
+    try:
+        if split_ctg_set:
+            full, flank, HT, clm, frag_link, coord, _ = H.parse_alignments(
+                iter(aln), fa_dict, args, bin_size, frag_len_dict, Nx_frag_set, split_ctg_set, 'int32', 'int32')
+        else:
+            full, flank, HT, clm, frag_link, coord = H.parse_alignments_for_ctgs(
+                iter(aln), fa_dict, args, frag_len_dict, Nx_frag_set, 'int32', 'int32')
+    finally:
+        H.cal_concordance_ratio = orig_ccr
+    # ---- integer views
+    cid = {n_: i for i, n_ in enumerate(names)}
+    frag_names, ctg_frag0, ctg_split = [], [], []
+    for n_ in names:
+        ctg_frag0.append(len(frag_names))
+        if n_ in split_ctg_set:
+            ctg_split.append(1)
+            nb = int(np.ceil(fa_dict[n_][1] / bin_size))
+            frag_names += ['{}_bin{}'.format(n_, k + 1) for k in range(nb)]
+        else:
+            ctg_split.append(0)
+            frag_names.append(n_)
+    fid = {n_: i for i, n_ in enumerate(frag_names)}
+
+    def rank(lst):
+        order = sorted(range(len(lst)), key=lambda i: lst[i])
+        r = np.empty(len(lst), np.int32)
+        r[order] = np.arange(len(lst), dtype=np.int32)
+        return r
+    out = dict(
+        names=np.array(names), frag_names=np.array(frag_names),
+        ctg_rank=rank(names), ctg_len=np.array([fa_dict[n_][1] for n_ in names], np.int64),
+        ctg_frag0=np.array(ctg_frag0, np.int32), ctg_split=np.array(ctg_split, np.uint8),
+        bin_size=np.int64(bin_size if split_ctg_set else 0),
+        frag_rank=rank(frag_names), frag_len=np.array([frag_len_dict[f] for f in frag_names], np.int64),
+        frag_nx=np.array([f in Nx_frag_set for f in frag_names], np.uint8),
+        flank=np.int64(flank_kb * 1000), bins=np.int32(bool(split_ctg_set)),
+        max_read_pairs=np.int32(max_read_pairs),
+        id1=id1.astype(np.int32), pos1=p1.astype(np.int64), id2=id2.astype(np.int32), pos2=p2.astype(np.int64),
+        full_i=np.array([cid[k[0]] for k in full], np.int32), full_j=np.array([cid[k[1]] for k in full], np.int32),
+        full_cnt=np.array(list(full.values()), np.int64),
+        flank_i=np.array([fid[k[0]] for k in flank], np.int32), flank_j=np.array([fid[k[1]] for k in flank], np.int32),
+        flank_cnt=np.array(list(flank.values()), np.int64),
+        frag_links=np.array([frag_link.get(f, 0) for f in frag_names], np.int64),
+    )
+    ht = np.zeros((len(full), 4), np.int64)
+    kidx = {k: i for i, k in enumerate(full)}
+    for (a, b), c in HT.items():
+        k = kidx[(a[:-2], b[:-2])]
+        ht[k, (a[-1] == 'T') * 2 + (b[-1] == 'T')] = c
+    out['ht_cnt'] = ht
+    clm_ptr, clm_all = [0], []
+    for k in full:
+        clm_all += list(clm[k])
+        clm_ptr.append(len(clm_all))
+    out['clm_ptr'] = np.array(clm_ptr, np.int64)
+    out['clm'] = np.array(clm_all, np.int64)
+    if max_read_pairs:
+        crd_ptr, crd_all = [0], []
+        for k in full:
+            v = coord[k]
+            v = list(v[0]) if isinstance(v, list) else list(v)
+            crd_all += v
+            crd_ptr.append(len(crd_all))
+        out['crd_ptr'] = np.array(crd_ptr, np.int64)
+        out['crd'] = np.array(crd_all, np.int64)
+    # ---- dict_to_matrix on a filtered fragment set (drop ~15 % of the Nx set, keep some link-less)
+    fset = set(f for f in Nx_frag_set if rng.random() > 0.15)
+    mat, fidx = H.dict_to_matrix(flank, fset, dense_matrix=False, add_self_loops=True)
+    p, j, x = canon(mat)
+    out['d2m_in_set'] = np.array([f in fset for f in frag_names], np.uint8)
+    out['d2m_p'], out['d2m_j'], out['d2m_x'] = p, j, x
+    out['d2m_frag_index'] = np.array([fidx.get(f, -1) for f in frag_names], np.int32)
+    # normalize_by_nlinks variant (:718-724): values become python floats before the float32 cast
+    flank2 = dict(flank)
+    H.normalize_by_nlinks(flank2, frag_link)
+    mat2, _ = H.dict_to_matrix(flank2, fset, dense_matrix=False, add_self_loops=True)
+    out['d2m_nlinks_x'] = canon(mat2)[2]
+    print('ingest case: ctgs', len(names), 'frags', len(frag_names), 'pairs', len(aln), 'full keys', len(full),
+          'flank keys', len(flank), 'bins' if split_ctg_set else 'ctgs', 'matrix', mat.shape, mat.nnz)
+    return out
+
+
+def gen_ingest(path_ctgs, path_bins):
+    np.savez_compressed(path_ctgs, **ingest_case(3, 600_000, 12_000, 30_000, 3, 80, 0, 11, 5))
+    np.savez_compressed(path_bins, **ingest_case(2, 500_000, 25_000, 30_000, 2, 90, 16, 21, 4))
+
+
+def gen_pipeline(path):
+    """ingest -> dict_to_matrix -> run_mcl_clustering on a ~C1-shaped toy: expected cluster files."""
+    import tempfile
+    g = synth.make_genome(4, 1_500_000, 30_000, cv=0.3, min_len=5000, seed=5)
+    names = list(g.names)
+    fa_dict = {n_: [None, int(l), int(r)] for n_, l, r in zip(names, g.length, g.re_sites)}
+    id1, p1, id2, p2 = [t.numpy() for t in synth.sample_pairs(g, 120_000, seed=6, cis=0.9)]
+    keep = id1 != id2
+    id1, p1, id2, p2 = id1[keep], p1[keep], id2[keep], p2[keep]
+    aln = ((names[a], names[b], int(x), int(y)) for a, x, b, y in zip(id1, p1, id2, p2))
+    args = Args()
+    args.flank = 500
+    args.remove_allelic_links = 0
+    args.remove_concentrated_links = False
+    args.max_read_pairs = 200
+    args.nwindows = 50
+    frag_len_dict = {n_: fa_dict[n_][1] for n_ in names}
+    Nx_set = set(names)
+    full, flank, HT, clm, frag_link, coord = H.parse_alignments_for_ctgs(
+        aln, fa_dict, args, frag_len_dict, Nx_set, 'int32', 'int32')
+    # filtered_frags: python set built the way filter_fragments() leaves it is order-irrelevant for
+    # linked fragments; we keep every contig (neutral filters) and store the link-less order used.
+    mat, fidx = H.dict_to_matrix(flank, Nx_set, dense_matrix=False, add_self_loops=True)
+    cwd = os.getcwd()
+    out = dict(names=np.array(names), length=g.length, re_sites=g.re_sites,
+               id1=id1.astype(np.int16) if len(names) < 32768 else id1, pos1=p1, id2=id2.astype(np.int16) if len(names) < 32768 else id2, pos2=p2,
+               frag_index=np.array([fidx[n_] for n_ in names], np.int32), nchrs=np.int32(4))
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        try:
+            H.logger.setLevel('INFO')
+            import logging
+            fh = logging.FileHandler('log.txt', 'w')
+            H.logger.addHandler(fh)
+            res, nrounds = H.run_mcl_clustering(mat, set(), frag_len_dict, fidx, 2, 1.2, 2.0, 0.4, 200, 1e-4,
+                                                fa_dict, 4, False)
+            H.logger.removeHandler(fh)
+            fh.close()
+            H.logger.setLevel('WARNING')
+            infl = []
+            for d in sorted(os.listdir('.')):
+                if d.startswith('inflation_'):
+                    infl.append(d.split('_', 1)[1])
+                    out['clusters_txt_' + infl[-1]] = np.array(open('{0}/mcl_{0}.clusters.txt'.format(d)).read())
+                    groups = sorted(f for f in os.listdir(d) if f.startswith('group'))
+                    out['group_files_' + infl[-1]] = np.array(groups)
+                    out['group0_txt_' + infl[-1]] = np.array(open(os.path.join(d, groups[0])).read())
+            out['inflations'] = np.array(infl)
+            out['log_recommend'] = np.array([l.strip() for l in open('log.txt') if 'You could try' in l] or [''])
+        finally:
+            os.chdir(cwd)
+    print('pipeline case: ctgs', len(names), 'pairs', len(id1), 'inflations', infl, 'matrix', mat.shape, mat.nnz,
+          'recommend:', out['log_recommend'])
+    np.savez_compressed(path, **out)
+
+
+if __name__ == '__main__':
+    assert os.environ.get('PYTHONHASHSEED') == '0', 'run with PYTHONHASHSEED=0'
+    gen_mcl(os.path.join(HERE, 'mcl_cases.npz'))
+    gen_ingest(os.path.join(HERE, 'ingest_ctgs.npz'), os.path.join(HERE, 'ingest_bins.npz'))
+    gen_pipeline(os.path.join(HERE, 'pipeline_toy.npz'))

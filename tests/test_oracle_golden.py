@@ -1,0 +1,116 @@
+"""The oracle (oracle/hhx_oracle.c) against golden vectors produced by the reference's own Python
+functions (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+
+from oracle import oracle as orc
+
+
+def tri(g, prefix):
+    return g[prefix + '_p'], g[prefix + '_j'], g[prefix + '_x']
+
+
+def assert_close_csr(a, b, rtol, what):
+    assert np.array_equal(a[0], b[0]), what + ': indptr'
+    assert np.array_equal(a[1], b[1]), what + ': indices'
+    np.testing.assert_allclose(a[2], b[2], rtol=rtol, atol=0, err_msg=what)
+
+
+def test_normalize_bit_exact(golden_mcl):
+    g = golden_mcl
+    for tag in g['cases']:
+        p, j, x = tri(g, tag + '_link')
+        assert np.array_equal(orc.normalize_l1(p, x), g[tag + '_norm_x'])
+
+
+def test_spgemm_matches_scipy_standin(golden_mcl):
+    g = golden_mcl
+    for tag in g['cases']:
+        A = tri(g, tag + '_norm')
+        C = orc.spgemm(A, A, mode=0)
+        # float32 accumulation in ascending-k order == scipy csr_matmat on canonical input: bit exact
+        ref = tri(g, tag + '_m2')
+        assert np.array_equal(C[0], ref[0]) and np.array_equal(C[1], ref[1])
+        assert np.array_equal(C[2], ref[2])
+        # fixed-point mode (the HIP kernel's specification) agrees to float32 round-off
+        F = orc.spgemm(A, A, mode=1, fx_shift=62)
+        assert_close_csr(F, ref, 1e-6, 'fixed-point spgemm')
+
+
+def test_mcl_iterations(golden_mcl):
+    g = golden_mcl
+    for tag in g['cases']:
+        infl = float(g[tag + '_inflation'])
+        niter = int(g[tag + '_niter'])
+        cur = tri(g, tag + '_m2')
+        last = None
+        for it in range(niter):
+            if it:
+                cur = orc.spgemm(cur, cur, mode=0)
+            x = orc.normalize_l1(cur[0], orc.power(cur[2], infl))
+            cur = orc.prune((cur[0], cur[1], x), 1e-4)
+            ref = tri(g, '%s_it%d' % (tag, it))
+            # power(): numpy's SIMD powf is within 1 ulp of libm's; everything else is exact
+            assert_close_csr(cur, ref, 0 if infl == 2.0 else 5e-7, '%s iter %d' % (tag, it))
+            if infl != 2.0:
+                cur = ref      # re-anchor so that 1-ulp pow differences do not compound
+            if it > 1:
+                d = orc.convergence_stat(cur, last)
+                assert (d <= np.float32(1e-8)) == (it == niter - 1), (tag, it, d)
+            last = cur
+
+
+def test_mcl_driver_and_interpret(golden_mcl):
+    g = golden_mcl
+    for tag in g['cases']:
+        infl = float(g[tag + '_inflation'])
+        niter = int(g[tag + '_niter'])
+        p, j, x, n_iter, conv, stats = orc.mcl(tri(g, tag + '_m2'), 2, infl, 200, 1e-4, want_stats=True)
+        assert conv and n_iter == niter
+        ref = tri(g, '%s_it%d' % (tag, niter - 1))
+        assert_close_csr((p, j, x), ref, 0 if infl == 2.0 else 1e-5, tag + ' final')
+        assert stats[0, 3] == 0 and (stats[1:, 3] > 0).all()
+        att, ptr, mem = orc.interpret((p, j, x))
+        got = {tuple(mem[ptr[a]:ptr[a + 1]].tolist()) for a in range(len(att))}
+        cp, cl = g[tag + '_clusters_ptr'], g[tag + '_clusters']
+        want = {tuple(cl[cp[a]:cp[a + 1]].tolist()) for a in range(len(cp) - 1)}
+        assert got == want
+        # fixed-point spgemm mode gives the same partition
+        p2, j2, x2, n2, c2 = orc.mcl(tri(g, tag + '_m2'), 2, infl, 200, 1e-4, spgemm_mode=1)
+        att, ptr, mem = orc.interpret((p2, j2, x2))
+        assert {tuple(mem[ptr[a]:ptr[a + 1]].tolist()) for a in range(len(att))} == want
+
+
+def table_of(g):
+    return orc.FragTable(g['ctg_rank'], g['ctg_len'], g['ctg_frag0'], g['ctg_split'], int(g['bin_size']),
+                         g['frag_rank'], g['frag_len'], g['frag_nx'])
+
+
+def test_ingest(golden_ingest):
+    g = golden_ingest
+    for chunk in (None, 997):
+        out = orc.ingest(table_of(g), g['id1'], g['pos1'], g['id2'], g['pos2'], int(g['flank']),
+                         bins=bool(g['bins']), want_clm=True, max_read_pairs=int(g['max_read_pairs']), chunk=chunk)
+        for k in ('full_i', 'full_j', 'full_cnt', 'ht_cnt', 'flank_i', 'flank_j', 'flank_cnt', 'frag_links',
+                  'clm_ptr', 'clm', 'crd_ptr', 'crd'):
+            assert np.array_equal(out[k], g[k]), k
+
+
+def test_dict_to_matrix(golden_ingest):
+    g = golden_ingest
+    in_set = g['d2m_in_set']
+    linked = np.zeros(len(in_set), bool)
+    ok = in_set[g['flank_i']].astype(bool) & in_set[g['flank_j']].astype(bool)
+    linked[g['flank_i'][ok]] = True
+    linked[g['flank_j'][ok]] = True
+    n_rest = int(in_set.sum() - linked.sum())
+    p, j, x, fidx, n_linked = orc.dict_to_matrix(g['flank_i'], g['flank_j'], g['flank_cnt'].astype(np.float64),
+                                                 len(in_set), in_set, n_rest)
+    assert np.array_equal(p, g['d2m_p']) and np.array_equal(j, g['d2m_j']) and np.array_equal(x, g['d2m_x'])
+    ref_idx = g['d2m_frag_index']
+    assert np.array_equal(fidx[linked], ref_idx[linked])         # first-seen order of linked fragments
+    assert (ref_idx[in_set.astype(bool) & ~linked] >= n_linked).all()
+    # normalize_by_nlinks (:718-724): python-float division, then the float32 cast of :368
+    fl = g['frag_links'].astype(np.float64)
+    val = g['flank_cnt'] / (fl[g['flank_i']] * fl[g['flank_j']]) ** 0.5
+    x2 = orc.dict_to_matrix(g['flank_i'], g['flank_j'], val, len(in_set), in_set, n_rest)[2]
+    assert np.array_equal(x2, g['d2m_nlinks_x'])
