@@ -1,0 +1,327 @@
+"""ctypes binding of libhaphic_hip.so (include/haphic_hip.h).
+
+This is the stub a HapHiC maintainer would add next to scripts/HapHiC_cluster.py.
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, loading / the first
+call raises, exactly as a missing sparse_dot_mkl would — but loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, 'libhaphic_hip.so')
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+c_u8p = C.POINTER(C.c_uint8)
+c_vpp = C.POINTER(C.c_void_p)
+
+
+class IngestConfig(C.Structure):
+    _fields_ = [('n_ctg', C.c_int32), ('n_frag', C.c_int32),
+                ('ctg_rank', c_i32p), ('ctg_len', c_i64p), ('ctg_frag0', c_i32p), ('ctg_split', c_u8p),
+                ('frag_rank', c_i32p), ('frag_len', c_i64p), ('frag_nx', c_u8p),
+                ('bin_size', C.c_int64), ('flank', C.c_int64), ('bins', C.c_int32), ('skip_intra', C.c_int32),
+                ('expected_keys', C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/haphic_hip.h declares
+SIGNATURES = {
+    'hhx_last_error': (C.c_char_p, []),
+    'hhx_version': (C.c_int, []),
+    'hhx_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'hhx_set_device': (C.c_int, [C.c_int]),
+    'hhx_set_stream': (C.c_int, [C.c_void_p]),
+    'hhx_synchronize': (C.c_int, []),
+    'hhx_pool_trim': (C.c_int, []),
+    'hhx_csr_from_host': (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, c_vpp]),
+    'hhx_csr_from_device': (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, c_vpp]),
+    'hhx_csr_shape': (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i64p]),
+    'hhx_csr_to_host': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'hhx_csr_device_ptrs': (C.c_int, [C.c_void_p, c_vpp, c_vpp, c_vpp]),
+    'hhx_csr_copy': (C.c_int, [C.c_void_p, c_vpp]),
+    'hhx_csr_row_block': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_vpp]),
+    'hhx_csr_free': (C.c_int, [C.c_void_p]),
+    'hhx_normalize_l1': (C.c_int, [C.c_void_p]),
+    'hhx_inflate': (C.c_int, [C.c_void_p, C.c_double]),
+    'hhx_prune': (C.c_int, [C.c_void_p, C.c_double, c_vpp]),
+    'hhx_inflate_prune': (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_vpp]),
+    'hhx_spgemm': (C.c_int, [C.c_void_p, C.c_void_p, c_vpp]),
+    'hhx_spgemm_ex': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_vpp, c_i64p]),
+    'hhx_convergence_stat': (C.c_int, [C.c_void_p, C.c_void_p, c_f32p]),
+    'hhx_mcl': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, c_vpp, C.POINTER(C.c_int),
+                          C.POINTER(C.c_int), C.c_void_p]),
+    'hhx_interpret': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i32p]),
+    'hhx_dict_to_matrix': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_void_p,
+                                     C.c_int32, C.c_int, C.c_void_p, c_i32p, c_vpp]),
+    'hhx_ingest_create': (C.c_int, [C.POINTER(IngestConfig), c_vpp]),
+    'hhx_ingest_push': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    'hhx_ingest_finalize': (C.c_int, [C.c_void_p, c_i64p, c_i64p]),
+    'hhx_ingest_fetch': (C.c_int, [C.c_void_p] + [C.c_void_p] * 8),
+    'hhx_ingest_flank_device': (C.c_int, [C.c_void_p, c_vpp, c_vpp, c_vpp]),
+    'hhx_ingest_destroy': (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and bind every declared symbol (does not touch the GPU)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError('haphic_amd: %s is missing — build it with `python -m haphic_amd.build` '
+                              '(hipcc --offload-arch=gfx950); there is no CPU fallback' % SO_PATH)
+        lib = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError('libhaphic_hip: ' + load().hhx_last_error().decode('utf-8', 'replace'))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().hhx_device_count(C.byref(n)))
+    return n.value
+
+
+def ptr(a):
+    """host pointer of a C-contiguous numpy array (or None)"""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceCSR:
+    """Device-resident CSR(T) == the reference's CSC(M) triple (hhx_csr handle)."""
+
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+
+    @classmethod
+    def from_arrays(cls, indptr, indices, data, n_cols=None):
+        indptr = np.ascontiguousarray(indptr, np.int32)
+        indices = np.ascontiguousarray(indices, np.int32)
+        data = np.ascontiguousarray(data, np.float32)
+        n_rows = len(indptr) - 1
+        out = C.c_void_p()
+        check(load().hhx_csr_from_host(n_rows, n_rows if n_cols is None else n_cols, ptr(indptr), ptr(indices),
+                                       ptr(data), C.byref(out)))
+        return cls(out)
+
+    @classmethod
+    def from_scipy_csc(cls, m):
+        """scipy CSC of M, canonicalised (sorted indices, duplicates summed) like the reference's own
+        intermediate matrices after `.power()` (scipy _deduped_data)."""
+        m = m.tocsc()
+        if not m.has_canonical_format:
+            m = m.copy()
+            m.sum_duplicates()
+        return cls.from_arrays(m.indptr, m.indices, m.data.astype(np.float32, copy=False), n_cols=m.shape[0])
+
+    @classmethod
+    def from_device(cls, n_rows, n_cols, nnz, indptr_ptr, indices_ptr, data_ptr):
+        out = C.c_void_p()
+        check(load().hhx_csr_from_device(n_rows, n_cols, nnz, C.c_void_p(indptr_ptr), C.c_void_p(indices_ptr),
+                                         C.c_void_p(data_ptr), C.byref(out)))
+        return cls(out)
+
+    @property
+    def shape3(self):
+        r, c, z = C.c_int32(), C.c_int32(), C.c_int64()
+        check(load().hhx_csr_shape(self.h, C.byref(r), C.byref(c), C.byref(z)))
+        return r.value, c.value, z.value
+
+    @property
+    def nnz(self):
+        return self.shape3[2]
+
+    def to_arrays(self):
+        r, c, z = self.shape3
+        indptr = np.empty(r + 1, np.int32)
+        indices = np.empty(z, np.int32)
+        data = np.empty(z, np.float32)
+        check(load().hhx_csr_to_host(self.h, ptr(indptr), ptr(indices), ptr(data)))
+        return indptr, indices, data
+
+    def to_scipy_csc(self):
+        import scipy.sparse as sp
+        r, c, _ = self.shape3
+        indptr, indices, data = self.to_arrays()
+        return sp.csc_matrix((data, indices, indptr), shape=(c, r))
+
+    def device_ptrs(self):
+        a, b, d = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(load().hhx_csr_device_ptrs(self.h, C.byref(a), C.byref(b), C.byref(d)))
+        return a.value or 0, b.value or 0, d.value or 0
+
+    def copy(self):
+        out = C.c_void_p()
+        check(load().hhx_csr_copy(self.h, C.byref(out)))
+        return DeviceCSR(out)
+
+    def row_block(self, r0, r1):
+        out = C.c_void_p()
+        check(load().hhx_csr_row_block(self.h, r0, r1, C.byref(out)))
+        return DeviceCSR(out)
+
+    def free(self):
+        if self.h is not None and self.h.value:
+            load().hhx_csr_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------- thin functional wrappers
+def normalize_l1(m):
+    check(load().hhx_normalize_l1(m.h))
+    return m
+
+
+def inflate(m, inflation):
+    check(load().hhx_inflate(m.h, float(inflation)))
+    return m
+
+
+def prune(m, pruning):
+    out = C.c_void_p()
+    check(load().hhx_prune(m.h, float(pruning), C.byref(out)))
+    return DeviceCSR(out)
+
+
+def inflate_prune(c, inflation, pruning):
+    out = C.c_void_p()
+    check(load().hhx_inflate_prune(c.h, float(inflation), float(pruning), C.byref(out)))
+    return DeviceCSR(out)
+
+
+def spgemm(a, b, fx_shift=-1, want_products=False):
+    out = C.c_void_p()
+    f = C.c_int64(0)
+    check(load().hhx_spgemm_ex(a.h, b.h, int(fx_shift), C.byref(out), C.byref(f) if want_products else None))
+    return (DeviceCSR(out), f.value) if want_products else DeviceCSR(out)
+
+
+def convergence_stat(m, last):
+    s = C.c_float(0)
+    check(load().hhx_convergence_stat(m.h, last.h, C.byref(s)))
+    return s.value
+
+
+def mcl(pre_expanded, expansion, inflation, max_iter, pruning, want_stats=False):
+    out = C.c_void_p()
+    n_iter, conv = C.c_int(0), C.c_int(0)
+    stats = np.zeros((max(int(max_iter), 1), 4), np.int64)
+    check(load().hhx_mcl(pre_expanded.h, int(expansion), float(inflation), int(max_iter), float(pruning),
+                         C.byref(out), C.byref(n_iter), C.byref(conv), ptr(stats)))
+    res = (DeviceCSR(out), n_iter.value, bool(conv.value))
+    return res + (stats[:n_iter.value],) if want_stats else res
+
+
+def interpret(m):
+    r, _, z = m.shape3
+    att = np.empty(max(r, 1), np.int32)
+    att_ptr = np.empty(r + 1, np.int32)
+    members = np.empty(max(z, 1), np.int32)
+    na = C.c_int32(0)
+    check(load().hhx_interpret(m.h, ptr(att), ptr(att_ptr), ptr(members), C.byref(na)))
+    na = na.value
+    return att[:na], att_ptr[:na + 1], members[:att_ptr[na]]
+
+
+def dict_to_matrix(frag_i, frag_j, value, n_frag, in_set, n_rest, add_self_loops=True, on_device=False, n_keys=None):
+    """frag_i/frag_j/value: numpy arrays (on_device=False) or raw device pointers (ints, on_device=True)."""
+    in_set = np.ascontiguousarray(in_set, np.uint8)
+    frag_index = np.empty(max(n_frag, 1), np.int32)
+    n_linked = C.c_int32(0)
+    out = C.c_void_p()
+    if on_device:
+        a, b, v = C.c_void_p(frag_i), C.c_void_p(frag_j), C.c_void_p(value)
+        nk = int(n_keys)
+    else:
+        fi = np.ascontiguousarray(frag_i, np.int32)
+        fj = np.ascontiguousarray(frag_j, np.int32)
+        fv = np.ascontiguousarray(value, np.float64)
+        a, b, v = ptr(fi), ptr(fj), ptr(fv)
+        nk = fi.size
+    check(load().hhx_dict_to_matrix(nk, a, b, v, int(on_device), int(n_frag), ptr(in_set), int(n_rest),
+                                    int(add_self_loops), ptr(frag_index), C.byref(n_linked), C.byref(out)))
+    return DeviceCSR(out), frag_index[:n_frag], n_linked.value
+
+
+class Ingest:
+    """hhx_ingest handle: push batches of (id1, pos1, id2, pos2), then finalize/fetch."""
+
+    def __init__(self, table, flank, bins=False, skip_intra=False, expected_keys=0):
+        self._keep = table      # keeps the numpy arrays alive during create
+        cfg = IngestConfig()
+        cfg.n_ctg, cfg.n_frag = table.n_ctg, table.n_frag
+        cfg.ctg_rank = table.ctg_rank.ctypes.data_as(c_i32p)
+        cfg.ctg_len = table.ctg_len.ctypes.data_as(c_i64p)
+        cfg.ctg_frag0 = table.ctg_frag0.ctypes.data_as(c_i32p)
+        cfg.ctg_split = table.ctg_split.ctypes.data_as(c_u8p)
+        cfg.frag_rank = table.frag_rank.ctypes.data_as(c_i32p)
+        cfg.frag_len = table.frag_len.ctypes.data_as(c_i64p)
+        cfg.frag_nx = table.frag_nx.ctypes.data_as(c_u8p)
+        cfg.bin_size, cfg.flank = int(table.bin_size), int(flank)
+        cfg.bins, cfg.skip_intra = int(bool(bins)), int(bool(skip_intra))
+        cfg.expected_keys = int(expected_keys)
+        self.n_frag = table.n_frag
+        self.h = C.c_void_p()
+        check(load().hhx_ingest_create(C.byref(cfg), C.byref(self.h)))
+        self.n_full = self.n_flank = None
+
+    def push(self, id1, pos1, id2, pos2):
+        arrs = [np.ascontiguousarray(a, np.int32) for a in (id1, pos1, id2, pos2)]
+        check(load().hhx_ingest_push(self.h, arrs[0].size, *[ptr(a) for a in arrs], 0))
+
+    def push_device(self, n_pairs, id1_ptr, pos1_ptr, id2_ptr, pos2_ptr):
+        check(load().hhx_ingest_push(self.h, int(n_pairs), C.c_void_p(id1_ptr), C.c_void_p(pos1_ptr),
+                                     C.c_void_p(id2_ptr), C.c_void_p(pos2_ptr), 1))
+
+    def finalize(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(load().hhx_ingest_finalize(self.h, C.byref(a), C.byref(b)))
+        self.n_full, self.n_flank = a.value, b.value
+        return self.n_full, self.n_flank
+
+    def fetch(self):
+        if self.n_full is None:
+            self.finalize()
+        nf, nk = self.n_full, self.n_flank
+        out = dict(full_i=np.empty(nf, np.int32), full_j=np.empty(nf, np.int32), full_cnt=np.empty(nf, np.int64),
+                   ht_cnt=np.empty((nf, 4), np.int64), flank_i=np.empty(nk, np.int32), flank_j=np.empty(nk, np.int32),
+                   flank_cnt=np.empty(nk, np.int64), frag_links=np.empty(self.n_frag, np.int64))
+        check(load().hhx_ingest_fetch(self.h, ptr(out['full_i']), ptr(out['full_j']), ptr(out['full_cnt']),
+                                      ptr(out['ht_cnt']), ptr(out['flank_i']), ptr(out['flank_j']),
+                                      ptr(out['flank_cnt']), ptr(out['frag_links'])))
+        return out
+
+    def flank_device(self):
+        a, b, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(load().hhx_ingest_flank_device(self.h, C.byref(a), C.byref(b), C.byref(v)))
+        return a.value or 0, b.value or 0, v.value or 0
+
+    def destroy(self):
+        if self.h is not None and self.h.value:
+            load().hhx_ingest_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -1,0 +1,127 @@
+// Shared host/device plumbing of libhaphic_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/haphic_hip.h"
+
+typedef int32_t i32;
+typedef int64_t i64;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+namespace hhx {
+
+// ------------------------------------------------------------------ errors
+extern thread_local std::string g_err;
+extern thread_local hipStream_t g_stream;
+
+inline int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HHX_HIP(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return hhx::fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define HHX_TRY(expr)          \
+    do {                       \
+        int r_ = (expr);       \
+        if (r_) return r_;     \
+    } while (0)
+
+#define HHX_LAUNCH_CHECK() HHX_HIP(hipGetLastError())
+
+// ------------------------------------------------------------------ caching device allocator
+// MCL allocates a handful of buffers per iteration; hipMalloc/hipFree cost ~100 us each and
+// hipFree synchronises the device, so blocks are recycled by power-of-two size class.
+void *pool_alloc(size_t bytes);   // nullptr on failure (g_err set)
+void pool_free(void *p);
+void pool_trim();
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    int alloc(size_t count) {
+        release();
+        n = count;
+        p = (T *)pool_alloc((count ? count : 1) * sizeof(T));
+        return p ? 0 : 1;
+    }
+    void release() {
+        if (p) pool_free(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+// ------------------------------------------------------------------ scans / reductions (hhx_scan.hip)
+// exclusive scan of n int32 counts into int32 offsets out[0..n] (out[n] = total); total returned
+// through *total_host after a stream sync.  in and out may alias only if out == in is NOT used.
+int exclusive_scan_i32(const i32 *in, i32 *out, i64 n, i64 *total_host);
+int exclusive_scan_i64(const i64 *in, i64 *out, i64 n, i64 *total_host);
+
+}  // namespace hhx
+
+// ------------------------------------------------------------------ matrix handle
+struct hhx_csr {
+    i32 n_rows = 0, n_cols = 0;
+    i64 nnz = 0;
+    hhx::DevBuf<i32> indptr;
+    hhx::DevBuf<i32> indices;
+    hhx::DevBuf<float> data;
+};
+
+// ------------------------------------------------------------------ device helpers
+#ifdef __HIPCC__
+#define HHX_WAVE 64
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, HHX_WAVE);
+    return __shfl(v, 0, HHX_WAVE);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, HHX_WAVE));
+    return __shfl(v, 0, HHX_WAVE);
+}
+__device__ __forceinline__ i32 wave_sum_i32(i32 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, HHX_WAVE);
+    return __shfl(v, 0, HHX_WAVE);
+}
+__device__ __forceinline__ i64 wave_sum_i64(i64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, HHX_WAVE);
+    return __shfl(v, 0, HHX_WAVE);
+}
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (HHX_WAVE - 1); }
+#endif

@@ -1,0 +1,343 @@
+// Row-local MCL kernels on CSR(T): L1 normalise, inflate, prune, convergence, attractor read-out,
+// and the mcl() driver.  Reference: scripts/HapHiC_cluster.py:1987-2095 (prune, mcl, interpret_result)
+// and sklearn's _inplace_csr_row_normalize_l1 (double row sum, x = float(x / sum)).
+//
+// All of these are HBM-streaming kernels: one 64-lane wavefront owns one row, lanes stride the row
+// so that a wave reads 256 contiguous bytes of indices / values per instruction; row sums are
+// wave-level double reductions in a fixed tree (deterministic for a given row).
+#include "hhx_common.h"
+
+using namespace hhx;
+
+int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
+
+namespace {
+
+// Stochastic operands: every row of T sums to 1 and every entry is <= 1, so |C| <= 1 and a fixed
+// 2^60 scaling leaves 3 bits of headroom; no per-call bound reduction (and no host sync) is needed.
+constexpr int HHX_MCL_FX_SHIFT = 60;
+
+constexpr int ROW_T = 256;                       // 4 waves per workgroup, one row per wave
+constexpr int ROW_WAVES = ROW_T / HHX_WAVE;
+
+inline unsigned row_grid(i32 n_rows) {
+    i64 blocks = ((i64)n_rows + ROW_WAVES - 1) / ROW_WAVES;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 32) blocks = 256 * 32;    // grid-stride beyond 32 workgroups per CU
+    return (unsigned)blocks;
+}
+
+__device__ __forceinline__ float inflate_one(float x, double r, bool square) {
+    // numpy float32 `data ** r`: r == 2 -> x*x; otherwise powf with the exponent rounded to float32.
+    // pow in double then one rounding = correctly rounded powf (numpy's SIMD powf is within 1 ulp).
+    return square ? x * x : (float)pow((double)x, r);
+}
+
+// ---- L1 normalise in place ------------------------------------------------------------------
+__global__ __launch_bounds__(ROW_T) void k_normalize_l1(i32 n_rows, const i32 *__restrict__ indptr,
+                                                        float *__restrict__ data) {
+    const int lane = lane_id();
+    for (i32 row = blockIdx.x * ROW_WAVES + threadIdx.x / HHX_WAVE; row < n_rows; row += gridDim.x * ROW_WAVES) {
+        const i32 b = indptr[row], e = indptr[row + 1];
+        double s = 0.0;
+        for (i32 p = b + lane; p < e; p += HHX_WAVE) s += fabs((double)data[p]);
+        s = wave_sum_f64(s);
+        if (s == 0.0) continue;
+        for (i32 p = b + lane; p < e; p += HHX_WAVE) data[p] = (float)((double)data[p] / s);
+    }
+}
+
+// ---- inflate (+normalise) and prune statistics ---------------------------------------------
+// MODE 0: data already inflated+normalised (stand-alone prune()).
+// MODE 1: data = power(data, r); normalise; then prune statistics (mcl() steps 3+4 fused).
+// MODE 2: inflate + normalise only (no prune statistics).
+// Per row: cnt = number of survivors (entries >= thr plus the first row maximum), amax = position
+// of that maximum, s2 = double sum of the survivors (second normalisation, :2014).
+template <int MODE>
+__global__ __launch_bounds__(ROW_T) void k_inflate_stats(i32 n_rows, const i32 *__restrict__ indptr,
+                                                         float *__restrict__ data, double r, int square,
+                                                         float thr, i32 *__restrict__ cnt,
+                                                         i32 *__restrict__ amax, double *__restrict__ s2) {
+    const int lane = lane_id();
+    for (i32 row = blockIdx.x * ROW_WAVES + threadIdx.x / HHX_WAVE; row < n_rows; row += gridDim.x * ROW_WAVES) {
+        const i32 b = indptr[row], e = indptr[row + 1];
+        double s1 = 1.0;
+        if (MODE != 0) {
+            double s = 0.0;
+            for (i32 p = b + lane; p < e; p += HHX_WAVE) {
+                float v = inflate_one(data[p], r, square);
+                data[p] = v;
+                s += fabs((double)v);
+            }
+            s1 = wave_sum_f64(s);
+        }
+        // second sweep: normalised value q, survivors, first maximum
+        float best = -1.0f;
+        i32 best_p = 0x7fffffff;
+        i32 keep = 0;
+        double ssum = 0.0;
+        for (i32 p = b + lane; p < e; p += HHX_WAVE) {
+            float q = data[p];
+            if (MODE != 0 && s1 != 0.0) {
+                q = (float)((double)q / s1);
+                data[p] = q;
+            }
+            if (MODE != 2) {
+                if (q > best) { best = q; best_p = p; }     // strict >: keeps the lowest index per lane
+                if (q >= thr) { ++keep; ssum += fabs((double)q); }
+            }
+        }
+        if (MODE == 2) continue;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_down(best, o, HHX_WAVE);
+            i32 op = __shfl_down(best_p, o, HHX_WAVE);
+            if (ob > best || (ob == best && op < best_p)) { best = ob; best_p = op; }
+        }
+        best = __shfl(best, 0, HHX_WAVE);
+        best_p = __shfl(best_p, 0, HHX_WAVE);
+        keep = wave_sum_i32(keep);
+        ssum = wave_sum_f64(ssum);
+        if (lane == 0) {
+            if (e > b && !(best >= thr)) { ++keep; ssum += fabs((double)best); }   // restored maximum, :2010-2013
+            cnt[row] = keep;
+            amax[row] = (e > b) ? best_p : -1;
+            s2[row] = ssum;
+        }
+    }
+}
+
+// ---- prune write: ordered in-wave compaction + second normalisation -------------------------
+__global__ __launch_bounds__(ROW_T) void k_prune_write(i32 n_rows, const i32 *__restrict__ indptr,
+                                                       const i32 *__restrict__ indices,
+                                                       const float *__restrict__ data, float thr,
+                                                       const i32 *__restrict__ amax,
+                                                       const double *__restrict__ s2,
+                                                       const i32 *__restrict__ out_indptr,
+                                                       i32 *__restrict__ out_indices,
+                                                       float *__restrict__ out_data) {
+    const int lane = lane_id();
+    for (i32 row = blockIdx.x * ROW_WAVES + threadIdx.x / HHX_WAVE; row < n_rows; row += gridDim.x * ROW_WAVES) {
+        const i32 b = indptr[row], e = indptr[row + 1];
+        const i32 am = amax[row];
+        const double s = s2[row];
+        i32 o = out_indptr[row];
+        for (i32 p0 = b; p0 < e; p0 += HHX_WAVE) {
+            const i32 p = p0 + lane;
+            float q = 0.0f;
+            i32 c = 0;
+            bool k = false;
+            if (p < e) {
+                q = data[p];
+                c = indices[p];
+                k = (q >= thr) || (p == am);
+            }
+            const u64 mask = __ballot(k);
+            if (k) {
+                const i32 pos = o + __popcll(mask & ((1ull << lane) - 1ull));
+                out_indices[pos] = c;
+                out_data[pos] = (s != 0.0) ? (float)((double)q / s) : q;
+            }
+            o += __popcll(mask);
+        }
+    }
+}
+
+// ---- convergence statistic -------------------------------------------------------------------
+__device__ __forceinline__ i32 find_col(const i32 *__restrict__ idx, i32 b, i32 e, i32 c) {
+    while (b < e) {
+        i32 m = (b + e) >> 1;
+        i32 v = idx[m];
+        if (v < c) b = m + 1;
+        else e = m;
+    }
+    return b;
+}
+
+__global__ __launch_bounds__(ROW_T) void k_convergence(i32 n_rows, const i32 *__restrict__ ap,
+                                                       const i32 *__restrict__ aj, const float *__restrict__ ax,
+                                                       const i32 *__restrict__ bp, const i32 *__restrict__ bj,
+                                                       const float *__restrict__ bx, u32 *__restrict__ out_bits) {
+    const int lane = lane_id();
+    const float rtol = (float)1e-5;
+    float best = 0.0f;
+    for (i32 row = blockIdx.x * ROW_WAVES + threadIdx.x / HHX_WAVE; row < n_rows; row += gridDim.x * ROW_WAVES) {
+        const i32 ab = ap[row], ae = ap[row + 1], bb = bp[row], be = bp[row + 1];
+        for (i32 p = ab + lane; p < ae; p += HHX_WAVE) {       // entries of M (matched or M-only)
+            const i32 c = aj[p];
+            const i32 q = find_col(bj, bb, be, c);
+            const float l = (q < be && bj[q] == c) ? bx[q] : 0.0f;
+            const float d = fabsf(ax[p] - l) - rtol * fabsf(l);
+            best = fmaxf(best, d);
+        }
+        for (i32 q = bb + lane; q < be; q += HHX_WAVE) {       // entries only in `last`
+            const i32 c = bj[q];
+            const i32 p = find_col(aj, ab, ae, c);
+            if (!(p < ae && aj[p] == c)) {
+                const float l = bx[q];
+                const float d = fabsf(0.0f - l) - rtol * fabsf(l);
+                best = fmaxf(best, d);
+            }
+        }
+    }
+    best = wave_max_f32(best);
+    if (lane == 0 && best > 0.0f) atomicMax(out_bits, __float_as_uint(best));   // non-negative floats order as uints
+}
+
+int inflate_prune_impl(hhx_csr *c, int mode, double inflation, double pruning, hhx_csr **out) {
+    const i32 n = c->n_rows;
+    DevBuf<i32> cnt, amax, optr;
+    DevBuf<double> s2;
+    if (cnt.alloc((size_t)n + 1) || amax.alloc((size_t)n + 1) || s2.alloc((size_t)n + 1) || optr.alloc((size_t)n + 1)) return 1;
+    const float thr = (float)pruning;
+    const double r = (double)(float)inflation;
+    const int square = (inflation == 2.0);
+    if (mode == 0)
+        k_inflate_stats<0><<<row_grid(n), ROW_T, 0, g_stream>>>(n, c->indptr.p, c->data.p, r, square, thr, cnt.p, amax.p, s2.p);
+    else
+        k_inflate_stats<1><<<row_grid(n), ROW_T, 0, g_stream>>>(n, c->indptr.p, c->data.p, r, square, thr, cnt.p, amax.p, s2.p);
+    HHX_LAUNCH_CHECK();
+    i64 total = 0;
+    HHX_TRY(exclusive_scan_i32(cnt.p, optr.p, n, &total));
+    hhx_csr *p = nullptr;
+    HHX_TRY(hhx_csr_alloc_internal(n, c->n_cols, total, &p));
+    HHX_HIP(hipMemcpyAsync(p->indptr.p, optr.p, sizeof(i32) * ((size_t)n + 1), hipMemcpyDeviceToDevice, g_stream));
+    k_prune_write<<<row_grid(n), ROW_T, 0, g_stream>>>(n, c->indptr.p, c->indices.p, c->data.p, thr, amax.p, s2.p,
+                                                       p->indptr.p, p->indices.p, p->data.p);
+    HHX_LAUNCH_CHECK();
+    *out = p;
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int hhx_normalize_l1(hhx_csr *m) {
+    if (!m) return fail("null matrix");
+    k_normalize_l1<<<row_grid(m->n_rows), ROW_T, 0, g_stream>>>(m->n_rows, m->indptr.p, m->data.p);
+    HHX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hhx_inflate(hhx_csr *m, double inflation) {
+    if (!m) return fail("null matrix");
+    if (!(inflation > 0)) return fail("inflation must be positive");
+    k_inflate_stats<2><<<row_grid(m->n_rows), ROW_T, 0, g_stream>>>(m->n_rows, m->indptr.p, m->data.p,
+                                                                   (double)(float)inflation, inflation == 2.0, 0.0f,
+                                                                   nullptr, nullptr, nullptr);
+    HHX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hhx_prune(const hhx_csr *m, double pruning, hhx_csr **out) {
+    if (!m || !out) return fail("null pointer");
+    return inflate_prune_impl(const_cast<hhx_csr *>(m), 0, 2.0, pruning, out);   // mode 0 never writes m
+}
+
+extern "C" int hhx_inflate_prune(hhx_csr *c, double inflation, double pruning, hhx_csr **out) {
+    if (!c || !out) return fail("null pointer");
+    if (!(inflation > 0)) return fail("inflation must be positive");
+    return inflate_prune_impl(c, 1, inflation, pruning, out);
+}
+
+extern "C" int hhx_convergence_stat(const hhx_csr *m, const hhx_csr *last, float *stat) {
+    if (!m || !last || !stat) return fail("null pointer");
+    if (m->n_rows != last->n_rows) return fail("shape mismatch");
+    DevBuf<u32> bits;
+    if (bits.alloc(1)) return 1;
+    HHX_HIP(hipMemsetAsync(bits.p, 0, sizeof(u32), g_stream));
+    k_convergence<<<row_grid(m->n_rows), ROW_T, 0, g_stream>>>(m->n_rows, m->indptr.p, m->indices.p, m->data.p,
+                                                              last->indptr.p, last->indices.p, last->data.p, bits.p);
+    HHX_LAUNCH_CHECK();
+    u32 h = 0;
+    HHX_HIP(hipMemcpyAsync(&h, bits.p, sizeof(u32), hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    memcpy(stat, &h, sizeof(float));
+    return 0;
+}
+
+extern "C" int hhx_mcl(const hhx_csr *pre, int expansion, double inflation, int max_iter, double pruning,
+                       hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
+    if (!pre || !out || !n_iter || !converged) return fail("null pointer");
+    if (pre->n_rows != pre->n_cols) return fail("mcl needs a square matrix");
+    if (expansion < 1) return fail("expansion must be >= 1");
+    if (!(inflation > 0)) return fail("inflation must be positive");
+    *n_iter = 0;
+    *converged = 0;
+    hhx_csr *cur = nullptr;                  // matrix at the end of the previous iteration (== last_matrix)
+    int rc = 0;
+    for (int it = 0; it < max_iter && !rc; ++it) {
+        hhx_csr *c = nullptr;
+        i64 st_a = cur ? cur->nnz : pre->nnz, st_f = 0;
+        if (it == 0) {
+            rc = hhx_csr_copy(pre, &c);      // iteration 0 skips the expansion, :2030
+        } else {
+            // mkl_matrix_power(M, e) = M * M^(e-1)  ==  T^(e-1) * T on CSR(T), :2017-2023
+            hhx_csr *run = cur;
+            for (int e = 2; e <= expansion && !rc; ++e) {
+                hhx_csr *nx = nullptr;
+                i64 f = 0;
+                rc = hhx_spgemm_ex(run, cur, HHX_MCL_FX_SHIFT, &nx, &f);
+                st_f += f;
+                if (run != cur) hhx_csr_free(run);
+                run = nx;
+            }
+            if (!rc && run == cur) rc = hhx_csr_copy(cur, &run);    // expansion == 1
+            c = run;
+        }
+        if (rc) { if (c && c != cur) hhx_csr_free(c); break; }
+        const i64 st_c = c->nnz;
+        hhx_csr *p = nullptr;
+        rc = hhx_inflate_prune(c, inflation, pruning, &p);          // steps 3) + 4), :2037-2042
+        hhx_csr_free(c);
+        if (rc) break;
+        if (stats) { stats[4 * it] = st_a; stats[4 * it + 1] = st_c; stats[4 * it + 2] = p->nnz; stats[4 * it + 3] = st_f; }
+        *n_iter = it + 1;
+        if (it > 1) {                                               // step 5), :2044-2050
+            float d = 0.f;
+            rc = hhx_convergence_stat(p, cur, &d);
+            if (!rc && d <= (float)1e-8) {
+                *converged = 1;
+                if (cur) hhx_csr_free(cur);
+                cur = p;
+                break;
+            }
+        }
+        if (cur) hhx_csr_free(cur);
+        cur = p;                                                    // last_matrix = matrix.copy(), :2057
+    }
+    if (rc) { if (cur) hhx_csr_free(cur); return rc; }
+    if (!cur) rc = hhx_csr_copy(pre, &cur);                         // max_iter == 0
+    *out = cur;
+    return rc;
+}
+
+// interpret_result(), array half.  The final matrix holds ~n entries, so this is a host pass over a
+// D2H copy; the per-iteration work never leaves the device.
+extern "C" int hhx_interpret(const hhx_csr *m, i32 *att, i32 *att_ptr, i32 *members, i32 *n_att) {
+    if (!m || !att || !att_ptr || !members || !n_att) return fail("null pointer");
+    const i32 n = m->n_rows;
+    std::vector<i32> ip((size_t)n + 1), ix((size_t)m->nnz);
+    std::vector<float> dx((size_t)m->nnz);
+    HHX_TRY(hhx_csr_to_host(m, ip.data(), ix.data(), dx.data()));
+    std::vector<i32> slot((size_t)n, -1);
+    i32 na = 0;
+    for (i32 r = 0; r < n; ++r)
+        for (i32 p = ip[r]; p < ip[r + 1]; ++p)
+            if (ix[p] == r && dx[p] != 0.0f) { slot[r] = na; att[na++] = r; break; }
+    std::vector<i32> cnt((size_t)na + 1, 0);
+    for (i32 r = 0; r < n; ++r)
+        for (i32 p = ip[r]; p < ip[r + 1]; ++p)
+            if (dx[p] != 0.0f && ix[p] >= 0 && ix[p] < n && slot[ix[p]] >= 0) cnt[slot[ix[p]] + 1]++;
+    att_ptr[0] = 0;
+    for (i32 a = 0; a < na; ++a) att_ptr[a + 1] = att_ptr[a] + cnt[a + 1];
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (i32 r = 0; r < n; ++r)
+        for (i32 p = ip[r]; p < ip[r + 1]; ++p) {
+            if (dx[p] == 0.0f || ix[p] < 0 || ix[p] >= n) continue;
+            const i32 s = slot[ix[p]];
+            if (s >= 0) members[att_ptr[s] + cnt[s]++] = r;
+        }
+    *n_att = na;
+    return 0;
+}

@@ -1,0 +1,297 @@
+// Runtime plumbing: error state, stream, caching allocator, device scans, matrix handles.
+#include "hhx_common.h"
+
+namespace hhx {
+
+thread_local std::string g_err;
+thread_local hipStream_t g_stream = nullptr;
+
+// ------------------------------------------------------------------ pool
+namespace {
+std::mutex g_pool_mu;
+std::multimap<size_t, void *> g_free;           // size class -> block
+std::map<void *, size_t> g_live;                // block -> size class
+
+size_t size_class(size_t bytes) {
+    size_t c = 256;
+    while (c < bytes) {
+        // power-of-two classes up to 64 MiB, then 64 MiB granules (avoids 2x waste on multi-GB buffers)
+        if (c >= (size_t(64) << 20)) return (bytes + (size_t(64) << 20) - 1) / (size_t(64) << 20) * (size_t(64) << 20);
+        c <<= 1;
+    }
+    return c;
+}
+}  // namespace
+
+void *pool_alloc(size_t bytes) {
+    size_t c = size_class(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_free.find(c);
+        if (it != g_free.end()) {
+            void *p = it->second;
+            g_free.erase(it);
+            g_live[p] = c;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, c);
+    if (e != hipSuccess) {
+        pool_trim();
+        e = hipMalloc(&p, c);
+        if (e != hipSuccess) {
+            fail("hipMalloc(%zu bytes) failed: %s", c, hipGetErrorString(e));
+            return nullptr;
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_live[p] = c;
+    return p;
+}
+
+void pool_free(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_live.find(p);
+    if (it == g_live.end()) return;
+    // Stream-ordered reuse: every consumer runs on g_stream (one stream per thread), so a recycled
+    // block is only ever touched by work enqueued after its previous user.
+    g_free.emplace(it->second, p);
+    g_live.erase(it);
+}
+
+void pool_trim() {
+    std::vector<void *> blocks;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (auto &kv : g_free) blocks.push_back(kv.second);
+        g_free.clear();
+    }
+    if (!blocks.empty()) (void)hipDeviceSynchronize();
+    for (void *p : blocks) (void)hipFree(p);
+}
+
+// ------------------------------------------------------------------ exclusive scan
+// Tile = 256 threads x 8 items.  Level 0 scans tiles and emits tile sums; the sums are scanned
+// recursively; a final pass adds the tile offsets.
+constexpr int SCAN_T = 256, SCAN_I = 8, SCAN_TILE = SCAN_T * SCAN_I;
+
+template <class T>
+__global__ __launch_bounds__(SCAN_T) void k_scan_tiles(const T *in, T *out, T *tile_sums, i64 n) {
+    __shared__ T wsum[SCAN_T / HHX_WAVE];
+    i64 base = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_I;
+    T v[SCAN_I];
+    T local = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_I; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : T(0);
+        local += v[k];
+    }
+    // inclusive wave scan of `local`
+    T incl = local;
+#pragma unroll
+    for (int o = 1; o < HHX_WAVE; o <<= 1) {
+        T t = __shfl_up(incl, o, HHX_WAVE);
+        if (lane_id() >= o) incl += t;
+    }
+    int w = threadIdx.x / HHX_WAVE;
+    if (lane_id() == HHX_WAVE - 1) wsum[w] = incl;
+    __syncthreads();
+    T woff = 0;
+    for (int k = 0; k < w; ++k) woff += wsum[k];
+    T run = woff + incl - local;
+#pragma unroll
+    for (int k = 0; k < SCAN_I; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == SCAN_T - 1 && tile_sums) tile_sums[blockIdx.x] = run;
+}
+
+template <class T>
+__global__ __launch_bounds__(SCAN_T) void k_scan_add(T *out, const T *tile_off, i64 n) {
+    i64 base = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_I;
+    T off = tile_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_I; ++k)
+        if (base + k < n) out[base + k] += off;
+}
+
+template <class T>
+__global__ void k_set_last(T *out, i64 n, const T *in_last_src, const T *scan_last) {
+    // out[n] = out[n-1] + in[n-1]
+    out[n] = scan_last[0] + in_last_src[0];
+}
+
+template <class T>
+static int scan_rec(const T *in, T *out, i64 n) {
+    if (n <= 0) return 0;
+    i64 tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (tiles == 1) {
+        k_scan_tiles<T><<<1, SCAN_T, 0, g_stream>>>(in, out, nullptr, n);
+        HHX_LAUNCH_CHECK();
+        return 0;
+    }
+    DevBuf<T> sums, offs;
+    if (sums.alloc(tiles) || offs.alloc(tiles)) return 1;
+    k_scan_tiles<T><<<(unsigned)tiles, SCAN_T, 0, g_stream>>>(in, out, sums.p, n);
+    HHX_LAUNCH_CHECK();
+    HHX_TRY(scan_rec<T>(sums.p, offs.p, tiles));
+    k_scan_add<T><<<(unsigned)tiles, SCAN_T, 0, g_stream>>>(out, offs.p, n);
+    HHX_LAUNCH_CHECK();
+    return 0;
+}
+
+template <class T>
+static int scan_total(const T *in, T *out, i64 n, i64 *total_host) {
+    if (n == 0) {
+        HHX_HIP(hipMemsetAsync(out, 0, sizeof(T), g_stream));
+        if (total_host) *total_host = 0;
+        return 0;
+    }
+    // `in` must stay intact until out[n] is formed: read in[n-1] first via a 1-thread kernel after the scan
+    HHX_TRY(scan_rec<T>(in, out, n));
+    k_set_last<T><<<1, 1, 0, g_stream>>>(out, n, in + (n - 1), out + (n - 1));
+    HHX_LAUNCH_CHECK();
+    if (total_host) {
+        T t;
+        HHX_HIP(hipMemcpyAsync(&t, out + n, sizeof(T), hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+        *total_host = (i64)t;
+    }
+    return 0;
+}
+
+int exclusive_scan_i32(const i32 *in, i32 *out, i64 n, i64 *total_host) { return scan_total<i32>(in, out, n, total_host); }
+int exclusive_scan_i64(const i64 *in, i64 *out, i64 n, i64 *total_host) { return scan_total<i64>(in, out, n, total_host); }
+
+}  // namespace hhx
+
+using namespace hhx;
+
+// ------------------------------------------------------------------ C ABI: runtime
+extern "C" const char *hhx_last_error(void) { return g_err.c_str(); }
+extern "C" int hhx_version(void) { return 100; }
+extern "C" int hhx_device_count(int *count) {
+    HHX_HIP(hipGetDeviceCount(count));
+    return 0;
+}
+extern "C" int hhx_set_device(int device) {
+    HHX_HIP(hipSetDevice(device));
+    return 0;
+}
+extern "C" int hhx_set_stream(void *s) {
+    g_stream = (hipStream_t)s;
+    return 0;
+}
+extern "C" int hhx_synchronize(void) {
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+extern "C" int hhx_pool_trim(void) {
+    pool_trim();
+    return 0;
+}
+
+// ------------------------------------------------------------------ C ABI: matrices
+static int csr_alloc(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out) {
+    if (n_rows < 0 || n_cols < 0 || nnz < 0) return fail("negative matrix dimension");
+    if (nnz > INT32_MAX) return fail("nnz %lld exceeds the int32 index range of scipy CSC", (long long)nnz);
+    hhx_csr *m = new hhx_csr();
+    m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz;
+    if (m->indptr.alloc((size_t)n_rows + 1) || m->indices.alloc((size_t)nnz) || m->data.alloc((size_t)nnz)) {
+        delete m;
+        return 1;
+    }
+    *out = m;
+    return 0;
+}
+int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out) { return csr_alloc(n_rows, n_cols, nnz, out); }
+
+extern "C" int hhx_csr_from_host(i32 n_rows, i32 n_cols, const i32 *indptr, const i32 *indices, const float *data,
+                                 hhx_csr **out) {
+    if (!indptr || !out) return fail("hhx_csr_from_host: null pointer");
+    i64 nnz = indptr[n_rows];
+    hhx_csr *m = nullptr;
+    HHX_TRY(csr_alloc(n_rows, n_cols, nnz, &m));
+    hipError_t e = hipMemcpyAsync(m->indptr.p, indptr, sizeof(i32) * ((size_t)n_rows + 1), hipMemcpyHostToDevice, g_stream);
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(m->indices.p, indices, sizeof(i32) * (size_t)nnz, hipMemcpyHostToDevice, g_stream);
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(m->data.p, data, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    if (e != hipSuccess) { delete m; return fail("hhx_csr_from_host: copy failed: %s", hipGetErrorString(e)); }
+    *out = m;
+    return 0;
+}
+
+extern "C" int hhx_csr_from_device(i32 n_rows, i32 n_cols, i64 nnz, const i32 *indptr, const i32 *indices,
+                                   const float *data, hhx_csr **out) {
+    hhx_csr *m = nullptr;
+    HHX_TRY(csr_alloc(n_rows, n_cols, nnz, &m));
+    hipError_t e = hipMemcpyAsync(m->indptr.p, indptr, sizeof(i32) * ((size_t)n_rows + 1), hipMemcpyDeviceToDevice, g_stream);
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(m->indices.p, indices, sizeof(i32) * (size_t)nnz, hipMemcpyDeviceToDevice, g_stream);
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(m->data.p, data, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToDevice, g_stream);
+    if (e != hipSuccess) { delete m; return fail("hhx_csr_from_device: copy failed: %s", hipGetErrorString(e)); }
+    *out = m;
+    return 0;
+}
+
+extern "C" int hhx_csr_shape(const hhx_csr *m, i32 *n_rows, i32 *n_cols, i64 *nnz) {
+    if (!m) return fail("null matrix");
+    if (n_rows) *n_rows = m->n_rows;
+    if (n_cols) *n_cols = m->n_cols;
+    if (nnz) *nnz = m->nnz;
+    return 0;
+}
+
+extern "C" int hhx_csr_to_host(const hhx_csr *m, i32 *indptr, i32 *indices, float *data) {
+    if (!m) return fail("null matrix");
+    if (indptr) HHX_HIP(hipMemcpyAsync(indptr, m->indptr.p, sizeof(i32) * ((size_t)m->n_rows + 1), hipMemcpyDeviceToHost, g_stream));
+    if (indices && m->nnz) HHX_HIP(hipMemcpyAsync(indices, m->indices.p, sizeof(i32) * (size_t)m->nnz, hipMemcpyDeviceToHost, g_stream));
+    if (data && m->nnz) HHX_HIP(hipMemcpyAsync(data, m->data.p, sizeof(float) * (size_t)m->nnz, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+extern "C" int hhx_csr_device_ptrs(const hhx_csr *m, void **indptr, void **indices, void **data) {
+    if (!m) return fail("null matrix");
+    if (indptr) *indptr = m->indptr.p;
+    if (indices) *indices = m->indices.p;
+    if (data) *data = m->data.p;
+    return 0;
+}
+
+extern "C" int hhx_csr_copy(const hhx_csr *m, hhx_csr **out) {
+    if (!m) return fail("null matrix");
+    return hhx_csr_from_device(m->n_rows, m->n_cols, m->nnz, m->indptr.p, m->indices.p, m->data.p, out);
+}
+
+__global__ void k_rebase_indptr(const i32 *src, i32 *dst, i32 n, i32 base) {
+    i32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) dst[i] = src[i] - base;
+}
+
+extern "C" int hhx_csr_row_block(const hhx_csr *m, i32 r0, i32 r1, hhx_csr **out) {
+    if (!m) return fail("null matrix");
+    if (r0 < 0 || r1 < r0 || r1 > m->n_rows) return fail("row block [%d,%d) out of range", r0, r1);
+    i32 ends[2];
+    HHX_HIP(hipMemcpyAsync(&ends[0], m->indptr.p + r0, sizeof(i32), hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipMemcpyAsync(&ends[1], m->indptr.p + r1, sizeof(i32), hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    i64 nnz = ends[1] - ends[0];
+    hhx_csr *b = nullptr;
+    HHX_TRY(csr_alloc(r1 - r0, m->n_cols, nnz, &b));
+    i32 n = r1 - r0;
+    k_rebase_indptr<<<(n + 1 + 255) / 256, 256, 0, g_stream>>>(m->indptr.p + r0, b->indptr.p, n, ends[0]);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(b->indices.p, m->indices.p + ends[0], sizeof(i32) * (size_t)nnz, hipMemcpyDeviceToDevice, g_stream);
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(b->data.p, m->data.p + ends[0], sizeof(float) * (size_t)nnz, hipMemcpyDeviceToDevice, g_stream);
+    if (e != hipSuccess) { delete b; return fail("hhx_csr_row_block: %s", hipGetErrorString(e)); }
+    *out = b;
+    return 0;
+}
+
+extern "C" int hhx_csr_free(hhx_csr *m) {
+    delete m;
+    return 0;
+}

@@ -1,0 +1,149 @@
+/*
+ * haphic_hip.h — C ABI of libhaphic_hip.so: MI355X (gfx950) implementation of HapHiC's Hi-C
+ * link-matrix construction + Markov clustering hot path (scripts/HapHiC_cluster.py).
+ *
+ * The reference has no FFI/plugin API; its narrowest seams are module-level Python functions
+ * (SURVEY.md §8b, S1–S6).  Every entry point below names the reference interface it replaces
+ * (file:line, all in scripts/HapHiC_cluster.py).  The ctypes binding a maintainer would add is
+ * haphic_amd/_lib.py; the re-binding of the reference's names is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; hhx_last_error() gives the
+ *     thread-local message (the Python shim raises RuntimeError, as the reference does, e.g. :2507).
+ *   - plain pointers and sizes only.  "host" pointers are ordinary memory; "dev" pointers are HIP
+ *     device memory on the current device.  Kernels run on the stream set by hhx_set_stream()
+ *     (default: the null stream).
+ *   - matrices: the reference's column-stochastic M is scipy CSC (indptr,indices,data) with int32
+ *     indices and float32 data.  That triple is byte-for-byte CSR of T = M^T; the library works on
+ *     CSR(T).  "row" below == "column" in the reference.  Rows are kept sorted by index.
+ *   - hhx_csr is an opaque device-resident matrix owned by the library (release with hhx_csr_free).
+ */
+#ifndef HAPHIC_HIP_H
+#define HAPHIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hhx_csr hhx_csr;
+typedef struct hhx_ingest hhx_ingest;
+
+/* ---------------------------------------------------------------- runtime */
+const char *hhx_last_error(void);
+int hhx_version(void);
+int hhx_device_count(int *count);
+int hhx_set_device(int device);
+int hhx_set_stream(void *hip_stream);          /* hipStream_t; NULL = null stream (thread-local) */
+int hhx_synchronize(void);
+int hhx_pool_trim(void);                       /* release cached device memory */
+
+/* ---------------------------------------------------------------- matrices */
+/* build from / copy to host arrays (numpy: csc.indptr, csc.indices, csc.data) */
+int hhx_csr_from_host(int32_t n_rows, int32_t n_cols, const int32_t *indptr, const int32_t *indices,
+                      const float *data, hhx_csr **out);
+/* build by copying device arrays (e.g. torch tensors after an all-gather) */
+int hhx_csr_from_device(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *dev_indptr,
+                        const int32_t *dev_indices, const float *dev_data, hhx_csr **out);
+int hhx_csr_shape(const hhx_csr *m, int32_t *n_rows, int32_t *n_cols, int64_t *nnz);
+int hhx_csr_to_host(const hhx_csr *m, int32_t *indptr, int32_t *indices, float *data);
+int hhx_csr_device_ptrs(const hhx_csr *m, void **dev_indptr, void **dev_indices, void **dev_data);
+int hhx_csr_copy(const hhx_csr *m, hhx_csr **out);
+/* rows [r0, r1) as a new (r1-r0) x n_cols matrix: the row-block shard of SURVEY §8e */
+int hhx_csr_row_block(const hhx_csr *m, int32_t r0, int32_t r1, hhx_csr **out);
+int hhx_csr_free(hhx_csr *m);
+
+/* ---------------------------------------------------------------- S3: normalize / power / prune
+ * sklearn.preprocessing.normalize(M, norm='l1', axis=0), call sites :2014 :2038 :2144 — in place. */
+int hhx_normalize_l1(hhx_csr *m);
+/* `normalize(matrix.power(inflation), norm='l1', axis=0)` :2037-2038 — in place. */
+int hhx_inflate(hhx_csr *m, double inflation);
+/* prune(matrix, pruning, dense_matrix=False) :1987-2014: keep entries >= pruning, restore the row
+ * maximum, L1-normalise. */
+int hhx_prune(const hhx_csr *m, double pruning, hhx_csr **out);
+/* :2037-2042 fused: prune(normalize(power(C, inflation))); C is consumed (its data is overwritten). */
+int hhx_inflate_prune(hhx_csr *c, double inflation, double pruning, hhx_csr **out);
+
+/* ---------------------------------------------------------------- S1: expansion
+ * sparse_dot_mkl.dot_product_mkl(A_csc, B_csc) :39-43, used by mkl_matrix_power :2017-2023.
+ * On the CSC view out = A_csc * B_csc; in CSR(T) terms the caller passes (a = T_B, b = T_A), i.e.
+ * out_T = T_B * T_A.  a may be a row block (n_local x k) of the left operand (multi-GPU shard).
+ * Accumulation: each float32 product is formed exactly in double, converted to 64-bit fixed point
+ * (2^fx_shift scaling chosen from ||a||_inf * max|b|) and summed with integer adds, so the result is
+ * independent of summation order and of the GPU count; it is rounded to float32 once. */
+int hhx_spgemm(const hhx_csr *a, const hhx_csr *b, hhx_csr **out);
+/* same with an explicit fixed-point shift (tests); products counted into *n_products if non-NULL */
+int hhx_spgemm_ex(const hhx_csr *a, const hhx_csr *b, int fx_shift, hhx_csr **out, int64_t *n_products);
+
+/* ---------------------------------------------------------------- S2: convergence + whole mcl()
+ * :2044-2046  d = abs(M - last) - 1e-5*abs(last); *stat = max(0, d.max()) evaluated in float32. */
+int hhx_convergence_stat(const hhx_csr *m, const hhx_csr *last, float *stat);
+/* mcl(matrix, expansion, inflation, iters, pruning, dense_matrix=False) :2026-2062 on the
+ * pre-expanded matrix (run_mcl_clustering :2144-2147).  Not converging is not an error (:2058-2062):
+ * *converged = 0 and the last matrix is returned.  stats (may be NULL) receives 4 int64 per executed
+ * iteration: nnz entering, nnz after expansion, nnz after pruning, number of products. */
+int hhx_mcl(const hhx_csr *pre_expanded, int expansion, double inflation, int max_iter, double pruning,
+            hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
+
+/* ---------------------------------------------------------------- a12: interpret_result :2065-2095
+ * Array half: attractors (ascending) = rows with a non-zero diagonal; members of attractor a =
+ * rows of CSR(T) holding column a (ascending).  att[n], att_ptr[n+1], members[nnz] are host
+ * buffers.  The set-of-tuples and the partition check (:2084-2095) stay in Python. */
+int hhx_interpret(const hhx_csr *m, int32_t *att, int32_t *att_ptr, int32_t *members, int32_t *n_att);
+
+/* ---------------------------------------------------------------- S4: dict_to_matrix :310-373
+ * Input: the flank table in dict-insertion order (frag id pairs + value, device or host per
+ * `on_device`), frag_set membership flags, n_rest = number of link-less members of frag_set (their
+ * indices follow the linked ones; their order is CPython's set order and stays in Python).
+ * Output: CSR(T) with self-loops (value 1) when add_self_loops, and frag_index[n_frag] (host; -1 =
+ * not linked).  Index assignment = first appearance scanning the items in order, i before j. */
+int hhx_dict_to_matrix(int64_t n_keys, const int32_t *frag_i, const int32_t *frag_j, const double *value,
+                       int on_device, int32_t n_frag, const uint8_t *in_set_host, int32_t n_rest,
+                       int add_self_loops, int32_t *frag_index_host, int32_t *n_linked, hhx_csr **out);
+
+/* ---------------------------------------------------------------- S5: ingest
+ * parse_alignments_for_ctgs :1596-1655 (bins = 0) and parse_alignments :1658-1752 (bins = 1) on
+ * integer ids.  The Python shim maps names to ids once (haphic_amd/cluster.py: FragTable):
+ *   contig id c in [0,n_ctg); ctg_rank[c] = rank of the contig NAME under Python string order
+ *   (key orientation :1629); a split contig owns nbins consecutive fragment ids from ctg_frag0[c];
+ *   frag_rank[f] = rank of the fragment NAME (:1720); frag_nx[f] = membership in Nx_frag_set.
+ * A contig id < 0 (or >= n_ctg) = name absent from fa_dict (:1625).
+ * Positions are 0-based int32 as yielded by the generators (:1556 :1593).
+ */
+typedef struct {
+    int32_t n_ctg, n_frag;
+    const int32_t *ctg_rank;     /* [n_ctg]  host */
+    const int64_t *ctg_len;      /* [n_ctg]  host */
+    const int32_t *ctg_frag0;    /* [n_ctg]  host */
+    const uint8_t *ctg_split;    /* [n_ctg]  host */
+    const int32_t *frag_rank;    /* [n_frag] host */
+    const int64_t *frag_len;     /* [n_frag] host */
+    const uint8_t *frag_nx;      /* [n_frag] host */
+    int64_t bin_size;            /* only when bins */
+    int64_t flank;               /* bp (args.flank * 1000) */
+    int32_t bins;                /* 0: parse_alignments_for_ctgs, 1: parse_alignments */
+    int32_t skip_intra;          /* 1: drop ref == mref like pairs_generator_inter_ctgs :1582 */
+    int64_t expected_keys;       /* hash-table sizing hint (distinct contig pairs); 0 = auto */
+} hhx_ingest_config;
+
+int hhx_ingest_create(const hhx_ingest_config *cfg, hhx_ingest **out);
+/* one batch of read pairs in stream order; id/pos arrays are device (on_device=1) or host memory */
+int hhx_ingest_push(hhx_ingest *h, int64_t n_pairs, const int32_t *id1, const int32_t *pos1,
+                    const int32_t *id2, const int32_t *pos2, int on_device);
+/* close the stream: builds the insertion-ordered tables; sizes are returned */
+int hhx_ingest_finalize(hhx_ingest *h, int64_t *n_full_keys, int64_t *n_flank_keys);
+/* host copies, in dict insertion order: full_link_dict keys/counts, the HT_link_dict counts of each
+ * contig pair ([HH, HT, TH, TT] :404-416), flank_link_dict keys/counts, per-fragment flank link totals
+ * (frag_link_dict).  Any pointer may be NULL. */
+int hhx_ingest_fetch(hhx_ingest *h, int32_t *full_i, int32_t *full_j, int64_t *full_cnt, int64_t *ht_cnt,
+                     int32_t *flank_i, int32_t *flank_j, int64_t *flank_cnt, int64_t *frag_links);
+/* device-resident flank table (insertion order) for hhx_dict_to_matrix(on_device=1) */
+int hhx_ingest_flank_device(hhx_ingest *h, void **dev_frag_i, void **dev_frag_j, void **dev_value_f64);
+int hhx_ingest_destroy(hhx_ingest *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAPHIC_HIP_H */

@@ -1,0 +1,41 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU
+and exports exactly the symbols include/haphic_hip.h declares (no compute calls here)."""
+import os
+import re
+
+from haphic_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'haphic_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return set(re.findall(r'\b(hhx_[a-z0-9_]+)\s*\(', txt))
+
+
+def test_library_builds_and_exports_header():
+    build.build()
+    lib = _lib.load()
+    decl = declared_symbols()
+    assert decl, 'no declarations parsed'
+    assert decl == set(_lib.SIGNATURES), decl ^ set(_lib.SIGNATURES)
+    for name in decl:
+        assert hasattr(lib, name), name
+    assert lib.hhx_version() >= 100
+
+
+def test_header_cites_reference_lines():
+    txt = open(os.path.join(ROOT, 'include', 'haphic_hip.h')).read()
+    for cite in (':2017-2023', ':2026-2062', ':1987-2014', ':310-373', ':1596-1655', ':1658-1752', ':2065-2095'):
+        assert cite in txt, cite
+
+
+def test_no_oracle_in_product():
+    """the product package must never import or link the oracle (parity would be void)"""
+    pkg = os.path.join(ROOT, 'haphic_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, f), errors='replace').read()
+                assert not re.search(r'^\s*(from|import)\s+oracle|hhx_oracle|\borc_', src, flags=re.M), (dirpath, f)
