@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path of BASELINE.json on synthetic data, inputs resident in HBM.
+
+One "step" = one pass of the hot path over one batch: ingest P Hi-C read pairs into the link tables
+(hash-table kernel + insertion-order finalisation), dict_to_matrix, L1 normalise, pre-expansion (M^2)
+and mcl() at inflation 2.0 (:2026-2062), attractor read-out.
+
+metric/value  : Hi-C pairs/s through the link-matrix build (ingest + finalise + dict_to_matrix), the
+                first half of BASELINE.json's metric; the second half (MCL iterations/s) is reported
+                in the "mcl" object of the same JSON line.
+workload (N=1): BASELINE.json configs[1] — 10k contigs / 50M synthetic pairs, inflation 2.0,
+                dense-block off.  N>1: weak scaling, every rank ingests its own 50M-pair shard of the
+                same assembly; the link tables are merged with one exchange and the MCL row blocks
+                are all-gathered every iteration (haphic_amd/sharded.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--contigs', type=int, default=10000)
+    ap.add_argument('--pairs', type=int, default=50_000_000)
+    ap.add_argument('--nchrs', type=int, default=16)
+    ap.add_argument('--mean-len', type=int, default=50_000)
+    ap.add_argument('--inflation', type=float, default=2.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-pairs', type=int, default=20_000_000)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from haphic_amd import _lib, synth
+    from haphic_amd.cluster import FragTable
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    torch.cuda.set_device(local_rank)
+    _lib.check(_lib.load().hhx_set_device(local_rank))
+    dev = 'cuda:%d' % local_rank
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device(dev))
+
+    per_chr = max(1, args.contigs // args.nchrs)
+    gen = synth.make_genome(args.nchrs, per_chr * args.mean_len, args.mean_len, seed=12345)
+    n = gen.n
+    lex = gen.lexical_rank()
+    table = FragTable.for_contigs(lex, gen.length, np.ones(n, np.uint8))
+    flank = 500_000                                   # --flank 500 (kb), HapHiC_cluster.py default
+    # this rank's shard of the read-pair stream, generated straight into HBM
+    id1, p1, id2, p2 = synth.sample_pairs(gen, args.pairs, seed=12345 + rank, device=dev)
+    torch.cuda.synchronize()
+    in_set = np.ones(n, np.uint8)
+
+    if world > 1:
+        from haphic_amd import sharded
+    state = {}
+
+    def step():
+        t0 = time.perf_counter()
+        ing = _lib.Ingest(table, flank, bins=False, skip_intra=True, expected_keys=state.get('keys_hint', 1 << 25))
+        ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+        n_full, n_flank = ing.finalize()
+        if world > 1:
+            m, n_linked, n_flank = sharded.merge_flank_and_build(ing, n, in_set, dist, dev)
+        else:
+            fi, fj, fv = ing.flank_device()
+            m, fidx, n_linked = _lib.dict_to_matrix(fi, fj, fv, n, in_set, 0, on_device=True, n_keys=n_flank)
+            n_rest = n - n_linked
+            if n_rest:                                # link-less contigs get trailing indices
+                m.free()
+                m, fidx, n_linked = _lib.dict_to_matrix(fi, fj, fv, n, in_set, n_rest, on_device=True, n_keys=n_flank)
+        _lib.check(_lib.load().hhx_synchronize())
+        t1 = time.perf_counter()
+        state['keys_hint'] = max(int(n_full * 1.3), 1 << 16)
+        state['n_full'], state['n_flank'], state['nnz_link'] = n_full, n_flank, m.nnz
+        ing.destroy()
+        # ---- run_mcl_clustering :2144-2158 at one inflation
+        _lib.normalize_l1(m)
+        if world > 1:
+            res, n_iter, conv, stats, t_pre = sharded.mcl_sharded(m, 2, args.inflation, 200, 1e-4, dist, dev)
+        else:
+            pre, f_pre = _lib.spgemm(m, m, fx_shift=60, want_products=True)
+            _lib.check(_lib.load().hhx_synchronize())
+            t_pre = time.perf_counter() - t1
+            state['pre_products'], state['pre_nnz'] = f_pre, pre.nnz
+            t2 = time.perf_counter()
+            res, n_iter, conv, stats = _lib.mcl(pre, 2, args.inflation, 200, 1e-4, want_stats=True)
+            att, ptr, mem = _lib.interpret(res)
+            state['t_mcl'] = time.perf_counter() - t2
+            state['clusters'] = len(att)
+            pre.free()
+        t3 = time.perf_counter()
+        state.update(t_ingest=t1 - t0, t_pre=t_pre, n_iter=n_iter, conv=conv, stats=stats, t_total=t3 - t0)
+        if world > 1:
+            state['t_mcl'] = t3 - t1 - t_pre
+        res.free()
+        m.free()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    t_ing = t_mcl = t_pre = 0.0
+    iters = 0
+    for _ in range(args.steps):
+        step()
+        t_ing += state['t_ingest']; t_mcl += state['t_mcl']; t_pre += state['t_pre']; iters += state['n_iter']
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    tm = torch.tensor([elapsed, t_ing, t_mcl, t_pre], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    elapsed, t_ing, t_mcl, t_pre = tm.tolist()
+
+    if rank == 0:
+        K = args.steps
+        pairs_total = args.pairs * world * K
+        value = pairs_total / t_ing
+        stats = np.asarray(state['stats'])
+        # ---- roofline of the dominant kernel of the headline metric: k_ingest
+        ing_ms, ing_n = _lib.profile_get('ingest')
+        # 16 B read per pair + 12 B written per distinct key of each table + 4 B per fragment
+        alg_bytes = 16.0 * args.pairs + 12.0 * (state['n_full'] + state['n_flank']) + 4.0 * n
+        ach = alg_bytes / (ing_ms / max(ing_n, 1) * 1e-3) / 1e9 if ing_ms else None
+        roofline = {'kernel': 'k_ingest', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': (ach / HBM_PEAK_GBS) if ach else None, 'traffic': None,
+                    'alg_bytes_per_launch': alg_bytes, 'avg_launch_ms': ing_ms / max(ing_n, 1)}
+        # ---- MCL: expansion kernel roofline with SURVEY §8d's byte model, 8*(nnz_A + F) read + 8*nnz_C written
+        num_ms, num_n = _lib.profile_get('spgemm_numeric')
+        sym_ms, sym_n = _lib.profile_get('spgemm_symbolic')
+        infl_ms, _ = _lib.profile_get('inflate_stats')
+        prw_ms, _ = _lib.profile_get('prune_write')
+        cvg_ms, _ = _lib.profile_get('convergence')
+        exp_rows = stats[1:] if len(stats) > 1 else stats[:0]
+        sp_bytes = float((8 * (exp_rows[:, 0] + exp_rows[:, 3]) + 8 * exp_rows[:, 1]).sum()) if len(exp_rows) else 0.0
+        if world == 1:
+            sp_bytes += 8.0 * (state['nnz_link'] + state['pre_products']) + 8.0 * state['pre_nnz']   # the pre-expansion launch
+        sp_ach = sp_bytes * K / (num_ms * 1e-3) / 1e9 if num_ms else None
+        # B_iter of SURVEY §8d summed over the iterations of one mcl() call
+        b_iter = float((8 * (stats[:, 0] + stats[:, 3]) + 8 * stats[:, 1] + 8 * stats[:, 1] + 8 * stats[:, 2]
+                        + 16 * stats[:, 2] + 12 * n).sum()) if len(stats) else 0.0
+        mcl = {'iters_per_s': iters / t_mcl if t_mcl else None, 'n': int(n), 'iterations': int(state['n_iter']),
+               'converged': bool(state['conv']), 'inflation': args.inflation, 'ms_per_mcl': t_mcl / K * 1e3,
+               'pre_expansion_ms': t_pre / K * 1e3, 'clusters': state.get('clusters'),
+               'alg_bytes_per_mcl': b_iter, 'alg_GBs': b_iter * K / t_mcl / 1e9 if t_mcl else None,
+               'frac_hbm': b_iter * K / t_mcl / 1e9 / HBM_PEAK_GBS if t_mcl else None,
+               'stats_nnzA_nnzC_nnzP_F': stats.tolist(),
+               'kernel_ms_per_step': {'spgemm_symbolic': sym_ms / K, 'spgemm_numeric': num_ms / K, 'inflate_stats': infl_ms / K,
+                                      'prune_write': prw_ms / K, 'convergence': cvg_ms / K},
+               'roofline_spgemm_numeric': {'bound': 'hbm', 'achieved': sp_ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                           'frac': sp_ach / HBM_PEAK_GBS if sp_ach else None, 'traffic': None,
+                                           'launches_per_step': num_n / K}}
+        out = {'metric': 'Hi-C pairs/s ingested (link-matrix build) + MCL iters/s', 'value': value, 'unit': 'pairs/s',
+               'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': elapsed / K * 1e3,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int32 keys / u64 fixed-point + f32 values',
+               'data': 'synthetic',
+               'config': {'workload': 'C2: %d contigs / %d pairs per GPU, %d chr, mean contig %d bp, inflation %.1f, dense-block off'
+                                      % (n, args.pairs, args.nchrs, args.mean_len, args.inflation),
+                          'contigs': int(n), 'pairs_per_gpu': args.pairs, 'full_keys': int(state['n_full']),
+                          'flank_keys': int(state['n_flank']), 'link_matrix_nnz': int(state['nnz_link'])},
+               'ingest_ms_per_step': t_ing / K * 1e3, 'mcl': mcl, 'roofline': roofline}
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state):
+    """The oracle (a scalar C port of the reference algorithm, 1 thread) timed on this host on a bounded
+    sample of the same workload: the first S pairs for ingest, and mcl() on the link matrix those
+    pairs produce at 1/4 of the contigs (so that the CPU leg stays within ~30 s)."""
+    from oracle import oracle as orc
+    S = min(args.cpu_sample_pairs, id1.numel())
+    h = [a[:S].cpu().numpy() for a in (id1, p1, id2, p2)]
+    keep = h[0] != h[2]
+    t = orc.FragTable(table.ctg_rank, table.ctg_len, table.ctg_frag0, table.ctg_split, 0, table.frag_rank,
+                      table.frag_len, table.frag_nx)
+    a = (h[0][keep], h[1][keep].astype(np.int64), h[2][keep], h[3][keep].astype(np.int64))
+    t0 = time.perf_counter()
+    r = orc.ingest(t, a[0], a[1], a[2], a[3], flank)
+    dt = time.perf_counter() - t0
+    # MCL leg: contigs of the first quarter of the chromosomes only
+    nq = int((gen.chrom < max(1, gen.nchrs // 4)).sum())
+    sel = (r['flank_i'] < nq) & (r['flank_j'] < nq)
+    in_set = np.zeros(gen.n, np.uint8)
+    in_set[:nq] = 1
+    linked = np.zeros(gen.n, bool)
+    linked[r['flank_i'][sel]] = True
+    linked[r['flank_j'][sel]] = True
+    p, j, x, fidx, nl = orc.dict_to_matrix(r['flank_i'], r['flank_j'], r['flank_cnt'].astype(np.float64), gen.n, in_set,
+                                           int(nq - linked.sum()))
+    xn = orc.normalize_l1(p, x)
+    pre = orc.spgemm((p, j, xn), (p, j, xn), mode=0)
+    t1 = time.perf_counter()
+    res = orc.mcl(pre, 2, args.inflation, 200, 1e-4)
+    dm = time.perf_counter() - t1
+    return {'value': S / dt, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
+            'sample': 'ingest: first %d pairs of the rank-0 shard through the C oracle (hash-map port of '
+                      'parse_alignments_for_ctgs); mcl: oracle mcl() on the %d-contig sub-assembly (first quarter '
+                      'of the chromosomes) built from those pairs' % (S, nq),
+            'ingest_seconds': dt, 'mcl_iters_per_s': res[3] / dm, 'mcl_n': int(nq), 'mcl_iterations': int(res[3]),
+            'host_cpus': os.cpu_count()}
+
+
+if __name__ == '__main__':
+    main()

@@ -37,6 +37,9 @@ SIGNATURES = {
     'hhx_set_stream': (C.c_int, [C.c_void_p]),
     'hhx_synchronize': (C.c_int, []),
     'hhx_pool_trim': (C.c_int, []),
+    'hhx_profile_enable': (C.c_int, [C.c_int]),
+    'hhx_profile_reset': (C.c_int, []),
+    'hhx_profile_get': (C.c_int, [C.c_char_p, c_f64p, c_i64p]),
     'hhx_csr_from_host': (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, c_vpp]),
     'hhx_csr_from_device': (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, c_vpp]),
     'hhx_csr_shape': (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i64p]),
@@ -62,7 +65,9 @@ SIGNATURES = {
     'hhx_ingest_finalize': (C.c_int, [C.c_void_p, c_i64p, c_i64p]),
     'hhx_ingest_fetch': (C.c_int, [C.c_void_p] + [C.c_void_p] * 8),
     'hhx_ingest_flank_device': (C.c_int, [C.c_void_p, c_vpp, c_vpp, c_vpp]),
+    'hhx_ingest_flank_count_device': (C.c_int, [C.c_void_p, c_vpp]),
     'hhx_ingest_destroy': (C.c_int, [C.c_void_p]),
+    'hhx_table_merge': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, c_i64p, c_vpp, c_vpp, c_vpp, c_vpp]),
 }
 
 _lib = None
@@ -75,6 +80,14 @@ def load():
         if not os.path.exists(SO_PATH):
             raise ImportError('haphic_amd: %s is missing — build it with `python -m haphic_amd.build` '
                               '(hipcc --offload-arch=gfx950); there is no CPU fallback' % SO_PATH)
+        # torch ships its own libamdhip64.so.7 / libhsa-runtime64.so.1 and dlopens them by path; two HIP
+        # runtimes in one process cannot both own the GPU.  Importing torch first makes the dynamic
+        # linker resolve this library's DT_NEEDED libamdhip64.so.7 to the copy torch already loaded,
+        # so torch tensors (device memory, streams, RCCL) and these kernels share one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
@@ -93,6 +106,20 @@ def device_count():
     n = C.c_int(0)
     check(load().hhx_device_count(C.byref(n)))
     return n.value
+
+
+def profile_enable(on=True):
+    check(load().hhx_profile_enable(int(on)))
+
+
+def profile_reset():
+    check(load().hhx_profile_reset())
+
+
+def profile_get(kernel):
+    ms, n = C.c_double(0), C.c_int64(0)
+    check(load().hhx_profile_get(kernel.encode(), C.byref(ms), C.byref(n)))
+    return ms.value, n.value
 
 
 def ptr(a):
@@ -315,6 +342,11 @@ class Ingest:
         check(load().hhx_ingest_flank_device(self.h, C.byref(a), C.byref(b), C.byref(v)))
         return a.value or 0, b.value or 0, v.value or 0
 
+    def flank_count_device(self):
+        c = C.c_void_p()
+        check(load().hhx_ingest_flank_count_device(self.h, C.byref(c)))
+        return c.value or 0
+
     def destroy(self):
         if self.h is not None and self.h.value:
             load().hhx_ingest_destroy(self.h)
@@ -325,3 +357,12 @@ class Ingest:
             self.destroy()
         except Exception:
             pass
+
+
+def table_merge(n, i_ptr, j_ptr, cnt_ptr):
+    """hhx_table_merge on raw device pointers; returns (k, i_ptr, j_ptr, cnt_ptr, value_f64_ptr)."""
+    k = C.c_int64(0)
+    a, b, c, v = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    check(load().hhx_table_merge(int(n), C.c_void_p(i_ptr), C.c_void_p(j_ptr), C.c_void_p(cnt_ptr), C.byref(k),
+                                 C.byref(a), C.byref(b), C.byref(c), C.byref(v)))
+    return k.value, a.value or 0, b.value or 0, c.value or 0, v.value or 0

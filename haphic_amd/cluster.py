@@ -1,0 +1,429 @@
+"""Host-side mirror of the reference's interface for the hot path (scripts/HapHiC_cluster.py).
+
+Same names, argument meaning and error behaviour as the reference functions, so that they can be
+re-bound over the reference module (haphic_amd.patch_reference / INTEGRATION.md):
+
+    S1  dot_product_mkl(A, B)                       :39-43, :2017-2023
+    S3  normalize(M, norm='l1', axis=0), prune()    :1987-2014
+    S2  mcl(matrix, expansion, inflation, iters, pruning, dense_matrix)   :2026-2062
+    a12 interpret_result(result_matrix, dense_matrix)                     :2065-2095
+    S4  dict_to_matrix(link_dict, frag_set, dense_matrix, add_self_loops) :310-373
+    S5  parse_alignments_for_ctgs(...) / parse_alignments(...)            :1596-1752
+    S6  run_mcl_clustering(...)                                           :2132-2242
+
+All arithmetic runs in libhaphic_hip.so; there is no CPU fallback.  What stays in Python is what the
+reference's observable ordering depends on CPython for: the set-of-tuples in interpret_result
+(:2073-2095), the set difference that numbers link-less fragments (:357-359), stable sorts (:2197).
+"""
+import logging
+import os
+from collections import defaultdict
+from decimal import Decimal
+from math import ceil
+
+import numpy as np
+
+from . import _lib
+
+logger = logging.getLogger('HapHiC_cluster')   # same logger name family; handlers come from the caller
+
+
+# ------------------------------------------------------------------ integer view of the assembly
+class FragTable:
+    """Contig / fragment tables the id-based kernels need (see include/haphic_hip.h, ingest)."""
+
+    def __init__(self, ctg_names, ctg_rank, ctg_len, ctg_frag0, ctg_split, bin_size, frag_names, frag_rank,
+                 frag_len, frag_nx):
+        self.ctg_names = ctg_names
+        self.frag_names = frag_names
+        self.ctg_rank = np.ascontiguousarray(ctg_rank, np.int32)
+        self.ctg_len = np.ascontiguousarray(ctg_len, np.int64)
+        self.ctg_frag0 = np.ascontiguousarray(ctg_frag0, np.int32)
+        self.ctg_split = np.ascontiguousarray(ctg_split, np.uint8)
+        self.bin_size = int(bin_size)
+        self.frag_rank = np.ascontiguousarray(frag_rank, np.int32)
+        self.frag_len = np.ascontiguousarray(frag_len, np.int64)
+        self.frag_nx = np.ascontiguousarray(frag_nx, np.uint8)
+        self.n_ctg = len(self.ctg_rank)
+        self.n_frag = len(self.frag_rank)
+
+    @staticmethod
+    def _rank(names):
+        order = sorted(range(len(names)), key=names.__getitem__)     # Python str order == the reference's sorted()
+        r = np.empty(len(names), np.int32)
+        r[order] = np.arange(len(names), dtype=np.int32)
+        return r
+
+    @classmethod
+    def for_contigs(cls, ctg_rank, ctg_len, nx, names=None):
+        """no contig is split (parse_alignments_for_ctgs): fragment == contig"""
+        n = len(ctg_rank)
+        return cls(names, ctg_rank, ctg_len, np.arange(n, dtype=np.int32), np.zeros(n, np.uint8), 0, names, ctg_rank,
+                   ctg_len, nx)
+
+    @classmethod
+    def from_reference(cls, fa_dict, frag_len_dict, Nx_frag_set, split_ctg_set=(), bin_size=0):
+        """Build from the reference's own containers: fa_dict (parse_fasta :87-113) and the outputs of
+        stat_fragments (:188-296).  Fragment ids follow fa_dict order; a split contig owns
+        ceil(len / bin_size) consecutive ids named '{ctg}_bin{k}' (:233)."""
+        names = list(fa_dict)
+        frag_names, frag0, split = [], [], []
+        for c in names:
+            frag0.append(len(frag_names))
+            if c in split_ctg_set:
+                split.append(1)
+                nb = int(ceil(fa_dict[c][1] / bin_size))
+                frag_names.extend('{}_bin{}'.format(c, k + 1) for k in range(nb))
+            else:
+                split.append(0)
+                frag_names.append(c)
+        return cls(names, cls._rank(names), [fa_dict[c][1] for c in names], frag0, split,
+                   bin_size if split_ctg_set else 0, frag_names, cls._rank(frag_names),
+                   [frag_len_dict[f] for f in frag_names], [f in Nx_frag_set for f in frag_names])
+
+
+# ------------------------------------------------------------------ S1 / S3: matrix-level seams
+def _to_device(matrix):
+    return _lib.DeviceCSR.from_scipy_csc(matrix)
+
+
+def dot_product_mkl(matrix_a, matrix_b, **_ignored):
+    """Drop-in for sparse_dot_mkl.dot_product_mkl on scipy CSC float32 operands (:39-43).
+    out = A @ B; on the CSR(T) view that is T_B * T_A."""
+    a, b = _to_device(matrix_a), _to_device(matrix_b)
+    try:
+        return _lib.spgemm(b, a).to_scipy_csc()
+    finally:
+        a.free()
+        b.free()
+
+
+def normalize(matrix, norm='l1', axis=0):
+    """sklearn.preprocessing.normalize as the reference calls it (:2014 :2038 :2144): L1, axis=0, sparse."""
+    if norm != 'l1' or axis != 0:
+        raise ValueError('only normalize(norm="l1", axis=0) is on the hot path')
+    m = _to_device(matrix)
+    try:
+        return _lib.normalize_l1(m).to_scipy_csc()
+    finally:
+        m.free()
+
+
+def prune(matrix, pruning, dense_matrix=False):
+    """prune() :1987-2014"""
+    if dense_matrix:
+        raise ValueError('dense_matrix mode is not on the MI355X path; use the reference function')
+    m = _to_device(matrix)
+    try:
+        return _lib.prune(m, pruning).to_scipy_csc()
+    finally:
+        m.free()
+
+
+def mkl_matrix_power(matrix, n):
+    """mkl_matrix_power() :2017-2023 — M * M^(n-1), kept on the device between the products"""
+    t = _to_device(matrix)
+    run = t
+    try:
+        for _ in range(2, n + 1):
+            nxt = _lib.spgemm(run, t)          # T^(e-1) * T  ==  (M * M^(e-1))^T
+            if run is not t:
+                run.free()
+            run = nxt
+        return run.to_scipy_csc()
+    finally:
+        if run is not t:
+            run.free()
+        t.free()
+
+
+# ------------------------------------------------------------------ S2: mcl
+def mcl_device(pre_expanded, expansion, inflation, iters, pruning):
+    """mcl() on a device-resident pre-expanded matrix; logs like the reference (:2047 :2058)."""
+    res, n_iter, converged = _lib.mcl(pre_expanded, expansion, inflation, iters, pruning)
+    if converged:
+        logger.info('The matrix has converged after {} rounds of iterations '
+                    '(expansion: {}, inflation: {}, maximum iterations: {}, pruning threshold: {})'.format(
+                        n_iter, expansion, inflation, iters, pruning))
+    else:
+        logger.info('The matrix does not converge after {} rounds of iterations '
+                    '(expansion: {}, inflation: {}, maximum iterations: {}, pruning threshold: {})'.format(
+                        n_iter, expansion, inflation, iters, pruning))
+    return res
+
+
+def mcl(matrix, expansion, inflation, iters, pruning, dense_matrix=False):
+    """mcl() :2026-2062 — scipy CSC in, scipy CSC out; every iteration stays in HBM."""
+    if dense_matrix:
+        raise ValueError('dense_matrix mode is not on the MI355X path; use the reference function')
+    pre = _to_device(matrix)
+    try:
+        res = mcl_device(pre, expansion, inflation, iters, pruning)
+        try:
+            return res.to_scipy_csc()
+        finally:
+            res.free()
+    finally:
+        pre.free()
+
+
+def _clusters_from_arrays(att, att_ptr, members, shape):
+    # :2073-2095 — the SET of tuples (its iteration order decides group numbering on length ties)
+    clusters = set()
+    for a in range(len(att)):
+        clusters.add(tuple(members[att_ptr[a]:att_ptr[a + 1]].tolist()))
+    nodes = set()
+    for cluster in clusters:
+        for node in cluster:
+            if node in nodes:
+                return None
+            nodes.add(node)
+    if len(nodes) != shape:
+        return None
+    return list(clusters)
+
+
+def interpret_result_device(result):
+    att, att_ptr, members = _lib.interpret(result)
+    return _clusters_from_arrays(att, att_ptr, members, result.shape3[0])
+
+
+def interpret_result(result_matrix, dense_matrix=False):
+    """interpret_result() :2065-2095"""
+    if dense_matrix:
+        raise ValueError('dense_matrix mode is not on the MI355X path; use the reference function')
+    m = _to_device(result_matrix)
+    try:
+        return interpret_result_device(m)
+    finally:
+        m.free()
+
+
+# ------------------------------------------------------------------ S4: dict_to_matrix
+def dict_to_matrix(link_dict, frag_set, dense_matrix=True, add_self_loops=False, _device=False):
+    """dict_to_matrix() :310-373.  Returns (matrix, frag_index_dict); the matrix is scipy CSC unless
+    _device=True (then a DeviceCSR that run_mcl_clustering_device consumes without a host round trip)."""
+    names = {}
+    ids_i = np.empty(len(link_dict), np.int32)
+    ids_j = np.empty(len(link_dict), np.int32)
+    vals = np.empty(len(link_dict), np.float64)
+    for k, ((fi, fj), v) in enumerate(link_dict.items()):
+        ids_i[k] = names.setdefault(fi, len(names))
+        ids_j[k] = names.setdefault(fj, len(names))
+        vals[k] = v
+    for f in frag_set:
+        names.setdefault(f, len(names))
+    id_names = list(names)
+    in_set = np.fromiter((f in frag_set for f in id_names), np.uint8, len(id_names))
+    ok = in_set[ids_i].astype(bool) & in_set[ids_j].astype(bool)
+    linked = np.zeros(len(id_names), bool)
+    linked[ids_i[ok]] = True
+    linked[ids_j[ok]] = True
+    frags_in_dict = {id_names[i] for i in np.flatnonzero(linked)}
+    rest = frag_set - frags_in_dict                      # :357 — CPython set order, kept in Python
+    m, fidx, n_linked = _lib.dict_to_matrix(ids_i, ids_j, vals, max(len(id_names), 1), in_set if len(in_set) else
+                                            np.zeros(1, np.uint8), len(rest), add_self_loops=add_self_loops)
+    frag_index_dict = {}
+    order = np.argsort(fidx[linked], kind='stable')
+    for i in np.flatnonzero(linked)[order]:              # insertion order == index order (:337-349)
+        frag_index_dict[id_names[i]] = int(fidx[i])
+    index = n_linked
+    for frag in rest:
+        frag_index_dict[frag] = index
+        index += 1
+    if _device:
+        return m, frag_index_dict
+    try:
+        csc = m.to_scipy_csc()
+    finally:
+        m.free()
+    return (csc.toarray() if dense_matrix else csc), frag_index_dict
+
+
+# ------------------------------------------------------------------ S5: ingest
+def _ids_from_alignments(alignments, cid, chunk):
+    """(ref, mref, pos, mpos) iterator -> int32 arrays, `chunk` pairs at a time"""
+    b1, p1, b2, p2 = [np.empty(chunk, np.int32) for _ in range(4)]
+    k = 0
+    get = cid.get
+    for ref, mref, pos, mpos in alignments:
+        b1[k] = get(ref, -1)
+        b2[k] = get(mref, -1)
+        p1[k] = pos
+        p2[k] = mpos
+        k += 1
+        if k == chunk:
+            yield b1, p1, b2, p2, k
+            k = 0
+    if k:
+        yield b1[:k], p1[:k], b2[:k], p2[:k], k
+
+
+def ingest_links(alignments, table, flank, bins, chunk=1 << 22, expected_keys=0):
+    """Feed an alignment iterator (name tuples, as the reference's generators :1539-1593 yield them)
+    through the device ingest; returns the insertion-ordered tables as numpy arrays."""
+    cid = {n: i for i, n in enumerate(table.ctg_names)}
+    ing = _lib.Ingest(table, flank, bins=bins, skip_intra=False, expected_keys=expected_keys)
+    try:
+        for b1, p1, b2, p2, k in _ids_from_alignments(alignments, cid, chunk):
+            if not bins:
+                # ref == mref never reaches parse_alignments_for_ctgs from run() (:2862-2865) but the
+                # function itself accepts it; negative ids (unknown names) are filtered on the device
+                pass
+            ing.push(b1, p1, b2, p2)
+        ing.finalize()
+        return ing.fetch()
+    finally:
+        ing.destroy()
+
+
+def _link_dicts(out, table):
+    cn, fn = table.ctg_names, table.frag_names
+    full = defaultdict(int)
+    HT = defaultdict(int)
+    flank = defaultdict(int)
+    frag_link = defaultdict(int)
+    suffix = ('_H', '_T')
+    for i, j, c, ht in zip(out['full_i'].tolist(), out['full_j'].tolist(), out['full_cnt'].tolist(), out['ht_cnt'].tolist()):
+        full[(cn[i], cn[j])] = c
+        for q, v in enumerate(ht):
+            if v:
+                HT[(cn[i] + suffix[q >> 1], cn[j] + suffix[q & 1])] = v
+    for i, j, c in zip(out['flank_i'].tolist(), out['flank_j'].tolist(), out['flank_cnt'].tolist()):
+        flank[(fn[i], fn[j])] = c
+    for f, c in enumerate(out['frag_links'].tolist()):
+        if c:
+            frag_link[fn[f]] = c
+    return full, flank, HT, frag_link
+
+
+def parse_alignments_for_ctgs(alignments, fa_dict, args, ctg_len_dict, Nx_ctg_set, pos_int_type, dist_int_type):
+    """parse_alignments_for_ctgs() :1596-1655 — link tables from the device.  The CLM distance lists and
+    the per-pair coordinate records (:1643, :1652) are SURVEY §8f "next" rows: they are returned empty
+    here and the caller keeps the reference's own Python loop when it needs them."""
+    logger.info('Parsing input alignments...')
+    table = FragTable.from_reference(fa_dict, ctg_len_dict, Nx_ctg_set)
+    out = ingest_links(alignments, table, int(args.flank * 1000), bins=False)
+    full, flank, HT, frag_link = _link_dicts(out, table)
+    return full, flank, HT, defaultdict(list), frag_link, defaultdict(list)
+
+
+def parse_alignments(alignments, fa_dict, args, bin_size, frag_len_dict, Nx_frag_set, split_ctg_set, pos_int_type,
+                     dist_int_type):
+    """parse_alignments() :1658-1752 (some contigs split into bins); see parse_alignments_for_ctgs."""
+    logger.info('Parsing input alignments...')
+    table = FragTable.from_reference(fa_dict, frag_len_dict, Nx_frag_set, split_ctg_set, bin_size)
+    out = ingest_links(alignments, table, int(args.flank * 1000), bins=True)
+    full, flank, HT, frag_link = _link_dicts(out, table)
+    return full, flank, HT, defaultdict(list), frag_link, defaultdict(list), defaultdict(set)
+
+
+# ------------------------------------------------------------------ S6: run_mcl_clustering
+def _inflation_values(min_inflation, max_inflation, inflation_step):
+    # numpy.arange over Decimal objects (:2138-2155): start, start+step, ... < max+step
+    start, step = Decimal(str(min_inflation)), Decimal(str(inflation_step))
+    end = Decimal(str(max_inflation)) + step
+    vals = []
+    k = 0
+    count = int(ceil((end - start) / step))
+    while k < count:
+        vals.append(start + k * step)
+        k += 1
+    return vals
+
+
+def get_main_groups(result_clusters, len_ratio):
+    """:2098-2107"""
+    main_groups = len(result_clusters)
+    for k in range(len(result_clusters) - 1):
+        if result_clusters[k + 1][1] / result_clusters[k][1] < len_ratio:
+            return k + 1
+    return main_groups
+
+
+def recommend_inflation(result_stat, nchrs, len_ratio):
+    """:2110-2129 — the log line below is parsed by HapHiC_pipeline.py:385, wording is API"""
+    separated = sorted((infl for infl, groups in result_stat if groups >= nchrs))
+    if separated:
+        logger.info('You could try inflation from {} (length ratio = {})'.format(separated[0], len_ratio))
+        return True
+    if len_ratio > 0.5:
+        logger.info('The length ratio ({}) might be too strict, trying a lower one...'.format(len_ratio))
+        return False
+    logger.info('It seems that some chromosomes were grouped together (length ratio = {}) '
+                'You could check whether the parameters used are correct / appropriate and '
+                'then try to tune the parameters for assembly correction, contig / Hi-C link '
+                'filtration, or Markov clustering'.format(len_ratio))
+    return True
+
+
+def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, expansion, min_inflation,
+                       max_inflation, inflation_step, max_iter, pruning, fa_dict, nchrs, dense_matrix=False,
+                       outdir_root='.'):
+    """run_mcl_clustering() :2132-2242.  link_matrix: scipy CSC or a DeviceCSR.  The normalised,
+    pre-expanded matrix is built once and stays in HBM for the whole inflation sweep."""
+    if dense_matrix:
+        raise ValueError('dense_matrix mode is not on the MI355X path; use the reference function')
+    logger.info('Performing Markov clustering...')
+    index_frag = {i: f for f, i in frag_index_dict.items()}
+    own = not isinstance(link_matrix, _lib.DeviceCSR)
+    m = _to_device(link_matrix) if own else link_matrix.copy()
+    _lib.normalize_l1(m)                                             # :2144
+    pre = m
+    for _ in range(2, expansion + 1):                                # :2146-2147
+        nxt = _lib.spgemm(pre, m)
+        if pre is not m:
+            pre.free()
+        pre = nxt
+    result_clusters_list = []
+    mcl_nrounds = 0
+    for inflation in _inflation_values(min_inflation, max_inflation, inflation_step):
+        res = mcl_device(pre, expansion, float(inflation), max_iter, pruning)
+        mcl_nrounds += 1
+        clusters = interpret_result_device(res)
+        res.free()
+        if not clusters:
+            logger.info('Some fragments are missing / redundant, result of inflation {} will NOT be output'.format(inflation))
+            continue
+        groups = defaultdict(lambda: [[], 0])       # cluster number -> [contigs, total length]
+        split_votes = defaultdict(dict)             # split contig -> {cluster number: summed bin length}
+        for k, indexes in enumerate(clusters):
+            for i in indexes:
+                frag = index_frag[i]
+                if frag in bin_set:                                  # :2176-2183
+                    ctg = frag.rsplit('_bin', 1)[0]
+                    split_votes[ctg][k] = split_votes[ctg].get(k, 0) + frag_len_dict[frag]
+                else:
+                    groups[k][0].append(frag)
+                    groups[k][1] += fa_dict[frag][1]
+        for ctg, votes in split_votes.items():                       # :2190-2194
+            best = sorted(votes.keys(), key=lambda c: votes[c], reverse=True)[0]
+            groups[best][0].append(ctg)
+            groups[best][1] += fa_dict[ctg][1]
+        result_clusters = sorted(tuple(groups.values()), key=lambda g: g[1], reverse=True)   # stable, :2197
+        outdir = os.path.join(outdir_root, 'inflation_{}'.format(inflation))
+        os.makedirs(outdir, exist_ok=True)
+        with open(os.path.join(outdir, 'mcl_inflation_{}.clusters.txt'.format(inflation)), 'w') as fout:
+            fout.write('#Group\tnContigs\tContigs\n')
+            for k, (ctgs, group_len) in enumerate(result_clusters, 1):
+                ctgs.sort(key=lambda c: fa_dict[c][1], reverse=True)
+                fout.write('group{}_{}bp\t{}\t{}\n'.format(k, group_len, len(ctgs), ' '.join(ctgs)))
+        for k, (ctgs, group_len) in enumerate(result_clusters, 1):
+            with open(os.path.join(outdir, 'group{}_{}bp.txt'.format(k, group_len)), 'w') as fout:
+                fout.write('#Contig\tRECounts\tLength\n')
+                for ctg in ctgs:
+                    fout.write('{}\t{}\t{}\n'.format(ctg, fa_dict[ctg][2], fa_dict[ctg][1]))
+        result_clusters_list.append((inflation, result_clusters))
+    if pre is not m:
+        pre.free()
+    m.free()
+    max_nclusters = max([len(rc) for _, rc in result_clusters_list])
+    if max_nclusters < nchrs:
+        logger.warning('The maximum number of clusters ({}) is even less than the expected number of '
+                       'chromosomes ({}). You could try higher inflation.'.format(max_nclusters, nchrs))
+    else:
+        for len_ratio in (0.75, 0.7, 0.65, 0.6, 0.55, 0.5):
+            stat = [(infl, get_main_groups(rc, len_ratio)) for infl, rc in result_clusters_list]
+            if recommend_inflation(stat, nchrs, len_ratio):
+                break
+    return result_clusters_list, mcl_nrounds

@@ -82,6 +82,15 @@ struct DevBuf {
     }
 };
 
+// ------------------------------------------------------------------ optional per-kernel timing
+// RAII: records a HIP event pair on g_stream around the launches in its scope when profiling is on.
+struct KTimer {
+    const char *name;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    explicit KTimer(const char *n);
+    ~KTimer();
+};
+
 // ------------------------------------------------------------------ scans / reductions (hhx_scan.hip)
 // exclusive scan of n int32 counts into int32 offsets out[0..n] (out[n] = total); total returned
 // through *total_host after a stream sync.  in and out may alias only if out == in is NOT used.

@@ -308,8 +308,9 @@ extern "C" int hhx_ingest_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const
         const u64 need_flank = std::min<u64>(c[1] + (u64)n_pairs, h->max_keys_bound);
         HHX_TRY(ensure_capacity(h, need_full, need_flank));
     }
+    { KTimer kt("ingest");
     k_ingest<<<grid_for((u64)n_pairs), 256, 0, g_stream>>>(n_pairs, src[0], src[1], src[2], src[3], h->n_pushed, h->t, h->full.p,
-                                                            h->full_cap - 1, h->flank.p, h->flank_cap - 1, h->counters.p);
+                                                            h->full_cap - 1, h->flank.p, h->flank_cap - 1, h->counters.p); }
     HHX_LAUNCH_CHECK();
     h->n_pushed += (u64)n_pairs;
     if (!on_device) HHX_HIP(hipStreamSynchronize(g_stream));     // the staging buffers are reused by the next push
@@ -390,8 +391,87 @@ extern "C" int hhx_ingest_flank_device(hhx_ingest *h, void **fi, void **fj, void
     return 0;
 }
 
+extern "C" int hhx_ingest_flank_count_device(hhx_ingest *h, void **cnt_i64) {
+    if (!h || !h->finalized) return fail("ingest handle not finalized");
+    if (cnt_i64) *cnt_i64 = h->out_flank_cnt.p;
+    return 0;
+}
+
 extern "C" int hhx_ingest_destroy(hhx_ingest *h) {
     delete h;
+    return 0;
+}
+
+// ---- merge of chunk-ordered tables (multi-GPU exchange) -------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_merge_insert(i64 n, const i32 *__restrict__ ki, const i32 *__restrict__ kj,
+                                                      const i64 *__restrict__ w, FlankSlot *tab, u64 mask,
+                                                      unsigned long long *counters) {
+    for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (i64)gridDim.x * blockDim.x) {
+        const u64 s = find_or_insert(tab, mask, ((u64)(u32)ki[idx] << 32) | (u64)(u32)kj[idx], &counters[0]);
+        if (s == ~0ull) { atomicAdd(&counters[1], 1ull); continue; }
+        atomicMin((unsigned long long *)&tab[s].ord, (unsigned long long)idx);
+        atomicAdd((unsigned long long *)&tab[s].cnt, (unsigned long long)w[idx]);
+    }
+}
+__global__ __launch_bounds__(256) void k_merge_emit(const FlankSlot *tab, u64 cap, const u64 *bitmap, const i64 *prefix,
+                                                    i32 *out_i, i32 *out_j, i64 *out_cnt, double *out_val) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) {
+        if (tab[i].key == EMPTY_KEY) continue;
+        const i64 r = ord_rank(bitmap, prefix, tab[i].ord);
+        out_i[r] = (i32)(tab[i].key >> 32);
+        out_j[r] = (i32)(tab[i].key & 0xffffffffu);
+        out_cnt[r] = (i64)tab[i].cnt;
+        out_val[r] = (double)tab[i].cnt;
+    }
+}
+struct MergeOut {
+    DevBuf<i32> i, j;
+    DevBuf<i64> cnt;
+    DevBuf<double> val;
+};
+thread_local MergeOut g_merge_out;
+}  // namespace
+
+extern "C" int hhx_table_merge(i64 n, const i32 *ki, const i32 *kj, const i64 *w, i64 *n_out, void **oi, void **oj,
+                               void **ocnt, void **oval) {
+    if (n < 0 || !n_out) return fail("hhx_table_merge: bad argument");
+    const u64 cap = next_pow2((u64)(n > 0 ? n : 1) * 2);
+    DevBuf<FlankSlot> tab;
+    DevBuf<unsigned long long> counters;
+    if (tab.alloc(cap) || counters.alloc(2)) return 1;
+    HHX_HIP(hipMemsetAsync(counters.p, 0, 2 * sizeof(unsigned long long), g_stream));
+    k_clear<FlankSlot><<<grid_for(cap), 256, 0, g_stream>>>(tab.p, cap);
+    HHX_LAUNCH_CHECK();
+    if (n) {
+        k_merge_insert<<<grid_for((u64)n), 256, 0, g_stream>>>(n, ki, kj, w, tab.p, cap - 1, counters.p);
+        HHX_LAUNCH_CHECK();
+    }
+    unsigned long long c[2];
+    HHX_HIP(hipMemcpyAsync(c, counters.p, sizeof c, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    if (c[1]) return fail("hhx_table_merge: hash table overflow");
+    const i64 k = (i64)c[0];
+    const i64 n_words = n / 64 + 1;
+    DevBuf<u64> bitmap;
+    DevBuf<i64> wcnt, prefix;
+    MergeOut &o = g_merge_out;
+    if (bitmap.alloc((size_t)n_words) || wcnt.alloc((size_t)n_words) || prefix.alloc((size_t)n_words + 1) ||
+        o.i.alloc((size_t)k) || o.j.alloc((size_t)k) || o.cnt.alloc((size_t)k) || o.val.alloc((size_t)k)) return 1;
+    HHX_HIP(hipMemsetAsync(bitmap.p, 0, sizeof(u64) * (size_t)n_words, g_stream));
+    k_mark_ord<FlankSlot><<<grid_for(cap), 256, 0, g_stream>>>(tab.p, cap, bitmap.p);
+    HHX_LAUNCH_CHECK();
+    k_popc_words<<<grid_for((u64)n_words), 256, 0, g_stream>>>(bitmap.p, n_words, wcnt.p);
+    HHX_LAUNCH_CHECK();
+    HHX_TRY(exclusive_scan_i64(wcnt.p, prefix.p, n_words, nullptr));
+    k_merge_emit<<<grid_for(cap), 256, 0, g_stream>>>(tab.p, cap, bitmap.p, prefix.p, o.i.p, o.j.p, o.cnt.p, o.val.p);
+    HHX_LAUNCH_CHECK();
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    *n_out = k;
+    if (oi) *oi = o.i.p;
+    if (oj) *oj = o.j.p;
+    if (ocnt) *ocnt = o.cnt.p;
+    if (oval) *oval = o.val.p;
     return 0;
 }
 

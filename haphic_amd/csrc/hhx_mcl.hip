@@ -192,18 +192,21 @@ int inflate_prune_impl(hhx_csr *c, int mode, double inflation, double pruning, h
     const float thr = (float)pruning;
     const double r = (double)(float)inflation;
     const int square = (inflation == 2.0);
+    { KTimer kt("inflate_stats");
     if (mode == 0)
         k_inflate_stats<0><<<row_grid(n), ROW_T, 0, g_stream>>>(n, c->indptr.p, c->data.p, r, square, thr, cnt.p, amax.p, s2.p);
     else
         k_inflate_stats<1><<<row_grid(n), ROW_T, 0, g_stream>>>(n, c->indptr.p, c->data.p, r, square, thr, cnt.p, amax.p, s2.p);
+    }
     HHX_LAUNCH_CHECK();
     i64 total = 0;
     HHX_TRY(exclusive_scan_i32(cnt.p, optr.p, n, &total));
     hhx_csr *p = nullptr;
     HHX_TRY(hhx_csr_alloc_internal(n, c->n_cols, total, &p));
     HHX_HIP(hipMemcpyAsync(p->indptr.p, optr.p, sizeof(i32) * ((size_t)n + 1), hipMemcpyDeviceToDevice, g_stream));
+    { KTimer kt("prune_write");
     k_prune_write<<<row_grid(n), ROW_T, 0, g_stream>>>(n, c->indptr.p, c->indices.p, c->data.p, thr, amax.p, s2.p,
-                                                       p->indptr.p, p->indices.p, p->data.p);
+                                                       p->indptr.p, p->indices.p, p->data.p); }
     HHX_LAUNCH_CHECK();
     *out = p;
     return 0;
@@ -246,8 +249,9 @@ extern "C" int hhx_convergence_stat(const hhx_csr *m, const hhx_csr *last, float
     DevBuf<u32> bits;
     if (bits.alloc(1)) return 1;
     HHX_HIP(hipMemsetAsync(bits.p, 0, sizeof(u32), g_stream));
+    { KTimer kt("convergence");
     k_convergence<<<row_grid(m->n_rows), ROW_T, 0, g_stream>>>(m->n_rows, m->indptr.p, m->indices.p, m->data.p,
-                                                              last->indptr.p, last->indices.p, last->data.p, bits.p);
+                                                              last->indptr.p, last->indices.p, last->data.p, bits.p); }
     HHX_LAUNCH_CHECK();
     u32 h = 0;
     HHX_HIP(hipMemcpyAsync(&h, bits.p, sizeof(u32), hipMemcpyDeviceToHost, g_stream));

@@ -72,6 +72,41 @@ void pool_trim() {
     for (void *p : blocks) (void)hipFree(p);
 }
 
+// ------------------------------------------------------------------ kernel timing
+namespace {
+bool g_prof_on = false;
+struct ProfRec { std::string name; hipEvent_t e0, e1; };
+std::vector<ProfRec> g_prof_pending;
+std::map<std::string, std::pair<double, i64>> g_prof_total;
+std::mutex g_prof_mu;
+}  // namespace
+
+KTimer::KTimer(const char *n) : name(n) {
+    if (!g_prof_on) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+    (void)hipEventRecord(e0, g_stream);
+}
+KTimer::~KTimer() {
+    if (!e0 || !e1) return;
+    (void)hipEventRecord(e1, g_stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_pending.push_back({name, e0, e1});
+}
+static void prof_collect() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            auto &t = g_prof_total[r.name];
+            t.first += ms;
+            t.second += 1;
+        }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_prof_pending.clear();
+}
+
 // ------------------------------------------------------------------ exclusive scan
 // Tile = 256 threads x 8 items.  Level 0 scans tiles and emits tile sums; the sums are scanned
 // recursively; a final pass adds the tile offsets.
@@ -191,6 +226,25 @@ extern "C" int hhx_synchronize(void) {
 }
 extern "C" int hhx_pool_trim(void) {
     pool_trim();
+    return 0;
+}
+extern "C" int hhx_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+extern "C" int hhx_profile_reset(void) {
+    prof_collect();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_total.clear();
+    return 0;
+}
+extern "C" int hhx_profile_get(const char *kernel, double *total_ms, i64 *launches) {
+    if (!kernel) return fail("null kernel name");
+    prof_collect();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    auto it = g_prof_total.find(kernel);
+    if (total_ms) *total_ms = it == g_prof_total.end() ? 0.0 : it->second.first;
+    if (launches) *launches = it == g_prof_total.end() ? 0 : it->second.second;
     return 0;
 }
 

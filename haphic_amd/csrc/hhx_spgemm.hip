@@ -267,7 +267,7 @@ extern "C" int hhx_spgemm_ex(const hhx_csr *a, const hhx_csr *b, int fx_shift, h
         return fail("spgemm: %d columns exceed the LDS bitmap capacity of this build (max ~4.7M)", n_cols);
     i32 cap = (i32)((budget - fixed) / 8);
     cap &= ~63;
-    const size_t lds = (size_t)cap * 8 + fixed;
+    size_t lds = (size_t)cap * 8 + fixed;
     static bool attr_set = false;
     if (!attr_set) {
         HHX_HIP(hipFuncSetAttribute((const void *)k_spgemm_symbolic, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -279,8 +279,9 @@ extern "C" int hhx_spgemm_ex(const hhx_csr *a, const hhx_csr *b, int fx_shift, h
     if (row_nnz.alloc((size_t)n_rows + 1) || prods.alloc(1)) return 1;
     HHX_HIP(hipMemsetAsync(prods.p, 0, sizeof(u64), g_stream));
     const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(n_rows, 256 * 8));
+    { KTimer kt("spgemm_symbolic");
     k_spgemm_symbolic<<<grid, SG_T, fixed, g_stream>>>(n_rows, a->indptr.p, a->indices.p, b->indptr.p, b->indices.p, W, 0,
-                                                     row_nnz.p, prods.p);
+                                                     row_nnz.p, prods.p); }
     HHX_LAUNCH_CHECK();
     DevBuf<i32> cp;
     if (cp.alloc((size_t)n_rows + 1)) return 1;
@@ -292,12 +293,20 @@ extern "C" int hhx_spgemm_ex(const hhx_csr *a, const hhx_csr *b, int fx_shift, h
         HHX_HIP(hipStreamSynchronize(g_stream));
         *n_products = (i64)f;
     }
+    // Wide output rows (the un-pruned pre-expansion is nearly dense): if the average row would need
+    // several 64 KB accumulator windows, give the numeric kernel the whole 160 KB LDS (one workgroup per
+    // CU, up to ~19k accumulators) so that the products are traversed once instead of once per window.
+    if (n_rows > 0 && total / n_rows > cap / 2 && budget < 160 * 1024) {
+        const i32 big = (i32)((160 * 1024 - fixed) / 8) & ~63;
+        if (big > cap) { cap = big; lds = (size_t)cap * 8 + fixed; }
+    }
     hhx_csr *c = nullptr;
     HHX_TRY(hhx_csr_alloc_internal(n_rows, n_cols, total, &c));
     HHX_HIP(hipMemcpyAsync(c->indptr.p, cp.p, sizeof(i32) * ((size_t)n_rows + 1), hipMemcpyDeviceToDevice, g_stream));
+    { KTimer kt("spgemm_numeric");
     k_spgemm_numeric<<<grid, SG_T, lds, g_stream>>>(n_rows, a->indptr.p, a->indices.p, a->data.p, b->indptr.p, b->indices.p,
                                                     b->data.p, c->indptr.p, c->indices.p, c->data.p, W, cap,
-                                                    ldexp(1.0, shift), ldexp(1.0, -shift));
+                                                    ldexp(1.0, shift), ldexp(1.0, -shift)); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { hhx_csr_free(c); return fail("spgemm numeric launch: %s", hipGetErrorString(e)); }
     *out = c;

@@ -1,0 +1,225 @@
+"""Multi-GPU driver of the hot path: one process per GPU, torch.distributed ("nccl" == RCCL over xGMI).
+
+SURVEY §8e:
+  * ingest shards by contiguous chunks of the pair stream (pairs are independent, counts additive);
+    ONE exchange merges the per-chunk link tables: an all-gather of the (frag_i, frag_j, count) rows
+    in chunk order followed by a local hash merge that keeps first-occurrence order == the global dict
+    insertion order of the reference loop (hhx_table_merge).
+  * MCL shards T = M^T by row block (== column block of the reference's M).  Everything except the
+    right operand of the expansion is row-local, so per iteration there is ONE all-gather(v) of the
+    pruned row blocks (indices + values + row lengths) and ONE all-reduce(max) of the convergence
+    statistic.  Fixed-point accumulation makes the result bit-identical for any GPU count.
+
+The collective logic is written against a small `engine` interface so that tests/ can drive it on
+CPU (gloo, world_size 2) with an oracle-backed engine; the product engine is HipEngine (no fallback).
+"""
+import numpy as np
+
+from . import _lib
+
+
+# ------------------------------------------------------------------ engine: device matrices <-> torch
+class _DevArray:
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': typestr, 'data': (int(ptr), False), 'version': 2}
+
+
+class HipEngine:
+    """Matrices are _lib.DeviceCSR handles; tensors are torch views of their device buffers."""
+
+    def __init__(self, device):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+
+    def view(self, ptr, n, typestr, dtype):
+        if n == 0:
+            return self.torch.empty(0, dtype=dtype, device=self.device)
+        return self.torch.as_tensor(_DevArray(ptr, n, typestr), device=self.device)
+
+    def tensors(self, m):
+        r, c, z = m.shape3
+        a, b, d = m.device_ptrs()
+        t = self.torch
+        return self.view(a, r + 1, '<i4', t.int32), self.view(b, z, '<i4', t.int32), self.view(d, z, '<f4', t.float32)
+
+    def from_tensors(self, n_rows, n_cols, indptr, indices, data):
+        self.torch.cuda.current_stream(self.device).synchronize()
+        return _lib.DeviceCSR.from_device(n_rows, n_cols, int(indices.numel()), indptr.data_ptr(), indices.data_ptr(),
+                                          data.data_ptr())
+
+    def shape(self, m):
+        return m.shape3
+
+    def row_block(self, m, r0, r1):
+        return m.row_block(r0, r1)
+
+    def spgemm(self, a, b):
+        return _lib.spgemm(a, b, fx_shift=60, want_products=True)
+
+    def inflate_prune(self, c, inflation, pruning):
+        return _lib.inflate_prune(c, inflation, pruning)
+
+    def convergence_stat(self, m, last):
+        return _lib.convergence_stat(m, last)
+
+    def copy(self, m):
+        return m.copy()
+
+    def free(self, m):
+        m.free()
+
+    def sync(self):
+        _lib.check(_lib.load().hhx_synchronize())
+
+    def merge_tables(self, ti, tj, tc):
+        """chunk-ordered (i, j, count) rows -> distinct keys, summed, first-occurrence order"""
+        self.torch.cuda.current_stream(self.device).synchronize()
+        k, a, b, c, v = _lib.table_merge(ti.numel(), ti.data_ptr(), tj.data_ptr(), tc.data_ptr())
+        return k, a, b, c, v
+
+
+# ------------------------------------------------------------------ collectives on variable-size blocks
+def _all_gather_var(t, dist, torch):
+    """all-gather of 1-D tensors of different lengths (RCCL has no all-gather-v): gather the lengths,
+    pad to the maximum, one all_gather_into_tensor, then slice.  Returns the list of per-rank tensors."""
+    world = dist.get_world_size()
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = torch.empty(world, dtype=torch.int64, device=t.device)
+    dist.all_gather_into_tensor(sizes, n)
+    sizes = sizes.tolist()
+    mx = max(max(sizes), 1)
+    buf = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    buf[:t.numel()] = t
+    out = torch.empty(world * mx, dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, buf)
+    return [out[r * mx:r * mx + sizes[r]] for r in range(world)]
+
+
+def row_ranges(n, world):
+    """contiguous, near-equal row blocks"""
+    base, rem = divmod(n, world)
+    bounds = [0]
+    for r in range(world):
+        bounds.append(bounds[-1] + base + (1 if r < rem else 0))
+    return bounds
+
+
+def allgather_rows(engine, local, n_cols, dist):
+    """all-gather(v) of row blocks -> the full matrix on every rank (rows in rank order)"""
+    torch = engine.torch
+    ip, ix, dx = engine.tensors(local)
+    lens = (ip[1:] - ip[:-1]).contiguous()
+    lens_all = _all_gather_var(lens, dist, torch)
+    ix_all = _all_gather_var(ix.contiguous(), dist, torch)
+    dx_all = _all_gather_var(dx.contiguous(), dist, torch)
+    lens_cat = torch.cat(lens_all)
+    n_rows = int(lens_cat.numel())
+    indptr = torch.zeros(n_rows + 1, dtype=torch.int32, device=lens_cat.device)
+    indptr[1:] = torch.cumsum(lens_cat, 0).to(torch.int32)
+    return engine.from_tensors(n_rows, n_cols, indptr, torch.cat(ix_all).contiguous(), torch.cat(dx_all).contiguous())
+
+
+def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, dist, want_pre_time=False):
+    """run_mcl_clustering's pre-expansion (:2146-2147) + mcl() (:2026-2062) with T sharded by row block.
+    full_norm: the L1-normalised link matrix, replicated.  Returns (full result, n_iter, converged, stats[, t_pre])."""
+    import time
+    torch = engine.torch
+    n = engine.shape(full_norm)[0]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    b = row_ranges(n, world)
+    r0, r1 = b[rank], b[rank + 1]
+    t0 = time.perf_counter()
+    # pre-expansion: local rows of T^e
+    blk = engine.row_block(full_norm, r0, r1)
+    run = blk
+    for _ in range(2, expansion + 1):
+        nxt, _f = engine.spgemm(run, full_norm)
+        if run is not blk:
+            engine.free(run)
+        run = nxt
+    pre_local = run if run is not blk else engine.copy(blk)
+    if run is not blk:
+        engine.free(blk)
+    engine.sync()
+    t_pre = time.perf_counter() - t0
+    stats = []
+    cur_local = None      # this rank's rows of the matrix at the end of the previous iteration
+    cur_full = None       # the same matrix, all rows (right operand of the next expansion)
+    converged = False
+    n_iter = 0
+    for it in range(iters):
+        st_a = engine.shape(cur_full)[2] if cur_full is not None else None
+        st_f = 0
+        if it == 0:
+            c = engine.copy(pre_local)
+        else:
+            run = cur_local
+            for _ in range(2, expansion + 1):
+                nxt, f = engine.spgemm(run, cur_full)
+                st_f += f
+                if run is not cur_local:
+                    engine.free(run)
+                run = nxt
+            c = run if run is not cur_local else engine.copy(cur_local)
+        st_c = engine.shape(c)[2]
+        p = engine.inflate_prune(c, inflation, pruning)
+        engine.free(c)
+        n_iter = it + 1
+        red = torch.tensor([0.0, float(st_c), float(engine.shape(p)[2]), float(st_f)], dtype=torch.float64,
+                           device=engine.device)
+        if it > 1:
+            red[0] = engine.convergence_stat(p, cur_local)
+        mx = red[:1].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)            # convergence: one float, max over ranks
+        dist.all_reduce(red[1:], op=dist.ReduceOp.SUM)       # bookkeeping only (nnz / product counts)
+        full = allgather_rows(engine, p, n, dist)
+        if st_a is None:
+            st_a = int(red[1].item())                        # iteration 0 enters with the pre-expanded matrix
+        stats.append([st_a, int(red[1].item()), int(red[2].item()), int(red[3].item())])
+        if cur_local is not None:
+            engine.free(cur_local)
+            engine.free(cur_full)
+        cur_local, cur_full = p, full
+        if it > 1 and np.float32(mx.item()) <= np.float32(1e-8):
+            converged = True
+            break
+    engine.free(pre_local)
+    if cur_local is not None:
+        engine.free(cur_local)
+    res = cur_full
+    out = (res, n_iter, converged, np.asarray(stats, np.int64))
+    return out + (t_pre,) if want_pre_time else out
+
+
+# ------------------------------------------------------------------ product entry points (HIP engine)
+def mcl_sharded(full_norm, expansion, inflation, iters, pruning, dist, device):
+    eng = HipEngine(device)
+    return mcl_sharded_engine(eng, full_norm, expansion, inflation, iters, pruning, dist, want_pre_time=True)
+
+
+def merge_tables_engine(engine, ti, tj, tc, dist):
+    torch = engine.torch
+    gi = torch.cat(_all_gather_var(ti, dist, torch)).contiguous()
+    gj = torch.cat(_all_gather_var(tj, dist, torch)).contiguous()
+    gc = torch.cat(_all_gather_var(tc, dist, torch)).contiguous()
+    return engine.merge_tables(gi, gj, gc)
+
+
+def merge_flank_and_build(ing, n_frag, in_set, dist, device):
+    """exchange step of the sharded ingest + dict_to_matrix on the merged table (replicated)"""
+    eng = HipEngine(device)
+    t = eng.torch
+    fi, fj, _ = ing.flank_device()
+    fc = ing.flank_count_device()
+    k = ing.n_flank
+    ti = eng.view(fi, k, '<i4', t.int32)
+    tj = eng.view(fj, k, '<i4', t.int32)
+    tc = eng.view(fc, k, '<i8', t.int64)
+    km, a, b, c, v = merge_tables_engine(eng, ti, tj, tc, dist)
+    m, fidx, n_linked = _lib.dict_to_matrix(a, b, v, n_frag, in_set, 0, on_device=True, n_keys=km)
+    n_rest = int(np.count_nonzero(in_set)) - n_linked
+    if n_rest:
+        m.free()
+        m, fidx, n_linked = _lib.dict_to_matrix(a, b, v, n_frag, in_set, n_rest, on_device=True, n_keys=km)
+    return m, n_linked, km

@@ -39,6 +39,11 @@ int hhx_set_device(int device);
 int hhx_set_stream(void *hip_stream);          /* hipStream_t; NULL = null stream (thread-local) */
 int hhx_synchronize(void);
 int hhx_pool_trim(void);                       /* release cached device memory */
+/* per-kernel device timing with HIP events on the launch stream (bench.py's roofline leg):
+ * names: "ingest", "spgemm_symbolic", "spgemm_numeric", "inflate_stats", "prune_write", "convergence" */
+int hhx_profile_enable(int on);
+int hhx_profile_reset(void);
+int hhx_profile_get(const char *kernel, double *total_ms, int64_t *launches);
 
 /* ---------------------------------------------------------------- matrices */
 /* build from / copy to host arrays (numpy: csc.indptr, csc.indices, csc.data) */
@@ -141,7 +146,17 @@ int hhx_ingest_fetch(hhx_ingest *h, int32_t *full_i, int32_t *full_j, int64_t *f
                      int32_t *flank_i, int32_t *flank_j, int64_t *flank_cnt, int64_t *frag_links);
 /* device-resident flank table (insertion order) for hhx_dict_to_matrix(on_device=1) */
 int hhx_ingest_flank_device(hhx_ingest *h, void **dev_frag_i, void **dev_frag_j, void **dev_value_f64);
+int hhx_ingest_flank_count_device(hhx_ingest *h, void **dev_count_i64);   /* same rows, int64 counts */
 int hhx_ingest_destroy(hhx_ingest *h);
+
+/* Multi-GPU exchange step (ingest): merge link tables that were built from consecutive
+ * chunks of the pair stream and concatenated in chunk order.  Input: n (frag_i, frag_j, count) rows on
+ * the device; output (device, library-owned until the next call on this thread or hhx_pool_trim):
+ * one row per distinct key with the counts summed, in FIRST-OCCURRENCE order — which for
+ * chunk-ordered inputs is exactly the global dict insertion order of the reference loop. */
+int hhx_table_merge(int64_t n, const int32_t *dev_i, const int32_t *dev_j, const int64_t *dev_count,
+                    int64_t *n_out, void **dev_out_i, void **dev_out_j, void **dev_out_count,
+                    void **dev_out_value_f64);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,9 @@ def test_spgemm_rectangular_row_block():
 
 
 def test_inflate_prune_iterations(golden_mcl):
+    """inflate -> normalise -> prune -> normalise (+ convergence) per iteration.  The expansion feeding
+    each iteration is the reference's own float32 product (oracle mode 0 == scipy bit for bit), so this
+    isolates the row-local kernels, whose arithmetic the reference specifies exactly."""
     g = golden_mcl
     for tag in g['cases']:
         infl = float(g[tag + '_inflation'])
@@ -92,7 +95,7 @@ def test_inflate_prune_iterations(golden_mcl):
         last = None
         for it in range(niter):
             if it:
-                cur = _lib.spgemm(_lib.DeviceCSR.from_arrays(*cur), _lib.DeviceCSR.from_arrays(*cur)).to_arrays()
+                cur = orc.spgemm(cur, cur, mode=0)
             c = _lib.DeviceCSR.from_arrays(*cur)
             p = _lib.inflate_prune(c, infl, 1e-4)
             ref = tri(g, '%s_it%d' % (tag, it))
@@ -109,6 +112,21 @@ def test_inflate_prune_iterations(golden_mcl):
                 assert d == orc.convergence_stat(cur, last)
                 assert (d <= np.float32(1e-8)) == (it == niter - 1)
             last = cur
+
+
+def test_expansion_inside_iterations(golden_mcl):
+    """the HIP expansion on the reference's own per-iteration matrices: bit exact against the fixed-point
+    specification, and within float32 accumulation noise of the float32-accumulating stand-in (the
+    reference's MKL accumulation order is unspecified, so it is itself only reproducible to that noise)."""
+    g = golden_mcl
+    for tag in g['cases']:
+        for it in range(int(g[tag + '_niter']) - 1):
+            A = tri(g, '%s_it%d' % (tag, it))
+            d = _lib.DeviceCSR.from_arrays(*A)
+            got = _lib.spgemm(d, d, fx_shift=60).to_arrays()
+            spec = orc.spgemm(A, A, mode=1, fx_shift=60)
+            assert all(np.array_equal(x, y) for x, y in zip(got, spec))
+            assert_close_csr(got, orc.spgemm(A, A, mode=0), 2e-6, 'expansion %s it %d' % (tag, it))
 
 
 def clusters_of(att, ptr, mem):

@@ -1,0 +1,143 @@
+"""world_size-2 gloo tests of the multi-GPU driver (haphic_amd/sharded.py) on CPU.  The collective
+logic (row-block shard, all-gather(v), max all-reduce, chunk-ordered table merge) is the product code;
+the arithmetic is supplied by an oracle-backed engine that exists only in this test."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from haphic_amd import sharded, synth
+from oracle import oracle as orc
+
+
+class OracleEngine:
+    """matrices are (indptr, indices, data) numpy triples; tensors are CPU torch views"""
+    torch = torch
+    device = torch.device('cpu')
+
+    def tensors(self, m):
+        return tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in m)
+
+    def from_tensors(self, n_rows, n_cols, indptr, indices, data):
+        return (indptr.numpy().copy(), indices.numpy().copy(), data.numpy().copy())
+
+    def shape(self, m):
+        return len(m[0]) - 1, None, int(m[0][-1])
+
+    def row_block(self, m, r0, r1):
+        lo, hi = m[0][r0], m[0][r1]
+        return (m[0][r0:r1 + 1] - lo).astype(np.int32), m[1][lo:hi].copy(), m[2][lo:hi].copy()
+
+    def spgemm(self, a, b):
+        lens = np.diff(b[0])
+        return orc.spgemm(a, b, n_cols=len(b[0]) - 1, mode=1, fx_shift=60), int(lens[a[1]].sum())
+
+    def inflate_prune(self, c, inflation, pruning):
+        x = orc.normalize_l1(c[0], orc.power(c[2], inflation))
+        return orc.prune((c[0], c[1], x), pruning)
+
+    def convergence_stat(self, m, last):
+        return orc.convergence_stat(m, last)
+
+    def copy(self, m):
+        return tuple(a.copy() for a in m)
+
+    def free(self, m):
+        pass
+
+    def sync(self):
+        pass
+
+    def merge_tables(self, ti, tj, tc):
+        key = ti.numpy().astype(np.int64) << 32 | tj.numpy().astype(np.int64)
+        uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+        cnt = np.bincount(inv, weights=tc.numpy().astype(np.float64)).astype(np.int64)
+        order = np.argsort(first, kind='stable')
+        return len(uniq), (uniq[order] >> 32).astype(np.int32), (uniq[order] & 0xffffffff).astype(np.int32), cnt[order], None
+
+
+def stochastic(n, deg, seed):
+    import scipy.sparse as sp
+    m = sp.random(n, n, density=deg / n, random_state=seed, dtype=np.float32, format='csr')
+    blocks = sp.block_diag([sp.random(n // 4, n // 4, density=0.3, random_state=seed + k, dtype=np.float32) for k in range(4)])
+    m = (m * 0.05 + blocks + blocks.T + sp.identity(n, dtype=np.float32)).tocsr()
+    m.sort_indices()
+    return m.indptr.astype(np.int32), m.indices.astype(np.int32), orc.normalize_l1(m.indptr, m.data)
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        eng = OracleEngine()
+        # ---- MCL row-block shard
+        T = stochastic(400, 6, 5)
+        res, n_iter, conv, stats = sharded.mcl_sharded_engine(eng, T, 2, 2.0, 100, 1e-4, dist)
+        # ---- sharded ingest: each rank owns one contiguous chunk of the stream
+        gen = synth.make_genome(3, 400_000, 10_000, seed=2)
+        n = gen.n
+        lex = gen.lexical_rank()
+        t = orc.FragTable(lex, gen.length, np.arange(n, dtype=np.int32), np.zeros(n, np.uint8), 0, lex, gen.length,
+                          np.ones(n, np.uint8))
+        id1, p1, id2, p2 = [a.numpy() for a in synth.sample_pairs(gen, 40_000, seed=3)]
+        keep = id1 != id2
+        a = [x[keep] for x in (id1, p1, id2, p2)]
+        half = len(a[0]) // 2 + 17
+        sl = slice(0, half) if rank == 0 else slice(half, None)
+        loc = orc.ingest(t, a[0][sl], a[1][sl].astype(np.int64), a[2][sl], a[3][sl].astype(np.int64), 3000)
+        k, mi, mj, mc, _ = sharded.merge_tables_engine(eng, torch.from_numpy(loc['flank_i']), torch.from_numpy(loc['flank_j']),
+                                                       torch.from_numpy(loc['flank_cnt']), dist)
+        q.put((rank, res, n_iter, conv, stats, (k, mi, mj, mc)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_sharded_mcl_and_merge_world2():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda o: o[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process truth
+    T = stochastic(400, 6, 5)
+    pre = orc.spgemm(T, T, mode=1, fx_shift=60)
+    o = orc.mcl(pre, 2, 2.0, 100, 1e-4, spgemm_mode=1, fx_shift=60, want_stats=True)
+    for rank, res, n_iter, conv, stats, merged in outs:
+        assert (n_iter, conv) == (o[3], o[4])
+        assert all(np.array_equal(x, y) for x, y in zip(res, o[:3])), 'sharded MCL is not bit-identical to 1 process'
+        assert np.array_equal(stats, o[5])
+    gen = synth.make_genome(3, 400_000, 10_000, seed=2)
+    n = gen.n
+    lex = gen.lexical_rank()
+    t = orc.FragTable(lex, gen.length, np.arange(n, dtype=np.int32), np.zeros(n, np.uint8), 0, lex, gen.length, np.ones(n, np.uint8))
+    id1, p1, id2, p2 = [a.numpy() for a in synth.sample_pairs(gen, 40_000, seed=3)]
+    keep = id1 != id2
+    whole = orc.ingest(t, id1[keep], p1[keep].astype(np.int64), id2[keep], p2[keep].astype(np.int64), 3000)
+    for rank, *_rest, (k, mi, mj, mc) in outs:
+        assert k == len(whole['flank_i'])
+        assert np.array_equal(mi, whole['flank_i']) and np.array_equal(mj, whole['flank_j']) and np.array_equal(mc, whole['flank_cnt'])
+
+
+def test_row_ranges():
+    assert sharded.row_ranges(10, 3) == [0, 4, 7, 10]
+    assert sharded.row_ranges(2, 4) == [0, 1, 2, 2, 2]
