@@ -20,12 +20,36 @@ def assert_close_csr(a, b, rtol, what):
 
 
 def random_stochastic(n, deg, seed):
-    import scipy.sparse as sp
-    m = sp.random(n, n, density=deg / n, random_state=seed, dtype=np.float32, format='csr')
-    m = (m + sp.identity(n, dtype=np.float32, format='csr')).tocsr()
-    m.sort_indices()
-    x = orc.normalize_l1(m.indptr, m.data)
-    return m.indptr.astype(np.int32), m.indices.astype(np.int32), x
+    """row-stochastic CSR with ~deg random entries per row plus the diagonal (sorted, no duplicates)"""
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(n, dtype=np.int64), deg)
+    cols = rng.integers(0, n, rows.size)
+    key = np.unique(np.concatenate([rows * n + cols, np.arange(n, dtype=np.int64) * (n + 1)]))
+    r, c = key // n, key % n
+    indptr = np.zeros(n + 1, np.int32)
+    np.add.at(indptr, r + 1, 1)
+    indptr = np.cumsum(indptr).astype(np.int32)
+    x = rng.random(key.size).astype(np.float32) + np.float32(0.01)
+    return indptr, c.astype(np.int32), orc.normalize_l1(indptr, x)
+
+
+def clustered_stochastic(n, block, deg_in, deg_out, seed):
+    """like random_stochastic but most entries stay inside diagonal blocks (a clusterable graph, the
+    regime MCL is used in: expansion fill-in stays bounded by the block size)"""
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(n, dtype=np.int64), deg_in)
+    cols = (rows // block) * block + rng.integers(0, block, rows.size)
+    rows_o = np.repeat(np.arange(n, dtype=np.int64), deg_out)
+    cols_o = rng.integers(0, n, rows_o.size)
+    rr = np.concatenate([rows, rows_o, cols, cols_o, np.arange(n, dtype=np.int64)])
+    cc = np.minimum(np.concatenate([cols, cols_o, rows, rows_o, np.arange(n, dtype=np.int64)]), n - 1)
+    key = np.unique(rr * n + cc)
+    r, c = key // n, key % n
+    indptr = np.zeros(n + 1, np.int32)
+    np.add.at(indptr, r + 1, 1)
+    indptr = np.cumsum(indptr).astype(np.int32)
+    x = np.where(r // block == c // block, 20.0, 1.0).astype(np.float32) * (rng.random(key.size).astype(np.float32) + np.float32(0.5))
+    return indptr, c.astype(np.int32), orc.normalize_l1(indptr, x)
 
 
 # tolerance stated by BASELINE.json north_star: normalised values within 1e-6 relative
@@ -153,7 +177,7 @@ def test_mcl_whole(golden_mcl):
 
 
 def test_mcl_deterministic_and_larger():
-    A = random_stochastic(20000, 30, 11)
+    A = clustered_stochastic(20000, 200, 30, 1, 11)
     A2 = orc.spgemm(A, A, mode=1, fx_shift=60)
     pre = _lib.DeviceCSR.from_arrays(*A2)
     r1, n1, c1 = _lib.mcl(pre, 2, 2.0, 60, 1e-4)
