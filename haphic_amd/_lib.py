@@ -54,9 +54,12 @@ SIGNATURES = {
     'hhx_inflate_prune': (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_vpp]),
     'hhx_spgemm': (C.c_int, [C.c_void_p, C.c_void_p, c_vpp]),
     'hhx_spgemm_ex': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_vpp, c_i64p]),
+    'hhx_expand_inflate_prune': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, c_vpp, c_i64p, c_i64p]),
     'hhx_convergence_stat': (C.c_int, [C.c_void_p, C.c_void_p, c_f32p]),
     'hhx_mcl': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, c_vpp, C.POINTER(C.c_int),
                           C.POINTER(C.c_int), C.c_void_p]),
+    'hhx_mcl_normalized': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, c_vpp, C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.c_void_p]),
     'hhx_interpret': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i32p]),
     'hhx_dict_to_matrix': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_void_p,
                                      C.c_int32, C.c_int, C.c_void_p, c_i32p, c_vpp]),
@@ -248,11 +251,23 @@ def convergence_stat(m, last):
     return s.value
 
 
-def mcl(pre_expanded, expansion, inflation, max_iter, pruning, want_stats=False):
+def expand_inflate_prune(a, b, inflation, pruning, fx_shift=60):
+    """one fused iteration: prune(normalize(power(a*b, r))); returns (matrix, n_products, nnz_expanded)"""
+    out = C.c_void_p()
+    f, z = C.c_int64(0), C.c_int64(0)
+    check(load().hhx_expand_inflate_prune(a.h, b.h, int(fx_shift), float(inflation), float(pruning), C.byref(out),
+                                          C.byref(f), C.byref(z)))
+    return DeviceCSR(out), f.value, z.value
+
+
+def mcl(pre_expanded, expansion, inflation, max_iter, pruning, want_stats=False, normalized=False):
+    """normalized=False: the reference seam (matrix already pre-expanded); True: start from the
+    L1-normalised link matrix, pre-expansion fused into iteration 0 (hhx_mcl_normalized)."""
     out = C.c_void_p()
     n_iter, conv = C.c_int(0), C.c_int(0)
     stats = np.zeros((max(int(max_iter), 1), 4), np.int64)
-    check(load().hhx_mcl(pre_expanded.h, int(expansion), float(inflation), int(max_iter), float(pruning),
+    fn = load().hhx_mcl_normalized if normalized else load().hhx_mcl
+    check(fn(pre_expanded.h, int(expansion), float(inflation), int(max_iter), float(pruning),
                          C.byref(out), C.byref(n_iter), C.byref(conv), ptr(stats)))
     res = (DeviceCSR(out), n_iter.value, bool(conv.value))
     return res + (stats[:n_iter.value],) if want_stats else res

@@ -1,0 +1,622 @@
+// Fused MCL iteration:  P = prune(normalize(power(A * B, r)))  without ever writing the expanded
+// matrix C = A * B to HBM.  Reference: scripts/HapHiC_cluster.py mcl() :2030-2042 (expand, inflate,
+// prune) and run_mcl_clustering :2144-2147 (the un-pruned pre-expansion, which at n = 100k would be a
+// 10^10-entry matrix — it is consumed row by row here instead).
+//
+// One 256-thread workgroup owns one output row.  The row of A is staged in LDS (column k, a * 2^shift
+// as a double, and the [begin,end) of row k of B) so the inner loop has no dependent global loads; each
+// wave then walks one row of B at a time, lanes striding its entries (256 contiguous bytes of indices
+// and of values per wave instruction), four loads in flight per lane.
+// Accumulators are 64-bit fixed point in LDS (ds_add_u64; integer adds commute -> order-free, bit
+// reproducible for any GPU count).  Two row classes, chosen from the row's product count F_i:
+//   WINDOW : F_i >> n_cols.  Dense accumulators indexed by (column - window start); several windows if
+//            the row is wider than LDS, each window reading only its sub-range of every B row (rows
+//            are sorted -> two binary searches per staged entry), so the products are traversed once.
+//   COMPACT: light rows.  An n_cols-bit LDS bitmap + popcount prefix maps a column to its rank in the
+//            sorted output row; accumulators are indexed by rank.
+// Epilogue per window: x = float(acc), p = x^r, deterministic block sum S.  Entries that can still
+// survive the threshold against the running sum (a lower bound of the row sum) go to a candidate list
+// in HBM; when the row sum is final the candidates are tested exactly as the reference does
+// (q = float(p / S) >= float32(pruning), first row maximum restored, second L1 normalisation) and the
+// survivors are bump-allocated; a final pass packs the rows into CSR order.
+#include "hhx_common.h"
+
+using namespace hhx;
+
+int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
+
+namespace {
+
+constexpr int EX_T = 512;           // 8 waves: the window kernel often runs one workgroup per CU
+constexpr int EX_WAVES = EX_T / HHX_WAVE;
+constexpr int STAGE = 512;          // staged A entries per chunk
+constexpr int MAX_WIN = 512;
+
+struct ExParams {
+    const i32 *Ap, *Aj; const float *Ax;
+    const i32 *Bp, *Bj; const float *Bx;
+    i32 n_rows, n_cols;
+    double scale, inv_scale;        // 2^shift, 2^-shift
+    double r; int square; float thr;
+    // candidate + survivor pools (col, value) and the per-row table
+    i32 *cand_col; float *cand_val; i64 cand_cap;
+    i32 *out_col; float *out_val; i64 out_cap;
+    unsigned long long *cursors;    // [0] cand cursor [1] out cursor [2] overflow flag [3] nnz_C [4] products
+    i64 *row_off; i32 *row_cnt;
+};
+
+struct ExLds {
+    i64 *acc;            // [cap]
+    double *st_da;       // [STAGE]
+    i32 *st_qb, *st_qe;  // [STAGE]
+    double *red_d;       // [EX_T]
+    i32 *red_i;          // [EX_T]
+    float *red_f;        // [EX_T]
+    i64 *win_off;        // [MAX_WIN]
+    i32 *win_cnt;        // [MAX_WIN]
+    u32 *bitmap, *prefix;  // [W] each (compact mode only)
+};
+
+__host__ __device__ inline size_t ex_fixed_bytes(i32 W) {
+    return (size_t)STAGE * (8 + 4 + 4) + (size_t)EX_T * (8 + 4 + 4) + (size_t)MAX_WIN * (8 + 4) + (size_t)W * 8;
+}
+
+__device__ __forceinline__ ExLds ex_carve(unsigned char *smem, i32 cap, i32 W) {
+    ExLds l;
+    unsigned char *p = smem;
+    l.acc = (i64 *)p; p += (size_t)cap * 8;
+    l.st_da = (double *)p; p += STAGE * 8;
+    l.red_d = (double *)p; p += EX_T * 8;
+    l.win_off = (i64 *)p; p += MAX_WIN * 8;
+    l.st_qb = (i32 *)p; p += STAGE * 4;
+    l.st_qe = (i32 *)p; p += STAGE * 4;
+    l.red_i = (i32 *)p; p += EX_T * 4;
+    l.red_f = (float *)p; p += EX_T * 4;
+    l.win_cnt = (i32 *)p; p += MAX_WIN * 4;
+    l.bitmap = (u32 *)p; p += (size_t)W * 4;
+    l.prefix = (u32 *)p;
+    return l;
+}
+
+__device__ __forceinline__ float ex_inflate(float x, double r, int square) {
+    return square ? x * x : (float)pow((double)x, r);
+}
+
+__device__ __forceinline__ i32 lower_bound_i32(const i32 *__restrict__ a, i32 b, i32 e, i32 v) {
+    while (b < e) {
+        const i32 m = (b + e) >> 1;
+        if (a[m] < v) b = m + 1; else e = m;
+    }
+    return b;
+}
+
+// ---- deterministic block reductions (fixed tree: wave shuffles, then the 4 wave results in order)
+__device__ __forceinline__ double block_sum_f64(double v, double *red) {
+    v = wave_sum_f64(v);
+    __syncthreads();
+    if (lane_id() == 0) red[threadIdx.x / HHX_WAVE] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int k = 1; k < EX_WAVES; ++k) s += red[k];
+    return s;
+}
+__device__ __forceinline__ i32 block_sum_i32(i32 v, i32 *red) {
+    v = wave_sum_i32(v);
+    __syncthreads();
+    if (lane_id() == 0) red[threadIdx.x / HHX_WAVE] = v;
+    __syncthreads();
+    i32 s = red[0];
+#pragma unroll
+    for (int k = 1; k < EX_WAVES; ++k) s += red[k];
+    return s;
+}
+// exclusive scan of one i32 per thread; returns the thread's offset, *total = block total
+__device__ __forceinline__ i32 block_excl_scan_i32(i32 v, i32 *red, i32 *total) {
+    i32 incl = v;
+#pragma unroll
+    for (int o = 1; o < HHX_WAVE; o <<= 1) {
+        const i32 t = __shfl_up(incl, o, HHX_WAVE);
+        if (lane_id() >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane_id() == HHX_WAVE - 1) red[threadIdx.x / HHX_WAVE] = incl;
+    __syncthreads();
+    const int w = threadIdx.x / HHX_WAVE;
+    i32 off = 0;
+    i32 tot = 0;
+#pragma unroll
+    for (int k = 0; k < EX_WAVES; ++k) { if (k < w) off += red[k]; tot += red[k]; }
+    *total = tot;
+    return off + incl - v;
+}
+// argmax by (value desc, column asc)
+__device__ __forceinline__ void block_argmax(float &q, i32 &c, float *redf, i32 *redi) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float oq = __shfl_down(q, o, HHX_WAVE);
+        const i32 oc = __shfl_down(c, o, HHX_WAVE);
+        if (oq > q || (oq == q && oc < c)) { q = oq; c = oc; }
+    }
+    __syncthreads();
+    if (lane_id() == 0) { redf[threadIdx.x / HHX_WAVE] = q; redi[threadIdx.x / HHX_WAVE] = c; }
+    __syncthreads();
+    q = redf[0]; c = redi[0];
+    for (int k = 1; k < EX_WAVES; ++k)
+        if (redf[k] > q || (redf[k] == q && redi[k] < c)) { q = redf[k]; c = redi[k]; }
+}
+
+// ---- stage one chunk of the A row: (a * scale, begin, end) of every referenced B row, optionally
+// narrowed to the column window [c0, c1)
+template <bool NARROW>
+__device__ __forceinline__ void stage_chunk(const ExParams &P, const ExLds &l, i32 a0, i32 len, i32 c0, i32 c1) {
+    for (i32 t = threadIdx.x; t < len; t += EX_T) {
+        const i32 k = P.Aj[a0 + t];
+        i32 qb = P.Bp[k], qe = P.Bp[k + 1];
+        if (NARROW) {
+            qb = lower_bound_i32(P.Bj, qb, qe, c0);
+            qe = lower_bound_i32(P.Bj, qb, qe, c1);
+        }
+        l.st_da[t] = (double)P.Ax[a0 + t] * P.scale;
+        l.st_qb[t] = qb;
+        l.st_qe[t] = qe;
+    }
+}
+
+// ---- inner loops -------------------------------------------------------------------------------
+// window mode: acc[c - c0] += fixed(a * b)
+__device__ __forceinline__ void accumulate_window(const ExParams &P, const ExLds &l, i32 len, i32 c0) {
+    const int lane = lane_id(), wave = threadIdx.x / HHX_WAVE;
+    for (i32 e = wave; e < len; e += EX_WAVES) {
+        const double da = l.st_da[e];
+        const i32 qb = l.st_qb[e], qe = l.st_qe[e];
+        i32 q = qb + lane;
+        for (; q + 3 * HHX_WAVE < qe; q += 4 * HHX_WAVE) {      // 4 independent index+value loads in flight
+            const i32 j0 = P.Bj[q], j1 = P.Bj[q + HHX_WAVE], j2 = P.Bj[q + 2 * HHX_WAVE], j3 = P.Bj[q + 3 * HHX_WAVE];
+            const float b0 = P.Bx[q], b1 = P.Bx[q + HHX_WAVE], b2 = P.Bx[q + 2 * HHX_WAVE], b3 = P.Bx[q + 3 * HHX_WAVE];
+            atomicAdd((unsigned long long *)&l.acc[j0 - c0], (unsigned long long)(i64)(da * (double)b0));
+            atomicAdd((unsigned long long *)&l.acc[j1 - c0], (unsigned long long)(i64)(da * (double)b1));
+            atomicAdd((unsigned long long *)&l.acc[j2 - c0], (unsigned long long)(i64)(da * (double)b2));
+            atomicAdd((unsigned long long *)&l.acc[j3 - c0], (unsigned long long)(i64)(da * (double)b3));
+        }
+        for (; q < qe; q += HHX_WAVE)
+            atomicAdd((unsigned long long *)&l.acc[P.Bj[q] - c0], (unsigned long long)(i64)(da * (double)P.Bx[q]));
+    }
+}
+// compact mode: mark, then acc[rank(c)] += fixed(a * b)
+__device__ __forceinline__ void mark_compact(const ExParams &P, const ExLds &l, i32 len) {
+    const int lane = lane_id(), wave = threadIdx.x / HHX_WAVE;
+    for (i32 e = wave; e < len; e += EX_WAVES) {
+        const i32 qb = l.st_qb[e], qe = l.st_qe[e];
+        i32 q = qb + lane;
+        for (; q + 3 * HHX_WAVE < qe; q += 4 * HHX_WAVE) {
+            const i32 j0 = P.Bj[q], j1 = P.Bj[q + HHX_WAVE], j2 = P.Bj[q + 2 * HHX_WAVE], j3 = P.Bj[q + 3 * HHX_WAVE];
+            atomicOr(&l.bitmap[j0 >> 5], 1u << (j0 & 31));
+            atomicOr(&l.bitmap[j1 >> 5], 1u << (j1 & 31));
+            atomicOr(&l.bitmap[j2 >> 5], 1u << (j2 & 31));
+            atomicOr(&l.bitmap[j3 >> 5], 1u << (j3 & 31));
+        }
+        for (; q < qe; q += HHX_WAVE) {
+            const i32 j = P.Bj[q];
+            atomicOr(&l.bitmap[j >> 5], 1u << (j & 31));
+        }
+    }
+}
+__device__ __forceinline__ i32 rank_of(const ExLds &l, i32 c) {
+    return (i32)(l.prefix[c >> 5] + __popc(l.bitmap[c >> 5] & ((1u << (c & 31)) - 1u)));
+}
+__device__ __forceinline__ void accumulate_compact(const ExParams &P, const ExLds &l, i32 len, i32 r0, i32 rlen) {
+    const int lane = lane_id(), wave = threadIdx.x / HHX_WAVE;
+    for (i32 e = wave; e < len; e += EX_WAVES) {
+        const double da = l.st_da[e];
+        const i32 qb = l.st_qb[e], qe = l.st_qe[e];
+        i32 q = qb + lane;
+        for (; q + 3 * HHX_WAVE < qe; q += 4 * HHX_WAVE) {
+            const i32 j0 = P.Bj[q], j1 = P.Bj[q + HHX_WAVE], j2 = P.Bj[q + 2 * HHX_WAVE], j3 = P.Bj[q + 3 * HHX_WAVE];
+            const float b0 = P.Bx[q], b1 = P.Bx[q + HHX_WAVE], b2 = P.Bx[q + 2 * HHX_WAVE], b3 = P.Bx[q + 3 * HHX_WAVE];
+            const i32 s0 = rank_of(l, j0) - r0, s1 = rank_of(l, j1) - r0, s2 = rank_of(l, j2) - r0, s3 = rank_of(l, j3) - r0;
+            if ((u32)s0 < (u32)rlen) atomicAdd((unsigned long long *)&l.acc[s0], (unsigned long long)(i64)(da * (double)b0));
+            if ((u32)s1 < (u32)rlen) atomicAdd((unsigned long long *)&l.acc[s1], (unsigned long long)(i64)(da * (double)b1));
+            if ((u32)s2 < (u32)rlen) atomicAdd((unsigned long long *)&l.acc[s2], (unsigned long long)(i64)(da * (double)b2));
+            if ((u32)s3 < (u32)rlen) atomicAdd((unsigned long long *)&l.acc[s3], (unsigned long long)(i64)(da * (double)b3));
+        }
+        for (; q < qe; q += HHX_WAVE) {
+            const i32 s = rank_of(l, P.Bj[q]) - r0;
+            if ((u32)s < (u32)rlen) atomicAdd((unsigned long long *)&l.acc[s], (unsigned long long)(i64)(da * (double)P.Bx[q]));
+        }
+    }
+}
+
+// popcount prefix over the LDS bitmap (256 threads, contiguous chunk of words per thread)
+__device__ __forceinline__ i32 bitmap_prefix_total(const ExLds &l, i32 W) {
+    const int tid = threadIdx.x;
+    const i32 per = (W + EX_T - 1) / EX_T;
+    const i32 w0 = min(W, tid * per), w1 = min(W, w0 + per);
+    i32 local = 0;
+    for (i32 w = w0; w < w1; ++w) local += __popc(l.bitmap[w]);
+    i32 total;
+    i32 run = block_excl_scan_i32(local, l.red_i, &total);
+    for (i32 w = w0; w < w1; ++w) { l.prefix[w] = (u32)run; run += __popc(l.bitmap[w]); }
+    __syncthreads();
+    return total;
+}
+
+// ---- window epilogue: slots [0, wlen) hold the accumulators of columns col_of(slot) (ascending).
+// Turns them into p = x^r (stored back as float bits, -1 = absent), returns the window sum.
+template <bool COMPACT>
+__device__ __forceinline__ double window_power_sum(const ExParams &P, const ExLds &l, i32 wlen, i32 *nnz_local) {
+    const int tid = threadIdx.x;
+    const i32 per = (wlen + EX_T - 1) / EX_T;
+    const i32 s0 = min(wlen, tid * per), s1 = min(wlen, s0 + per);
+    double s = 0.0;
+    i32 nz = 0;
+    for (i32 t = s0; t < s1; ++t) {
+        const i64 a = l.acc[t];
+        float p = -1.0f;
+        if (COMPACT || a != 0) {
+            const float x = (float)((double)a * P.inv_scale);
+            p = ex_inflate(x, P.r, P.square);
+            s += (double)p;
+            ++nz;
+        }
+        ((float *)&l.acc[t])[0] = p;
+    }
+    *nnz_local = nz;
+    return block_sum_f64(s, l.red_d);
+}
+
+// column of slot t: window mode c0 + t; compact mode: enumerate the bitmap (thread-local walk)
+struct BitWalk {
+    i32 w, base; u32 bits;
+};
+
+// emits the candidates of one window (entries that may still survive given the running row sum, plus
+// the window maximum) in column order; returns their count (uniform) and records (offset,count)
+template <bool COMPACT>
+__device__ __forceinline__ void window_emit_candidates(const ExParams &P, const ExLds &l, i32 wlen, i32 c0, i32 r0,
+                                                       double s_run, i32 win_idx) {
+    const int tid = threadIdx.x;
+    const i32 per = (wlen + EX_T - 1) / EX_T;
+    const i32 s0 = min(wlen, tid * per), s1 = min(wlen, s0 + per);
+    // window maximum (first by column == lowest slot)
+    float bq = -1.0f; i32 bs = 0x7fffffff;
+    for (i32 t = s0; t < s1; ++t) {
+        const float p = ((float *)&l.acc[t])[0];
+        if (p > bq) { bq = p; bs = t; }
+    }
+    block_argmax(bq, bs, l.red_f, l.red_i);
+    i32 cnt = 0;
+    for (i32 t = s0; t < s1; ++t) {
+        const float p = ((float *)&l.acc[t])[0];
+        if (p >= 0.0f && (t == bs || (float)((double)p / s_run) >= P.thr)) ++cnt;
+    }
+    i32 total;
+    i32 off = block_excl_scan_i32(cnt, l.red_i, &total);
+    __syncthreads();
+    if (tid == 0) {
+        i64 base = 0;
+        if (total) {
+            base = (i64)atomicAdd(&P.cursors[0], (unsigned long long)total);
+            if (base + total > P.cand_cap) { atomicExch(&P.cursors[2], 1ull); base = -1; }
+        }
+        l.win_off[win_idx] = base;
+        l.win_cnt[win_idx] = base < 0 ? 0 : total;
+    }
+    __syncthreads();
+    const i64 base = l.win_off[win_idx];
+    if (base < 0 || total == 0) return;
+    // column of slot s0 in compact mode: find the (s0 + r0)-th set bit
+    i32 w = 0; u32 bits = 0;
+    if (COMPACT && s0 < s1) {
+        const i32 target = s0 + r0;
+        i32 lo = 0, hi = (P.n_cols + 31) / 32;        // last word with prefix <= target
+        while (hi - lo > 1) { const i32 m = (lo + hi) >> 1; if ((i32)l.prefix[m] <= target) lo = m; else hi = m; }
+        w = lo; bits = l.bitmap[w];
+        for (i32 skip = target - (i32)l.prefix[w]; skip > 0; --skip) bits &= bits - 1;
+    }
+    i64 o = base + off;
+    for (i32 t = s0; t < s1; ++t) {
+        i32 col;
+        if (COMPACT) {
+            while (!bits) { ++w; bits = l.bitmap[w]; }
+            col = (w << 5) + (__ffs(bits) - 1);
+            bits &= bits - 1;
+        } else col = c0 + t;
+        const float p = ((float *)&l.acc[t])[0];
+        if (p >= 0.0f && (t == bs || (float)((double)p / s_run) >= P.thr)) {
+            P.cand_col[o] = col;
+            P.cand_val[o] = p;
+            ++o;
+        }
+    }
+}
+
+// ---- row finalisation over the candidate segments -------------------------------------------------
+__device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, i32 row, i32 n_win, double s1) {
+    const int tid = threadIdx.x;
+    __threadfence_block();
+    __syncthreads();
+    // pass A: first row maximum of q = float(p / S)
+    float bq = -1.0f; i32 bc = 0x7fffffff;
+    for (i32 wv = 0; wv < n_win; ++wv) {
+        const i64 base = l.win_off[wv];
+        const i32 cnt = l.win_cnt[wv];
+        for (i32 t = tid; t < cnt; t += EX_T) {
+            const float p = P.cand_val[base + t];
+            const float q = s1 != 0.0 ? (float)((double)p / s1) : p;
+            const i32 c = P.cand_col[base + t];
+            if (q > bq || (q == bq && c < bc)) { bq = q; bc = c; }
+        }
+    }
+    block_argmax(bq, bc, l.red_f, l.red_i);
+    // pass B: survivor count and second-normalisation sum (candidate order == column order)
+    i32 keep = 0;
+    double s2 = 0.0;
+    for (i32 wv = 0; wv < n_win; ++wv) {
+        const i64 base = l.win_off[wv];
+        const i32 cnt = l.win_cnt[wv];
+        for (i32 t0 = 0; t0 < cnt; t0 += EX_T) {
+            const i32 t = t0 + tid;
+            double v = 0.0;
+            if (t < cnt) {
+                const float p = P.cand_val[base + t];
+                const float q = s1 != 0.0 ? (float)((double)p / s1) : p;
+                if (q >= P.thr || P.cand_col[base + t] == bc) { ++keep; v = (double)q; }
+            }
+            s2 += block_sum_f64(v, l.red_d);        // chunk sums added in order: deterministic
+        }
+    }
+    const i32 total = block_sum_i32(keep, l.red_i);
+    __syncthreads();
+    if (tid == 0) {
+        i64 base = 0;
+        if (total) {
+            base = (i64)atomicAdd(&P.cursors[1], (unsigned long long)total);
+            if (base + total > P.out_cap) { atomicExch(&P.cursors[2], 1ull); base = -1; }
+        }
+        P.row_off[row] = base;
+        P.row_cnt[row] = base < 0 ? 0 : total;
+        l.win_off[MAX_WIN - 1] = base;
+    }
+    __syncthreads();
+    i64 o = l.win_off[MAX_WIN - 1];
+    __syncthreads();
+    if (o < 0 || total == 0) return;
+    // pass C: ordered write of (column, float(q / S2))
+    for (i32 wv = 0; wv < n_win; ++wv) {
+        const i64 base = l.win_off[wv];
+        const i32 cnt = l.win_cnt[wv];
+        for (i32 t0 = 0; t0 < cnt; t0 += EX_T) {
+            const i32 t = t0 + tid;
+            bool k = false;
+            float q = 0.f;
+            i32 c = 0;
+            if (t < cnt) {
+                const float p = P.cand_val[base + t];
+                q = s1 != 0.0 ? (float)((double)p / s1) : p;
+                c = P.cand_col[base + t];
+                k = (q >= P.thr) || (c == bc);
+            }
+            i32 tot;
+            const i32 pos = block_excl_scan_i32(k ? 1 : 0, l.red_i, &tot);
+            if (k) {
+                P.out_col[o + pos] = c;
+                P.out_val[o + pos] = s2 != 0.0 ? (float)((double)q / s2) : q;
+            }
+            o += tot;
+            __syncthreads();
+        }
+    }
+}
+
+// ---- the two kernels ----------------------------------------------------------------------------
+__global__ __launch_bounds__(EX_T) void k_expand_window(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ExLds l = ex_carve(smem, cap, 0);
+    const int tid = threadIdx.x;
+    i64 nnzc = 0;
+    const i32 n_win = (P.n_cols + cap - 1) / cap;
+    for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const i32 row = rows[li];
+        const i32 a_b = P.Ap[row], a_e = P.Ap[row + 1];
+        double s_run = 0.0;
+        for (i32 wv = 0; wv < n_win; ++wv) {
+            const i32 c0 = wv * cap, c1 = min(P.n_cols, c0 + cap), wlen = c1 - c0;
+            for (i32 t = tid; t < wlen; t += EX_T) l.acc[t] = 0;
+            __syncthreads();
+            for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
+                const i32 len = min(STAGE, a_e - a0);
+                if (n_win > 1) stage_chunk<true>(P, l, a0, len, c0, c1);
+                else stage_chunk<false>(P, l, a0, len, c0, c1);
+                __syncthreads();
+                accumulate_window(P, l, len, c0);
+                __syncthreads();
+            }
+            i32 nz;
+            const double sw = window_power_sum<false>(P, l, wlen, &nz);
+            nnzc += nz;
+            s_run += sw;
+            window_emit_candidates<false>(P, l, wlen, c0, 0, s_run, wv);
+            __syncthreads();
+        }
+        finalize_row(P, l, row, n_win, s_run);
+        __syncthreads();
+    }
+    nnzc = wave_sum_i64(nnzc);          // products are counted by the classification pass (cursors[4])
+    if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
+}
+
+__global__ __launch_bounds__(EX_T) void k_expand_compact(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 W) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ExLds l = ex_carve(smem, cap, W);
+    const int tid = threadIdx.x;
+    i64 nnzc = 0;
+    for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const i32 row = rows[li];
+        const i32 a_b = P.Ap[row], a_e = P.Ap[row + 1];
+        for (i32 w = tid; w < W; w += EX_T) l.bitmap[w] = 0;
+        __syncthreads();
+        for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
+            const i32 len = min(STAGE, a_e - a0);
+            stage_chunk<false>(P, l, a0, len, 0, 0);
+            __syncthreads();
+            mark_compact(P, l, len);
+            __syncthreads();
+        }
+        const i32 nnz_row = bitmap_prefix_total(l, W);
+        nnzc += (tid == 0) ? nnz_row : 0;
+        double s_run = 0.0;
+        i32 n_win = 0;
+        for (i32 r0 = 0; r0 < nnz_row; r0 += cap, ++n_win) {      // rank windows (one for almost every row)
+            const i32 rlen = min(cap, nnz_row - r0);
+            for (i32 t = tid; t < rlen; t += EX_T) l.acc[t] = 0;
+            __syncthreads();
+            for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
+                const i32 len = min(STAGE, a_e - a0);
+                stage_chunk<false>(P, l, a0, len, 0, 0);
+                __syncthreads();
+                accumulate_compact(P, l, len, r0, rlen);
+                __syncthreads();
+            }
+            i32 nz;
+            s_run += window_power_sum<true>(P, l, rlen, &nz);
+            window_emit_candidates<true>(P, l, rlen, 0, r0, s_run, n_win);
+            __syncthreads();
+        }
+        if (nnz_row == 0) {
+            if (tid == 0) { P.row_off[row] = 0; P.row_cnt[row] = 0; }
+        } else finalize_row(P, l, row, n_win, s_run);
+        __syncthreads();
+    }
+    nnzc = wave_sum_i64(nnzc);
+    if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
+}
+
+// ---- classification: product count per row, row lists --------------------------------------------
+__global__ __launch_bounds__(256) void k_classify(i32 n_rows, const i32 *__restrict__ Ap, const i32 *__restrict__ Aj,
+                                                  const i32 *__restrict__ Bp, i64 window_min_products,
+                                                  i32 *__restrict__ list_window, i32 *__restrict__ list_compact,
+                                                  unsigned int *__restrict__ counts, unsigned long long *__restrict__ cursors) {
+    const int lane = lane_id();
+    i64 total = 0;
+    for (i32 row = blockIdx.x * 4 + threadIdx.x / HHX_WAVE; row < n_rows; row += gridDim.x * 4) {
+        i64 f = 0;
+        for (i32 p = Ap[row] + lane; p < Ap[row + 1]; p += HHX_WAVE) { const i32 k = Aj[p]; f += Bp[k + 1] - Bp[k]; }
+        f = wave_sum_i64(f);
+        if (lane == 0) {
+            total += f;
+            if (f >= window_min_products) list_window[atomicAdd(&counts[0], 1u)] = row;
+            else list_compact[atomicAdd(&counts[1], 1u)] = row;
+        }
+    }
+    if (lane == 0 && total) atomicAdd(&cursors[4], (unsigned long long)total);
+}
+
+// ---- pack the bump-allocated rows into CSR order ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_rows(i32 n_rows, const i64 *__restrict__ row_off, const i32 *__restrict__ indptr,
+                                                   const i32 *__restrict__ pool_col, const float *__restrict__ pool_val,
+                                                   i32 *__restrict__ out_j, float *__restrict__ out_x) {
+    const int lane = lane_id();
+    for (i32 row = blockIdx.x * 4 + threadIdx.x / HHX_WAVE; row < n_rows; row += gridDim.x * 4) {
+        const i32 b = indptr[row], e = indptr[row + 1];
+        const i64 src = row_off[row];
+        for (i32 t = lane; t < e - b; t += HHX_WAVE) { out_j[b + t] = pool_col[src + t]; out_x[b + t] = pool_val[src + t]; }
+    }
+}
+
+}  // namespace
+
+// C ABI --------------------------------------------------------------------------------------------
+extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int fx_shift, double inflation, double pruning,
+                                        hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
+    if (!a || !b || !out) return fail("null pointer");
+    if (a->n_cols != b->n_rows) return fail("expand shape mismatch");
+    if (!(inflation > 0)) return fail("inflation must be positive");
+    if (fx_shift < 0 || fx_shift > 1000) fx_shift = 60;
+    const i32 n_rows = a->n_rows, n_cols = b->n_cols;
+    const i32 W = (n_cols + 31) / 32;
+    // LDS plans
+    const size_t fixed_win = ex_fixed_bytes(0), fixed_cmp = ex_fixed_bytes(W);
+    // window kernel: whole row in one window if it fits 64 KB (2 workgroups/CU), else the full 160 KB
+    i32 cap_win = (i32)((64 * 1024 - fixed_win) / 8) & ~63;
+    if (cap_win < n_cols) cap_win = (i32)((160 * 1024 - fixed_win) / 8) & ~63;
+    if (cap_win > n_cols) cap_win = (n_cols + 63) & ~63;
+    if ((n_cols + cap_win - 1) / cap_win > MAX_WIN - 1) return fail("expand: %d columns need too many LDS windows", n_cols);
+    size_t budget_cmp = 64 * 1024;
+    if (fixed_cmp + 2048 * 8 > budget_cmp) budget_cmp = 160 * 1024;
+    if (fixed_cmp + 1024 * 8 > budget_cmp) return fail("expand: %d columns exceed the LDS bitmap capacity", n_cols);
+    const i32 cap_cmp = (i32)((budget_cmp - fixed_cmp) / 8) & ~63;
+    const size_t lds_win = (size_t)cap_win * 8 + fixed_win, lds_cmp = (size_t)cap_cmp * 8 + fixed_cmp;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_compact, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    // rows whose product count is well above the number of accumulator slots a dense sweep touches
+    const i64 window_min = std::max<i64>(4096, (i64)n_cols / 2);
+    DevBuf<i32> list_w, list_c, row_cnt, indptr;
+    DevBuf<i64> row_off;
+    DevBuf<unsigned int> counts;
+    DevBuf<unsigned long long> cursors;
+    if (list_w.alloc((size_t)n_rows + 1) || list_c.alloc((size_t)n_rows + 1) || row_cnt.alloc((size_t)n_rows + 1) ||
+        indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || counts.alloc(2) || cursors.alloc(8)) return 1;
+    i64 pool_cap = std::max<i64>(4 * a->nnz + 16 * (i64)n_rows, (i64)1 << 22);
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        DevBuf<i32> cand_col, out_col;
+        DevBuf<float> cand_val, out_val;
+        if (cand_col.alloc((size_t)pool_cap) || cand_val.alloc((size_t)pool_cap) || out_col.alloc((size_t)pool_cap) ||
+            out_val.alloc((size_t)pool_cap)) return 1;
+        HHX_HIP(hipMemsetAsync(counts.p, 0, 2 * sizeof(unsigned int), g_stream));
+        HHX_HIP(hipMemsetAsync(cursors.p, 0, 8 * sizeof(unsigned long long), g_stream));
+        k_classify<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 3) / 4, 4096)), 256, 0, g_stream>>>(
+            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, list_w.p, list_c.p, counts.p, cursors.p);
+        HHX_LAUNCH_CHECK();
+        unsigned int hc[2];
+        HHX_HIP(hipMemcpyAsync(hc, counts.p, sizeof hc, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+        ExParams P;
+        P.Ap = a->indptr.p; P.Aj = a->indices.p; P.Ax = a->data.p;
+        P.Bp = b->indptr.p; P.Bj = b->indices.p; P.Bx = b->data.p;
+        P.n_rows = n_rows; P.n_cols = n_cols;
+        P.scale = ldexp(1.0, fx_shift); P.inv_scale = ldexp(1.0, -fx_shift);
+        P.r = (double)(float)inflation; P.square = inflation == 2.0; P.thr = (float)pruning;
+        P.cand_col = cand_col.p; P.cand_val = cand_val.p; P.cand_cap = pool_cap;
+        P.out_col = out_col.p; P.out_val = out_val.p; P.out_cap = pool_cap;
+        P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
+        if (hc[0]) {
+            KTimer kt("expand_window");
+            const unsigned per_cu = lds_win > 80 * 1024 ? 1 : 2;
+            k_expand_window<<<std::min<unsigned>(hc[0], 256 * per_cu), EX_T, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win);
+        }
+        HHX_LAUNCH_CHECK();
+        if (hc[1]) {
+            KTimer kt("expand_compact");
+            const unsigned per_cu = lds_cmp > 80 * 1024 ? 1 : 2;
+            k_expand_compact<<<std::min<unsigned>(hc[1], 256 * per_cu * 4), EX_T, lds_cmp, g_stream>>>(P, list_c.p, (i32)hc[1], cap_cmp, W);
+        }
+        HHX_LAUNCH_CHECK();
+        unsigned long long cur[8];
+        HHX_HIP(hipMemcpyAsync(cur, cursors.p, sizeof cur, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+        if (cur[2]) {                                  // a pool overflowed: grow and redo the launch
+            pool_cap = std::max<i64>(pool_cap * 2, (i64)std::max(cur[0], cur[1]) + (i64)n_rows);
+            continue;
+        }
+        if (n_products) *n_products = (i64)cur[4];
+        if (nnz_expanded) *nnz_expanded = (i64)cur[3];
+        i64 total = 0;
+        HHX_TRY(exclusive_scan_i32(row_cnt.p, indptr.p, n_rows, &total));
+        hhx_csr *p = nullptr;
+        HHX_TRY(hhx_csr_alloc_internal(n_rows, n_cols, total, &p));
+        HHX_HIP(hipMemcpyAsync(p->indptr.p, indptr.p, sizeof(i32) * ((size_t)n_rows + 1), hipMemcpyDeviceToDevice, g_stream));
+        k_pack_rows<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 3) / 4, 8192)), 256, 0, g_stream>>>(
+            n_rows, row_off.p, p->indptr.p, out_col.p, out_val.p, p->indices.p, p->data.p);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);   // the pools are released on return
+        if (e != hipSuccess) { hhx_csr_free(p); return fail("expand pack: %s", hipGetErrorString(e)); }
+        *out = p;
+        return 0;
+    }
+    return fail("expand: survivor pool kept overflowing");
+}

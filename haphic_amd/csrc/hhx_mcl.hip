@@ -260,10 +260,13 @@ extern "C" int hhx_convergence_stat(const hhx_csr *m, const hhx_csr *last, float
     return 0;
 }
 
-extern "C" int hhx_mcl(const hhx_csr *pre, int expansion, double inflation, int max_iter, double pruning,
-                       hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
-    if (!pre || !out || !n_iter || !converged) return fail("null pointer");
-    if (pre->n_rows != pre->n_cols) return fail("mcl needs a square matrix");
+// mcl() driver.  pre_expanded != 0: `m` is the pre-expanded matrix (the reference seam, :2026);
+// pre_expanded == 0: `m` is the L1-normalised link matrix and the pre-expansion of :2146-2147 is
+// fused into iteration 0.  Every expansion that feeds an inflate+prune goes through the fused kernel.
+static int mcl_impl(const hhx_csr *m, int pre_expanded, int expansion, double inflation, int max_iter, double pruning,
+                    hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
+    if (!m || !out || !n_iter || !converged) return fail("null pointer");
+    if (m->n_rows != m->n_cols) return fail("mcl needs a square matrix");
     if (expansion < 1) return fail("expansion must be >= 1");
     if (!(inflation > 0)) return fail("inflation must be positive");
     *n_iter = 0;
@@ -271,29 +274,33 @@ extern "C" int hhx_mcl(const hhx_csr *pre, int expansion, double inflation, int 
     hhx_csr *cur = nullptr;                  // matrix at the end of the previous iteration (== last_matrix)
     int rc = 0;
     for (int it = 0; it < max_iter && !rc; ++it) {
-        hhx_csr *c = nullptr;
-        i64 st_a = cur ? cur->nnz : pre->nnz, st_f = 0;
-        if (it == 0) {
-            rc = hhx_csr_copy(pre, &c);      // iteration 0 skips the expansion, :2030
+        const hhx_csr *src = cur ? cur : m;  // operand of this iteration's expansion
+        const bool expand = (it > 0 || !pre_expanded) && expansion > 1;
+        i64 st_a = src->nnz, st_f = 0, st_c = 0;
+        hhx_csr *p = nullptr;
+        if (!expand) {
+            hhx_csr *c = nullptr;            // iteration 0 of the pre-expanded seam skips the expansion, :2030
+            rc = hhx_csr_copy(src, &c);
+            if (!rc) { st_c = c->nnz; rc = hhx_inflate_prune(c, inflation, pruning, &p); }
+            if (c) hhx_csr_free(c);
         } else {
             // mkl_matrix_power(M, e) = M * M^(e-1)  ==  T^(e-1) * T on CSR(T), :2017-2023
-            hhx_csr *run = cur;
-            for (int e = 2; e <= expansion && !rc; ++e) {
+            const hhx_csr *run = src;
+            for (int e = 2; e < expansion && !rc; ++e) {
                 hhx_csr *nx = nullptr;
                 i64 f = 0;
-                rc = hhx_spgemm_ex(run, cur, HHX_MCL_FX_SHIFT, &nx, &f);
+                rc = hhx_spgemm_ex(run, src, HHX_MCL_FX_SHIFT, &nx, &f);
                 st_f += f;
-                if (run != cur) hhx_csr_free(run);
+                if (run != src) hhx_csr_free(const_cast<hhx_csr *>(run));
                 run = nx;
             }
-            if (!rc && run == cur) rc = hhx_csr_copy(cur, &run);    // expansion == 1
-            c = run;
+            if (!rc) {
+                i64 f = 0;
+                rc = hhx_expand_inflate_prune(run, src, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);   // :2030-2042
+                st_f += f;
+            }
+            if (run != src && run) hhx_csr_free(const_cast<hhx_csr *>(run));
         }
-        if (rc) { if (c && c != cur) hhx_csr_free(c); break; }
-        const i64 st_c = c->nnz;
-        hhx_csr *p = nullptr;
-        rc = hhx_inflate_prune(c, inflation, pruning, &p);          // steps 3) + 4), :2037-2042
-        hhx_csr_free(c);
         if (rc) break;
         if (stats) { stats[4 * it] = st_a; stats[4 * it + 1] = st_c; stats[4 * it + 2] = p->nnz; stats[4 * it + 3] = st_f; }
         *n_iter = it + 1;
@@ -311,9 +318,19 @@ extern "C" int hhx_mcl(const hhx_csr *pre, int expansion, double inflation, int 
         cur = p;                                                    // last_matrix = matrix.copy(), :2057
     }
     if (rc) { if (cur) hhx_csr_free(cur); return rc; }
-    if (!cur) rc = hhx_csr_copy(pre, &cur);                         // max_iter == 0
+    if (!cur) rc = hhx_csr_copy(m, &cur);                           // max_iter == 0
     *out = cur;
     return rc;
+}
+
+extern "C" int hhx_mcl(const hhx_csr *pre, int expansion, double inflation, int max_iter, double pruning,
+                       hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
+    return mcl_impl(pre, 1, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats);
+}
+
+extern "C" int hhx_mcl_normalized(const hhx_csr *norm, int expansion, double inflation, int max_iter, double pruning,
+                                  hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
+    return mcl_impl(norm, 0, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats);
 }
 
 // interpret_result(), array half.  The final matrix holds ~n entries, so this is a host pass over a

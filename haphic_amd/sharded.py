@@ -60,6 +60,9 @@ class HipEngine:
     def inflate_prune(self, c, inflation, pruning):
         return _lib.inflate_prune(c, inflation, pruning)
 
+    def expand_inflate_prune(self, a, b, inflation, pruning):
+        return _lib.expand_inflate_prune(a, b, inflation, pruning, fx_shift=60)
+
     def convergence_stat(self, m, last):
         return _lib.convergence_stat(m, last)
 
@@ -120,51 +123,42 @@ def allgather_rows(engine, local, n_cols, dist):
     return engine.from_tensors(n_rows, n_cols, indptr, torch.cat(ix_all).contiguous(), torch.cat(dx_all).contiguous())
 
 
-def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, dist, want_pre_time=False):
+def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, dist):
     """run_mcl_clustering's pre-expansion (:2146-2147) + mcl() (:2026-2062) with T sharded by row block.
-    full_norm: the L1-normalised link matrix, replicated.  Returns (full result, n_iter, converged, stats[, t_pre])."""
-    import time
+    full_norm: the L1-normalised link matrix, replicated.  The pre-expansion is fused into iteration 0
+    (the expanded rows are consumed in LDS, never materialised).  Returns (full result, n_iter,
+    converged, stats)."""
     torch = engine.torch
     n = engine.shape(full_norm)[0]
     world, rank = dist.get_world_size(), dist.get_rank()
     b = row_ranges(n, world)
     r0, r1 = b[rank], b[rank + 1]
-    t0 = time.perf_counter()
-    # pre-expansion: local rows of T^e
-    blk = engine.row_block(full_norm, r0, r1)
-    run = blk
-    for _ in range(2, expansion + 1):
-        nxt, _f = engine.spgemm(run, full_norm)
-        if run is not blk:
-            engine.free(run)
-        run = nxt
-    pre_local = run if run is not blk else engine.copy(blk)
-    if run is not blk:
-        engine.free(blk)
-    engine.sync()
-    t_pre = time.perf_counter() - t0
     stats = []
-    cur_local = None      # this rank's rows of the matrix at the end of the previous iteration
-    cur_full = None       # the same matrix, all rows (right operand of the next expansion)
+    cur_local = engine.row_block(full_norm, r0, r1)   # this rank's rows of the current matrix
+    cur_full = full_norm                              # all rows: right operand of the expansion
+    own_full = False
     converged = False
     n_iter = 0
     for it in range(iters):
-        st_a = engine.shape(cur_full)[2] if cur_full is not None else None
+        st_a = engine.shape(cur_full)[2]
         st_f = 0
-        if it == 0:
-            c = engine.copy(pre_local)
+        run = cur_local
+        for _ in range(2, expansion):                 # T^(e-1) rows, :2017-2023
+            nxt, f = engine.spgemm(run, cur_full)
+            st_f += f
+            if run is not cur_local:
+                engine.free(run)
+            run = nxt
+        if expansion > 1:
+            p, f, st_c = engine.expand_inflate_prune(run, cur_full, inflation, pruning)   # :2030-2042 fused
+            st_f += f
         else:
-            run = cur_local
-            for _ in range(2, expansion + 1):
-                nxt, f = engine.spgemm(run, cur_full)
-                st_f += f
-                if run is not cur_local:
-                    engine.free(run)
-                run = nxt
-            c = run if run is not cur_local else engine.copy(cur_local)
-        st_c = engine.shape(c)[2]
-        p = engine.inflate_prune(c, inflation, pruning)
-        engine.free(c)
+            c = engine.copy(run)
+            st_c = engine.shape(c)[2]
+            p = engine.inflate_prune(c, inflation, pruning)
+            engine.free(c)
+        if run is not cur_local:
+            engine.free(run)
         n_iter = it + 1
         red = torch.tensor([0.0, float(st_c), float(engine.shape(p)[2]), float(st_f)], dtype=torch.float64,
                            device=engine.device)
@@ -173,29 +167,25 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
         mx = red[:1].clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)            # convergence: one float, max over ranks
         dist.all_reduce(red[1:], op=dist.ReduceOp.SUM)       # bookkeeping only (nnz / product counts)
-        full = allgather_rows(engine, p, n, dist)
-        if st_a is None:
-            st_a = int(red[1].item())                        # iteration 0 enters with the pre-expanded matrix
+        full = allgather_rows(engine, p, n, dist)            # the per-iteration all-gather(v)
         stats.append([st_a, int(red[1].item()), int(red[2].item()), int(red[3].item())])
-        if cur_local is not None:
-            engine.free(cur_local)
+        engine.free(cur_local)
+        if own_full:
             engine.free(cur_full)
-        cur_local, cur_full = p, full
+        cur_local, cur_full, own_full = p, full, True
         if it > 1 and np.float32(mx.item()) <= np.float32(1e-8):
             converged = True
             break
-    engine.free(pre_local)
-    if cur_local is not None:
-        engine.free(cur_local)
-    res = cur_full
-    out = (res, n_iter, converged, np.asarray(stats, np.int64))
-    return out + (t_pre,) if want_pre_time else out
+    engine.free(cur_local)
+    if not own_full:
+        cur_full = engine.copy(cur_full)
+    return cur_full, n_iter, converged, np.asarray(stats, np.int64)
 
 
 # ------------------------------------------------------------------ product entry points (HIP engine)
 def mcl_sharded(full_norm, expansion, inflation, iters, pruning, dist, device):
     eng = HipEngine(device)
-    return mcl_sharded_engine(eng, full_norm, expansion, inflation, iters, pruning, dist, want_pre_time=True)
+    return mcl_sharded_engine(eng, full_norm, expansion, inflation, iters, pruning, dist)
 
 
 def merge_tables_engine(engine, ti, tj, tc, dist):

@@ -82,6 +82,12 @@ int hhx_spgemm(const hhx_csr *a, const hhx_csr *b, hhx_csr **out);
 /* same with an explicit fixed-point shift (tests); products counted into *n_products if non-NULL */
 int hhx_spgemm_ex(const hhx_csr *a, const hhx_csr *b, int fx_shift, hhx_csr **out, int64_t *n_products);
 
+/* One fused MCL iteration on the device, :2030-2042: out = prune(normalize(power(a * b, inflation))),
+ * the expanded matrix a*b is consumed row by row in LDS and never written to HBM (at n = 100k the
+ * un-pruned pre-expansion of :2147 has 10^10 entries).  a may be a row block.  fx_shift < 0: 60. */
+int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int fx_shift, double inflation, double pruning,
+                             hhx_csr **out, int64_t *n_products, int64_t *nnz_expanded);
+
 /* ---------------------------------------------------------------- S2: convergence + whole mcl()
  * :2044-2046  d = abs(M - last) - 1e-5*abs(last); *stat = max(0, d.max()) evaluated in float32. */
 int hhx_convergence_stat(const hhx_csr *m, const hhx_csr *last, float *stat);
@@ -91,6 +97,10 @@ int hhx_convergence_stat(const hhx_csr *m, const hhx_csr *last, float *stat);
  * iteration: nnz entering, nnz after expansion, nnz after pruning, number of products. */
 int hhx_mcl(const hhx_csr *pre_expanded, int expansion, double inflation, int max_iter, double pruning,
             hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
+/* run_mcl_clustering :2144-2158 for one inflation, starting from the L1-normalised link matrix: the
+ * pre-expansion (:2146-2147) is fused into iteration 0 instead of being materialised. */
+int hhx_mcl_normalized(const hhx_csr *normalized, int expansion, double inflation, int max_iter, double pruning,
+                       hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
 
 /* ---------------------------------------------------------------- a12: interpret_result :2065-2095
  * Array half: attractors (ascending) = rows with a non-zero diagonal; members of attractor a =

@@ -257,3 +257,52 @@ def test_ingest_random_vs_oracle_and_device_path():
     p, j, x = m.to_arrays()
     assert n_linked == rl and np.array_equal(fidx, ridx)
     assert np.array_equal(p, rp) and np.array_equal(j, rj) and np.array_equal(x, rx)
+
+
+def oracle_fused(A, B, infl, pruning=1e-4, shift=60):
+    c = orc.spgemm(A, B, n_cols=len(B[0]) - 1, mode=1, fx_shift=shift)
+    x = orc.normalize_l1(c[0], orc.power(c[2], infl))
+    return orc.prune((c[0], c[1], x), pruning), int(c[0][-1])
+
+
+@pytest.mark.parametrize('n,block,deg_in,deg_out,infl', [
+    (3000, 100, 20, 1, 2.0),        # window mode, one window
+    (40000, 400, 60, 1, 2.0),       # window mode, several column windows (n_cols > LDS capacity)
+    (40000, 50, 4, 0, 2.0),         # compact (bitmap-rank) mode
+    (5000, 100, 10, 2, 1.4),        # pow() path
+    (70000, 10, 2, 1, 3.0),         # tiny rows
+])
+def test_fused_expand_inflate_prune(n, block, deg_in, deg_out, infl):
+    A = clustered_stochastic(n, block, deg_in, deg_out, 31)
+    d = _lib.DeviceCSR.from_arrays(*A)
+    p, f, nnz_c = _lib.expand_inflate_prune(d, d, infl, 1e-4)
+    ref, ref_nnz_c = oracle_fused(A, A, infl)
+    got = p.to_arrays()
+    assert nnz_c == ref_nnz_c
+    assert f == int(np.diff(A[0])[A[1]].sum())
+    assert_close_csr(got, ref, RTOL, 'fused iteration')
+    # row-block (multi-GPU shard) gives the same rows
+    r0, r1 = n // 3, n // 3 + n // 5
+    pb, _, _ = _lib.expand_inflate_prune(d.row_block(r0, r1), d, infl, 1e-4)
+    gb = pb.to_arrays()
+    lo, hi = got[0][r0], got[0][r1]
+    assert np.array_equal(gb[0], got[0][r0:r1 + 1] - lo)
+    assert np.array_equal(gb[1], got[1][lo:hi]) and np.array_equal(gb[2], got[2][lo:hi])
+    # deterministic
+    p2, _, _ = _lib.expand_inflate_prune(d, d, infl, 1e-4)
+    assert all(np.array_equal(x, y) for x, y in zip(p2.to_arrays(), got))
+
+
+def test_mcl_normalized_fuses_pre_expansion(golden_mcl):
+    g = golden_mcl
+    for tag in g['cases']:
+        infl = float(g[tag + '_inflation'])
+        niter = int(g[tag + '_niter'])
+        norm = _lib.DeviceCSR.from_arrays(*tri(g, tag + '_norm'))
+        res, n_iter, conv, stats = _lib.mcl(norm, 2, infl, 200, 1e-4, want_stats=True, normalized=True)
+        assert conv and n_iter == niter
+        assert_close_csr(res.to_arrays(), tri(g, '%s_it%d' % (tag, niter - 1)), 1e-5, str(tag) + ' final')
+        want = {tuple(g[tag + '_clusters'][g[tag + '_clusters_ptr'][a]:g[tag + '_clusters_ptr'][a + 1]].tolist())
+                for a in range(len(g[tag + '_clusters_ptr']) - 1)}
+        assert clusters_of(*_lib.interpret(res)) == want
+        assert stats[0, 0] == len(g[tag + '_norm_j']) and stats[0, 1] == len(g[tag + '_m2_j']) and stats[0, 3] > 0

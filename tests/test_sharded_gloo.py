@@ -40,6 +40,10 @@ class OracleEngine:
         x = orc.normalize_l1(c[0], orc.power(c[2], inflation))
         return orc.prune((c[0], c[1], x), pruning)
 
+    def expand_inflate_prune(self, a, b, inflation, pruning):
+        c, f = self.spgemm(a, b)
+        return self.inflate_prune(c, inflation, pruning), f, int(c[0][-1])
+
     def convergence_stat(self, m, last):
         return orc.convergence_stat(m, last)
 
@@ -125,7 +129,9 @@ def test_sharded_mcl_and_merge_world2():
     for rank, res, n_iter, conv, stats, merged in outs:
         assert (n_iter, conv) == (o[3], o[4])
         assert all(np.array_equal(x, y) for x, y in zip(res, o[:3])), 'sharded MCL is not bit-identical to 1 process'
-        assert np.array_equal(stats, o[5])
+        # iteration 0 of the sharded driver includes the fused pre-expansion: nnz entering = nnz(T), F > 0
+        assert np.array_equal(stats[1:], o[5][1:]) and np.array_equal(stats[0, 1:3], o[5][0, 1:3])
+        assert stats[0, 0] == T[0][-1] and stats[0, 3] == int(np.diff(T[0])[T[1]].sum())
     gen = synth.make_genome(3, 400_000, 10_000, seed=2)
     n = gen.n
     lex = gen.lexical_rank()
