@@ -79,7 +79,7 @@ def main():
 
     def step():
         t0 = time.perf_counter()
-        ing = _lib.Ingest(table, flank, bins=False, skip_intra=True, expected_keys=state.get('keys_hint', 1 << 25))
+        ing = _lib.Ingest(table, flank, bins=False, skip_intra=True, expected_keys=state.get('keys_hint', min(args.pairs, n * (n + 1) // 2)))
         ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
         n_full, n_flank = ing.finalize()
         if world > 1:
