@@ -1,10 +1,9 @@
 #!/bin/bash
-# first GPU pass: parity tests, smoke, bench, kernel trace
+# GPU pass 2: kernel trace of the C2 bench, then the C3 (100k contigs / 500M pairs) probe
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-rocminfo | grep -E "Marketing Name|gfx" | head -4 > gpurun_out/rocminfo.txt 2>&1
-nproc >> gpurun_out/rocminfo.txt; lscpu | grep "Model name" >> gpurun_out/rocminfo.txt
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-timeout 240 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
-timeout 600 python bench.py --steps 2 --warmup 1 > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log
-tail -5 gpurun_out/pytest_gpu.log; tail -3 gpurun_out/smoke.log; tail -c 3000 gpurun_out/bench.log
+cd $GRAFT_REPO_ROOT
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c2 -o c2 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_c2.log 2>&1; echo "rc=$?" >> gpurun_out/prof_c2.log
+ls -R gpurun_out/prof_c2 | head -30
+timeout 900 python bench.py --contigs 100000 --pairs 500000000 --nchrs 24 --mean-len 30000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/bench_c3.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3.log
+tail -c 6000 gpurun_out/bench_c3.log
