@@ -8,10 +8,13 @@ and mcl() at inflation 2.0 (:2026-2062), attractor read-out.
 metric/value  : Hi-C pairs/s through the link-matrix build (ingest + finalise + dict_to_matrix), the
                 first half of BASELINE.json's metric; the second half (MCL iterations/s) is reported
                 in the "mcl" object of the same JSON line.
-workload (N=1): BASELINE.json configs[1] — 10k contigs / 50M synthetic pairs, inflation 2.0,
-                dense-block off.  N>1: weak scaling, every rank ingests its own 50M-pair shard of the
-                same assembly; the link tables are merged with one exchange and the MCL row blocks
-                are all-gathered every iteration (haphic_amd/sharded.py).
+workload (N=1): the configuration BASELINE.json's metric is quoted on ("@100k contigs"), configs[2]:
+                100k contigs / 500M synthetic pairs, inflation 2.0 — it fits one MI355X (8 GB of pairs,
+                ~45 GB of tables).  configs[1] (10k / 50M): --contigs 10000 --pairs 50000000 --nchrs 16
+                --mean-len 50000.  N>1: STRONG scaling of the same job ("1->8 MI355X row-block shard"):
+                rank r ingests the r-th contiguous chunk of the 500M-pair stream, the link tables are
+                merged with one exchange, and the MCL row blocks are all-gathered every iteration
+                (haphic_amd/sharded.py).
 """
 import argparse
 import json
@@ -31,12 +34,12 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s a
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--contigs', type=int, default=10000)
-    ap.add_argument('--pairs', type=int, default=50_000_000)
-    ap.add_argument('--nchrs', type=int, default=16)
-    ap.add_argument('--mean-len', type=int, default=50_000)
+    ap.add_argument('--contigs', type=int, default=100000)
+    ap.add_argument('--pairs', type=int, default=500_000_000, help='total pairs of the job (split over ranks)')
+    ap.add_argument('--nchrs', type=int, default=24)
+    ap.add_argument('--mean-len', type=int, default=30_000)
     ap.add_argument('--inflation', type=float, default=2.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-pairs', type=int, default=20_000_000)
@@ -69,7 +72,8 @@ def main():
     table = FragTable.for_contigs(lex, gen.length, np.ones(n, np.uint8))
     flank = 500_000                                   # --flank 500 (kb), HapHiC_cluster.py default
     # this rank's shard of the read-pair stream, generated straight into HBM
-    id1, p1, id2, p2 = synth.sample_pairs(gen, args.pairs, seed=12345 + rank, device=dev)
+    local_pairs = args.pairs // world
+    id1, p1, id2, p2 = synth.sample_pairs(gen, local_pairs, seed=12345 + rank, device=dev)
     torch.cuda.synchronize()
     in_set = np.ones(n, np.uint8)
 
@@ -79,7 +83,7 @@ def main():
 
     def step():
         t0 = time.perf_counter()
-        ing = _lib.Ingest(table, flank, bins=False, skip_intra=True, expected_keys=state.get('keys_hint', min(args.pairs, n * (n + 1) // 2)))
+        ing = _lib.Ingest(table, flank, bins=False, skip_intra=True, expected_keys=state.get('keys_hint', min(local_pairs, n * (n + 1) // 2)))
         ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
         n_full, n_flank = ing.finalize()
         if world > 1:
@@ -140,13 +144,13 @@ def main():
 
     if rank == 0:
         K = args.steps
-        pairs_total = args.pairs * world * K
+        pairs_total = local_pairs * world * K
         value = pairs_total / t_ing
         stats = np.asarray(state['stats'])
         # ---- roofline of the dominant kernel of the headline metric: k_ingest
         ing_ms, ing_n = _lib.profile_get('ingest')
         # 16 B read per pair + 12 B written per distinct key of each table + 4 B per fragment
-        alg_bytes = 16.0 * args.pairs + 12.0 * (state['n_full'] + state['n_flank']) + 4.0 * n
+        alg_bytes = 16.0 * local_pairs + 12.0 * (state['n_full'] + state['n_flank']) + 4.0 * n
         ach = alg_bytes / (ing_ms / max(ing_n, 1) * 1e-3) / 1e9 if ing_ms else None
         roofline = {'kernel': 'k_ingest', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': (ach / HBM_PEAK_GBS) if ach else None, 'traffic': None,
@@ -177,11 +181,11 @@ def main():
                                            'launches_per_step': (num_n + sym_n) / K}}
         out = {'metric': 'Hi-C pairs/s ingested (link-matrix build) + MCL iters/s', 'value': value, 'unit': 'pairs/s',
                'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': elapsed / K * 1e3,
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int32 keys / u64 fixed-point + f32 values',
+               'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int32 keys / u64 fixed-point + f32 values',
                'data': 'synthetic',
-               'config': {'workload': 'C2: %d contigs / %d pairs per GPU, %d chr, mean contig %d bp, inflation %.1f, dense-block off'
-                                      % (n, args.pairs, args.nchrs, args.mean_len, args.inflation),
-                          'contigs': int(n), 'pairs_per_gpu': args.pairs, 'full_keys': int(state['n_full']),
+               'config': {'workload': '%d contigs / %d pairs (whole job, %d per GPU), %d chr, mean contig %d bp, inflation %.1f, dense-block off'
+                                      % (n, local_pairs * world, local_pairs, args.nchrs, args.mean_len, args.inflation),
+                          'contigs': int(n), 'pairs_per_gpu': local_pairs, 'full_keys': int(state['n_full']),
                           'flank_keys': int(state['n_flank']), 'link_matrix_nnz': int(state['nnz_link'])},
                'ingest_ms_per_step': t_ing / K * 1e3, 'mcl': mcl, 'roofline': roofline}
         if not args.no_cpu_baseline:

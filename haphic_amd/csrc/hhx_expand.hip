@@ -27,10 +27,15 @@ int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
 
 namespace {
 
-constexpr int EX_T = 512;           // 8 waves: the window kernel often runs one workgroup per CU
-constexpr int EX_WAVES = EX_T / HHX_WAVE;
-constexpr int STAGE = 512;          // staged A entries per chunk
-constexpr int MAX_WIN = 512;
+constexpr int EX_T_WIN = 1024;      // window kernel: 16 waves, one workgroup per CU (it owns all of LDS) — the B-row
+                                    // stream is latency-bound, so as many loads in flight as the CU can hold
+constexpr int EX_T_CMP = 256;       // compact kernel: light rows, several workgroups per CU
+constexpr int EX_T_MAX = 1024;
+constexpr int EX_WAVES_MAX = EX_T_MAX / HHX_WAVE;
+#define EX_T ((int)blockDim.x)      // device code below is written for either width
+#define EX_WAVES ((int)blockDim.x / HHX_WAVE)
+constexpr int STAGE = 1024;         // staged A entries per chunk
+constexpr int MAX_WIN = 128;
 
 struct ExParams {
     const i32 *Ap, *Aj; const float *Ax;
@@ -43,22 +48,23 @@ struct ExParams {
     i32 *out_col; float *out_val; i64 out_cap;
     unsigned long long *cursors;    // [0] cand cursor [1] out cursor [2] overflow flag [3] nnz_C [4] products
     i64 *row_off; i32 *row_cnt;
+    const i32 *win_ptr; i32 n_win;  // [n_rows(B)][n_win + 1] split points of every B row at the column windows
 };
 
 struct ExLds {
     i64 *acc;            // [cap]
     double *st_da;       // [STAGE]
     i32 *st_qb, *st_qe;  // [STAGE]
-    double *red_d;       // [EX_T]
-    i32 *red_i;          // [EX_T]
-    float *red_f;        // [EX_T]
+    double *red_d;       // [EX_WAVES_MAX]
+    i32 *red_i;          // [EX_WAVES_MAX]
+    float *red_f;        // [EX_WAVES_MAX]
     i64 *win_off;        // [MAX_WIN]
     i32 *win_cnt;        // [MAX_WIN]
     u32 *bitmap, *prefix;  // [W] each (compact mode only)
 };
 
 __host__ __device__ inline size_t ex_fixed_bytes(i32 W) {
-    return (size_t)STAGE * (8 + 4 + 4) + (size_t)EX_T * (8 + 4 + 4) + (size_t)MAX_WIN * (8 + 4) + (size_t)W * 8;
+    return (size_t)STAGE * (8 + 4 + 4) + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + (size_t)MAX_WIN * (8 + 4) + (size_t)W * 8;
 }
 
 __device__ __forceinline__ ExLds ex_carve(unsigned char *smem, i32 cap, i32 W) {
@@ -66,12 +72,12 @@ __device__ __forceinline__ ExLds ex_carve(unsigned char *smem, i32 cap, i32 W) {
     unsigned char *p = smem;
     l.acc = (i64 *)p; p += (size_t)cap * 8;
     l.st_da = (double *)p; p += STAGE * 8;
-    l.red_d = (double *)p; p += EX_T * 8;
+    l.red_d = (double *)p; p += EX_WAVES_MAX * 8;
     l.win_off = (i64 *)p; p += MAX_WIN * 8;
     l.st_qb = (i32 *)p; p += STAGE * 4;
     l.st_qe = (i32 *)p; p += STAGE * 4;
-    l.red_i = (i32 *)p; p += EX_T * 4;
-    l.red_f = (float *)p; p += EX_T * 4;
+    l.red_i = (i32 *)p; p += EX_WAVES_MAX * 4;
+    l.red_f = (float *)p; p += EX_WAVES_MAX * 4;
     l.win_cnt = (i32 *)p; p += MAX_WIN * 4;
     l.bitmap = (u32 *)p; p += (size_t)W * 4;
     l.prefix = (u32 *)p;
@@ -97,7 +103,6 @@ __device__ __forceinline__ double block_sum_f64(double v, double *red) {
     if (lane_id() == 0) red[threadIdx.x / HHX_WAVE] = v;
     __syncthreads();
     double s = red[0];
-#pragma unroll
     for (int k = 1; k < EX_WAVES; ++k) s += red[k];
     return s;
 }
@@ -107,7 +112,6 @@ __device__ __forceinline__ i32 block_sum_i32(i32 v, i32 *red) {
     if (lane_id() == 0) red[threadIdx.x / HHX_WAVE] = v;
     __syncthreads();
     i32 s = red[0];
-#pragma unroll
     for (int k = 1; k < EX_WAVES; ++k) s += red[k];
     return s;
 }
@@ -125,7 +129,6 @@ __device__ __forceinline__ i32 block_excl_scan_i32(i32 v, i32 *red, i32 *total) 
     const int w = threadIdx.x / HHX_WAVE;
     i32 off = 0;
     i32 tot = 0;
-#pragma unroll
     for (int k = 0; k < EX_WAVES; ++k) { if (k < w) off += red[k]; tot += red[k]; }
     *total = tot;
     return off + incl - v;
@@ -149,14 +152,14 @@ __device__ __forceinline__ void block_argmax(float &q, i32 &c, float *redf, i32 
 // ---- stage one chunk of the A row: (a * scale, begin, end) of every referenced B row, optionally
 // narrowed to the column window [c0, c1)
 template <bool NARROW>
-__device__ __forceinline__ void stage_chunk(const ExParams &P, const ExLds &l, i32 a0, i32 len, i32 c0, i32 c1) {
+__device__ __forceinline__ void stage_chunk(const ExParams &P, const ExLds &l, i32 a0, i32 len, i32 wv) {
     for (i32 t = threadIdx.x; t < len; t += EX_T) {
         const i32 k = P.Aj[a0 + t];
-        i32 qb = P.Bp[k], qe = P.Bp[k + 1];
-        if (NARROW) {
-            qb = lower_bound_i32(P.Bj, qb, qe, c0);
-            qe = lower_bound_i32(P.Bj, qb, qe, c1);
-        }
+        i32 qb, qe;
+        if (NARROW) {       // B row k restricted to column window wv: precomputed split points (k_window_ptrs)
+            const i32 *wp = P.win_ptr + (size_t)k * (P.n_win + 1) + wv;
+            qb = wp[0]; qe = wp[1];
+        } else { qb = P.Bp[k]; qe = P.Bp[k + 1]; }
         l.st_da[t] = (double)P.Ax[a0 + t] * P.scale;
         l.st_qb[t] = qb;
         l.st_qe[t] = qe;
@@ -171,16 +174,26 @@ __device__ __forceinline__ void accumulate_window(const ExParams &P, const ExLds
         const double da = l.st_da[e];
         const i32 qb = l.st_qb[e], qe = l.st_qe[e];
         i32 q = qb + lane;
-        for (; q + 3 * HHX_WAVE < qe; q += 4 * HHX_WAVE) {      // 4 independent index+value loads in flight
-            const i32 j0 = P.Bj[q], j1 = P.Bj[q + HHX_WAVE], j2 = P.Bj[q + 2 * HHX_WAVE], j3 = P.Bj[q + 3 * HHX_WAVE];
-            const float b0 = P.Bx[q], b1 = P.Bx[q + HHX_WAVE], b2 = P.Bx[q + 2 * HHX_WAVE], b3 = P.Bx[q + 3 * HHX_WAVE];
-            atomicAdd((unsigned long long *)&l.acc[j0 - c0], (unsigned long long)(i64)(da * (double)b0));
-            atomicAdd((unsigned long long *)&l.acc[j1 - c0], (unsigned long long)(i64)(da * (double)b1));
-            atomicAdd((unsigned long long *)&l.acc[j2 - c0], (unsigned long long)(i64)(da * (double)b2));
-            atomicAdd((unsigned long long *)&l.acc[j3 - c0], (unsigned long long)(i64)(da * (double)b3));
+        for (; q + 7 * HHX_WAVE < qe; q += 8 * HHX_WAVE) {      // 8 independent index+value loads in flight
+            i32 j[8]; float b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { j[u] = P.Bj[q + u * HHX_WAVE]; b[u] = P.Bx[q + u * HHX_WAVE]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                atomicAdd((unsigned long long *)&l.acc[j[u] - c0], (unsigned long long)(i64)(da * (double)b[u]));
         }
-        for (; q < qe; q += HHX_WAVE)
-            atomicAdd((unsigned long long *)&l.acc[P.Bj[q] - c0], (unsigned long long)(i64)(da * (double)P.Bx[q]));
+        if (q < qe) {                                          // tail: up to 7 predicated loads, still issued together
+            i32 j[7]; float b[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const i32 qq = q + u * HHX_WAVE;
+                j[u] = qq < qe ? P.Bj[qq] : -1;
+                b[u] = qq < qe ? P.Bx[qq] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                if (j[u] >= 0) atomicAdd((unsigned long long *)&l.acc[j[u] - c0], (unsigned long long)(i64)(da * (double)b[u]));
+        }
     }
 }
 // compact mode: mark, then acc[rank(c)] += fixed(a * b)
@@ -410,12 +423,12 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
 }
 
 // ---- the two kernels ----------------------------------------------------------------------------
-__global__ __launch_bounds__(EX_T) void k_expand_window(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap) {
+__global__ __launch_bounds__(EX_T_WIN) void k_expand_window(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ExLds l = ex_carve(smem, cap, 0);
     const int tid = threadIdx.x;
     i64 nnzc = 0;
-    const i32 n_win = (P.n_cols + cap - 1) / cap;
+    const i32 n_win = P.n_win;
     for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
         const i32 row = rows[li];
         const i32 a_b = P.Ap[row], a_e = P.Ap[row + 1];
@@ -426,8 +439,8 @@ __global__ __launch_bounds__(EX_T) void k_expand_window(ExParams P, const i32 *_
             __syncthreads();
             for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
                 const i32 len = min(STAGE, a_e - a0);
-                if (n_win > 1) stage_chunk<true>(P, l, a0, len, c0, c1);
-                else stage_chunk<false>(P, l, a0, len, c0, c1);
+                if (n_win > 1) stage_chunk<true>(P, l, a0, len, wv);
+                else stage_chunk<false>(P, l, a0, len, wv);
                 __syncthreads();
                 accumulate_window(P, l, len, c0);
                 __syncthreads();
@@ -446,7 +459,7 @@ __global__ __launch_bounds__(EX_T) void k_expand_window(ExParams P, const i32 *_
     if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
 }
 
-__global__ __launch_bounds__(EX_T) void k_expand_compact(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 W) {
+__global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ExLds l = ex_carve(smem, cap, W);
     const int tid = threadIdx.x;
@@ -458,7 +471,7 @@ __global__ __launch_bounds__(EX_T) void k_expand_compact(ExParams P, const i32 *
         __syncthreads();
         for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
             const i32 len = min(STAGE, a_e - a0);
-            stage_chunk<false>(P, l, a0, len, 0, 0);
+            stage_chunk<false>(P, l, a0, len, 0);
             __syncthreads();
             mark_compact(P, l, len);
             __syncthreads();
@@ -473,7 +486,7 @@ __global__ __launch_bounds__(EX_T) void k_expand_compact(ExParams P, const i32 *
             __syncthreads();
             for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
                 const i32 len = min(STAGE, a_e - a0);
-                stage_chunk<false>(P, l, a0, len, 0, 0);
+                stage_chunk<false>(P, l, a0, len, 0);
                 __syncthreads();
                 accumulate_compact(P, l, len, r0, rlen);
                 __syncthreads();
@@ -510,6 +523,17 @@ __global__ __launch_bounds__(256) void k_classify(i32 n_rows, const i32 *__restr
         }
     }
     if (lane == 0 && total) atomicAdd(&cursors[4], (unsigned long long)total);
+}
+
+// ---- split points of every B row at the column-window boundaries (window kernel, n_win > 1) -------------
+__global__ __launch_bounds__(256) void k_window_ptrs(i32 n_rows, const i32 *__restrict__ Bp, const i32 *__restrict__ Bj,
+                                                     i32 cap, i32 n_win, i32 *__restrict__ out) {
+    const i64 total = (i64)n_rows * (n_win + 1);
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+        const i32 k = (i32)(t / (n_win + 1)), w = (i32)(t % (n_win + 1));
+        const i32 qb = Bp[k], qe = Bp[k + 1];
+        out[t] = w == 0 ? qb : (w == n_win ? qe : lower_bound_i32(Bj, qb, qe, w * cap));
+    }
 }
 
 // ---- pack the bump-allocated rows into CSR order ---------------------------------------------------
@@ -561,6 +585,15 @@ extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int 
     DevBuf<unsigned long long> cursors;
     if (list_w.alloc((size_t)n_rows + 1) || list_c.alloc((size_t)n_rows + 1) || row_cnt.alloc((size_t)n_rows + 1) ||
         indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || counts.alloc(2) || cursors.alloc(8)) return 1;
+    const i32 n_win = (n_cols + cap_win - 1) / cap_win;
+    DevBuf<i32> win_ptr;
+    if (n_win > 1) {
+        if (win_ptr.alloc((size_t)b->n_rows * (n_win + 1))) return 1;
+        const i64 total = (i64)b->n_rows * (n_win + 1);
+        k_window_ptrs<<<(unsigned)std::min<i64>((total + 255) / 256, 65536), 256, 0, g_stream>>>(b->n_rows, b->indptr.p, b->indices.p,
+                                                                                             cap_win, n_win, win_ptr.p);
+        HHX_LAUNCH_CHECK();
+    }
     i64 pool_cap = std::max<i64>(4 * a->nnz + 16 * (i64)n_rows, (i64)1 << 22);
     for (int attempt = 0; attempt < 6; ++attempt) {
         DevBuf<i32> cand_col, out_col;
@@ -584,16 +617,17 @@ extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int 
         P.cand_col = cand_col.p; P.cand_val = cand_val.p; P.cand_cap = pool_cap;
         P.out_col = out_col.p; P.out_val = out_val.p; P.out_cap = pool_cap;
         P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
+        P.win_ptr = win_ptr.p; P.n_win = n_win;
         if (hc[0]) {
             KTimer kt("expand_window");
             const unsigned per_cu = lds_win > 80 * 1024 ? 1 : 2;
-            k_expand_window<<<std::min<unsigned>(hc[0], 256 * per_cu), EX_T, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win);
+            k_expand_window<<<std::min<unsigned>(hc[0], 256 * per_cu), EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win);
         }
         HHX_LAUNCH_CHECK();
         if (hc[1]) {
             KTimer kt("expand_compact");
             const unsigned per_cu = lds_cmp > 80 * 1024 ? 1 : 2;
-            k_expand_compact<<<std::min<unsigned>(hc[1], 256 * per_cu * 4), EX_T, lds_cmp, g_stream>>>(P, list_c.p, (i32)hc[1], cap_cmp, W);
+            k_expand_compact<<<std::min<unsigned>(hc[1], 256 * per_cu * 4), EX_T_CMP, lds_cmp, g_stream>>>(P, list_c.p, (i32)hc[1], cap_cmp, W);
         }
         HHX_LAUNCH_CHECK();
         unsigned long long cur[8];
