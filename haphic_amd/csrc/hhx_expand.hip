@@ -35,7 +35,7 @@ constexpr int EX_WAVES_MAX = EX_T_MAX / HHX_WAVE;
 #define EX_T ((int)blockDim.x)      // device code below is written for either width
 #define EX_WAVES ((int)blockDim.x / HHX_WAVE)
 constexpr int STAGE = 1024;         // staged A entries per chunk
-constexpr int MAX_WIN = 128;
+constexpr int MAX_WIN = 512;
 
 struct ExParams {
     const i32 *Ap, *Aj; const float *Ax;
@@ -49,6 +49,9 @@ struct ExParams {
     unsigned long long *cursors;    // [0] cand cursor [1] out cursor [2] overflow flag [3] nnz_C [4] products
     i64 *row_off; i32 *row_cnt;
     const i32 *win_ptr; i32 n_win;  // [n_rows(B)][n_win + 1] split points of every B row at the column windows
+    // window class, one launch per column window: per-row state carried between the launches
+    double *s_run;                  // [n_rows] running sum of p over the windows done so far
+    i64 *g_win_off; i32 *g_win_cnt; // [n_rows][n_win] candidate segment of every (row, window)
 };
 
 struct ExLds {
@@ -168,32 +171,54 @@ __device__ __forceinline__ void stage_chunk(const ExParams &P, const ExLds &l, i
 
 // ---- inner loops -------------------------------------------------------------------------------
 // window mode: acc[c - c0] += fixed(a * b)
+// A wave walks its staged B-row segments (wave, wave + nw, ...) as a sequence of TILES of up to U * 64
+// consecutive entries and keeps two tiles in flight: the loads of tile t+1 are issued before the LDS
+// atomics of tile t, so a wave never sits out a full memory round trip per segment (segments are short
+// when the row is cut into many column windows).  All cursor state is wave-uniform.
+constexpr int TILE_U = 8;
+struct SegCursor {
+    i32 e, q, qe; double da; bool valid;
+};
+__device__ __forceinline__ void seg_open(const ExLds &l, SegCursor &c, i32 len) {
+    c.valid = c.e < len;
+    if (c.valid) { c.da = l.st_da[c.e]; c.q = l.st_qb[c.e]; c.qe = l.st_qe[c.e]; }
+}
+struct Tile {
+    i32 j[TILE_U]; float b[TILE_U]; double da; bool valid;
+};
+__device__ __forceinline__ void tile_fetch(const ExParams &P, const ExLds &l, SegCursor &c, i32 len, Tile &t) {
+    t.valid = c.valid;
+    if (!c.valid) return;
+    t.da = c.da;
+    const i32 q0 = c.q + lane_id();
+#pragma unroll
+    for (int u = 0; u < TILE_U; ++u) {
+        const i32 qq = q0 + u * HHX_WAVE;
+        const bool in = qq < c.qe;
+        t.j[u] = in ? P.Bj[qq] : -1;
+        t.b[u] = in ? P.Bx[qq] : 0.0f;
+    }
+    c.q += TILE_U * HHX_WAVE;
+    if (c.q >= c.qe) { c.e += EX_WAVES; seg_open(l, c, len); }
+}
+__device__ __forceinline__ void tile_consume(const ExLds &l, const Tile &t, i32 c0) {
+#pragma unroll
+    for (int u = 0; u < TILE_U; ++u)
+        if (t.j[u] >= 0) atomicAdd((unsigned long long *)&l.acc[t.j[u] - c0], (unsigned long long)(i64)(t.da * (double)t.b[u]));
+}
 __device__ __forceinline__ void accumulate_window(const ExParams &P, const ExLds &l, i32 len, i32 c0) {
-    const int lane = lane_id(), wave = threadIdx.x / HHX_WAVE;
-    for (i32 e = wave; e < len; e += EX_WAVES) {
-        const double da = l.st_da[e];
-        const i32 qb = l.st_qb[e], qe = l.st_qe[e];
-        i32 q = qb + lane;
-        for (; q + 7 * HHX_WAVE < qe; q += 8 * HHX_WAVE) {      // 8 independent index+value loads in flight
-            i32 j[8]; float b[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { j[u] = P.Bj[q + u * HHX_WAVE]; b[u] = P.Bx[q + u * HHX_WAVE]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                atomicAdd((unsigned long long *)&l.acc[j[u] - c0], (unsigned long long)(i64)(da * (double)b[u]));
-        }
-        if (q < qe) {                                          // tail: up to 7 predicated loads, still issued together
-            i32 j[7]; float b[7];
-#pragma unroll
-            for (int u = 0; u < 7; ++u) {
-                const i32 qq = q + u * HHX_WAVE;
-                j[u] = qq < qe ? P.Bj[qq] : -1;
-                b[u] = qq < qe ? P.Bx[qq] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 7; ++u)
-                if (j[u] >= 0) atomicAdd((unsigned long long *)&l.acc[j[u] - c0], (unsigned long long)(i64)(da * (double)b[u]));
-        }
+    SegCursor c;
+    c.e = threadIdx.x / HHX_WAVE;
+    c.q = c.qe = 0; c.da = 0.0;
+    seg_open(l, c, len);
+    Tile ta, tb;
+    tile_fetch(P, l, c, len, ta);
+    while (ta.valid) {
+        tile_fetch(P, l, c, len, tb);
+        tile_consume(l, ta, c0);
+        if (!tb.valid) break;
+        tile_fetch(P, l, c, len, ta);
+        tile_consume(l, tb, c0);
     }
 }
 // compact mode: mark, then acc[rank(c)] += fixed(a * b)
@@ -287,7 +312,7 @@ struct BitWalk {
 // the window maximum) in column order; returns their count (uniform) and records (offset,count)
 template <bool COMPACT>
 __device__ __forceinline__ void window_emit_candidates(const ExParams &P, const ExLds &l, i32 wlen, i32 c0, i32 r0,
-                                                       double s_run, i32 win_idx) {
+                                                       double s_run, i64 *seg_off, i32 *seg_cnt) {
     const int tid = threadIdx.x;
     const i32 per = (wlen + EX_T - 1) / EX_T;
     const i32 s0 = min(wlen, tid * per), s1 = min(wlen, s0 + per);
@@ -312,11 +337,12 @@ __device__ __forceinline__ void window_emit_candidates(const ExParams &P, const 
             base = (i64)atomicAdd(&P.cursors[0], (unsigned long long)total);
             if (base + total > P.cand_cap) { atomicExch(&P.cursors[2], 1ull); base = -1; }
         }
-        l.win_off[win_idx] = base;
-        l.win_cnt[win_idx] = base < 0 ? 0 : total;
+        *seg_off = base;                       // LDS (compact kernel) or HBM (window passes)
+        *seg_cnt = base < 0 ? 0 : total;
+        l.win_off[MAX_WIN - 1] = base;         // broadcast slot
     }
     __syncthreads();
-    const i64 base = l.win_off[win_idx];
+    const i64 base = l.win_off[MAX_WIN - 1];
     if (base < 0 || total == 0) return;
     // column of slot s0 in compact mode: find the (s0 + r0)-th set bit
     i32 w = 0; u32 bits = 0;
@@ -345,15 +371,16 @@ __device__ __forceinline__ void window_emit_candidates(const ExParams &P, const 
 }
 
 // ---- row finalisation over the candidate segments -------------------------------------------------
-__device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, i32 row, i32 n_win, double s1) {
+__device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, i32 row, i32 n_win, double s1,
+                                             const i64 *win_off, const i32 *win_cnt) {
     const int tid = threadIdx.x;
     __threadfence_block();
     __syncthreads();
     // pass A: first row maximum of q = float(p / S)
     float bq = -1.0f; i32 bc = 0x7fffffff;
     for (i32 wv = 0; wv < n_win; ++wv) {
-        const i64 base = l.win_off[wv];
-        const i32 cnt = l.win_cnt[wv];
+        const i64 base = win_off[wv];
+        const i32 cnt = win_cnt[wv];
         for (i32 t = tid; t < cnt; t += EX_T) {
             const float p = P.cand_val[base + t];
             const float q = s1 != 0.0 ? (float)((double)p / s1) : p;
@@ -366,8 +393,8 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
     i32 keep = 0;
     double s2 = 0.0;
     for (i32 wv = 0; wv < n_win; ++wv) {
-        const i64 base = l.win_off[wv];
-        const i32 cnt = l.win_cnt[wv];
+        const i64 base = win_off[wv];
+        const i32 cnt = win_cnt[wv];
         for (i32 t0 = 0; t0 < cnt; t0 += EX_T) {
             const i32 t = t0 + tid;
             double v = 0.0;
@@ -397,8 +424,8 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
     if (o < 0 || total == 0) return;
     // pass C: ordered write of (column, float(q / S2))
     for (i32 wv = 0; wv < n_win; ++wv) {
-        const i64 base = l.win_off[wv];
-        const i32 cnt = l.win_cnt[wv];
+        const i64 base = win_off[wv];
+        const i32 cnt = win_cnt[wv];
         for (i32 t0 = 0; t0 < cnt; t0 += EX_T) {
             const i32 t = t0 + tid;
             bool k = false;
@@ -423,40 +450,53 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
 }
 
 // ---- the two kernels ----------------------------------------------------------------------------
-__global__ __launch_bounds__(EX_T_WIN) void k_expand_window(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap) {
+// Window class.  The loop nest is WINDOW-OUTER: one launch per column window, every launch sweeping all
+// the rows.  While window w is being processed the only part of B that is read is its column slice
+// B[:, w] (nnz_B / n_win entries), which raises the Infinity Cache / L2 hit rate of the B-row stream
+// compared with a row-outer nest (measured at n = 100k, 6 windows: 1.59 s vs 1.76 s before tile
+// pipelining), and the per-row epilogue (finalize) becomes its own uniform launch.
+__global__ __launch_bounds__(EX_T_WIN) void k_expand_window_pass(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap,
+                                                                 i32 wv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ExLds l = ex_carve(smem, cap, 0);
     const int tid = threadIdx.x;
     i64 nnzc = 0;
     const i32 n_win = P.n_win;
+    const i32 c0 = wv * cap, c1 = min(P.n_cols, c0 + cap), wlen = c1 - c0;
     for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
         const i32 row = rows[li];
         const i32 a_b = P.Ap[row], a_e = P.Ap[row + 1];
-        double s_run = 0.0;
-        for (i32 wv = 0; wv < n_win; ++wv) {
-            const i32 c0 = wv * cap, c1 = min(P.n_cols, c0 + cap), wlen = c1 - c0;
-            for (i32 t = tid; t < wlen; t += EX_T) l.acc[t] = 0;
+        for (i32 t = tid; t < wlen; t += EX_T) l.acc[t] = 0;
+        __syncthreads();
+        for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
+            const i32 len = min(STAGE, a_e - a0);
+            if (n_win > 1) stage_chunk<true>(P, l, a0, len, wv);
+            else stage_chunk<false>(P, l, a0, len, wv);
             __syncthreads();
-            for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
-                const i32 len = min(STAGE, a_e - a0);
-                if (n_win > 1) stage_chunk<true>(P, l, a0, len, wv);
-                else stage_chunk<false>(P, l, a0, len, wv);
-                __syncthreads();
-                accumulate_window(P, l, len, c0);
-                __syncthreads();
-            }
-            i32 nz;
-            const double sw = window_power_sum<false>(P, l, wlen, &nz);
-            nnzc += nz;
-            s_run += sw;
-            window_emit_candidates<false>(P, l, wlen, c0, 0, s_run, wv);
+            accumulate_window(P, l, len, c0);
             __syncthreads();
         }
-        finalize_row(P, l, row, n_win, s_run);
+        i32 nz;
+        const double sw = window_power_sum<false>(P, l, wlen, &nz);
+        nnzc += nz;
+        const double s_run = (wv == 0 ? 0.0 : P.s_run[row]) + sw;        // windows are launched in order
+        window_emit_candidates<false>(P, l, wlen, c0, 0, s_run, &P.g_win_off[(size_t)row * n_win + wv],
+                                      &P.g_win_cnt[(size_t)row * n_win + wv]);
         __syncthreads();
+        if (tid == 0) P.s_run[row] = s_run;
     }
     nnzc = wave_sum_i64(nnzc);          // products are counted by the classification pass (cursors[4])
     if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
+}
+
+__global__ __launch_bounds__(EX_T_CMP) void k_expand_window_finalize(ExParams P, const i32 *__restrict__ rows, i32 n_list) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ExLds l = ex_carve(smem, 0, 0);
+    for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const i32 row = rows[li];
+        finalize_row(P, l, row, P.n_win, P.s_run[row], &P.g_win_off[(size_t)row * P.n_win], &P.g_win_cnt[(size_t)row * P.n_win]);
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 W) {
@@ -493,12 +533,12 @@ __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i
             }
             i32 nz;
             s_run += window_power_sum<true>(P, l, rlen, &nz);
-            window_emit_candidates<true>(P, l, rlen, 0, r0, s_run, n_win);
+            window_emit_candidates<true>(P, l, rlen, 0, r0, s_run, &l.win_off[n_win], &l.win_cnt[n_win]);
             __syncthreads();
         }
         if (nnz_row == 0) {
             if (tid == 0) { P.row_off[row] = 0; P.row_cnt[row] = 0; }
-        } else finalize_row(P, l, row, n_win, s_run);
+        } else finalize_row(P, l, row, n_win, s_run, l.win_off, l.win_cnt);
         __syncthreads();
     }
     nnzc = wave_sum_i64(nnzc);
@@ -559,33 +599,49 @@ extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int 
     if (fx_shift < 0 || fx_shift > 1000) fx_shift = 60;
     const i32 n_rows = a->n_rows, n_cols = b->n_cols;
     const i32 W = (n_cols + 31) / 32;
-    // LDS plans
+    // ---- plans
     const size_t fixed_win = ex_fixed_bytes(0), fixed_cmp = ex_fixed_bytes(W);
-    // window kernel: whole row in one window if it fits 64 KB (2 workgroups/CU), else the full 160 KB
-    i32 cap_win = (i32)((64 * 1024 - fixed_win) / 8) & ~63;
-    if (cap_win < n_cols) cap_win = (i32)((160 * 1024 - fixed_win) / 8) & ~63;
-    if (cap_win > n_cols) cap_win = (n_cols + 63) & ~63;
-    if ((n_cols + cap_win - 1) / cap_win > MAX_WIN - 1) return fail("expand: %d columns need too many LDS windows", n_cols);
+    // window class: the column window must fit LDS (8 B per column).  Measured on MI355X (n = 100k, 330M
+    // entries): the fewest, widest windows win — 6 windows 1.41 s, 13 windows 1.54 s, 27 windows 2.24 s —
+    // because the per-segment cost grows faster than the Infinity Cache hit rate of a narrower column slice
+    // B[:, w].  HHX_CACHE_SLICE_MB (MB of B per slice) forces more windows for experiments.
+    static const i64 slice_bytes = []() {
+        const char *e = getenv("HHX_CACHE_SLICE_MB");
+        const i64 mb = e ? atoll(e) : 0;
+        return mb > 0 ? mb << 20 : (i64)1 << 60;
+    }();
+    const i32 cap_max = (i32)((160 * 1024 - fixed_win) / 8) & ~63;
+    i64 n_win64 = ((i64)n_cols + cap_max - 1) / cap_max;
+    const i64 by_cache = (b->nnz * 8 + slice_bytes - 1) / slice_bytes;
+    const i64 widest = std::max<i64>(1, (i64)n_cols / 2048);           // never narrower than 2048 columns
+    n_win64 = std::max(n_win64, std::min(by_cache, widest));
+    i32 cap_win = (i32)((((i64)n_cols + n_win64 - 1) / n_win64 + 63) & ~63);
+    if (cap_win > cap_max) cap_win = cap_max;
+    const i32 n_win = (n_cols + cap_win - 1) / cap_win;
     size_t budget_cmp = 64 * 1024;
     if (fixed_cmp + 2048 * 8 > budget_cmp) budget_cmp = 160 * 1024;
     if (fixed_cmp + 1024 * 8 > budget_cmp) return fail("expand: %d columns exceed the LDS bitmap capacity", n_cols);
     const i32 cap_cmp = (i32)((budget_cmp - fixed_cmp) / 8) & ~63;
+    if (n_cols / 2 / cap_cmp + 2 > MAX_WIN - 1) return fail("expand: %d columns need too many LDS rank windows", n_cols);
     const size_t lds_win = (size_t)cap_win * 8 + fixed_win, lds_cmp = (size_t)cap_cmp * 8 + fixed_cmp;
     static bool attr_set = false;
     if (!attr_set) {
-        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_expand_compact, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    static const bool debug = getenv("HHX_DEBUG") != nullptr;
     // rows whose product count is well above the number of accumulator slots a dense sweep touches
     const i64 window_min = std::max<i64>(4096, (i64)n_cols / 2);
-    DevBuf<i32> list_w, list_c, row_cnt, indptr;
-    DevBuf<i64> row_off;
+    DevBuf<i32> list_w, list_c, row_cnt, indptr, g_win_cnt;
+    DevBuf<i64> row_off, g_win_off;
+    DevBuf<double> s_run;
     DevBuf<unsigned int> counts;
     DevBuf<unsigned long long> cursors;
     if (list_w.alloc((size_t)n_rows + 1) || list_c.alloc((size_t)n_rows + 1) || row_cnt.alloc((size_t)n_rows + 1) ||
-        indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || counts.alloc(2) || cursors.alloc(8)) return 1;
-    const i32 n_win = (n_cols + cap_win - 1) / cap_win;
+        indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || counts.alloc(2) || cursors.alloc(8) ||
+        s_run.alloc((size_t)n_rows + 1) || g_win_off.alloc((size_t)n_rows * n_win + 1) || g_win_cnt.alloc((size_t)n_rows * n_win + 1))
+        return 1;
     DevBuf<i32> win_ptr;
     if (n_win > 1) {
         if (win_ptr.alloc((size_t)b->n_rows * (n_win + 1))) return 1;
@@ -594,11 +650,13 @@ extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int 
                                                                                              cap_win, n_win, win_ptr.p);
         HHX_LAUNCH_CHECK();
     }
+    // candidate pool: early windows test against a partial row sum and admit more than finally survive
     i64 pool_cap = std::max<i64>(4 * a->nnz + 16 * (i64)n_rows, (i64)1 << 22);
+    i64 cand_cap = n_win > 1 ? 2 * pool_cap : pool_cap;
     for (int attempt = 0; attempt < 6; ++attempt) {
         DevBuf<i32> cand_col, out_col;
         DevBuf<float> cand_val, out_val;
-        if (cand_col.alloc((size_t)pool_cap) || cand_val.alloc((size_t)pool_cap) || out_col.alloc((size_t)pool_cap) ||
+        if (cand_col.alloc((size_t)cand_cap) || cand_val.alloc((size_t)cand_cap) || out_col.alloc((size_t)pool_cap) ||
             out_val.alloc((size_t)pool_cap)) return 1;
         HHX_HIP(hipMemsetAsync(counts.p, 0, 2 * sizeof(unsigned int), g_stream));
         HHX_HIP(hipMemsetAsync(cursors.p, 0, 8 * sizeof(unsigned long long), g_stream));
@@ -614,14 +672,18 @@ extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int 
         P.n_rows = n_rows; P.n_cols = n_cols;
         P.scale = ldexp(1.0, fx_shift); P.inv_scale = ldexp(1.0, -fx_shift);
         P.r = (double)(float)inflation; P.square = inflation == 2.0; P.thr = (float)pruning;
-        P.cand_col = cand_col.p; P.cand_val = cand_val.p; P.cand_cap = pool_cap;
+        P.cand_col = cand_col.p; P.cand_val = cand_val.p; P.cand_cap = cand_cap;
         P.out_col = out_col.p; P.out_val = out_val.p; P.out_cap = pool_cap;
         P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
         P.win_ptr = win_ptr.p; P.n_win = n_win;
+        P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
         if (hc[0]) {
             KTimer kt("expand_window");
             const unsigned per_cu = lds_win > 80 * 1024 ? 1 : 2;
-            k_expand_window<<<std::min<unsigned>(hc[0], 256 * per_cu), EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win);
+            for (i32 wv = 0; wv < n_win; ++wv)
+                k_expand_window_pass<<<std::min<unsigned>(hc[0], 256 * per_cu), EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0],
+                                                                                                           cap_win, wv);
+            k_expand_window_finalize<<<std::min<unsigned>(hc[0], 256 * 8), EX_T_CMP, fixed_win, g_stream>>>(P, list_w.p, (i32)hc[0]);
         }
         HHX_LAUNCH_CHECK();
         if (hc[1]) {
@@ -633,8 +695,13 @@ extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int 
         unsigned long long cur[8];
         HHX_HIP(hipMemcpyAsync(cur, cursors.p, sizeof cur, hipMemcpyDeviceToHost, g_stream));
         HHX_HIP(hipStreamSynchronize(g_stream));
-        if (cur[2]) {                                  // a pool overflowed: grow and redo the launch
-            pool_cap = std::max<i64>(pool_cap * 2, (i64)std::max(cur[0], cur[1]) + (i64)n_rows);
+        if (debug)
+            fprintf(stderr, "[hhx expand] %d x %d, nnzA %lld nnzB %lld: window rows %u (n_win %d x %d cols, lds %zu), compact rows %u; "
+                    "candidates %llu / %lld, survivors %llu / %lld%s\n", n_rows, n_cols, (long long)a->nnz, (long long)b->nnz, hc[0], n_win,
+                    cap_win, lds_win, hc[1], cur[0], (long long)cand_cap, cur[1], (long long)pool_cap, cur[2] ? "  OVERFLOW -> retry" : "");
+        if (cur[2]) {                                  // a pool overflowed: grow and redo the launches
+            if ((i64)cur[0] > cand_cap) cand_cap = std::max<i64>(cand_cap * 2, (i64)cur[0] + (i64)n_rows);
+            if ((i64)cur[1] > pool_cap) pool_cap = std::max<i64>(pool_cap * 2, (i64)cur[1] + (i64)n_rows);
             continue;
         }
         if (n_products) *n_products = (i64)cur[4];

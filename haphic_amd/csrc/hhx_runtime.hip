@@ -27,11 +27,14 @@ void *pool_alloc(size_t bytes) {
     size_t c = size_class(bytes);
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        auto it = g_free.find(c);
-        if (it != g_free.end()) {
+        // best fit: the smallest cached block that is large enough and wastes at most 3/4 of itself.
+        // hipMalloc costs ~30 ms per GB on this platform (0.48 s for a 17 GB table), so re-using a
+        // somewhat larger block beats a fresh allocation by orders of magnitude.
+        auto it = g_free.lower_bound(c);
+        if (it != g_free.end() && it->first <= 4 * c) {
             void *p = it->second;
+            g_live[p] = it->first;
             g_free.erase(it);
-            g_live[p] = c;
             return p;
         }
     }
