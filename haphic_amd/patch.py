@@ -1,0 +1,53 @@
+"""Re-binding of the reference's own seams (SURVEY §8b S1–S6) onto the MI355X library.
+
+    import HapHiC_cluster as H          # the unmodified reference module
+    import haphic_amd.patch
+    haphic_amd.patch.patch_reference(H) # then H.run(args) / HapHiC_pipeline as usual
+
+Nothing under /root/reference is edited; the reference resolves these names at call time through its
+module globals, so `setattr` on the module is all that is needed."""
+from . import cluster
+
+# seam -> (reference line, replacement)
+SEAMS = {
+    'dot_product_mkl': ('HapHiC_cluster.py:39-43', cluster.dot_product_mkl),            # S1
+    'mkl_matrix_power': ('HapHiC_cluster.py:2017-2023', cluster.mkl_matrix_power),      # S1 (keeps M^(e-1) on the device)
+    'mcl': ('HapHiC_cluster.py:2026-2062', cluster.mcl),                                # S2
+    'prune': ('HapHiC_cluster.py:1987-2014', cluster.prune),                            # S3
+    'interpret_result': ('HapHiC_cluster.py:2065-2095', cluster.interpret_result),      # a12
+    'run_mcl_clustering': ('HapHiC_cluster.py:2132-2242', cluster.run_mcl_clustering),  # S6
+}
+# S4/S5 are opt-in: dict_to_matrix is also called in dense mode by the filters (:603 :868), and the
+# device ingest does not produce the CLM distance lists / coordinate records yet.
+OPTIONAL = {
+    'dict_to_matrix': ('HapHiC_cluster.py:310-373', cluster.dict_to_matrix),
+    'parse_alignments_for_ctgs': ('HapHiC_cluster.py:1596-1655', cluster.parse_alignments_for_ctgs),
+    'parse_alignments': ('HapHiC_cluster.py:1658-1752', cluster.parse_alignments),
+}
+
+
+def patch_reference(H, ingest=False, matrix_build=False):
+    """H: the imported reference module (HapHiC_cluster).  Returns {name: original} so the caller can undo."""
+    from . import _lib
+    _lib.load()                          # fail loudly here if the HIP library is missing
+    saved = {}
+    seams = dict(SEAMS)
+    if matrix_build:
+        seams['dict_to_matrix'] = OPTIONAL['dict_to_matrix']
+    if ingest:
+        seams['parse_alignments_for_ctgs'] = OPTIONAL['parse_alignments_for_ctgs']
+        seams['parse_alignments'] = OPTIONAL['parse_alignments']
+    for name, (_cite, fn) in seams.items():
+        saved[name] = getattr(H, name, None)
+        setattr(H, name, fn)
+    saved['INTEL_MKL'] = getattr(H, 'INTEL_MKL', None)
+    H.INTEL_MKL = True                   # :2764-2768 would otherwise force the dense (numpy) mode
+    return saved
+
+
+def unpatch_reference(H, saved):
+    for name, fn in saved.items():
+        if fn is None and hasattr(H, name):
+            delattr(H, name)
+        elif fn is not None:
+            setattr(H, name, fn)

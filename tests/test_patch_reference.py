@@ -1,0 +1,40 @@
+"""CPU: the re-binding of the reference's seams (haphic_amd/patch.py).  Needs the reference checkout,
+which only exists in the dev container — skipped elsewhere (nothing in -m gpu reads /root/reference)."""
+import os
+import sys
+import types
+
+import pytest
+
+REF = '/root/reference/scripts'
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
+def test_patch_binds_every_seam():
+    for name, attrs in (('pysam', {'set_verbosity': lambda *a, **k: None, 'AlignmentFile': None}),
+                        ('portion', {'closed': None, 'empty': None})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+    sys.path.insert(0, REF)
+    try:
+        import HapHiC_cluster as H
+    finally:
+        sys.path.remove(REF)
+    from haphic_amd import cluster, patch
+    import inspect
+    # the mirror keeps the reference's signatures (same names, same positional order)
+    for name in ('mcl', 'prune', 'interpret_result', 'dict_to_matrix', 'parse_alignments_for_ctgs', 'parse_alignments',
+                 'run_mcl_clustering', 'mkl_matrix_power'):
+        ref_params = list(inspect.signature(getattr(H, name)).parameters)
+        our_params = [p for p in inspect.signature(getattr(cluster, name)).parameters if not p.startswith('_') and p != 'outdir_root']
+        assert our_params[:len(ref_params)] == ref_params, (name, ref_params, our_params)
+    saved = patch.patch_reference(H, ingest=True, matrix_build=True)
+    try:
+        assert H.mcl is cluster.mcl and H.run_mcl_clustering is cluster.run_mcl_clustering
+        assert H.dot_product_mkl is cluster.dot_product_mkl and H.INTEL_MKL is True
+        assert H.parse_alignments_for_ctgs is cluster.parse_alignments_for_ctgs
+    finally:
+        patch.unpatch_reference(H, saved)
+    assert H.mcl is not cluster.mcl
