@@ -83,21 +83,19 @@ def main():
 
     def step():
         t0 = time.perf_counter()
-        ing = _lib.Ingest(table, flank, bins=False, skip_intra=True, expected_keys=state.get('keys_hint', min(local_pairs, n * (n + 1) // 2)))
+        ing = _lib.Ingest(table, flank, bins=False, skip_intra=True)
+        ing.set_ordinal_base(rank * local_pairs)
         ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
         n_full, n_flank = ing.finalize()
         if world > 1:
-            m, n_linked, n_flank = sharded.merge_flank_and_build(ing, n, in_set, dist, dev)
+            m, n_linked, merged = sharded.merge_flank_and_build(ing, table, flank, False, in_set, dist, dev)
+            n_full, n_flank = merged.n_full, merged.n_flank
+            merged.destroy()
         else:
-            fi, fj, fv = ing.flank_device()
-            m, fidx, n_linked = _lib.dict_to_matrix(fi, fj, fv, n, in_set, 0, on_device=True, n_keys=n_flank)
-            n_rest = n - n_linked
-            if n_rest:                                # link-less contigs get trailing indices
-                m.free()
-                m, fidx, n_linked = _lib.dict_to_matrix(fi, fj, fv, n, in_set, n_rest, on_device=True, n_keys=n_flank)
+            # dict_to_matrix fused onto the device-resident table; link-less contigs get trailing indices
+            m, fidx, n_linked = ing.link_matrix(in_set)
         _lib.check(_lib.load().hhx_synchronize())
         t1 = time.perf_counter()
-        state['keys_hint'] = max(int(n_full * 1.3), 1 << 16)
         state['n_full'], state['n_flank'], state['nnz_link'] = n_full, n_flank, m.nnz
         ing.destroy()
         # ---- run_mcl_clustering :2144-2158 at one inflation

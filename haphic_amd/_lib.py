@@ -70,7 +70,10 @@ SIGNATURES = {
     'hhx_ingest_flank_device': (C.c_int, [C.c_void_p, c_vpp, c_vpp, c_vpp]),
     'hhx_ingest_flank_count_device': (C.c_int, [C.c_void_p, c_vpp]),
     'hhx_ingest_destroy': (C.c_int, [C.c_void_p]),
-    'hhx_table_merge': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, c_i64p, c_vpp, c_vpp, c_vpp, c_vpp]),
+    'hhx_ingest_set_ordinal_base': (C.c_int, [C.c_void_p, C.c_int64]),
+    'hhx_ingest_link_matrix': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, c_i32p, c_vpp]),
+    'hhx_ingest_table_device': (C.c_int, [C.c_void_p, C.c_int, c_i64p, c_vpp, c_vpp, c_vpp, c_vpp, c_vpp]),
+    'hhx_ingest_push_table': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None
@@ -362,6 +365,35 @@ class Ingest:
         check(load().hhx_ingest_flank_count_device(self.h, C.byref(c)))
         return c.value or 0
 
+    def set_ordinal_base(self, base):
+        """global stream ordinal of this handle's first pair (multi-GPU chunk offset); before the first push"""
+        check(load().hhx_ingest_set_ordinal_base(self.h, int(base)))
+
+    def link_matrix(self, in_set, n_rest=-1, add_self_loops=True):
+        """dict_to_matrix fused onto the device-resident flank table: (DeviceCSR, frag_index, n_linked)"""
+        if self.n_full is None:
+            self.finalize()
+        in_set = np.ascontiguousarray(in_set, np.uint8)
+        frag_index = np.empty(max(self.n_frag, 1), np.int32)
+        n_linked = C.c_int32(0)
+        out = C.c_void_p()
+        check(load().hhx_ingest_link_matrix(self.h, ptr(in_set), int(n_rest), int(add_self_loops), ptr(frag_index),
+                                            C.byref(n_linked), C.byref(out)))
+        return DeviceCSR(out), frag_index[:self.n_frag], n_linked.value
+
+    def table_device(self, which=0):
+        """aggregated table (unordered): (n_rows, key_ptr, ord_full_ptr, ord_flank_ptr, ht_ptr, flank_ptr)"""
+        if self.n_full is None:
+            self.finalize()
+        n = C.c_int64(0)
+        p = [C.c_void_p() for _ in range(5)]
+        check(load().hhx_ingest_table_device(self.h, int(which), C.byref(n), *[C.byref(x) for x in p]))
+        return (n.value,) + tuple(x.value or 0 for x in p)
+
+    def push_table(self, which, n_rows, key_ptr, ord_full_ptr, ord_flank_ptr, ht_ptr, flank_ptr):
+        check(load().hhx_ingest_push_table(self.h, int(which), int(n_rows), C.c_void_p(key_ptr), C.c_void_p(ord_full_ptr),
+                                           C.c_void_p(ord_flank_ptr), C.c_void_p(ht_ptr), C.c_void_p(flank_ptr)))
+
     def destroy(self):
         if self.h is not None and self.h.value:
             load().hhx_ingest_destroy(self.h)
@@ -372,12 +404,3 @@ class Ingest:
             self.destroy()
         except Exception:
             pass
-
-
-def table_merge(n, i_ptr, j_ptr, cnt_ptr):
-    """hhx_table_merge on raw device pointers; returns (k, i_ptr, j_ptr, cnt_ptr, value_f64_ptr)."""
-    k = C.c_int64(0)
-    a, b, c, v = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-    check(load().hhx_table_merge(int(n), C.c_void_p(i_ptr), C.c_void_p(j_ptr), C.c_void_p(cnt_ptr), C.byref(k),
-                                 C.byref(a), C.byref(b), C.byref(c), C.byref(v)))
-    return k.value, a.value or 0, b.value or 0, c.value or 0, v.value or 0

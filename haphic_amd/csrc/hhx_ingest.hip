@@ -1,148 +1,483 @@
 // Hi-C read-pair binning into the contig x contig (full / HT) and fragment x fragment (flank) link
-// tables, and dict_to_matrix.  Reference: scripts/HapHiC_cluster.py:1596-1752 (parse_alignments*),
-// :299-307 (is_flank), :404-416 (update_HT_link_dict), :310-373 (dict_to_matrix).
+// tables.  Reference: scripts/HapHiC_cluster.py:1596-1752 (parse_alignments_for_ctgs, parse_alignments),
+// :299-307 (is_flank), :404-416 (update_HT_link_dict).
 //
-// Design (HBM-bound integer work, no sort):
-//   * one thread per read pair, 16 B of coalesced input (4 x int32 SoA streams);
-//   * two open-addressing hash tables in HBM with 32-byte slots (key, first-seen ordinal, counters)
-//     so that all atomics of one pair on one table land in ONE 32-byte sector; the tables are sized
-//     for a load factor <= 0.5 out of 288 GB, never rehashed inside a batch;
-//   * counts are integer atomics (order-free, deterministic); the Python dict INSERTION ORDER that
-//     dict_to_matrix's index assignment depends on (:337-349) is recovered exactly from an atomicMin
-//     of the pair's stream ordinal per key: a bitmap over ordinals + a popcount prefix scan gives each
-//     key its rank in first-seen order (no sort of the keys).
-#include "hhx_common.h"
+// The reference updates Python dicts pair by pair.  Here the same tables are built as a streaming
+// group-by, with every pass reading and writing HBM sequentially (or in bucket-sized runs):
+//   map      one thread per read pair: membership / orientation / bin conversion / flank test, exactly
+//            the predicate chain of :1622-1653 (:1696-1750), producing ONE 64-bit record per surviving
+//            pair: key (i << 29 | j) + HT quadrant + "counts in full_link_dict" + "counts in
+//            flank_link_dict" bits, plus the pair's 32-bit ordinal in the batch;
+//   partition  records are bucketed by the top bits of a 64-bit mix of the key in one or two radix
+//            levels (LDS histogram per 4096-record tile, one global atomic per (tile, bucket) to
+//            reserve the output range, grouped writes).  No ordering inside a bucket is needed — the
+//            ordinal travels with the record — so there is no stable-sort machinery;
+//   aggregate  one workgroup per bucket (~1k records): an LDS hash table keyed by the record key
+//            accumulates the four HT counters, the flank counter and the MINIMUM ordinal seen by each
+//            dict (ds_cmpst_b64 insert, ds_add / ds_min updates), then writes one row per distinct key.
+// Counts and minima are order-independent integers, so the tables are bit-reproducible.  The Python
+// dict INSERTION ORDER that dict_to_matrix's index assignment depends on (:337-349) is the order of the
+// first-seen ordinals; it is recovered only where someone asks for it (hhx_ingest_fetch, the S5 seam)
+// by ranking the ordinals with a bitmap + popcount prefix — the fused device path
+// (hhx_ingest_link_matrix) uses the ordinals directly and never materialises the order.
+// Several pushes produce several aggregated runs; hhx_ingest_finalize merges them with the same
+// partition + aggregate pipeline (rows instead of pairs), which is also the multi-GPU exchange step.
+#include "hhx_ingest.h"
 
 using namespace hhx;
 
-int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
-
 namespace {
 
-constexpr u64 EMPTY_KEY = ~0ull;
-
-struct __attribute__((aligned(32))) FullSlot {   // contig pair
-    u64 key;        // (ctg_i << 32) | ctg_j
-    u64 ord;        // min stream ordinal
-    u32 ht[4];      // [HH, HT, TH, TT]
-};
-struct __attribute__((aligned(32))) FlankSlot {  // fragment pair
-    u64 key;
-    u64 ord;
-    u64 cnt;
-    u64 pad;
-};
-
-__device__ __forceinline__ u64 mix64(u64 x) {
+__device__ __host__ __forceinline__ u64 mix64(u64 x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return x;
 }
-
-// returns slot index or ~0 on a full table; *n_keys counts fresh insertions
-template <class Slot>
-__device__ __forceinline__ u64 find_or_insert(Slot *tab, u64 mask, u64 key, unsigned long long *n_keys) {
-    u64 h = mix64(key) & mask;
-    for (u64 probe = 0; probe <= mask; ++probe) {
-        // keys never change once set: a stale (non-coherent) read can only show EMPTY, and then the
-        // device-scope CAS below returns the true occupant.
-        u64 cur = *(volatile u64 *)&tab[h].key;
-        if (cur == key) return h;
-        if (cur == EMPTY_KEY) {
-            u64 old = atomicCAS((unsigned long long *)&tab[h].key, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-            if (old == EMPTY_KEY) { atomicAdd(n_keys, 1ull); return h; }
-            if (old == key) return h;
-        }
-        h = (h + 1) & mask;
-    }
-    return ~0ull;
+__device__ __forceinline__ u32 bucket_of(u64 key, int total_bits) {
+    return total_bits ? (u32)(mix64(key) >> (64 - total_bits)) : 0u;
 }
-
-struct DevTables {           // device-resident copies of hhx_ingest_config arrays
-    const i32 *ctg_rank;
-    const i64 *ctg_len;
-    const i32 *ctg_frag0;
-    const unsigned char *ctg_split;
-    const i32 *frag_rank;
-    const i64 *frag_len;
-    const unsigned char *frag_nx;
-    i32 n_ctg, n_frag;
-    i64 bin_size, flank;
-    i32 bins, skip_intra;
-};
 
 __device__ __forceinline__ bool is_flank(i64 coord, i64 length, i64 flank) {   // :299-307
     return flank == 0 || coord <= flank || coord > length - flank;
 }
 
-__global__ __launch_bounds__(256) void k_ingest(i64 n_pairs, const i32 *__restrict__ id1, const i32 *__restrict__ pos1,
-                                                const i32 *__restrict__ id2, const i32 *__restrict__ pos2, u64 ord0,
-                                                DevTables t, FullSlot *full, u64 full_mask, FlankSlot *flank, u64 flank_mask,
-                                                unsigned long long *counters /* [0]=full keys [1]=flank keys [2]=overflow */) {
-    for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < n_pairs; idx += (i64)gridDim.x * blockDim.x) {
-        const i32 r = id1[idx], m = id2[idx];
-        if (t.skip_intra && r == m) continue;                                   // pairs_generator_inter_ctgs :1582
-        if (t.bins && r == m && (r < 0 || r >= t.n_ctg || !t.ctg_split[r])) continue;   // :1699
-        if (r < 0 || m < 0 || r >= t.n_ctg || m >= t.n_ctg) continue;          // :1625 / :1702
-        i32 ci = r, cj = m;
-        i64 xi = (i64)pos1[idx] + 1, xj = (i64)pos2[idx] + 1;                   // 1-based, :1629
-        if (t.ctg_rank[r] > t.ctg_rank[m] || (r == m && xi > xj)) { ci = m; cj = r; const i64 tx = xi; xi = xj; xj = tx; }
-        i32 fi = t.ctg_frag0[ci], fj = t.ctg_frag0[cj];
-        i64 yi = xi, yj = xj;
-        if (t.bins) {                                                           // convert_frags :1662-1670
-            if (t.ctg_split[ci]) { const i64 nb = (xi + t.bin_size - 1) / t.bin_size; fi += (i32)(nb - 1); yi = xi - (nb - 1) * t.bin_size; }
-            if (t.ctg_split[cj]) { const i64 nb = (xj + t.bin_size - 1) / t.bin_size; fj += (i32)(nb - 1); yj = xj - (nb - 1) * t.bin_size; }
-            if (fi == fj) continue;                                             // :1715
-            if (t.frag_rank[fi] > t.frag_rank[fj]) { const i32 tf = fi; fi = fj; fj = tf; const i64 ty = yi; yi = yj; yj = ty; }   // :1719-1720
+// ---- map: one read pair -> at most one record of stream `stream` ------------------------------------
+// stream 0: the contig-pair table (full_link_dict + HT_link_dict; also flank_link_dict when no contig is
+//           split, because fragment == contig then);  stream 1 (bins only): the fragment-pair flank table.
+__device__ __forceinline__ bool map_pair(const DevTables &t, int stream, bool combined, i32 r, i32 m, i32 p1, i32 p2, u64 &rec) {
+    if (t.skip_intra && r == m) return false;                                    // pairs_generator_inter_ctgs :1582
+    if (t.bins && r == m && (r < 0 || r >= t.n_ctg || !t.ctg_split[r])) return false;   // :1699
+    if (r < 0 || m < 0 || r >= t.n_ctg || m >= t.n_ctg) return false;           // :1625 / :1702
+    i32 ci = r, cj = m;
+    i64 xi = (i64)p1 + 1, xj = (i64)p2 + 1;                                      // 1-based, :1629
+    if (t.ctg_rank[r] > t.ctg_rank[m] || (r == m && xi > xj)) { ci = m; cj = r; const i64 tx = xi; xi = xj; xj = tx; }
+    i32 fi = t.ctg_frag0[ci], fj = t.ctg_frag0[cj];
+    i64 yi = xi, yj = xj;
+    if (t.bins) {                                                                // convert_frags :1662-1670
+        if (t.ctg_split[ci]) { const i64 nb = (xi + t.bin_size - 1) / t.bin_size; fi += (i32)(nb - 1); yi = xi - (nb - 1) * t.bin_size; }
+        if (t.ctg_split[cj]) { const i64 nb = (xj + t.bin_size - 1) / t.bin_size; fj += (i32)(nb - 1); yj = xj - (nb - 1) * t.bin_size; }
+        if (fi == fj) return false;                                              // :1715
+        if (t.frag_rank[fi] > t.frag_rank[fj]) { const i32 tf = fi; fi = fj; fj = tf; const i64 ty = yi; yi = yj; yj = ty; }   // :1719-1720
+    }
+    const bool flank_ok = t.frag_nx[fi] && t.frag_nx[fj] && is_flank(yi, t.frag_len[fi], t.flank) &&
+                          is_flank(yj, t.frag_len[fj], t.flank);                 // :1636 / :1726
+    const bool full_ok = !(t.bins && r == m);                                    // :1736
+    const u64 ht = (u64)((xi * 2 > t.ctg_len[ci]) * 2 + (xj * 2 > t.ctg_len[cj]));   // :404-416
+    if (combined) {
+        rec = ((u64)(u32)ci << ID_BITS) | (u64)(u32)cj | (ht << HT_SHIFT) | FULL_BIT | (flank_ok ? FLANK_BIT : 0);
+        return true;
+    }
+    if (stream == 0) {
+        if (!full_ok) return false;
+        rec = ((u64)(u32)ci << ID_BITS) | (u64)(u32)cj | (ht << HT_SHIFT) | FULL_BIT;
+        return true;
+    }
+    if (!flank_ok) return false;
+    rec = ((u64)(u32)fi << ID_BITS) | (u64)(u32)fj | FLANK_BIT;
+    return true;
+}
+
+// ---- record sources ---------------------------------------------------------------------------------
+struct SrcPairs {
+    const i32 *id1, *pos1, *id2, *pos2;
+    DevTables t;
+    int stream, combined;
+};
+__device__ __forceinline__ bool src_get(const SrcPairs &s, i64 idx, u64 &rec, u32 &ord) {
+    ord = (u32)idx;
+    return map_pair(s.t, s.stream, s.combined != 0, s.id1[idx], s.id2[idx], s.pos1[idx], s.pos2[idx], rec);
+}
+struct SrcRecs {
+    const u64 *rec;
+    const u32 *ord;
+};
+__device__ __forceinline__ bool src_get(const SrcRecs &s, i64 idx, u64 &rec, u32 &ord) {
+    rec = s.rec[idx];
+    ord = s.ord[idx];
+    return true;
+}
+struct SrcRows {            // table rows to be merged: the record is the bare key, the "ordinal" the row index
+    const u64 *key;
+};
+__device__ __forceinline__ bool src_get(const SrcRows &s, i64 idx, u64 &rec, u32 &ord) {
+    rec = s.key[idx] & KEY_MASK;
+    ord = (u32)idx;
+    return true;
+}
+
+// ---- radix partition ------------------------------------------------------------------------------------
+constexpr int PT = 512, P_ITEMS = 8, P_TILE = PT * P_ITEMS, MAX_BINS = 2048;
+
+struct PartLevel {
+    int total_bits;     // bucket id = top total_bits of mix64(key)
+    int shift;          // digit of this level = bucket >> shift
+    int lds_bits;       // low lds_bits of the digit index the LDS histogram; the rest ("group") is constant
+                        // within a tile except where a tile straddles two level-1 buckets
+};
+
+template <class Src>
+__device__ __forceinline__ u32 tile_group(const Src &src, i64 first, i64 n, const PartLevel &L) {
+    if (L.shift + L.lds_bits >= L.total_bits) return 0;          // level 1: the LDS histogram spans the whole digit
+    u64 rec; u32 ord;
+    (void)src_get(src, first < n ? first : n - 1, rec, ord);     // level-2 sources have no invalid records
+    return (bucket_of(rec & KEY_MASK, L.total_bits) >> L.shift) >> L.lds_bits;
+}
+
+template <class Src>
+__global__ __launch_bounds__(PT) void k_part_count(Src src, i64 n, PartLevel L, unsigned long long *__restrict__ ghist) {
+    __shared__ u32 hist[MAX_BINS];
+    __shared__ u32 s_grp;
+    const int tid = threadIdx.x, nb = 1 << L.lds_bits;
+    for (int t = tid; t < nb; t += PT) hist[t] = 0;
+    u32 cur = 0xffffffffu;
+    const i64 n_tiles = (n + P_TILE - 1) / P_TILE;
+    for (i64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const i64 base = tile * P_TILE;
+        if (tid == 0) s_grp = tile_group(src, base, n, L);
+        __syncthreads();
+        const u32 tg = s_grp;
+        if (tg != cur) {                                         // flush the histogram of the previous group
+            if (cur != 0xffffffffu)
+                for (int t = tid; t < nb; t += PT) {
+                    if (hist[t]) atomicAdd(&ghist[((u64)cur << L.lds_bits) | (u64)t], (unsigned long long)hist[t]);
+                    hist[t] = 0;
+                }
+            cur = tg;
+            __syncthreads();
         }
-        const u64 ord = ord0 + (u64)idx;
-        if (t.frag_nx[fi] && t.frag_nx[fj] && is_flank(yi, t.frag_len[fi], t.flank) && is_flank(yj, t.frag_len[fj], t.flank)) {
-            const u64 s = find_or_insert(flank, flank_mask, ((u64)(u32)fi << 32) | (u64)(u32)fj, &counters[1]);
-            if (s == ~0ull) { atomicAdd(&counters[2], 1ull); continue; }
-            atomicMin((unsigned long long *)&flank[s].ord, (unsigned long long)ord);
-            atomicAdd((unsigned long long *)&flank[s].cnt, 1ull);
+#pragma unroll
+        for (int k = 0; k < P_ITEMS; ++k) {
+            const i64 idx = base + (i64)k * PT + tid;
+            u64 rec; u32 ord;
+            if (idx < n && src_get(src, idx, rec, ord)) {
+                const u32 d = bucket_of(rec & KEY_MASK, L.total_bits) >> L.shift;
+                if ((d >> L.lds_bits) == tg) atomicAdd(&hist[d & (u32)(nb - 1)], 1u);
+                else atomicAdd(&ghist[d], 1ull);
+            }
         }
-        if (t.bins && r == m) continue;                                         // :1736
-        const u64 s = find_or_insert(full, full_mask, ((u64)(u32)ci << 32) | (u64)(u32)cj, &counters[0]);
-        if (s == ~0ull) { atomicAdd(&counters[2], 1ull); continue; }
-        atomicMin((unsigned long long *)&full[s].ord, (unsigned long long)ord);
-        const int ti = xi * 2 > t.ctg_len[ci], tj = xj * 2 > t.ctg_len[cj];    // :404-416
-        atomicAdd(&full[s].ht[ti * 2 + tj], 1u);
+        __syncthreads();
+    }
+    if (cur != 0xffffffffu)
+        for (int t = tid; t < nb; t += PT)
+            if (hist[t]) atomicAdd(&ghist[((u64)cur << L.lds_bits) | (u64)t], (unsigned long long)hist[t]);
+}
+
+template <class Src>
+__global__ __launch_bounds__(PT) void k_part_scatter(Src src, i64 n, PartLevel L, unsigned long long *__restrict__ cursor,
+                                                     u64 *__restrict__ out_rec, u32 *__restrict__ out_ord) {
+    __shared__ u32 hist[MAX_BINS];
+    __shared__ unsigned long long sbase[MAX_BINS];
+    __shared__ u32 s_grp;
+    const int tid = threadIdx.x, nb = 1 << L.lds_bits;
+    const i64 n_tiles = (n + P_TILE - 1) / P_TILE;
+    for (i64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const i64 base = tile * P_TILE;
+        for (int t = tid; t < nb; t += PT) hist[t] = 0;
+        if (tid == 0) s_grp = tile_group(src, base, n, L);
+        __syncthreads();
+        const u32 tg = s_grp;
+        u64 rec[P_ITEMS];
+        u32 ord[P_ITEMS], loc[P_ITEMS], rank[P_ITEMS];
+#pragma unroll
+        for (int k = 0; k < P_ITEMS; ++k) {
+            const i64 idx = base + (i64)k * PT + tid;
+            loc[k] = 0xffffffffu;
+            if (idx < n && src_get(src, idx, rec[k], ord[k])) {
+                const u32 d = bucket_of(rec[k] & KEY_MASK, L.total_bits) >> L.shift;
+                if ((d >> L.lds_bits) == tg) {
+                    loc[k] = d & (u32)(nb - 1);
+                    rank[k] = atomicAdd(&hist[loc[k]], 1u);
+                } else {                                         // straddling record: reserve its slot directly
+                    const unsigned long long pos = atomicAdd(&cursor[d], 1ull);
+                    out_rec[pos] = rec[k];
+                    out_ord[pos] = ord[k];
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < nb; t += PT) {
+            const u32 c = hist[t];
+            if (c) sbase[t] = atomicAdd(&cursor[((u64)tg << L.lds_bits) | (u64)t], (unsigned long long)c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < P_ITEMS; ++k)
+            if (loc[k] != 0xffffffffu) {
+                const unsigned long long pos = sbase[loc[k]] + rank[k];
+                out_rec[pos] = rec[k];
+                out_ord[pos] = ord[k];
+            }
+        __syncthreads();
     }
 }
 
-template <class Slot>
-__global__ __launch_bounds__(256) void k_clear(Slot *tab, u64 cap) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) {
-        Slot s;
-        memset(&s, 0, sizeof s);
-        s.key = EMPTY_KEY;
-        s.ord = ~0ull;
-        tab[i] = s;
+// ---- aggregation: LDS hash table per bucket -----------------------------------------------------------
+constexpr int AG_T = 512, AG_CAP = 2048;
+
+struct AggParams {
+    const u64 *rec;                       // partitioned records
+    const u32 *ord;
+    const unsigned long long *base;       // [n_buckets + 1]
+    u32 n_buckets, buckets_per_wg;
+    u64 ord_base;                         // MODE 0: global ordinal of pair 0 of the batch
+    const u64 *in_ord_full, *in_ord_flank;   // MODE 1: payload rows, indexed by ord
+    const u32 *in_ht, *in_fl;
+    u64 *o_key, *o_ord_full, *o_ord_flank;   // gapped output: workgroup w writes from base[w * buckets_per_wg]
+    u32 *o_ht, *o_fl;
+    unsigned long long *seg_count;        // [n_wg]
+    unsigned int *overflow;
+};
+
+// MODE 0: pair records (flags inside rec, 32-bit batch ordinals).  MODE 1: table rows (64-bit ordinals + counts gathered by row).
+template <int MODE>
+struct AggLds;
+template <>
+struct AggLds<0> { typedef u32 ord_t; };
+template <>
+struct AggLds<1> { typedef u64 ord_t; };
+
+template <int MODE>
+__global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
+    typedef typename AggLds<MODE>::ord_t ord_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *s_key = (u64 *)smem;
+    ord_t *s_of = (ord_t *)(s_key + AG_CAP);
+    ord_t *s_ok = s_of + AG_CAP;
+    u32 *s_cnt = (u32 *)(s_ok + AG_CAP);          // [5][AG_CAP]: HH, HT, TH, TT, flank
+    u32 *s_scan = s_cnt + 5 * AG_CAP;              // [AG_T / 64 + 1]
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / HHX_WAVE;
+    const ord_t ORD_NONE = (ord_t)~(ord_t)0;
+    const u32 b0 = blockIdx.x * A.buckets_per_wg;
+    const u32 b1 = min(A.n_buckets, b0 + A.buckets_per_wg);
+    if (b0 >= A.n_buckets) { if (tid == 0) A.seg_count[blockIdx.x] = 0; return; }
+    unsigned long long out_pos = A.base[b0];
+    const unsigned long long seg_start = out_pos;
+    for (u32 b = b0; b < b1; ++b) {
+        const unsigned long long rb = A.base[b], re = A.base[b + 1];
+        const u64 n = re - rb;
+        if (n == 0) continue;
+        u32 tsize = AG_CAP;
+        if (2 * n <= AG_CAP) { tsize = 64; while (tsize < 2 * n) tsize <<= 1; }
+        for (u32 s = tid; s < tsize; s += AG_T) {
+            s_key[s] = EMPTY_KEY; s_of[s] = ORD_NONE; s_ok[s] = ORD_NONE;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) s_cnt[c * AG_CAP + s] = 0;
+        }
+        __syncthreads();
+        for (u64 i = rb + tid; i < re; i += AG_T) {
+            const u64 rec = A.rec[i];
+            const u32 ord = A.ord[i];
+            const u64 key = rec & KEY_MASK;
+            u32 slot = (u32)mix64(key) & (tsize - 1);
+            u32 probe = 0;
+            for (; probe < tsize; ++probe) {
+                const u64 cur = *(volatile u64 *)&s_key[slot];
+                if (cur == key) break;
+                if (cur == EMPTY_KEY) {
+                    const u64 old = atomicCAS((unsigned long long *)&s_key[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                    if (old == EMPTY_KEY || old == key) break;
+                }
+                slot = (slot + 1) & (tsize - 1);
+            }
+            if (probe == tsize) { atomicExch(A.overflow, 1u); continue; }
+            if constexpr (MODE == 0) {
+                if (rec & FULL_BIT) {
+                    atomicMin((u32 *)&s_of[slot], ord);
+                    atomicAdd(&s_cnt[(u32)((rec >> HT_SHIFT) & 3) * AG_CAP + slot], 1u);
+                }
+                if (rec & FLANK_BIT) {
+                    atomicMin((u32 *)&s_ok[slot], ord);
+                    atomicAdd(&s_cnt[4 * AG_CAP + slot], 1u);
+                }
+            } else {
+                atomicMin((unsigned long long *)&s_of[slot], (unsigned long long)A.in_ord_full[ord]);
+                atomicMin((unsigned long long *)&s_ok[slot], (unsigned long long)A.in_ord_flank[ord]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const u32 v = A.in_ht[(u64)ord * 4 + c];
+                    if (v) atomicAdd(&s_cnt[c * AG_CAP + slot], v);
+                }
+                const u32 f = A.in_fl[ord];
+                if (f) atomicAdd(&s_cnt[4 * AG_CAP + slot], f);
+            }
+        }
+        __syncthreads();
+        // compaction: contiguous chunk of slots per thread, block exclusive scan of the occupied counts
+        const u32 per = tsize >= AG_T ? tsize / AG_T : 1;
+        const u32 s0 = min(tsize, (u32)tid * per), s1 = min(tsize, s0 + per);
+        u32 mine = 0;
+        for (u32 s = s0; s < s1; ++s) mine += s_key[s] != EMPTY_KEY;
+        u32 incl = mine;
+#pragma unroll
+        for (int o = 1; o < HHX_WAVE; o <<= 1) {
+            const u32 v = __shfl_up(incl, o, HHX_WAVE);
+            if (lane >= o) incl += v;
+        }
+        if (lane == HHX_WAVE - 1) s_scan[wave] = incl;
+        __syncthreads();
+        u32 woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < AG_T / HHX_WAVE; ++w) { if (w < wave) woff += s_scan[w]; total += s_scan[w]; }
+        unsigned long long o = out_pos + woff + incl - mine;
+        for (u32 s = s0; s < s1; ++s) {
+            const u64 key = s_key[s];
+            if (key == EMPTY_KEY) continue;
+            A.o_key[o] = key;
+            if constexpr (MODE == 0) {
+                A.o_ord_full[o] = s_of[s] == ORD_NONE ? NO_ORD : A.ord_base + (u64)s_of[s];
+                A.o_ord_flank[o] = s_ok[s] == ORD_NONE ? NO_ORD : A.ord_base + (u64)s_ok[s];
+            } else {
+                A.o_ord_full[o] = (u64)s_of[s];
+                A.o_ord_flank[o] = (u64)s_ok[s];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) A.o_ht[o * 4 + c] = s_cnt[c * AG_CAP + s];
+            A.o_fl[o] = s_cnt[4 * AG_CAP + s];
+            ++o;
+        }
+        out_pos += total;
+        __syncthreads();
     }
+    if (tid == 0) A.seg_count[blockIdx.x] = out_pos - seg_start;
 }
 
-__global__ __launch_bounds__(256) void k_rehash_full(const FullSlot *old, u64 old_cap, FullSlot *nw, u64 mask, unsigned long long *dummy) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < old_cap; i += (u64)gridDim.x * blockDim.x) {
-        if (old[i].key == EMPTY_KEY) continue;
-        const u64 s = find_or_insert(nw, mask, old[i].key, dummy);
-        nw[s].ord = old[i].ord;                                   // one writer per key
-        for (int k = 0; k < 4; ++k) nw[s].ht[k] = old[i].ht[k];
-    }
-}
-__global__ __launch_bounds__(256) void k_rehash_flank(const FlankSlot *old, u64 old_cap, FlankSlot *nw, u64 mask, unsigned long long *dummy) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < old_cap; i += (u64)gridDim.x * blockDim.x) {
-        if (old[i].key == EMPTY_KEY) continue;
-        const u64 s = find_or_insert(nw, mask, old[i].key, dummy);
-        nw[s].ord = old[i].ord;
-        nw[s].cnt = old[i].cnt;
-    }
+template <int MODE>
+constexpr size_t agg_lds_bytes() {
+    return (size_t)AG_CAP * (8 + 2 * sizeof(typename AggLds<MODE>::ord_t) + 5 * 4) + (AG_T / HHX_WAVE + 1) * 4;
 }
 
-// ---- insertion order: bitmap over ordinals + popcount prefix -----------------------------------
-template <class Slot>
-__global__ __launch_bounds__(256) void k_mark_ord(const Slot *tab, u64 cap, u64 *bitmap) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x)
-        if (tab[i].key != EMPTY_KEY) atomicOr((unsigned long long *)&bitmap[tab[i].ord >> 6], 1ull << (tab[i].ord & 63));
+// gapped segments -> dense run
+__global__ __launch_bounds__(256) void k_compact_run(AggParams A, const i64 *__restrict__ seg_off, u64 *__restrict__ key,
+                                                     u64 *__restrict__ ord_full, u64 *__restrict__ ord_flank, u32 *__restrict__ ht,
+                                                     u32 *__restrict__ fl) {
+    const u32 b0 = blockIdx.x * A.buckets_per_wg;
+    if (b0 >= A.n_buckets) return;
+    const unsigned long long src = A.base[b0];
+    const i64 dst = seg_off[blockIdx.x];
+    const i64 cnt = (i64)A.seg_count[blockIdx.x];
+    for (i64 t = threadIdx.x; t < cnt; t += blockDim.x) {
+        key[dst + t] = A.o_key[src + t];
+        ord_full[dst + t] = A.o_ord_full[src + t];
+        ord_flank[dst + t] = A.o_ord_flank[src + t];
+        fl[dst + t] = A.o_fl[src + t];
+    }
+    for (i64 t = threadIdx.x; t < cnt * 4; t += blockDim.x) ht[dst * 4 + t] = A.o_ht[src * 4 + t];
+}
+
+inline unsigned grid_for(u64 n, unsigned per = 256) {
+    u64 b = (n + per - 1) / per;
+    if (b < 1) b = 1;
+    if (b > 256 * 16) b = 256 * 16;
+    return (unsigned)b;
+}
+
+__global__ __launch_bounds__(256) void k_u64_copy(const unsigned long long *src, unsigned long long *dst, i64 n) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// ---- host driver: records from `src` (n items, some may be dropped by the map) -> one aggregated run ----
+struct Payload {            // MODE 1 only
+    const u64 *ord_full = nullptr, *ord_flank = nullptr;
+    const u32 *ht = nullptr, *fl = nullptr;
+};
+
+template <class Src, int MODE>
+int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, LinkRun **out) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        HHX_HIP(hipFuncSetAttribute((const void *)k_aggregate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_aggregate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    LinkRun *run = new LinkRun();
+    if (n_items <= 0) { *out = run; return run->alloc(0) ? (delete run, 1) : 0; }
+    if (n_items >= ((i64)1 << 32) - 1) { delete run; return fail("ingest: at most 2^32 - 2 pairs per push (got %lld)", (long long)n_items); }
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        // buckets of ~<= 1024 records: at most half of the 2048-slot LDS table even if every record is a new key
+        int total_bits = 0;
+        while ((n_items >> total_bits) > 1024 && total_bits < 22) ++total_bits;
+        total_bits = std::min(22, total_bits + 2 * attempt);
+        const int bits1 = total_bits <= 10 ? total_bits : (total_bits + 1) / 2, bits2 = total_bits - bits1;
+        const u32 nb1 = 1u << bits1, n_buckets = 1u << total_bits;
+        const unsigned pgrid = (unsigned)std::max<i64>(1, std::min<i64>((n_items + P_TILE - 1) / P_TILE, 256 * 4));
+        // ---- level 1
+        DevBuf<unsigned long long> hist1, cur1;
+        DevBuf<i64> base1;
+        if (hist1.alloc(nb1 + 1) || cur1.alloc(nb1 + 1) || base1.alloc(nb1 + 2)) { delete run; return 1; }
+        HHX_HIP(hipMemsetAsync(hist1.p, 0, sizeof(unsigned long long) * (nb1 + 1), g_stream));
+        const PartLevel L1{total_bits, bits2, bits1};
+        k_part_count<Src><<<pgrid, PT, 0, g_stream>>>(src, n_items, L1, hist1.p);
+        HHX_LAUNCH_CHECK();
+        i64 n_valid = 0;
+        HHX_TRY(exclusive_scan_i64((const i64 *)hist1.p, base1.p, nb1, &n_valid));
+        if (n_valid == 0) { *out = run; return run->alloc(0) ? (delete run, 1) : 0; }
+        DevBuf<u64> rec1, rec2;
+        DevBuf<u32> ord1, ord2;
+        if (rec1.alloc((size_t)n_valid) || ord1.alloc((size_t)n_valid)) { delete run; return 1; }
+        k_u64_copy<<<grid_for(nb1 + 1), 256, 0, g_stream>>>((const unsigned long long *)base1.p, cur1.p, nb1 + 1);
+        k_part_scatter<Src><<<pgrid, PT, 0, g_stream>>>(src, n_items, L1, cur1.p, rec1.p, ord1.p);
+        HHX_LAUNCH_CHECK();
+        const u64 *recs = rec1.p;
+        const u32 *ords = ord1.p;
+        DevBuf<unsigned long long> hist2, cur2;
+        DevBuf<i64> base2;
+        const i64 *base = base1.p;
+        if (bits2 > 0) {                                        // ---- level 2
+            if (hist2.alloc(n_buckets + 1) || cur2.alloc(n_buckets + 1) || base2.alloc((size_t)n_buckets + 2) ||
+                rec2.alloc((size_t)n_valid) || ord2.alloc((size_t)n_valid)) { delete run; return 1; }
+            HHX_HIP(hipMemsetAsync(hist2.p, 0, sizeof(unsigned long long) * (n_buckets + 1), g_stream));
+            const PartLevel L2{total_bits, 0, bits2};
+            const SrcRecs s2{rec1.p, ord1.p};
+            const unsigned g2 = (unsigned)std::max<i64>(1, std::min<i64>((n_valid + P_TILE - 1) / P_TILE, 256 * 4));
+            k_part_count<SrcRecs><<<g2, PT, 0, g_stream>>>(s2, n_valid, L2, hist2.p);
+            HHX_LAUNCH_CHECK();
+            HHX_TRY(exclusive_scan_i64((const i64 *)hist2.p, base2.p, n_buckets, nullptr));
+            k_u64_copy<<<grid_for(n_buckets + 1), 256, 0, g_stream>>>((const unsigned long long *)base2.p, cur2.p, n_buckets + 1);
+            k_part_scatter<SrcRecs><<<g2, PT, 0, g_stream>>>(s2, n_valid, L2, cur2.p, rec2.p, ord2.p);
+            HHX_LAUNCH_CHECK();
+            recs = rec2.p; ords = ord2.p; base = base2.p;
+        }
+        // ---- aggregate
+        const u32 n_wg = std::min<u32>(n_buckets, 1024);
+        AggParams A{};
+        A.rec = recs; A.ord = ords; A.base = (const unsigned long long *)base;
+        A.n_buckets = n_buckets; A.buckets_per_wg = (n_buckets + n_wg - 1) / n_wg;
+        A.ord_base = ord_base;
+        A.in_ord_full = pl.ord_full; A.in_ord_flank = pl.ord_flank; A.in_ht = pl.ht; A.in_fl = pl.fl;
+        DevBuf<u64> g_key, g_of, g_ok;
+        DevBuf<u32> g_ht, g_fl;
+        DevBuf<unsigned long long> seg_count;
+        DevBuf<i64> seg_off;
+        DevBuf<unsigned int> overflow;
+        if (g_key.alloc((size_t)n_valid) || g_of.alloc((size_t)n_valid) || g_ok.alloc((size_t)n_valid) || g_ht.alloc((size_t)n_valid * 4) ||
+            g_fl.alloc((size_t)n_valid) || seg_count.alloc(n_wg + 1) || seg_off.alloc(n_wg + 2) || overflow.alloc(1)) { delete run; return 1; }
+        if (bits2 > 0) { rec1.release(); ord1.release(); }
+        HHX_HIP(hipMemsetAsync(overflow.p, 0, sizeof(unsigned int), g_stream));
+        A.o_key = g_key.p; A.o_ord_full = g_of.p; A.o_ord_flank = g_ok.p; A.o_ht = g_ht.p; A.o_fl = g_fl.p;
+        A.seg_count = seg_count.p; A.overflow = overflow.p;
+        { KTimer kt("aggregate");
+        k_aggregate<MODE><<<n_wg, AG_T, agg_lds_bytes<MODE>(), g_stream>>>(A); }
+        HHX_LAUNCH_CHECK();
+        i64 n_keys = 0;
+        HHX_TRY(exclusive_scan_i64((const i64 *)seg_count.p, seg_off.p, n_wg, &n_keys));
+        unsigned int ov = 0;
+        HHX_HIP(hipMemcpyAsync(&ov, overflow.p, sizeof ov, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+        if (ov) continue;                                       // a bucket held more distinct keys than LDS: more buckets
+        if (run->alloc(n_keys)) { delete run; return 1; }
+        k_compact_run<<<n_wg, 256, 0, g_stream>>>(A, seg_off.p, run->key.p, run->ord_full.p, run->ord_flank.p, run->ht.p, run->fl.p);
+        HHX_LAUNCH_CHECK();
+        HHX_HIP(hipStreamSynchronize(g_stream));                // the gapped buffers are released on return
+        *out = run;
+        return 0;
+    }
+    delete run;
+    return fail("ingest: LDS aggregation kept overflowing (pathological key distribution)");
+}
+
+// ---- insertion order: bitmap over ordinals + popcount prefix -----------------------------------------
+__global__ __launch_bounds__(256) void k_mark_ord(const u64 *__restrict__ ord, i64 n, u64 *bitmap) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x)
+        if (ord[i] != NO_ORD) atomicOr((unsigned long long *)&bitmap[ord[i] >> 6], 1ull << (ord[i] & 63));
 }
 __global__ __launch_bounds__(256) void k_popc_words(const u64 *bitmap, i64 n_words, i64 *out) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (i64)gridDim.x * blockDim.x) out[i] = __popcll(bitmap[i]);
@@ -150,137 +485,180 @@ __global__ __launch_bounds__(256) void k_popc_words(const u64 *bitmap, i64 n_wor
 __device__ __forceinline__ i64 ord_rank(const u64 *bitmap, const i64 *prefix, u64 ord) {
     return prefix[ord >> 6] + __popcll(bitmap[ord >> 6] & ((1ull << (ord & 63)) - 1ull));
 }
-__global__ __launch_bounds__(256) void k_emit_full(const FullSlot *tab, u64 cap, const u64 *bitmap, const i64 *prefix,
-                                                   i32 *out_i, i32 *out_j, i64 *out_cnt, i64 *out_ht) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) {
-        if (tab[i].key == EMPTY_KEY) continue;
-        const i64 r = ord_rank(bitmap, prefix, tab[i].ord);
-        out_i[r] = (i32)(tab[i].key >> 32);
-        out_j[r] = (i32)(tab[i].key & 0xffffffffu);
+__global__ __launch_bounds__(256) void k_emit_full(const u64 *__restrict__ key, const u64 *__restrict__ ord, const u32 *__restrict__ ht, i64 n,
+                                                   const u64 *bitmap, const i64 *prefix, i32 *out_i, i32 *out_j, i64 *out_cnt, i64 *out_ht) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        if (ord[i] == NO_ORD) continue;
+        const i64 r = ord_rank(bitmap, prefix, ord[i]);
+        out_i[r] = (i32)(key[i] >> ID_BITS);
+        out_j[r] = (i32)(key[i] & ID_MASK);
         i64 tot = 0;
-        for (int k = 0; k < 4; ++k) { out_ht[4 * r + k] = tab[i].ht[k]; tot += tab[i].ht[k]; }
+        for (int k = 0; k < 4; ++k) { out_ht[4 * r + k] = ht[4 * i + k]; tot += ht[4 * i + k]; }
         out_cnt[r] = tot;                                           // full_link_dict :1649 == sum of the HT counts
     }
 }
-__global__ __launch_bounds__(256) void k_emit_flank(const FlankSlot *tab, u64 cap, const u64 *bitmap, const i64 *prefix,
-                                                    i32 *out_i, i32 *out_j, i64 *out_cnt, double *out_val,
-                                                    unsigned long long *frag_links) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) {
-        if (tab[i].key == EMPTY_KEY) continue;
-        const i64 r = ord_rank(bitmap, prefix, tab[i].ord);
-        const i32 fi = (i32)(tab[i].key >> 32), fj = (i32)(tab[i].key & 0xffffffffu);
+__global__ __launch_bounds__(256) void k_emit_flank(const u64 *__restrict__ key, const u64 *__restrict__ ord, const u32 *__restrict__ fl, i64 n,
+                                                    const u64 *bitmap, const i64 *prefix, i32 *out_i, i32 *out_j, i64 *out_cnt,
+                                                    double *out_val, unsigned long long *frag_links) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        if (ord[i] == NO_ORD) continue;
+        const i64 r = ord_rank(bitmap, prefix, ord[i]);
+        const i32 fi = (i32)(key[i] >> ID_BITS), fj = (i32)(key[i] & ID_MASK);
         out_i[r] = fi;
         out_j[r] = fj;
-        out_cnt[r] = (i64)tab[i].cnt;
-        out_val[r] = (double)tab[i].cnt;
-        atomicAdd(&frag_links[fi], (unsigned long long)tab[i].cnt);  // ctg_link_dict / frag_link_dict :1638-1639
-        atomicAdd(&frag_links[fj], (unsigned long long)tab[i].cnt);
+        out_cnt[r] = (i64)fl[i];
+        out_val[r] = (double)fl[i];
+        atomicAdd(&frag_links[fi], (unsigned long long)fl[i]);      // ctg_link_dict / frag_link_dict :1638-1639
+        atomicAdd(&frag_links[fj], (unsigned long long)fl[i]);
+    }
+}
+// [0] rows with a full ordinal, [1] rows with a flank ordinal, [2] 1 + largest ordinal
+__global__ __launch_bounds__(256) void k_run_stats(const u64 *__restrict__ of, const u64 *__restrict__ ok, i64 n, unsigned long long *out) {
+    unsigned long long a = 0, b = 0, mx = 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        if (of[i] != NO_ORD) { ++a; mx = max(mx, (unsigned long long)of[i] + 1); }
+        if (ok[i] != NO_ORD) { ++b; mx = max(mx, (unsigned long long)ok[i] + 1); }
+    }
+    a = (unsigned long long)wave_sum_i64((i64)a);
+    b = (unsigned long long)wave_sum_i64((i64)b);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned long long)__shfl_down((long long)mx, o, HHX_WAVE));
+    if (lane_id() == 0) {
+        if (a) atomicAdd(&out[0], a);
+        if (b) atomicAdd(&out[1], b);
+        if (mx) atomicMax(&out[2], mx);
     }
 }
 
-inline unsigned grid_for(u64 n) {
-    u64 b = (n + 255) / 256;
-    if (b < 1) b = 1;
-    if (b > 256 * 16) b = 256 * 16;
-    return (unsigned)b;
-}
-
-u64 next_pow2(u64 x) {
-    u64 p = 1024;
-    while (p < x) p <<= 1;
-    return p;
-}
-
-}  // namespace
-
-struct hhx_ingest {
-    DevTables t{};
-    DevBuf<i32> ctg_rank, ctg_frag0, frag_rank;
-    DevBuf<i64> ctg_len, frag_len;
-    DevBuf<unsigned char> ctg_split, frag_nx;
-    DevBuf<FullSlot> full;
-    DevBuf<FlankSlot> flank;
-    u64 full_cap = 0, flank_cap = 0;
-    DevBuf<unsigned long long> counters;       // [0] full keys, [1] flank keys, [2] overflow, [3] scratch
-    u64 n_pushed = 0;                          // stream ordinal of the next pair
-    u64 max_keys_bound = 0;
-    bool finalized = false;
-    bool hint_given = false;
-    i64 n_full = 0, n_flank = 0;
-    DevBuf<i32> out_full_i, out_full_j, out_flank_i, out_flank_j;
-    DevBuf<i64> out_full_cnt, out_ht, out_flank_cnt;
-    DevBuf<double> out_flank_val;
-    DevBuf<unsigned long long> frag_links;
-    // staging for host-side inputs
-    DevBuf<i32> stage[4];
-};
-
 template <class T>
-static int upload(DevBuf<T> &d, const T *h, size_t n) {
+int upload(DevBuf<T> &d, const T *h, size_t n) {
     if (d.alloc(n)) return 1;
     if (n) HHX_HIP(hipMemcpyAsync(d.p, h, n * sizeof(T), hipMemcpyHostToDevice, g_stream));
     return 0;
 }
 
-static int ensure_capacity(hhx_ingest *h, u64 need_full, u64 need_flank) {
-    // (re)allocate the tables so that `need` keys keep the load factor <= 0.5
-    auto grow_full = [&](u64 cap) -> int {
-        DevBuf<FullSlot> nw;
-        if (nw.alloc(cap)) return 1;
-        k_clear<FullSlot><<<grid_for(cap), 256, 0, g_stream>>>(nw.p, cap);
+int run_stats(const LinkRun *r, i64 *n_full, i64 *n_flank, u64 *ord_limit) {
+    unsigned long long h[3] = {0, 0, 0};
+    if (r && r->n) {
+        DevBuf<unsigned long long> d;
+        if (d.alloc(3)) return 1;
+        HHX_HIP(hipMemsetAsync(d.p, 0, sizeof h, g_stream));
+        k_run_stats<<<grid_for((u64)r->n), 256, 0, g_stream>>>(r->ord_full.p, r->ord_flank.p, r->n, d.p);
         HHX_LAUNCH_CHECK();
-        if (h->full_cap) {
-            k_rehash_full<<<grid_for(h->full_cap), 256, 0, g_stream>>>(h->full.p, h->full_cap, nw.p, cap - 1, h->counters.p + 3);
-            HHX_LAUNCH_CHECK();
-        }
-        h->full = std::move(nw);
-        h->full_cap = cap;
-        return 0;
-    };
-    auto grow_flank = [&](u64 cap) -> int {
-        DevBuf<FlankSlot> nw;
-        if (nw.alloc(cap)) return 1;
-        k_clear<FlankSlot><<<grid_for(cap), 256, 0, g_stream>>>(nw.p, cap);
-        HHX_LAUNCH_CHECK();
-        if (h->flank_cap) {
-            k_rehash_flank<<<grid_for(h->flank_cap), 256, 0, g_stream>>>(h->flank.p, h->flank_cap, nw.p, cap - 1, h->counters.p + 3);
-            HHX_LAUNCH_CHECK();
-        }
-        h->flank = std::move(nw);
-        h->flank_cap = cap;
-        return 0;
-    };
-    if (need_full * 2 > h->full_cap) HHX_TRY(grow_full(next_pow2(need_full * 2)));
-    if (need_flank * 2 > h->flank_cap) HHX_TRY(grow_flank(next_pow2(need_flank * 2)));
+        HHX_HIP(hipMemcpyAsync(h, d.p, sizeof h, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+    }
+    if (n_full) *n_full = (i64)h[0];
+    if (n_flank) *n_flank = (i64)h[1];
+    if (ord_limit) *ord_limit = std::max<u64>(*ord_limit, h[2]);
     return 0;
 }
 
+// merge the runs of one table into a single run (rows re-aggregated by key: counts add, ordinals take the minimum)
+int merge_runs(std::vector<LinkRun *> &runs) {
+    if (runs.size() <= 1) return 0;
+    i64 total = 0;
+    for (auto *r : runs) total += r->n;
+    LinkRun cat;
+    if (cat.alloc(total)) return 1;
+    i64 off = 0;
+    for (auto *r : runs) {
+        if (r->n) {
+            HHX_HIP(hipMemcpyAsync(cat.key.p + off, r->key.p, 8 * (size_t)r->n, hipMemcpyDeviceToDevice, g_stream));
+            HHX_HIP(hipMemcpyAsync(cat.ord_full.p + off, r->ord_full.p, 8 * (size_t)r->n, hipMemcpyDeviceToDevice, g_stream));
+            HHX_HIP(hipMemcpyAsync(cat.ord_flank.p + off, r->ord_flank.p, 8 * (size_t)r->n, hipMemcpyDeviceToDevice, g_stream));
+            HHX_HIP(hipMemcpyAsync(cat.ht.p + 4 * off, r->ht.p, 16 * (size_t)r->n, hipMemcpyDeviceToDevice, g_stream));
+            HHX_HIP(hipMemcpyAsync(cat.fl.p + off, r->fl.p, 4 * (size_t)r->n, hipMemcpyDeviceToDevice, g_stream));
+        }
+        off += r->n;
+    }
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    for (auto *r : runs) delete r;
+    runs.clear();
+    LinkRun *merged = nullptr;
+    Payload pl;
+    pl.ord_full = cat.ord_full.p; pl.ord_flank = cat.ord_flank.p; pl.ht = cat.ht.p; pl.fl = cat.fl.p;
+    const SrcRows src{cat.key.p};
+    HHX_TRY((build_run<SrcRows, 1>(src, total, pl, 0, &merged)));
+    runs.push_back(merged);
+    return 0;
+}
+
+// insertion-ordered host-visible tables (the S5 seam): rank the first-seen ordinals
+int materialize(hhx_ingest *h) {
+    OrderedTables &o = h->ordered;
+    if (o.ready) return 0;
+    const LinkRun *rf = h->table(0), *rk = h->table(1);
+    const i64 n_words = (i64)(h->ord_limit / 64) + 1;
+    DevBuf<u64> bitmap;
+    DevBuf<i64> wcnt, prefix;
+    if (bitmap.alloc((size_t)n_words) || wcnt.alloc((size_t)n_words) || prefix.alloc((size_t)n_words + 1)) return 1;
+    if (o.full_i.alloc((size_t)h->n_full) || o.full_j.alloc((size_t)h->n_full) || o.full_cnt.alloc((size_t)h->n_full) ||
+        o.ht.alloc((size_t)h->n_full * 4) || o.flank_i.alloc((size_t)h->n_flank) || o.flank_j.alloc((size_t)h->n_flank) ||
+        o.flank_cnt.alloc((size_t)h->n_flank) || o.flank_val.alloc((size_t)h->n_flank) || o.frag_links.alloc((size_t)h->t.n_frag))
+        return 1;
+    HHX_HIP(hipMemsetAsync(o.frag_links.p, 0, sizeof(unsigned long long) * (size_t)h->t.n_frag, g_stream));
+    if (rf && rf->n) {
+        HHX_HIP(hipMemsetAsync(bitmap.p, 0, sizeof(u64) * (size_t)n_words, g_stream));
+        k_mark_ord<<<grid_for((u64)rf->n), 256, 0, g_stream>>>(rf->ord_full.p, rf->n, bitmap.p);
+        HHX_LAUNCH_CHECK();
+        k_popc_words<<<grid_for((u64)n_words), 256, 0, g_stream>>>(bitmap.p, n_words, wcnt.p);
+        HHX_LAUNCH_CHECK();
+        HHX_TRY(exclusive_scan_i64(wcnt.p, prefix.p, n_words, nullptr));
+        k_emit_full<<<grid_for((u64)rf->n), 256, 0, g_stream>>>(rf->key.p, rf->ord_full.p, rf->ht.p, rf->n, bitmap.p, prefix.p, o.full_i.p,
+                                                                 o.full_j.p, o.full_cnt.p, o.ht.p);
+        HHX_LAUNCH_CHECK();
+    }
+    if (rk && rk->n) {
+        HHX_HIP(hipMemsetAsync(bitmap.p, 0, sizeof(u64) * (size_t)n_words, g_stream));
+        k_mark_ord<<<grid_for((u64)rk->n), 256, 0, g_stream>>>(rk->ord_flank.p, rk->n, bitmap.p);
+        HHX_LAUNCH_CHECK();
+        k_popc_words<<<grid_for((u64)n_words), 256, 0, g_stream>>>(bitmap.p, n_words, wcnt.p);
+        HHX_LAUNCH_CHECK();
+        HHX_TRY(exclusive_scan_i64(wcnt.p, prefix.p, n_words, nullptr));
+        k_emit_flank<<<grid_for((u64)rk->n), 256, 0, g_stream>>>(rk->key.p, rk->ord_flank.p, rk->fl.p, rk->n, bitmap.p, prefix.p, o.flank_i.p,
+                                                                  o.flank_j.p, o.flank_cnt.p, o.flank_val.p, o.frag_links.p);
+        HHX_LAUNCH_CHECK();
+    }
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    o.n_full = h->n_full; o.n_flank = h->n_flank;
+    o.ready = true;
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
 extern "C" int hhx_ingest_create(const hhx_ingest_config *cfg, hhx_ingest **out) {
     if (!cfg || !out) return fail("null pointer");
     if (cfg->n_ctg <= 0 || cfg->n_frag <= 0) return fail("empty contig table");
     if (cfg->bins && cfg->bin_size <= 0) return fail("bins mode needs bin_size > 0");
+    if ((i64)cfg->n_ctg >= ((i64)1 << ID_BITS) || (i64)cfg->n_frag >= ((i64)1 << ID_BITS))
+        return fail("ingest: more than 2^29 contigs / fragments");
     hhx_ingest *h = new hhx_ingest();
     int rc = upload(h->ctg_rank, cfg->ctg_rank, (size_t)cfg->n_ctg) || upload(h->ctg_len, cfg->ctg_len, (size_t)cfg->n_ctg) ||
              upload(h->ctg_frag0, cfg->ctg_frag0, (size_t)cfg->n_ctg) || upload(h->ctg_split, cfg->ctg_split, (size_t)cfg->n_ctg) ||
              upload(h->frag_rank, cfg->frag_rank, (size_t)cfg->n_frag) || upload(h->frag_len, cfg->frag_len, (size_t)cfg->n_frag) ||
-             upload(h->frag_nx, cfg->frag_nx, (size_t)cfg->n_frag) || h->counters.alloc(4);
+             upload(h->frag_nx, cfg->frag_nx, (size_t)cfg->n_frag);
     if (rc) { delete h; return 1; }
-    hipError_t e = hipMemsetAsync(h->counters.p, 0, 4 * sizeof(unsigned long long), g_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    hipError_t e = hipStreamSynchronize(g_stream);
     if (e != hipSuccess) { delete h; return fail("ingest_create: %s", hipGetErrorString(e)); }
     h->t.ctg_rank = h->ctg_rank.p; h->t.ctg_len = h->ctg_len.p; h->t.ctg_frag0 = h->ctg_frag0.p; h->t.ctg_split = h->ctg_split.p;
     h->t.frag_rank = h->frag_rank.p; h->t.frag_len = h->frag_len.p; h->t.frag_nx = h->frag_nx.p;
     h->t.n_ctg = cfg->n_ctg; h->t.n_frag = cfg->n_frag; h->t.bin_size = cfg->bin_size; h->t.flank = cfg->flank;
     h->t.bins = cfg->bins; h->t.skip_intra = cfg->skip_intra;
-    // distinct unordered pairs (with the diagonal) bound the key count
-    const double nb = (double)cfg->n_frag * ((double)cfg->n_frag + 1) / 2;
-    h->max_keys_bound = nb > 9e18 ? ~0ull : (u64)nb;
-    h->hint_given = cfg->expected_keys > 0;
-    u64 hint = cfg->expected_keys > 0 ? (u64)cfg->expected_keys : (u64)1 << 16;
-    if (hint > h->max_keys_bound) hint = h->max_keys_bound;
-    rc = ensure_capacity(h, hint, hint);
-    if (rc) { delete h; return rc; }
+    // one table serves both dicts when every contig is its own fragment (parse_alignments_for_ctgs)
+    bool identity = !cfg->bins && cfg->n_ctg == cfg->n_frag;
+    for (i32 c = 0; identity && c < cfg->n_ctg; ++c) identity = cfg->ctg_frag0[c] == c;
+    h->combined = identity;
     *out = h;
+    return 0;
+}
+
+extern "C" int hhx_ingest_set_ordinal_base(hhx_ingest *h, int64_t base) {
+    if (!h) return fail("null handle");
+    if (h->n_pushed || base < 0) return fail("hhx_ingest_set_ordinal_base: call before the first push, with base >= 0");
+    h->ord_base = (u64)base;
     return 0;
 }
 
@@ -297,69 +675,50 @@ extern "C" int hhx_ingest_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const
             src[k] = h->stage[k].p;
         }
     }
-    // capacity: with a caller hint the tables keep their size (an undersized hint overflows and
-    // hhx_ingest_finalize reports it); without one every pair of the batch could be a new key,
-    // bounded by the number of distinct fragment pairs.
-    if (!h->hint_given) {
-        unsigned long long c[4];
-        HHX_HIP(hipMemcpyAsync(c, h->counters.p, sizeof c, hipMemcpyDeviceToHost, g_stream));
-        HHX_HIP(hipStreamSynchronize(g_stream));
-        const u64 need_full = std::min<u64>(c[0] + (u64)n_pairs, h->max_keys_bound);
-        const u64 need_flank = std::min<u64>(c[1] + (u64)n_pairs, h->max_keys_bound);
-        HHX_TRY(ensure_capacity(h, need_full, need_flank));
-    }
+    const u64 ord0 = h->ord_base + h->n_pushed;
     { KTimer kt("ingest");
-    k_ingest<<<grid_for((u64)n_pairs), 256, 0, g_stream>>>(n_pairs, src[0], src[1], src[2], src[3], h->n_pushed, h->t, h->full.p,
-                                                            h->full_cap - 1, h->flank.p, h->flank_cap - 1, h->counters.p); }
-    HHX_LAUNCH_CHECK();
+    for (int stream = 0; stream < (h->combined ? 1 : 2); ++stream) {
+        const SrcPairs sp{src[0], src[1], src[2], src[3], h->t, stream, h->combined ? 1 : 0};
+        LinkRun *run = nullptr;
+        HHX_TRY((build_run<SrcPairs, 0>(sp, n_pairs, Payload(), ord0, &run)));
+        h->runs[stream].push_back(run);
+    } }
     h->n_pushed += (u64)n_pairs;
-    if (!on_device) HHX_HIP(hipStreamSynchronize(g_stream));     // the staging buffers are reused by the next push
+    h->ord_limit = std::max<u64>(h->ord_limit, h->ord_base + h->n_pushed);
+    return 0;
+}
+
+extern "C" int hhx_ingest_push_table(hhx_ingest *h, int which, i64 n_rows, const uint64_t *key, const uint64_t *ord_full,
+                                     const uint64_t *ord_flank, const uint32_t *ht, const uint32_t *flank) {
+    if (!h) return fail("null handle");
+    if (h->finalized) return fail("ingest handle already finalized");
+    if (n_rows < 0 || which < 0 || which > 1) return fail("hhx_ingest_push_table: bad argument");
+    if (n_rows == 0) return 0;
+    LinkRun *r = new LinkRun();
+    if (r->alloc(n_rows)) { delete r; return 1; }
+    hipError_t e = hipMemcpyAsync(r->key.p, key, 8 * (size_t)n_rows, hipMemcpyDeviceToDevice, g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->ord_full.p, ord_full, 8 * (size_t)n_rows, hipMemcpyDeviceToDevice, g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->ord_flank.p, ord_flank, 8 * (size_t)n_rows, hipMemcpyDeviceToDevice, g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->ht.p, ht, 16 * (size_t)n_rows, hipMemcpyDeviceToDevice, g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->fl.p, flank, 4 * (size_t)n_rows, hipMemcpyDeviceToDevice, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    if (e != hipSuccess) { delete r; return fail("hhx_ingest_push_table: %s", hipGetErrorString(e)); }
+    h->runs[(h->combined || which == 0) ? 0 : 1].push_back(r);
     return 0;
 }
 
 extern "C" int hhx_ingest_finalize(hhx_ingest *h, i64 *n_full_keys, i64 *n_flank_keys) {
     if (!h) return fail("null handle");
     if (!h->finalized) {
-        unsigned long long c[4];
-        HHX_HIP(hipMemcpyAsync(c, h->counters.p, sizeof c, hipMemcpyDeviceToHost, g_stream));
-        HHX_HIP(hipStreamSynchronize(g_stream));
-        if (c[2]) return fail("ingest: hash table overflow (%llu pairs dropped): raise expected_keys or push smaller batches", c[2]);
-        h->n_full = (i64)c[0];
-        h->n_flank = (i64)c[1];
-        const i64 n_words = (i64)(h->n_pushed / 64) + 1;
-        DevBuf<u64> bitmap;
-        DevBuf<i64> wcnt, prefix;
-        if (bitmap.alloc((size_t)n_words) || wcnt.alloc((size_t)n_words) || prefix.alloc((size_t)n_words + 1)) return 1;
-        if (h->out_full_i.alloc((size_t)h->n_full) || h->out_full_j.alloc((size_t)h->n_full) || h->out_full_cnt.alloc((size_t)h->n_full) ||
-            h->out_ht.alloc((size_t)h->n_full * 4) || h->out_flank_i.alloc((size_t)h->n_flank) || h->out_flank_j.alloc((size_t)h->n_flank) ||
-            h->out_flank_cnt.alloc((size_t)h->n_flank) || h->out_flank_val.alloc((size_t)h->n_flank) || h->frag_links.alloc((size_t)h->t.n_frag))
-            return 1;
-        HHX_HIP(hipMemsetAsync(h->frag_links.p, 0, sizeof(unsigned long long) * (size_t)h->t.n_frag, g_stream));
-        // full table
-        HHX_HIP(hipMemsetAsync(bitmap.p, 0, sizeof(u64) * (size_t)n_words, g_stream));
-        k_mark_ord<FullSlot><<<grid_for(h->full_cap), 256, 0, g_stream>>>(h->full.p, h->full_cap, bitmap.p);
-        HHX_LAUNCH_CHECK();
-        k_popc_words<<<grid_for((u64)n_words), 256, 0, g_stream>>>(bitmap.p, n_words, wcnt.p);
-        HHX_LAUNCH_CHECK();
-        HHX_TRY(exclusive_scan_i64(wcnt.p, prefix.p, n_words, nullptr));
-        k_emit_full<<<grid_for(h->full_cap), 256, 0, g_stream>>>(h->full.p, h->full_cap, bitmap.p, prefix.p, h->out_full_i.p,
-                                                                   h->out_full_j.p, h->out_full_cnt.p, h->out_ht.p);
-        HHX_LAUNCH_CHECK();
-        // flank table
-        HHX_HIP(hipMemsetAsync(bitmap.p, 0, sizeof(u64) * (size_t)n_words, g_stream));
-        k_mark_ord<FlankSlot><<<grid_for(h->flank_cap), 256, 0, g_stream>>>(h->flank.p, h->flank_cap, bitmap.p);
-        HHX_LAUNCH_CHECK();
-        k_popc_words<<<grid_for((u64)n_words), 256, 0, g_stream>>>(bitmap.p, n_words, wcnt.p);
-        HHX_LAUNCH_CHECK();
-        HHX_TRY(exclusive_scan_i64(wcnt.p, prefix.p, n_words, nullptr));
-        k_emit_flank<<<grid_for(h->flank_cap), 256, 0, g_stream>>>(h->flank.p, h->flank_cap, bitmap.p, prefix.p, h->out_flank_i.p,
-                                                                     h->out_flank_j.p, h->out_flank_cnt.p, h->out_flank_val.p,
-                                                                     h->frag_links.p);
-        HHX_LAUNCH_CHECK();
-        HHX_HIP(hipStreamSynchronize(g_stream));
-        // the tables are no longer needed
-        h->full.release();
-        h->flank.release();
+        { KTimer kt("ingest_merge");
+        HHX_TRY(merge_runs(h->runs[0]));
+        HHX_TRY(merge_runs(h->runs[1])); }
+        i64 a = 0, b = 0, c = 0, d = 0;
+        HHX_TRY(run_stats(h->table(0), &a, &b, &h->ord_limit));
+        if (!h->combined) HHX_TRY(run_stats(h->table(1), &c, &d, &h->ord_limit));
+        h->n_full = a;
+        h->n_flank = h->combined ? b : d;
+        for (auto &s : h->stage) s.release();
         h->finalized = true;
     }
     if (n_full_keys) *n_full_keys = h->n_full;
@@ -367,291 +726,61 @@ extern "C" int hhx_ingest_finalize(hhx_ingest *h, i64 *n_full_keys, i64 *n_flank
     return 0;
 }
 
+extern "C" int hhx_ingest_table_device(hhx_ingest *h, int which, i64 *n_rows, void **key, void **ord_full, void **ord_flank,
+                                       void **ht, void **flank) {
+    if (!h || !h->finalized) return fail("ingest handle not finalized");
+    const LinkRun *r = h->table(which);
+    if (n_rows) *n_rows = r ? r->n : 0;
+    if (key) *key = r ? r->key.p : nullptr;
+    if (ord_full) *ord_full = r ? r->ord_full.p : nullptr;
+    if (ord_flank) *ord_flank = r ? r->ord_flank.p : nullptr;
+    if (ht) *ht = r ? r->ht.p : nullptr;
+    if (flank) *flank = r ? r->fl.p : nullptr;
+    return 0;
+}
+
 extern "C" int hhx_ingest_fetch(hhx_ingest *h, i32 *full_i, i32 *full_j, i64 *full_cnt, i64 *ht_cnt, i32 *flank_i, i32 *flank_j,
                                 i64 *flank_cnt, i64 *frag_links) {
     if (!h || !h->finalized) return fail("ingest handle not finalized");
-    const size_t nf = (size_t)h->n_full, nk = (size_t)h->n_flank;
-    if (full_i && nf) HHX_HIP(hipMemcpyAsync(full_i, h->out_full_i.p, 4 * nf, hipMemcpyDeviceToHost, g_stream));
-    if (full_j && nf) HHX_HIP(hipMemcpyAsync(full_j, h->out_full_j.p, 4 * nf, hipMemcpyDeviceToHost, g_stream));
-    if (full_cnt && nf) HHX_HIP(hipMemcpyAsync(full_cnt, h->out_full_cnt.p, 8 * nf, hipMemcpyDeviceToHost, g_stream));
-    if (ht_cnt && nf) HHX_HIP(hipMemcpyAsync(ht_cnt, h->out_ht.p, 32 * nf, hipMemcpyDeviceToHost, g_stream));
-    if (flank_i && nk) HHX_HIP(hipMemcpyAsync(flank_i, h->out_flank_i.p, 4 * nk, hipMemcpyDeviceToHost, g_stream));
-    if (flank_j && nk) HHX_HIP(hipMemcpyAsync(flank_j, h->out_flank_j.p, 4 * nk, hipMemcpyDeviceToHost, g_stream));
-    if (flank_cnt && nk) HHX_HIP(hipMemcpyAsync(flank_cnt, h->out_flank_cnt.p, 8 * nk, hipMemcpyDeviceToHost, g_stream));
-    if (frag_links) HHX_HIP(hipMemcpyAsync(frag_links, h->frag_links.p, 8 * (size_t)h->t.n_frag, hipMemcpyDeviceToHost, g_stream));
+    HHX_TRY(materialize(h));
+    const OrderedTables &o = h->ordered;
+    const size_t nf = (size_t)o.n_full, nk = (size_t)o.n_flank;
+    if (full_i && nf) HHX_HIP(hipMemcpyAsync(full_i, o.full_i.p, 4 * nf, hipMemcpyDeviceToHost, g_stream));
+    if (full_j && nf) HHX_HIP(hipMemcpyAsync(full_j, o.full_j.p, 4 * nf, hipMemcpyDeviceToHost, g_stream));
+    if (full_cnt && nf) HHX_HIP(hipMemcpyAsync(full_cnt, o.full_cnt.p, 8 * nf, hipMemcpyDeviceToHost, g_stream));
+    if (ht_cnt && nf) HHX_HIP(hipMemcpyAsync(ht_cnt, o.ht.p, 32 * nf, hipMemcpyDeviceToHost, g_stream));
+    if (flank_i && nk) HHX_HIP(hipMemcpyAsync(flank_i, o.flank_i.p, 4 * nk, hipMemcpyDeviceToHost, g_stream));
+    if (flank_j && nk) HHX_HIP(hipMemcpyAsync(flank_j, o.flank_j.p, 4 * nk, hipMemcpyDeviceToHost, g_stream));
+    if (flank_cnt && nk) HHX_HIP(hipMemcpyAsync(flank_cnt, o.flank_cnt.p, 8 * nk, hipMemcpyDeviceToHost, g_stream));
+    if (frag_links) HHX_HIP(hipMemcpyAsync(frag_links, o.frag_links.p, 8 * (size_t)h->t.n_frag, hipMemcpyDeviceToHost, g_stream));
     HHX_HIP(hipStreamSynchronize(g_stream));
     return 0;
 }
 
 extern "C" int hhx_ingest_flank_device(hhx_ingest *h, void **fi, void **fj, void **val) {
     if (!h || !h->finalized) return fail("ingest handle not finalized");
-    if (fi) *fi = h->out_flank_i.p;
-    if (fj) *fj = h->out_flank_j.p;
-    if (val) *val = h->out_flank_val.p;
+    HHX_TRY(materialize(h));
+    if (fi) *fi = h->ordered.flank_i.p;
+    if (fj) *fj = h->ordered.flank_j.p;
+    if (val) *val = h->ordered.flank_val.p;
     return 0;
 }
 
 extern "C" int hhx_ingest_flank_count_device(hhx_ingest *h, void **cnt_i64) {
     if (!h || !h->finalized) return fail("ingest handle not finalized");
-    if (cnt_i64) *cnt_i64 = h->out_flank_cnt.p;
+    HHX_TRY(materialize(h));
+    if (cnt_i64) *cnt_i64 = h->ordered.flank_cnt.p;
     return 0;
+}
+
+extern "C" int hhx_ingest_link_matrix(hhx_ingest *h, const uint8_t *in_set_host, int32_t n_rest, int add_self_loops,
+                                      int32_t *frag_index_host, int32_t *n_linked, hhx_csr **out) {
+    if (!h || !h->finalized) return fail("ingest handle not finalized");
+    KTimer kt("link_matrix");
+    return hhx_link_matrix_from_run(h->table(1), h->t.n_frag, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked, out);
 }
 
 extern "C" int hhx_ingest_destroy(hhx_ingest *h) {
     delete h;
-    return 0;
-}
-
-// ---- merge of chunk-ordered tables (multi-GPU exchange) -------------------------------------------
-namespace {
-__global__ __launch_bounds__(256) void k_merge_insert(i64 n, const i32 *__restrict__ ki, const i32 *__restrict__ kj,
-                                                      const i64 *__restrict__ w, FlankSlot *tab, u64 mask,
-                                                      unsigned long long *counters) {
-    for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (i64)gridDim.x * blockDim.x) {
-        const u64 s = find_or_insert(tab, mask, ((u64)(u32)ki[idx] << 32) | (u64)(u32)kj[idx], &counters[0]);
-        if (s == ~0ull) { atomicAdd(&counters[1], 1ull); continue; }
-        atomicMin((unsigned long long *)&tab[s].ord, (unsigned long long)idx);
-        atomicAdd((unsigned long long *)&tab[s].cnt, (unsigned long long)w[idx]);
-    }
-}
-__global__ __launch_bounds__(256) void k_merge_emit(const FlankSlot *tab, u64 cap, const u64 *bitmap, const i64 *prefix,
-                                                    i32 *out_i, i32 *out_j, i64 *out_cnt, double *out_val) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) {
-        if (tab[i].key == EMPTY_KEY) continue;
-        const i64 r = ord_rank(bitmap, prefix, tab[i].ord);
-        out_i[r] = (i32)(tab[i].key >> 32);
-        out_j[r] = (i32)(tab[i].key & 0xffffffffu);
-        out_cnt[r] = (i64)tab[i].cnt;
-        out_val[r] = (double)tab[i].cnt;
-    }
-}
-struct MergeOut {
-    DevBuf<i32> i, j;
-    DevBuf<i64> cnt;
-    DevBuf<double> val;
-};
-thread_local MergeOut g_merge_out;
-}  // namespace
-
-extern "C" int hhx_table_merge(i64 n, const i32 *ki, const i32 *kj, const i64 *w, i64 *n_out, void **oi, void **oj,
-                               void **ocnt, void **oval) {
-    if (n < 0 || !n_out) return fail("hhx_table_merge: bad argument");
-    const u64 cap = next_pow2((u64)(n > 0 ? n : 1) * 2);
-    DevBuf<FlankSlot> tab;
-    DevBuf<unsigned long long> counters;
-    if (tab.alloc(cap) || counters.alloc(2)) return 1;
-    HHX_HIP(hipMemsetAsync(counters.p, 0, 2 * sizeof(unsigned long long), g_stream));
-    k_clear<FlankSlot><<<grid_for(cap), 256, 0, g_stream>>>(tab.p, cap);
-    HHX_LAUNCH_CHECK();
-    if (n) {
-        k_merge_insert<<<grid_for((u64)n), 256, 0, g_stream>>>(n, ki, kj, w, tab.p, cap - 1, counters.p);
-        HHX_LAUNCH_CHECK();
-    }
-    unsigned long long c[2];
-    HHX_HIP(hipMemcpyAsync(c, counters.p, sizeof c, hipMemcpyDeviceToHost, g_stream));
-    HHX_HIP(hipStreamSynchronize(g_stream));
-    if (c[1]) return fail("hhx_table_merge: hash table overflow");
-    const i64 k = (i64)c[0];
-    const i64 n_words = n / 64 + 1;
-    DevBuf<u64> bitmap;
-    DevBuf<i64> wcnt, prefix;
-    MergeOut &o = g_merge_out;
-    if (bitmap.alloc((size_t)n_words) || wcnt.alloc((size_t)n_words) || prefix.alloc((size_t)n_words + 1) ||
-        o.i.alloc((size_t)k) || o.j.alloc((size_t)k) || o.cnt.alloc((size_t)k) || o.val.alloc((size_t)k)) return 1;
-    HHX_HIP(hipMemsetAsync(bitmap.p, 0, sizeof(u64) * (size_t)n_words, g_stream));
-    k_mark_ord<FlankSlot><<<grid_for(cap), 256, 0, g_stream>>>(tab.p, cap, bitmap.p);
-    HHX_LAUNCH_CHECK();
-    k_popc_words<<<grid_for((u64)n_words), 256, 0, g_stream>>>(bitmap.p, n_words, wcnt.p);
-    HHX_LAUNCH_CHECK();
-    HHX_TRY(exclusive_scan_i64(wcnt.p, prefix.p, n_words, nullptr));
-    k_merge_emit<<<grid_for(cap), 256, 0, g_stream>>>(tab.p, cap, bitmap.p, prefix.p, o.i.p, o.j.p, o.cnt.p, o.val.p);
-    HHX_LAUNCH_CHECK();
-    HHX_HIP(hipStreamSynchronize(g_stream));
-    *n_out = k;
-    if (oi) *oi = o.i.p;
-    if (oj) *oj = o.j.p;
-    if (ocnt) *ocnt = o.cnt.p;
-    if (oval) *oval = o.val.p;
-    return 0;
-}
-
-// ================================================================================================
-// dict_to_matrix :310-373 on device
-// ================================================================================================
-namespace {
-
-// first appearance of every fragment scanning the items in order, i before j (:337-349)
-__global__ __launch_bounds__(256) void k_first_pos(i64 n_keys, const i32 *__restrict__ fi, const i32 *__restrict__ fj,
-                                                   const unsigned char *__restrict__ in_set, unsigned long long *first_pos) {
-    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n_keys; k += (i64)gridDim.x * blockDim.x) {
-        const i32 a = fi[k], b = fj[k];
-        if (!in_set[a] || !in_set[b]) continue;
-        atomicMin(&first_pos[a], (unsigned long long)(2 * k));
-        atomicMin(&first_pos[b], (unsigned long long)(2 * k + 1));
-    }
-}
-__global__ __launch_bounds__(256) void k_mark_first(i32 n_frag, const unsigned long long *first_pos, u64 *bitmap) {
-    for (i32 f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frag; f += gridDim.x * blockDim.x)
-        if (first_pos[f] != ~0ull) atomicOr((unsigned long long *)&bitmap[first_pos[f] >> 6], 1ull << (first_pos[f] & 63));
-}
-__global__ __launch_bounds__(256) void k_frag_index(i32 n_frag, const unsigned long long *first_pos, const u64 *bitmap,
-                                                    const i64 *prefix, i32 *frag_index) {
-    for (i32 f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frag; f += gridDim.x * blockDim.x)
-        frag_index[f] = first_pos[f] == ~0ull ? -1 : (i32)ord_rank(bitmap, prefix, first_pos[f]);
-}
-__global__ __launch_bounds__(256) void k_row_counts(i64 n_keys, const i32 *__restrict__ fi, const i32 *__restrict__ fj,
-                                                    const i32 *__restrict__ frag_index, i32 *cnt) {
-    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n_keys; k += (i64)gridDim.x * blockDim.x) {
-        const i32 a = frag_index[fi[k]], b = frag_index[fj[k]];
-        if (a < 0 || b < 0) continue;
-        atomicAdd(&cnt[a], 1);
-        atomicAdd(&cnt[b], 1);
-    }
-}
-__global__ __launch_bounds__(256) void k_init_counts(i32 shape, i32 *cnt, i32 v) {
-    for (i32 r = blockIdx.x * blockDim.x + threadIdx.x; r < shape; r += gridDim.x * blockDim.x) cnt[r] = v;
-}
-// unsorted fill (atomic cursors) ...
-__global__ __launch_bounds__(256) void k_fill(i64 n_keys, const i32 *__restrict__ fi, const i32 *__restrict__ fj,
-                                              const double *__restrict__ val, const i32 *__restrict__ frag_index,
-                                              const i32 *__restrict__ indptr, i32 *cursor, i32 *tj, float *tx) {
-    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n_keys; k += (i64)gridDim.x * blockDim.x) {
-        const i32 a = frag_index[fi[k]], b = frag_index[fj[k]];
-        if (a < 0 || b < 0) continue;
-        const float v = (float)val[k];                              // dtype=float32 at :368
-        i32 p = indptr[a] + atomicAdd(&cursor[a], 1);
-        tj[p] = b; tx[p] = v;
-        p = indptr[b] + atomicAdd(&cursor[b], 1);
-        tj[p] = a; tx[p] = v;
-    }
-}
-__global__ __launch_bounds__(256) void k_fill_diag(i32 shape, const i32 *__restrict__ indptr, i32 *cursor, i32 *tj, float *tx) {
-    for (i32 r = blockIdx.x * blockDim.x + threadIdx.x; r < shape; r += gridDim.x * blockDim.x) {
-        const i32 p = indptr[r] + atomicAdd(&cursor[r], 1);
-        tj[p] = r; tx[p] = 1.0f;                                    // self loops :362-364
-    }
-}
-// ... then each row is put in column order with an LDS bitmap rank (columns of a row are unique):
-// the same no-sort trick as the SpGEMM output.
-__global__ __launch_bounds__(256) void k_sort_rows(i32 shape, i32 W, const i32 *__restrict__ indptr, const i32 *__restrict__ tj,
-                                                   const float *__restrict__ tx, i32 *__restrict__ oj, float *__restrict__ ox) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32 *bitmap = (u32 *)smem, *prefix = bitmap + W, *scratch = prefix + W;
-    const int tid = threadIdx.x;
-    for (i32 row = blockIdx.x; row < shape; row += gridDim.x) {
-        const i32 b = indptr[row], e = indptr[row + 1];
-        if (e - b <= 1) {
-            if (tid == 0 && e > b) { oj[b] = tj[b]; ox[b] = tx[b]; }
-            continue;
-        }
-        for (i32 w = tid; w < W; w += 256) bitmap[w] = 0;
-        __syncthreads();
-        for (i32 p = b + tid; p < e; p += 256) atomicOr(&bitmap[tj[p] >> 5], 1u << (tj[p] & 31));
-        __syncthreads();
-        // exclusive popcount prefix over the words (serial chunk per thread + 256-entry scan)
-        const i32 per = (W + 255) / 256, w0 = tid * per, w1 = min(W, w0 + per);
-        u32 local = 0;
-        for (i32 w = w0; w < w1; ++w) local += __popc(bitmap[w]);
-        scratch[tid] = local;
-        __syncthreads();
-        if (tid < 64) {
-            u32 v0 = scratch[tid * 4], v1 = scratch[tid * 4 + 1], v2 = scratch[tid * 4 + 2], v3 = scratch[tid * 4 + 3];
-            u32 s = v0 + v1 + v2 + v3, incl = s;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                u32 t = __shfl_up(incl, o, 64);
-                if (tid >= o) incl += t;
-            }
-            u32 ex = incl - s;
-            scratch[tid * 4] = ex; scratch[tid * 4 + 1] = ex + v0; scratch[tid * 4 + 2] = ex + v0 + v1; scratch[tid * 4 + 3] = ex + v0 + v1 + v2;
-        }
-        __syncthreads();
-        u32 run = scratch[tid];
-        for (i32 w = w0; w < w1; ++w) { prefix[w] = run; run += __popc(bitmap[w]); }
-        __syncthreads();
-        for (i32 p = b + tid; p < e; p += 256) {
-            const i32 c = tj[p];
-            const i32 r = (i32)(prefix[c >> 5] + __popc(bitmap[c >> 5] & ((1u << (c & 31)) - 1u)));
-            oj[b + r] = c;
-            ox[b + r] = tx[p];
-        }
-        __syncthreads();
-    }
-}
-
-}  // namespace
-
-extern "C" int hhx_dict_to_matrix(i64 n_keys, const i32 *frag_i, const i32 *frag_j, const double *value, int on_device,
-                                  i32 n_frag, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,
-                                  i32 *frag_index_host, i32 *n_linked_out, hhx_csr **out) {
-    if (!out || !in_set_host || n_frag <= 0 || n_keys < 0 || n_rest < 0) return fail("hhx_dict_to_matrix: bad argument");
-    DevBuf<i32> sfi, sfj;
-    DevBuf<double> sval;
-    if (!on_device && n_keys) {
-        if (upload(sfi, frag_i, (size_t)n_keys) || upload(sfj, frag_j, (size_t)n_keys) || upload(sval, value, (size_t)n_keys)) return 1;
-        frag_i = sfi.p; frag_j = sfj.p; value = sval.p;
-    }
-    DevBuf<unsigned char> in_set;
-    if (upload(in_set, (const unsigned char *)in_set_host, (size_t)n_frag)) return 1;
-    DevBuf<unsigned long long> first_pos;
-    DevBuf<i32> frag_index;
-    if (first_pos.alloc((size_t)n_frag) || frag_index.alloc((size_t)n_frag)) return 1;
-    HHX_HIP(hipMemsetAsync(first_pos.p, 0xff, sizeof(unsigned long long) * (size_t)n_frag, g_stream));
-    const i64 n_words = (2 * n_keys) / 64 + 1;
-    DevBuf<u64> bitmap;
-    DevBuf<i64> wcnt, prefix;
-    if (bitmap.alloc((size_t)n_words) || wcnt.alloc((size_t)n_words) || prefix.alloc((size_t)n_words + 1)) return 1;
-    HHX_HIP(hipMemsetAsync(bitmap.p, 0, sizeof(u64) * (size_t)n_words, g_stream));
-    if (n_keys) {
-        k_first_pos<<<grid_for((u64)n_keys), 256, 0, g_stream>>>(n_keys, frag_i, frag_j, in_set.p, first_pos.p);
-        HHX_LAUNCH_CHECK();
-    }
-    k_mark_first<<<grid_for((u64)n_frag), 256, 0, g_stream>>>(n_frag, first_pos.p, bitmap.p);
-    HHX_LAUNCH_CHECK();
-    k_popc_words<<<grid_for((u64)n_words), 256, 0, g_stream>>>(bitmap.p, n_words, wcnt.p);
-    HHX_LAUNCH_CHECK();
-    i64 n_linked = 0;
-    HHX_TRY(exclusive_scan_i64(wcnt.p, prefix.p, n_words, &n_linked));
-    k_frag_index<<<grid_for((u64)n_frag), 256, 0, g_stream>>>(n_frag, first_pos.p, bitmap.p, prefix.p, frag_index.p);
-    HHX_LAUNCH_CHECK();
-    const i64 shape64 = n_linked + n_rest;
-    if (shape64 > INT32_MAX) return fail("matrix order exceeds int32");
-    const i32 shape = (i32)shape64;
-    DevBuf<i32> cnt, indptr, cursor;
-    if (cnt.alloc((size_t)shape + 1) || indptr.alloc((size_t)shape + 1) || cursor.alloc((size_t)shape + 1)) return 1;
-    k_init_counts<<<grid_for((u64)shape + 1), 256, 0, g_stream>>>(shape, cnt.p, add_self_loops ? 1 : 0);
-    HHX_LAUNCH_CHECK();
-    if (n_keys) {
-        k_row_counts<<<grid_for((u64)n_keys), 256, 0, g_stream>>>(n_keys, frag_i, frag_j, frag_index.p, cnt.p);
-        HHX_LAUNCH_CHECK();
-    }
-    i64 nnz = 0;
-    HHX_TRY(exclusive_scan_i32(cnt.p, indptr.p, shape, &nnz));
-    hhx_csr *m = nullptr;
-    HHX_TRY(hhx_csr_alloc_internal(shape, shape, nnz, &m));
-    DevBuf<i32> tj;
-    DevBuf<float> tx;
-    if (tj.alloc((size_t)nnz) || tx.alloc((size_t)nnz)) { hhx_csr_free(m); return 1; }
-    hipError_t e = hipMemsetAsync(cursor.p, 0, sizeof(i32) * ((size_t)shape + 1), g_stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(m->indptr.p, indptr.p, sizeof(i32) * ((size_t)shape + 1), hipMemcpyDeviceToDevice, g_stream);
-    if (e != hipSuccess) { hhx_csr_free(m); return fail("dict_to_matrix: %s", hipGetErrorString(e)); }
-    if (n_keys) k_fill<<<grid_for((u64)n_keys), 256, 0, g_stream>>>(n_keys, frag_i, frag_j, value, frag_index.p, indptr.p, cursor.p, tj.p, tx.p);
-    if (add_self_loops && shape) k_fill_diag<<<grid_for((u64)shape), 256, 0, g_stream>>>(shape, indptr.p, cursor.p, tj.p, tx.p);
-    const i32 W = (shape + 31) / 32;
-    const size_t lds = (size_t)W * 8 + 256 * 4;
-    if (lds > 160 * 1024) { hhx_csr_free(m); return fail("dict_to_matrix: matrix order %d exceeds the LDS bitmap capacity", shape); }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_sort_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    if (shape) k_sort_rows<<<(unsigned)std::min<i64>(shape, 256 * 8), 256, lds, g_stream>>>(shape, W, indptr.p, tj.p, tx.p, m->indices.p, m->data.p);
-    e = hipGetLastError();
-    if (e == hipSuccess && frag_index_host)
-        e = hipMemcpyAsync(frag_index_host, frag_index.p, sizeof(i32) * (size_t)n_frag, hipMemcpyDeviceToHost, g_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
-    if (e != hipSuccess) { hhx_csr_free(m); return fail("dict_to_matrix: %s", hipGetErrorString(e)); }
-    if (n_linked_out) *n_linked_out = (i32)n_linked;
-    *out = m;
     return 0;
 }

@@ -1,0 +1,264 @@
+// dict_to_matrix, scripts/HapHiC_cluster.py:310-373, on the device: link table -> symmetric float32
+// CSR(T) (== the reference's CSC) with unit self loops.
+//
+// Two front ends share the kernels:
+//   hhx_dict_to_matrix        rows (frag_i, frag_j, value) ALREADY in dict insertion order (the S4 seam):
+//                             the row position k is the key's ordinal;
+//   hhx_link_matrix_from_run  an aggregated ingest table in arbitrary order whose rows carry the stream
+//                             ordinal of their first flank-qualified pair (hhx_ingest_link_matrix): the
+//                             insertion order is never materialised.
+// Index assignment (:337-349): a fragment's matrix index is the rank of its first appearance when the
+// items are scanned in insertion order, i before j — i.e. the rank of min over its keys of
+// 2 * ordinal + side.  atomicMin per fragment, then the rank of that position among the fragments (tiled
+// all-pairs count, no sort).  Rows are filled with atomic cursors and put in column order with an LDS
+// bitmap rank (columns of a row are unique).
+#include "hhx_ingest.h"
+
+using namespace hhx;
+
+int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
+
+namespace {
+
+struct RowsView {           // insertion-ordered arrays
+    const i32 *fi, *fj;
+    const double *val;
+    __device__ __forceinline__ bool get(i64 k, i32 &a, i32 &b, u64 &ord, float &v) const {
+        a = fi[k]; b = fj[k]; ord = (u64)k;
+        v = (float)val[k];                                      // dtype=float32 at :368
+        return true;
+    }
+};
+struct RunView {            // aggregated ingest table
+    const u64 *key, *ord_flank;
+    const u32 *fl;
+    __device__ __forceinline__ bool get(i64 k, i32 &a, i32 &b, u64 &ord, float &v) const {
+        ord = ord_flank[k];
+        if (ord == NO_ORD) return false;                        // the key never entered flank_link_dict
+        a = (i32)(key[k] >> ID_BITS); b = (i32)(key[k] & ID_MASK);
+        v = (float)fl[k];
+        return true;
+    }
+};
+
+template <class View>
+__global__ __launch_bounds__(256) void k_first_pos(View vw, i64 n_keys, const unsigned char *__restrict__ in_set,
+                                                   unsigned long long *first_pos) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n_keys; k += (i64)gridDim.x * blockDim.x) {
+        i32 a, b; u64 ord; float v;
+        if (!vw.get(k, a, b, ord, v) || !in_set[a] || !in_set[b]) continue;
+        atomicMin(&first_pos[a], (unsigned long long)(2 * ord));
+        atomicMin(&first_pos[b], (unsigned long long)(2 * ord + 1));
+    }
+}
+// Matrix index of a fragment = number of linked fragments whose first position is smaller.  The positions
+// 2 * ordinal + side are distinct (a position names one side of one read pair) but sparse in
+// [0, 2 * #pairs), so they are ranked by a tiled all-pairs count over the n_frag values (LDS broadcast
+// tiles; 10^10 compares at n = 100k, a fraction of a millisecond on 256 CUs) instead of a bitmap.
+__global__ __launch_bounds__(256) void k_rank_first(i32 n_frag, const unsigned long long *__restrict__ first_pos,
+                                                    i32 *__restrict__ frag_index, unsigned int *n_linked) {
+    __shared__ unsigned long long tile[1024];
+    const i32 f = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long mine = f < n_frag ? first_pos[f] : ~0ull;
+    i32 rank = 0;
+    for (i32 t0 = 0; t0 < n_frag; t0 += 1024) {
+        for (i32 t = threadIdx.x; t < 1024; t += blockDim.x) tile[t] = (t0 + t < n_frag) ? first_pos[t0 + t] : ~0ull;
+        __syncthreads();
+        if (mine != ~0ull) {
+#pragma unroll 8
+            for (i32 t = 0; t < 1024; ++t) rank += tile[t] < mine;
+        }
+        __syncthreads();
+    }
+    if (f < n_frag) {
+        frag_index[f] = mine == ~0ull ? -1 : rank;
+        if (mine != ~0ull) atomicAdd(n_linked, 1u);
+    }
+}
+template <class View>
+__global__ __launch_bounds__(256) void k_row_counts(View vw, i64 n_keys, const i32 *__restrict__ frag_index, i32 *cnt) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n_keys; k += (i64)gridDim.x * blockDim.x) {
+        i32 a, b; u64 ord; float v;
+        if (!vw.get(k, a, b, ord, v)) continue;
+        a = frag_index[a]; b = frag_index[b];
+        if (a < 0 || b < 0) continue;
+        atomicAdd(&cnt[a], 1);
+        atomicAdd(&cnt[b], 1);
+    }
+}
+__global__ __launch_bounds__(256) void k_init_counts(i32 shape, i32 *cnt, i32 v) {
+    for (i32 r = blockIdx.x * blockDim.x + threadIdx.x; r < shape; r += gridDim.x * blockDim.x) cnt[r] = v;
+}
+// unsorted fill (atomic cursors) ...
+template <class View>
+__global__ __launch_bounds__(256) void k_fill(View vw, i64 n_keys, const i32 *__restrict__ frag_index, const i32 *__restrict__ indptr,
+                                              i32 *cursor, i32 *tj, float *tx) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n_keys; k += (i64)gridDim.x * blockDim.x) {
+        i32 a, b; u64 ord; float v;
+        if (!vw.get(k, a, b, ord, v)) continue;
+        a = frag_index[a]; b = frag_index[b];
+        if (a < 0 || b < 0) continue;
+        i32 p = indptr[a] + atomicAdd(&cursor[a], 1);
+        tj[p] = b; tx[p] = v;
+        p = indptr[b] + atomicAdd(&cursor[b], 1);
+        tj[p] = a; tx[p] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_fill_diag(i32 shape, const i32 *__restrict__ indptr, i32 *cursor, i32 *tj, float *tx) {
+    for (i32 r = blockIdx.x * blockDim.x + threadIdx.x; r < shape; r += gridDim.x * blockDim.x) {
+        const i32 p = indptr[r] + atomicAdd(&cursor[r], 1);
+        tj[p] = r; tx[p] = 1.0f;                                    // self loops :362-364
+    }
+}
+// ... then each row is put in column order with an LDS bitmap rank (columns of a row are unique):
+// the same no-sort trick as the SpGEMM output.
+__global__ __launch_bounds__(256) void k_sort_rows(i32 shape, i32 W, const i32 *__restrict__ indptr, const i32 *__restrict__ tj,
+                                                   const float *__restrict__ tx, i32 *__restrict__ oj, float *__restrict__ ox) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32 *bitmap = (u32 *)smem, *prefix = bitmap + W, *scratch = prefix + W;
+    const int tid = threadIdx.x;
+    for (i32 row = blockIdx.x; row < shape; row += gridDim.x) {
+        const i32 b = indptr[row], e = indptr[row + 1];
+        if (e - b <= 1) {
+            if (tid == 0 && e > b) { oj[b] = tj[b]; ox[b] = tx[b]; }
+            continue;
+        }
+        for (i32 w = tid; w < W; w += 256) bitmap[w] = 0;
+        __syncthreads();
+        for (i32 p = b + tid; p < e; p += 256) atomicOr(&bitmap[tj[p] >> 5], 1u << (tj[p] & 31));
+        __syncthreads();
+        // exclusive popcount prefix over the words (serial chunk per thread + 256-entry scan)
+        const i32 per = (W + 255) / 256, w0 = tid * per, w1 = min(W, w0 + per);
+        u32 local = 0;
+        for (i32 w = w0; w < w1; ++w) local += __popc(bitmap[w]);
+        scratch[tid] = local;
+        __syncthreads();
+        if (tid < 64) {
+            u32 v0 = scratch[tid * 4], v1 = scratch[tid * 4 + 1], v2 = scratch[tid * 4 + 2], v3 = scratch[tid * 4 + 3];
+            u32 s = v0 + v1 + v2 + v3, incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                u32 t = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += t;
+            }
+            u32 ex = incl - s;
+            scratch[tid * 4] = ex; scratch[tid * 4 + 1] = ex + v0; scratch[tid * 4 + 2] = ex + v0 + v1; scratch[tid * 4 + 3] = ex + v0 + v1 + v2;
+        }
+        __syncthreads();
+        u32 run = scratch[tid];
+        for (i32 w = w0; w < w1; ++w) { prefix[w] = run; run += __popc(bitmap[w]); }
+        __syncthreads();
+        for (i32 p = b + tid; p < e; p += 256) {
+            const i32 c = tj[p];
+            const i32 r = (i32)(prefix[c >> 5] + __popc(bitmap[c >> 5] & ((1u << (c & 31)) - 1u)));
+            oj[b + r] = c;
+            ox[b + r] = tx[p];
+        }
+        __syncthreads();
+    }
+}
+
+inline unsigned grid_for(u64 n) {
+    u64 b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 256 * 16) b = 256 * 16;
+    return (unsigned)b;
+}
+
+template <class View>
+int build_matrix(const View &vw, i64 n_keys, i32 n_frag, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,
+                 i32 *frag_index_host, i32 *n_linked_out, hhx_csr **out) {
+    DevBuf<unsigned char> in_set;
+    if (in_set.alloc((size_t)n_frag)) return 1;
+    HHX_HIP(hipMemcpyAsync(in_set.p, in_set_host, (size_t)n_frag, hipMemcpyHostToDevice, g_stream));
+    DevBuf<unsigned long long> first_pos;
+    DevBuf<i32> frag_index;
+    DevBuf<unsigned int> nl;
+    if (first_pos.alloc((size_t)n_frag) || frag_index.alloc((size_t)n_frag) || nl.alloc(1)) return 1;
+    HHX_HIP(hipMemsetAsync(first_pos.p, 0xff, sizeof(unsigned long long) * (size_t)n_frag, g_stream));
+    HHX_HIP(hipMemsetAsync(nl.p, 0, sizeof(unsigned int), g_stream));
+    if (n_keys) {
+        k_first_pos<View><<<grid_for((u64)n_keys), 256, 0, g_stream>>>(vw, n_keys, in_set.p, first_pos.p);
+        HHX_LAUNCH_CHECK();
+    }
+    k_rank_first<<<(unsigned)((n_frag + 255) / 256), 256, 0, g_stream>>>(n_frag, first_pos.p, frag_index.p, nl.p);
+    HHX_LAUNCH_CHECK();
+    unsigned int n_linked = 0;
+    HHX_HIP(hipMemcpyAsync(&n_linked, nl.p, sizeof n_linked, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    if (n_rest < 0) {                                           // every link-less member of frag_set follows the linked ones
+        i64 members = 0;
+        for (i32 f = 0; f < n_frag; ++f) members += in_set_host[f] != 0;
+        n_rest = (i32)(members - (i64)n_linked);
+    }
+    const i64 shape64 = (i64)n_linked + n_rest;
+    if (shape64 > INT32_MAX) return fail("matrix order exceeds int32");
+    const i32 shape = (i32)shape64;
+    DevBuf<i32> cnt, indptr, cursor;
+    if (cnt.alloc((size_t)shape + 1) || indptr.alloc((size_t)shape + 2) || cursor.alloc((size_t)shape + 1)) return 1;
+    k_init_counts<<<grid_for((u64)shape + 1), 256, 0, g_stream>>>(shape, cnt.p, add_self_loops ? 1 : 0);
+    HHX_LAUNCH_CHECK();
+    if (n_keys) {
+        k_row_counts<View><<<grid_for((u64)n_keys), 256, 0, g_stream>>>(vw, n_keys, frag_index.p, cnt.p);
+        HHX_LAUNCH_CHECK();
+    }
+    i64 nnz = 0;
+    HHX_TRY(exclusive_scan_i32(cnt.p, indptr.p, shape, &nnz));
+    hhx_csr *m = nullptr;
+    HHX_TRY(hhx_csr_alloc_internal(shape, shape, nnz, &m));
+    DevBuf<i32> tj;
+    DevBuf<float> tx;
+    if (tj.alloc((size_t)nnz) || tx.alloc((size_t)nnz)) { hhx_csr_free(m); return 1; }
+    hipError_t e = hipMemsetAsync(cursor.p, 0, sizeof(i32) * ((size_t)shape + 1), g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(m->indptr.p, indptr.p, sizeof(i32) * ((size_t)shape + 1), hipMemcpyDeviceToDevice, g_stream);
+    if (e != hipSuccess) { hhx_csr_free(m); return fail("dict_to_matrix: %s", hipGetErrorString(e)); }
+    if (n_keys) k_fill<View><<<grid_for((u64)n_keys), 256, 0, g_stream>>>(vw, n_keys, frag_index.p, indptr.p, cursor.p, tj.p, tx.p);
+    if (add_self_loops && shape) k_fill_diag<<<grid_for((u64)shape), 256, 0, g_stream>>>(shape, indptr.p, cursor.p, tj.p, tx.p);
+    const i32 W = (shape + 31) / 32;
+    const size_t lds = (size_t)W * 8 + 256 * 4;
+    if (lds > 160 * 1024) { hhx_csr_free(m); return fail("dict_to_matrix: matrix order %d exceeds the LDS bitmap capacity", shape); }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_sort_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (shape) k_sort_rows<<<(unsigned)std::min<i64>(shape, 256 * 8), 256, lds, g_stream>>>(shape, W, indptr.p, tj.p, tx.p, m->indices.p, m->data.p);
+    e = hipGetLastError();
+    if (e == hipSuccess && frag_index_host)
+        e = hipMemcpyAsync(frag_index_host, frag_index.p, sizeof(i32) * (size_t)n_frag, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    if (e != hipSuccess) { hhx_csr_free(m); return fail("dict_to_matrix: %s", hipGetErrorString(e)); }
+    if (n_linked_out) *n_linked_out = (i32)n_linked;
+    *out = m;
+    return 0;
+}
+
+template <class T>
+int upload(DevBuf<T> &d, const T *h, size_t n) {
+    if (d.alloc(n)) return 1;
+    if (n) HHX_HIP(hipMemcpyAsync(d.p, h, n * sizeof(T), hipMemcpyHostToDevice, g_stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int hhx_dict_to_matrix(i64 n_keys, const i32 *frag_i, const i32 *frag_j, const double *value, int on_device,
+                                  i32 n_frag, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,
+                                  i32 *frag_index_host, i32 *n_linked_out, hhx_csr **out) {
+    if (!out || !in_set_host || n_frag <= 0 || n_keys < 0) return fail("hhx_dict_to_matrix: bad argument");
+    DevBuf<i32> sfi, sfj;
+    DevBuf<double> sval;
+    if (!on_device && n_keys) {
+        if (upload(sfi, frag_i, (size_t)n_keys) || upload(sfj, frag_j, (size_t)n_keys) || upload(sval, value, (size_t)n_keys)) return 1;
+        frag_i = sfi.p; frag_j = sfj.p; value = sval.p;
+    }
+    const RowsView vw{frag_i, frag_j, value};
+    return build_matrix(vw, n_keys, n_frag, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked_out, out);
+}
+
+int hhx_link_matrix_from_run(const LinkRun *run, i32 n_frag, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,
+                             i32 *frag_index_host, i32 *n_linked_out, hhx_csr **out) {
+    if (!out || !in_set_host || n_frag <= 0) return fail("hhx_ingest_link_matrix: bad argument");
+    const RunView vw{run ? run->key.p : nullptr, run ? run->ord_flank.p : nullptr, run ? run->fl.p : nullptr};
+    return build_matrix(vw, run ? run->n : 0, n_frag, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked_out, out);
+}

@@ -2,9 +2,11 @@
 
 SURVEY §8e:
   * ingest shards by contiguous chunks of the pair stream (pairs are independent, counts additive);
-    ONE exchange merges the per-chunk link tables: an all-gather of the (frag_i, frag_j, count) rows
-    in chunk order followed by a local hash merge that keeps first-occurrence order == the global dict
-    insertion order of the reference loop (hhx_table_merge).
+    rank r numbers its pairs from the global ordinal of its chunk (hhx_ingest_set_ordinal_base), so
+    the first-seen ordinals of the per-rank tables are comparable.  ONE exchange merges them: an
+    all-gather(v) of the aggregated rows (key, first-seen ordinals, counts) followed by the same
+    partition + LDS-aggregate pipeline the ingest itself uses (hhx_ingest_push_table + finalize):
+    counts add, ordinals take the minimum == the reference loop run over the whole stream.
   * MCL shards T = M^T by row block (== column block of the reference's M).  Everything except the
     right operand of the expansion is row-local, so per iteration there is ONE all-gather(v) of the
     pruned row blocks (indices + values + row lengths) and ONE all-reduce(max) of the convergence
@@ -75,11 +77,12 @@ class HipEngine:
     def sync(self):
         _lib.check(_lib.load().hhx_synchronize())
 
-    def merge_tables(self, ti, tj, tc):
-        """chunk-ordered (i, j, count) rows -> distinct keys, summed, first-occurrence order"""
-        self.torch.cuda.current_stream(self.device).synchronize()
-        k, a, b, c, v = _lib.table_merge(ti.numel(), ti.data_ptr(), tj.data_ptr(), tc.data_ptr())
-        return k, a, b, c, v
+    def table_tensors(self, n, ptrs):
+        """torch views (int64 / int32 bit patterns) of an aggregated ingest table: key, ord_full, ord_flank, ht, fl"""
+        t = self.torch
+        key, of, ok, ht, fl = ptrs
+        return [self.view(key, n, '<i8', t.int64), self.view(of, n, '<i8', t.int64), self.view(ok, n, '<i8', t.int64),
+                self.view(ht, 4 * n, '<i4', t.int32), self.view(fl, n, '<i4', t.int32)]
 
 
 # ------------------------------------------------------------------ collectives on variable-size blocks
@@ -188,28 +191,22 @@ def mcl_sharded(full_norm, expansion, inflation, iters, pruning, dist, device):
     return mcl_sharded_engine(eng, full_norm, expansion, inflation, iters, pruning, dist)
 
 
-def merge_tables_engine(engine, ti, tj, tc, dist):
+def gather_tables(engine, tensors, dist):
+    """the ingest exchange: all-gather(v) of every column of the per-rank aggregated tables, rank order"""
     torch = engine.torch
-    gi = torch.cat(_all_gather_var(ti, dist, torch)).contiguous()
-    gj = torch.cat(_all_gather_var(tj, dist, torch)).contiguous()
-    gc = torch.cat(_all_gather_var(tc, dist, torch)).contiguous()
-    return engine.merge_tables(gi, gj, gc)
+    return [torch.cat(_all_gather_var(t.contiguous(), dist, torch)).contiguous() for t in tensors]
 
 
-def merge_flank_and_build(ing, n_frag, in_set, dist, device):
-    """exchange step of the sharded ingest + dict_to_matrix on the merged table (replicated)"""
+def merge_flank_and_build(ing, table, flank, bins, in_set, dist, device):
+    """exchange step of the sharded ingest + dict_to_matrix on the merged table (replicated on every rank).
+    `ing`: this rank's finalized Ingest (ordinal base = number of pairs held by lower ranks)."""
     eng = HipEngine(device)
-    t = eng.torch
-    fi, fj, _ = ing.flank_device()
-    fc = ing.flank_count_device()
-    k = ing.n_flank
-    ti = eng.view(fi, k, '<i4', t.int32)
-    tj = eng.view(fj, k, '<i4', t.int32)
-    tc = eng.view(fc, k, '<i8', t.int64)
-    km, a, b, c, v = merge_tables_engine(eng, ti, tj, tc, dist)
-    m, fidx, n_linked = _lib.dict_to_matrix(a, b, v, n_frag, in_set, 0, on_device=True, n_keys=km)
-    n_rest = int(np.count_nonzero(in_set)) - n_linked
-    if n_rest:
-        m.free()
-        m, fidx, n_linked = _lib.dict_to_matrix(a, b, v, n_frag, in_set, n_rest, on_device=True, n_keys=km)
-    return m, n_linked, km
+    merged = _lib.Ingest(table, flank, bins=bins)
+    for which in ((0,) if not bins else (0, 1)):
+        n, *ptrs = ing.table_device(which)
+        g = gather_tables(eng, eng.table_tensors(n, ptrs), dist)
+        eng.torch.cuda.current_stream(eng.device).synchronize()
+        merged.push_table(which, g[0].numel(), *[t.data_ptr() for t in g])
+    merged.finalize()
+    m, fidx, n_linked = merged.link_matrix(in_set)
+    return m, n_linked, merged

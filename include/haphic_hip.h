@@ -40,7 +40,9 @@ int hhx_set_stream(void *hip_stream);          /* hipStream_t; NULL = null strea
 int hhx_synchronize(void);
 int hhx_pool_trim(void);                       /* release cached device memory */
 /* per-kernel device timing with HIP events on the launch stream (bench.py's roofline leg):
- * names: "ingest", "spgemm_symbolic", "spgemm_numeric", "inflate_stats", "prune_write", "convergence" */
+ * names: "ingest" (map + partition + aggregate of one push), "aggregate", "ingest_merge", "link_matrix",
+ * "spgemm_symbolic", "spgemm_numeric", "expand_window", "expand_compact", "inflate_stats", "prune_write",
+ * "convergence" */
 int hhx_profile_enable(int on);
 int hhx_profile_reset(void);
 int hhx_profile_get(const char *kernel, double *total_ms, int64_t *launches);
@@ -140,33 +142,46 @@ typedef struct {
     int64_t flank;               /* bp (args.flank * 1000) */
     int32_t bins;                /* 0: parse_alignments_for_ctgs, 1: parse_alignments */
     int32_t skip_intra;          /* 1: drop ref == mref like pairs_generator_inter_ctgs :1582 */
-    int64_t expected_keys;       /* hash-table sizing hint (distinct contig pairs); 0 = auto */
+    int64_t expected_keys;       /* unused (kept for ABI stability): the tables are sized on the device */
 } hhx_ingest_config;
 
 int hhx_ingest_create(const hhx_ingest_config *cfg, hhx_ingest **out);
-/* one batch of read pairs in stream order; id/pos arrays are device (on_device=1) or host memory */
+/* global stream ordinal of this handle's first pair: rank r of a multi-GPU job passes the number of pairs
+ * held by ranks < r, so that first-seen ordinals are comparable across ranks.  Before the first push. */
+int hhx_ingest_set_ordinal_base(hhx_ingest *h, int64_t base);
+/* one batch of read pairs in stream order (at most 2^32 - 2 per call); id/pos arrays are device
+ * (on_device=1) or host memory.  Each push is aggregated on the device into one run of distinct keys. */
 int hhx_ingest_push(hhx_ingest *h, int64_t n_pairs, const int32_t *id1, const int32_t *pos1,
                     const int32_t *id2, const int32_t *pos2, int on_device);
-/* close the stream: builds the insertion-ordered tables; sizes are returned */
+/* close the stream: merges the runs into one table per dict; the numbers of keys are returned */
 int hhx_ingest_finalize(hhx_ingest *h, int64_t *n_full_keys, int64_t *n_flank_keys);
 /* host copies, in dict insertion order: full_link_dict keys/counts, the HT_link_dict counts of each
  * contig pair ([HH, HT, TH, TT] :404-416), flank_link_dict keys/counts, per-fragment flank link totals
- * (frag_link_dict).  Any pointer may be NULL. */
+ * (frag_link_dict).  Any pointer may be NULL.  The insertion order is materialised on the first call. */
 int hhx_ingest_fetch(hhx_ingest *h, int32_t *full_i, int32_t *full_j, int64_t *full_cnt, int64_t *ht_cnt,
                      int32_t *flank_i, int32_t *flank_j, int64_t *flank_cnt, int64_t *frag_links);
 /* device-resident flank table (insertion order) for hhx_dict_to_matrix(on_device=1) */
 int hhx_ingest_flank_device(hhx_ingest *h, void **dev_frag_i, void **dev_frag_j, void **dev_value_f64);
 int hhx_ingest_flank_count_device(hhx_ingest *h, void **dev_count_i64);   /* same rows, int64 counts */
+/* dict_to_matrix :310-373 fused onto the handle's flank table (hhx_dict_to_matrix semantics; the dict
+ * insertion order is taken from the first-seen ordinals and never materialised).  n_rest < 0: every
+ * link-less member of in_set gets a trailing index (their relative order is CPython's set order and is
+ * decided by the Python caller). */
+int hhx_ingest_link_matrix(hhx_ingest *h, const uint8_t *in_set_host, int32_t n_rest, int add_self_loops,
+                           int32_t *frag_index_host, int32_t *n_linked, hhx_csr **out);
 int hhx_ingest_destroy(hhx_ingest *h);
 
-/* Multi-GPU exchange step (ingest): merge link tables that were built from consecutive
- * chunks of the pair stream and concatenated in chunk order.  Input: n (frag_i, frag_j, count) rows on
- * the device; output (device, library-owned until the next call on this thread or hhx_pool_trim):
- * one row per distinct key with the counts summed, in FIRST-OCCURRENCE order — which for
- * chunk-ordered inputs is exactly the global dict insertion order of the reference loop. */
-int hhx_table_merge(int64_t n, const int32_t *dev_i, const int32_t *dev_j, const int64_t *dev_count,
-                    int64_t *n_out, void **dev_out_i, void **dev_out_j, void **dev_out_count,
-                    void **dev_out_value_f64);
+/* Multi-GPU exchange step (ingest).  The aggregated table of a finalized handle, device
+ * SoA in no particular order: key = (i << 29) | j, first-seen global ordinals of the key in
+ * full_link_dict / flank_link_dict (UINT64_MAX = never), HT counts [n][4], flank count.
+ * which = 0: contig-pair table, 1: fragment-pair flank table (the same table unless contigs are split).
+ * hhx_ingest_push_table feeds such rows (e.g. the all-gathered tables of every rank) into another handle;
+ * its finalize merges them: counts add, ordinals take the minimum — exactly the reference loop run over
+ * the concatenated stream. */
+int hhx_ingest_table_device(hhx_ingest *h, int which, int64_t *n_rows, void **dev_key_u64, void **dev_ord_full_u64,
+                            void **dev_ord_flank_u64, void **dev_ht_u32x4, void **dev_flank_u32);
+int hhx_ingest_push_table(hhx_ingest *h, int which, int64_t n_rows, const uint64_t *dev_key, const uint64_t *dev_ord_full,
+                          const uint64_t *dev_ord_flank, const uint32_t *dev_ht, const uint32_t *dev_flank);
 
 #ifdef __cplusplus
 }

@@ -257,6 +257,51 @@ def test_ingest_random_vs_oracle_and_device_path():
     p, j, x = m.to_arrays()
     assert n_linked == rl and np.array_equal(fidx, ridx)
     assert np.array_equal(p, rp) and np.array_equal(j, rj) and np.array_equal(x, rx)
+    # fused path: straight from the unordered aggregated table + first-seen ordinals
+    m2, fidx2, nl2 = ing.link_matrix(in_set, n_rest)
+    assert nl2 == rl and np.array_equal(fidx2, ridx)
+    assert all(np.array_equal(a, b) for a, b in zip(m2.to_arrays(), (rp, rj, rx)))
+    m3, _, nl3 = ing.link_matrix(in_set)                       # n_rest < 0: computed from in_set
+    assert nl3 == rl and all(np.array_equal(a, b) for a, b in zip(m3.to_arrays(), (rp, rj, rx)))
+
+
+def test_ingest_table_exchange_roundtrip():
+    """two handles ingest the two halves of a stream (second one with the ordinal base of its chunk); pushing
+    both aggregated tables into a third handle reproduces the tables of the whole stream — the multi-GPU
+    exchange step on one GPU"""
+    import torch
+    from haphic_amd import synth
+    gen = synth.make_genome(5, 1_000_000, 15_000, seed=4)
+    n = gen.n
+    t = orc.FragTable(gen.lexical_rank(), gen.length, np.arange(n, dtype=np.int32), np.zeros(n, np.uint8), 0,
+                      gen.lexical_rank(), gen.length, np.ones(n, np.uint8))
+    id1, p1, id2, p2 = synth.sample_pairs(gen, 300_000, seed=5, device='cuda')
+    half = 170_001
+    parts = []
+    for lo, hi in ((0, half), (half, 300_000)):
+        ing = _lib.Ingest(t, 4000, bins=False, skip_intra=True)
+        ing.set_ordinal_base(lo)
+        a = [x[lo:hi].contiguous() for x in (id1, p1, id2, p2)]
+        ing.push_device(hi - lo, *[x.data_ptr() for x in a])
+        torch.cuda.synchronize()
+        ing.finalize()
+        parts.append(ing)
+    merged = _lib.Ingest(t, 4000, bins=False, skip_intra=True)
+    for ing in parts:
+        nrows, *ptrs = ing.table_device(0)
+        merged.push_table(0, nrows, *ptrs)
+    got = merged.fetch()
+    whole = _lib.Ingest(t, 4000, bins=False, skip_intra=True)
+    whole.push_device(300_000, id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+    torch.cuda.synchronize()
+    ref = whole.fetch()
+    for k in ('full_i', 'full_j', 'full_cnt', 'ht_cnt', 'flank_i', 'flank_j', 'flank_cnt', 'frag_links'):
+        assert np.array_equal(got[k], ref[k]), k
+    h = [a.cpu().numpy() for a in (id1, p1, id2, p2)]
+    keep = h[0] != h[2]
+    o = orc.ingest(t, h[0][keep], h[1][keep].astype(np.int64), h[2][keep], h[3][keep].astype(np.int64), 4000)
+    for k in ('full_i', 'full_j', 'full_cnt', 'ht_cnt', 'flank_i', 'flank_j', 'flank_cnt', 'frag_links'):
+        assert np.array_equal(got[k], o[k]), k
 
 
 def oracle_fused(A, B, infl, pruning=1e-4, shift=60):

@@ -82,14 +82,17 @@ def test_sharded_hip_engine_world1_nccl():
         t = orc.FragTable(lex, gen.length, np.arange(n, dtype=np.int32), np.zeros(n, np.uint8), 0, lex, gen.length,
                           np.ones(n, np.uint8))
         id1, p1, id2, p2 = synth.sample_pairs(gen, 60_000, seed=3, device='cuda:0')
-        ing = _lib.Ingest(t, 3000, bins=False, skip_intra=True, expected_keys=1 << 17)
+        ing = _lib.Ingest(t, 3000, bins=False, skip_intra=True)
         ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+        torch.cuda.synchronize()
         ing.finalize()
         in_set = np.ones(n, np.uint8)
-        m, n_linked, km = sharded.merge_flank_and_build(ing, n, in_set, dist, 'cuda:0')
-        fi, fj, fv = ing.flank_device()
-        m1, fidx, nl1 = _lib.dict_to_matrix(fi, fj, fv, n, in_set, n - n_linked, on_device=True, n_keys=ing.n_flank)
-        assert km == ing.n_flank and nl1 == n_linked
+        m, n_linked, merged = sharded.merge_flank_and_build(ing, t, 3000, False, in_set, dist, 'cuda:0')
+        m1, fidx, nl1 = ing.link_matrix(in_set)
+        assert merged.n_flank == ing.n_flank and nl1 == n_linked
         assert all(np.array_equal(x, y) for x, y in zip(m.to_arrays(), m1.to_arrays()))
+        a, b = merged.fetch(), ing.fetch()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
     finally:
         dist.destroy_process_group()

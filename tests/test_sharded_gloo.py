@@ -56,13 +56,6 @@ class OracleEngine:
     def sync(self):
         pass
 
-    def merge_tables(self, ti, tj, tc):
-        key = ti.numpy().astype(np.int64) << 32 | tj.numpy().astype(np.int64)
-        uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
-        cnt = np.bincount(inv, weights=tc.numpy().astype(np.float64)).astype(np.int64)
-        order = np.argsort(first, kind='stable')
-        return len(uniq), (uniq[order] >> 32).astype(np.int32), (uniq[order] & 0xffffffff).astype(np.int32), cnt[order], None
-
 
 def stochastic(n, deg, seed):
     import scipy.sparse as sp
@@ -94,9 +87,20 @@ def _worker(rank, world, port, q):
         half = len(a[0]) // 2 + 17
         sl = slice(0, half) if rank == 0 else slice(half, None)
         loc = orc.ingest(t, a[0][sl], a[1][sl].astype(np.int64), a[2][sl], a[3][sl].astype(np.int64), 3000)
-        k, mi, mj, mc, _ = sharded.merge_tables_engine(eng, torch.from_numpy(loc['flank_i']), torch.from_numpy(loc['flank_j']),
-                                                       torch.from_numpy(loc['flank_cnt']), dist)
-        q.put((rank, res, n_iter, conv, stats, (k, mi, mj, mc)))
+        # this rank's aggregated table: key, first-seen ordinal (chunk base + position in the chunk's
+        # insertion order: order-preserving, and earlier chunks win), count
+        base = 0 if rank == 0 else half
+        key = (loc['flank_i'].astype(np.int64) << 29) | loc['flank_j'].astype(np.int64)
+        ordk = base + np.arange(len(key), dtype=np.int64)
+        g = sharded.gather_tables(eng, [torch.from_numpy(key), torch.from_numpy(ordk), torch.from_numpy(loc['flank_cnt'])], dist)
+        gk, go, gc = [x.numpy() for x in g]
+        uniq, inv = np.unique(gk, return_inverse=True)
+        cnt = np.bincount(inv, weights=gc.astype(np.float64)).astype(np.int64)
+        first = np.full(len(uniq), np.iinfo(np.int64).max)
+        np.minimum.at(first, inv, go)
+        order = np.argsort(first, kind='stable')
+        merged = (len(uniq), (uniq[order] >> 29).astype(np.int32), (uniq[order] & ((1 << 29) - 1)).astype(np.int32), cnt[order])
+        q.put((rank, res, n_iter, conv, stats, merged))
     finally:
         dist.destroy_process_group()
 
