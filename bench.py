@@ -99,13 +99,14 @@ def main():
         state['n_full'], state['n_flank'], state['nnz_link'] = n_full, n_flank, m.nnz
         ing.destroy()
         # ---- run_mcl_clustering :2144-2158 at one inflation
-        _lib.normalize_l1(m)
         t2 = time.perf_counter()
         if world > 1:
+            _lib.normalize_l1(m)                                                # :2144
             res, n_iter, conv, stats = sharded.mcl_sharded(m, 2, args.inflation, 200, 1e-4, dist, dev)
         else:
-            # pre-expansion (:2146-2147) fused into iteration 0: the 10^8..10^10-entry M^2 never exists
-            res, n_iter, conv, stats = _lib.mcl(m, 2, args.inflation, 200, 1e-4, want_stats=True, normalized=True)
+            # normalisation (:2144) and pre-expansion (:2146-2147) fused into iteration 0: the 10^8..10^10-entry
+            # M^2 never exists, and iteration 0 streams the link matrix as 16-bit counts
+            res, n_iter, conv, stats = _lib.mcl(m, 2, args.inflation, 200, 1e-4, want_stats=True, links=True)
         att, ptr, mem = _lib.interpret(res)
         state['t_mcl'] = time.perf_counter() - t2
         state['clusters'] = len(att)
@@ -185,7 +186,9 @@ def main():
                                       % (n, local_pairs * world, local_pairs, args.nchrs, args.mean_len, args.inflation),
                           'contigs': int(n), 'pairs_per_gpu': local_pairs, 'full_keys': int(state['n_full']),
                           'flank_keys': int(state['n_flank']), 'link_matrix_nnz': int(state['nnz_link'])},
-               'ingest_ms_per_step': t_ing / K * 1e3, 'mcl': mcl, 'roofline': roofline}
+               'ingest_ms_per_step': t_ing / K * 1e3,
+               'ingest_kernels_ms': {k: _lib.profile_get(k)[0] / K for k in ('ingest', 'part_count1', 'part_scatter1', 'part_count2', 'part_scatter2', 'aggregate', 'compact', 'ingest_merge', 'link_matrix')},
+               'mcl': mcl, 'roofline': roofline}
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state)
         print(json.dumps(out))

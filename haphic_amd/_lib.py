@@ -60,6 +60,8 @@ SIGNATURES = {
                           C.POINTER(C.c_int), C.c_void_p]),
     'hhx_mcl_normalized': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, c_vpp, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.c_void_p]),
+    'hhx_mcl_links': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, c_vpp, C.POINTER(C.c_int),
+                                C.POINTER(C.c_int), C.c_void_p]),
     'hhx_interpret': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i32p]),
     'hhx_dict_to_matrix': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_void_p,
                                      C.c_int32, C.c_int, C.c_void_p, c_i32p, c_vpp]),
@@ -254,7 +256,7 @@ def convergence_stat(m, last):
     return s.value
 
 
-def expand_inflate_prune(a, b, inflation, pruning, fx_shift=60):
+def expand_inflate_prune(a, b, inflation, pruning, fx_shift=52):
     """one fused iteration: prune(normalize(power(a*b, r))); returns (matrix, n_products, nnz_expanded)"""
     out = C.c_void_p()
     f, z = C.c_int64(0), C.c_int64(0)
@@ -263,13 +265,14 @@ def expand_inflate_prune(a, b, inflation, pruning, fx_shift=60):
     return DeviceCSR(out), f.value, z.value
 
 
-def mcl(pre_expanded, expansion, inflation, max_iter, pruning, want_stats=False, normalized=False):
+def mcl(pre_expanded, expansion, inflation, max_iter, pruning, want_stats=False, normalized=False, links=False):
     """normalized=False: the reference seam (matrix already pre-expanded); True: start from the
-    L1-normalised link matrix, pre-expansion fused into iteration 0 (hhx_mcl_normalized)."""
+    L1-normalised link matrix, pre-expansion fused into iteration 0 (hhx_mcl_normalized); links=True: start
+    from the raw link matrix of dict_to_matrix (hhx_mcl_links: normalisation fused too)."""
     out = C.c_void_p()
     n_iter, conv = C.c_int(0), C.c_int(0)
     stats = np.zeros((max(int(max_iter), 1), 4), np.int64)
-    fn = load().hhx_mcl_normalized if normalized else load().hhx_mcl
+    fn = load().hhx_mcl_links if links else (load().hhx_mcl_normalized if normalized else load().hhx_mcl)
     check(fn(pre_expanded.h, int(expansion), float(inflation), int(max_iter), float(pruning),
                          C.byref(out), C.byref(n_iter), C.byref(conv), ptr(stats)))
     res = (DeviceCSR(out), n_iter.value, bool(conv.value))

@@ -40,8 +40,16 @@ constexpr int MAX_WIN = 512;
 struct ExParams {
     const i32 *Ap, *Aj; const float *Ax;
     const i32 *Bp, *Bj; const float *Bx;
+    // window kernel operand stream: 16-bit column offsets inside the column window (the windows are at most
+    // 17k columns wide) and either the float32 value (6 B per product; measured HBM-bound: 1.15e12 products in
+    // 1.08 s = 6.4 TB/s at n = 100k) or, when B = D^-1 * L with integer link counts L (iteration 0 of
+    // run_mcl_clustering: the normalised raw link matrix), the 16-bit COUNT (4 B per product) from which the
+    // value float(count / rowsum) is rebuilt bit-exactly on the fly.  The 4-byte stream turned out f64-ALU
+    // bound (1.42 s) on MI355X, so it is opt-in (HHX_CODED=1) and the 6-byte stream is the default.
+    const unsigned short *Bc16, *Bn16;
+    const double *Bs;               // [n_rows(B)] L1 row sums of L (coded operand only)
     i32 n_rows, n_cols;
-    double scale, inv_scale;        // 2^shift, 2^-shift
+    double scale, inv_scale;        // 2^(shift-52), 2^(52-shift): products are rounded on the 2^-52 grid of [1,2)
     double r; int square; float thr;
     // candidate + survivor pools (col, value) and the per-row table
     i32 *cand_col; float *cand_val; i64 cand_cap;
@@ -55,8 +63,10 @@ struct ExParams {
 };
 
 struct ExLds {
-    i64 *acc;            // [cap]
+    double *acc;         // [cap] exact sums of grid-rounded products (see acc_add)
     double *st_da;       // [STAGE]
+    double *st_s;        // [STAGE] row sum of the staged B row (coded operand only)
+    i64 *bcast;          // [1] block broadcast slot
     i32 *st_qb, *st_qe;  // [STAGE]
     double *red_d;       // [EX_WAVES_MAX]
     i32 *red_i;          // [EX_WAVES_MAX]
@@ -66,22 +76,26 @@ struct ExLds {
     u32 *bitmap, *prefix;  // [W] each (compact mode only)
 };
 
-__host__ __device__ inline size_t ex_fixed_bytes(i32 W) {
-    return (size_t)STAGE * (8 + 4 + 4) + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + (size_t)MAX_WIN * (8 + 4) + (size_t)W * 8;
+// nslots: entries of the LDS (offset, count) segment table (compact kernel: MAX_WIN; the window passes keep it in HBM)
+__host__ __device__ inline size_t ex_fixed_bytes(i32 W, int nslots, bool coded) {
+    return (size_t)STAGE * (8 + 4 + 4 + (coded ? 8 : 0)) + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + (size_t)nslots * (8 + 4) +
+           (size_t)W * 8;
 }
 
-__device__ __forceinline__ ExLds ex_carve(unsigned char *smem, i32 cap, i32 W) {
+__device__ __forceinline__ ExLds ex_carve(unsigned char *smem, i32 cap, i32 W, int nslots, bool coded) {
     ExLds l;
     unsigned char *p = smem;
-    l.acc = (i64 *)p; p += (size_t)cap * 8;
+    l.acc = (double *)p; p += (size_t)cap * 8;
     l.st_da = (double *)p; p += STAGE * 8;
+    l.st_s = (double *)p; p += coded ? STAGE * 8 : 0;
     l.red_d = (double *)p; p += EX_WAVES_MAX * 8;
-    l.win_off = (i64 *)p; p += MAX_WIN * 8;
+    l.bcast = (i64 *)p; p += 8;
+    l.win_off = (i64 *)p; p += (size_t)nslots * 8;
     l.st_qb = (i32 *)p; p += STAGE * 4;
     l.st_qe = (i32 *)p; p += STAGE * 4;
     l.red_i = (i32 *)p; p += EX_WAVES_MAX * 4;
     l.red_f = (float *)p; p += EX_WAVES_MAX * 4;
-    l.win_cnt = (i32 *)p; p += MAX_WIN * 4;
+    l.win_cnt = (i32 *)p; p += (size_t)nslots * 4;
     l.bitmap = (u32 *)p; p += (size_t)W * 4;
     l.prefix = (u32 *)p;
     return l;
@@ -154,7 +168,7 @@ __device__ __forceinline__ void block_argmax(float &q, i32 &c, float *redf, i32 
 
 // ---- stage one chunk of the A row: (a * scale, begin, end) of every referenced B row, optionally
 // narrowed to the column window [c0, c1)
-template <bool NARROW>
+template <bool NARROW, bool CODED = false>
 __device__ __forceinline__ void stage_chunk(const ExParams &P, const ExLds &l, i32 a0, i32 len, i32 wv) {
     for (i32 t = threadIdx.x; t < len; t += EX_T) {
         const i32 k = P.Aj[a0 + t];
@@ -164,12 +178,24 @@ __device__ __forceinline__ void stage_chunk(const ExParams &P, const ExLds &l, i
             qb = wp[0]; qe = wp[1];
         } else { qb = P.Bp[k]; qe = P.Bp[k + 1]; }
         l.st_da[t] = (double)P.Ax[a0 + t] * P.scale;
+        if (CODED) l.st_s[t] = P.Bs[k];
         l.st_qb[t] = qb;
         l.st_qe[t] = qe;
     }
 }
 
 // ---- inner loops -------------------------------------------------------------------------------
+// Fixed-point accumulation without integers.  The operands are stochastic (0 <= a, b <= 1, row sums 1), so a
+// scaled product p = a * b * 2^(shift-52) lies in [0, 1]: (p + 1.0) - 1.0 rounds it (to nearest, ties to even)
+// to a multiple of 2^-52, and any sum of such multiples below 2 is exactly representable in a double —
+// every ds_add_f64 is therefore EXACT, the additions commute, and the row is bit-reproducible for any order
+// of lanes, waves or GPUs, exactly like 64-bit integer adds but at 4 instead of ~9 f64 VALU ops per product
+// (the f64 -> i64 conversion was the kernel's bottleneck).  Specification: oracle mode 1,
+// sum of rint(a * b * 2^shift), one rounding to float32 at the end.
+__device__ __forceinline__ void acc_add(double *slot, double p) {
+    atomicAdd(slot, (p + 1.0) - 1.0);
+}
+
 // window mode: acc[c - c0] += fixed(a * b)
 // A wave walks its staged B-row segments (wave, wave + nw, ...) as a sequence of TILES of up to U * 64
 // consecutive entries and keeps two tiles in flight: the loads of tile t+1 are issued before the LDS
@@ -177,48 +203,79 @@ __device__ __forceinline__ void stage_chunk(const ExParams &P, const ExLds &l, i
 // when the row is cut into many column windows).  All cursor state is wave-uniform.
 constexpr int TILE_U = 8;
 struct SegCursor {
-    i32 e, q, qe; double da; bool valid;
+    i32 e, q, qe; double da, s, r; bool valid;
 };
+template <bool CODED>
 __device__ __forceinline__ void seg_open(const ExLds &l, SegCursor &c, i32 len) {
     c.valid = c.e < len;
-    if (c.valid) { c.da = l.st_da[c.e]; c.q = l.st_qb[c.e]; c.qe = l.st_qe[c.e]; }
+    if (c.valid) {
+        c.da = l.st_da[c.e]; c.q = l.st_qb[c.e]; c.qe = l.st_qe[c.e];
+        if (CODED) { c.s = l.st_s[c.e]; c.r = 1.0 / c.s; }
+    }
 }
 struct Tile {
-    i32 j[TILE_U]; float b[TILE_U]; double da; bool valid;
+    u32 j[TILE_U], v[TILE_U];      // window-local column (0xffffffff = none); float bits or link count
+    double da, s, r; bool valid;
 };
+// value of a count-coded entry: float(count / s) exactly as sklearn's normalisation forms it
+// (x = float(double(x) / sum)).  Fast path: count * (1/s) is within 2 ulp(double) of the correctly rounded
+// quotient, so both round to the same float unless a float rounding boundary (a double whose low 29 mantissa
+// bits are 1000...0) lies that close — then, about once per 10^8 entries, the exact division is done.
+__device__ __forceinline__ float coded_value(u32 cnt, double s, double r) {
+    const double q = (double)cnt * r;
+    const u32 low = (u32)__double_as_longlong(q) & 0x1fffffffu;
+    if (__builtin_expect(low - 0x0ffffffcu <= 8u, 0)) return (float)((double)cnt / s);
+    return (float)q;
+}
+// Issues the loads of the next tile.  The loads are UNCONDITIONAL (out-of-range lanes and an exhausted
+// cursor read entry 0 and are masked afterwards) and always TILE_U * 2 in number: with no per-lane branches
+// around them the compiler's s_waitcnt pass can count, so consuming tile t waits with vmcnt(16) for the
+// older tile only while the loads of tile t+1 stay in flight (with predicated loads it emitted vmcnt(0)
+// before every LDS atomic and the prefetch was worthless).
+template <bool CODED>
 __device__ __forceinline__ void tile_fetch(const ExParams &P, const ExLds &l, SegCursor &c, i32 len, Tile &t) {
     t.valid = c.valid;
-    if (!c.valid) return;
-    t.da = c.da;
-    const i32 q0 = c.q + lane_id();
+    t.da = c.da; t.s = c.s; t.r = c.r;
+    const i32 q0 = c.q + lane_id(), qe = c.valid ? c.qe : 0;
 #pragma unroll
     for (int u = 0; u < TILE_U; ++u) {
         const i32 qq = q0 + u * HHX_WAVE;
-        const bool in = qq < c.qe;
-        t.j[u] = in ? P.Bj[qq] : -1;
-        t.b[u] = in ? P.Bx[qq] : 0.0f;
+        const bool in = qq < qe;
+        const i32 qs = in ? qq : 0;
+        const u32 col = (u32)P.Bc16[qs];
+        const u32 val = CODED ? (u32)P.Bn16[qs] : __float_as_uint(P.Bx[qs]);
+        t.j[u] = in ? col : 0xffffffffu;
+        t.v[u] = val;
     }
-    c.q += TILE_U * HHX_WAVE;
-    if (c.q >= c.qe) { c.e += EX_WAVES; seg_open(l, c, len); }
+    if (c.valid) {
+        c.q += TILE_U * HHX_WAVE;
+        if (c.q >= c.qe) { c.e += EX_WAVES; seg_open<CODED>(l, c, len); }
+    }
 }
-__device__ __forceinline__ void tile_consume(const ExLds &l, const Tile &t, i32 c0) {
+template <bool CODED>
+__device__ __forceinline__ void tile_consume(const ExLds &l, const Tile &t) {
 #pragma unroll
     for (int u = 0; u < TILE_U; ++u)
-        if (t.j[u] >= 0) atomicAdd((unsigned long long *)&l.acc[t.j[u] - c0], (unsigned long long)(i64)(t.da * (double)t.b[u]));
+        if (t.j[u] != 0xffffffffu) {
+            const float b = CODED ? coded_value(t.v[u], t.s, t.r) : __uint_as_float(t.v[u]);
+            acc_add(&l.acc[t.j[u]], t.da * (double)b);
+        }
 }
-__device__ __forceinline__ void accumulate_window(const ExParams &P, const ExLds &l, i32 len, i32 c0) {
+template <bool CODED>
+__device__ __forceinline__ void accumulate_window(const ExParams &P, const ExLds &l, i32 len) {
     SegCursor c;
     c.e = threadIdx.x / HHX_WAVE;
-    c.q = c.qe = 0; c.da = 0.0;
-    seg_open(l, c, len);
+    c.q = c.qe = 0; c.da = 0.0; c.s = 1.0; c.r = 1.0;
+    seg_open<CODED>(l, c, len);
     Tile ta, tb;
-    tile_fetch(P, l, c, len, ta);
-    while (ta.valid) {
-        tile_fetch(P, l, c, len, tb);
-        tile_consume(l, ta, c0);
+    tile_fetch<CODED>(P, l, c, len, ta);
+    for (;;) {
+        tile_fetch<CODED>(P, l, c, len, tb);
+        tile_consume<CODED>(l, ta);
         if (!tb.valid) break;
-        tile_fetch(P, l, c, len, ta);
-        tile_consume(l, tb, c0);
+        tile_fetch<CODED>(P, l, c, len, ta);
+        tile_consume<CODED>(l, tb);
+        if (!ta.valid) break;
     }
 }
 // compact mode: mark, then acc[rank(c)] += fixed(a * b)
@@ -253,14 +310,14 @@ __device__ __forceinline__ void accumulate_compact(const ExParams &P, const ExLd
             const i32 j0 = P.Bj[q], j1 = P.Bj[q + HHX_WAVE], j2 = P.Bj[q + 2 * HHX_WAVE], j3 = P.Bj[q + 3 * HHX_WAVE];
             const float b0 = P.Bx[q], b1 = P.Bx[q + HHX_WAVE], b2 = P.Bx[q + 2 * HHX_WAVE], b3 = P.Bx[q + 3 * HHX_WAVE];
             const i32 s0 = rank_of(l, j0) - r0, s1 = rank_of(l, j1) - r0, s2 = rank_of(l, j2) - r0, s3 = rank_of(l, j3) - r0;
-            if ((u32)s0 < (u32)rlen) atomicAdd((unsigned long long *)&l.acc[s0], (unsigned long long)(i64)(da * (double)b0));
-            if ((u32)s1 < (u32)rlen) atomicAdd((unsigned long long *)&l.acc[s1], (unsigned long long)(i64)(da * (double)b1));
-            if ((u32)s2 < (u32)rlen) atomicAdd((unsigned long long *)&l.acc[s2], (unsigned long long)(i64)(da * (double)b2));
-            if ((u32)s3 < (u32)rlen) atomicAdd((unsigned long long *)&l.acc[s3], (unsigned long long)(i64)(da * (double)b3));
+            if ((u32)s0 < (u32)rlen) acc_add(&l.acc[s0], da * (double)b0);
+            if ((u32)s1 < (u32)rlen) acc_add(&l.acc[s1], da * (double)b1);
+            if ((u32)s2 < (u32)rlen) acc_add(&l.acc[s2], da * (double)b2);
+            if ((u32)s3 < (u32)rlen) acc_add(&l.acc[s3], da * (double)b3);
         }
         for (; q < qe; q += HHX_WAVE) {
             const i32 s = rank_of(l, P.Bj[q]) - r0;
-            if ((u32)s < (u32)rlen) atomicAdd((unsigned long long *)&l.acc[s], (unsigned long long)(i64)(da * (double)P.Bx[q]));
+            if ((u32)s < (u32)rlen) acc_add(&l.acc[s], da * (double)P.Bx[q]);
         }
     }
 }
@@ -289,10 +346,10 @@ __device__ __forceinline__ double window_power_sum(const ExParams &P, const ExLd
     double s = 0.0;
     i32 nz = 0;
     for (i32 t = s0; t < s1; ++t) {
-        const i64 a = l.acc[t];
+        const double a = l.acc[t];
         float p = -1.0f;
-        if (COMPACT || a != 0) {
-            const float x = (float)((double)a * P.inv_scale);
+        if (COMPACT || a != 0.0) {
+            const float x = (float)(a * P.inv_scale);
             p = ex_inflate(x, P.r, P.square);
             s += (double)p;
             ++nz;
@@ -339,10 +396,10 @@ __device__ __forceinline__ void window_emit_candidates(const ExParams &P, const 
         }
         *seg_off = base;                       // LDS (compact kernel) or HBM (window passes)
         *seg_cnt = base < 0 ? 0 : total;
-        l.win_off[MAX_WIN - 1] = base;         // broadcast slot
+        *l.bcast = base;
     }
     __syncthreads();
-    const i64 base = l.win_off[MAX_WIN - 1];
+    const i64 base = *l.bcast;
     if (base < 0 || total == 0) return;
     // column of slot s0 in compact mode: find the (s0 + r0)-th set bit
     i32 w = 0; u32 bits = 0;
@@ -416,10 +473,10 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
         }
         P.row_off[row] = base;
         P.row_cnt[row] = base < 0 ? 0 : total;
-        l.win_off[MAX_WIN - 1] = base;
+        *l.bcast = base;
     }
     __syncthreads();
-    i64 o = l.win_off[MAX_WIN - 1];
+    i64 o = *l.bcast;
     __syncthreads();
     if (o < 0 || total == 0) return;
     // pass C: ordered write of (column, float(q / S2))
@@ -455,10 +512,11 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
 // B[:, w] (nnz_B / n_win entries), which raises the Infinity Cache / L2 hit rate of the B-row stream
 // compared with a row-outer nest (measured at n = 100k, 6 windows: 1.59 s vs 1.76 s before tile
 // pipelining), and the per-row epilogue (finalize) becomes its own uniform launch.
+template <bool CODED>
 __global__ __launch_bounds__(EX_T_WIN) void k_expand_window_pass(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap,
                                                                  i32 wv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ExLds l = ex_carve(smem, cap, 0);
+    const ExLds l = ex_carve(smem, cap, 0, 0, CODED);
     const int tid = threadIdx.x;
     i64 nnzc = 0;
     const i32 n_win = P.n_win;
@@ -466,14 +524,14 @@ __global__ __launch_bounds__(EX_T_WIN) void k_expand_window_pass(ExParams P, con
     for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
         const i32 row = rows[li];
         const i32 a_b = P.Ap[row], a_e = P.Ap[row + 1];
-        for (i32 t = tid; t < wlen; t += EX_T) l.acc[t] = 0;
+        for (i32 t = tid; t < wlen; t += EX_T) l.acc[t] = 0.0;
         __syncthreads();
         for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
             const i32 len = min(STAGE, a_e - a0);
-            if (n_win > 1) stage_chunk<true>(P, l, a0, len, wv);
-            else stage_chunk<false>(P, l, a0, len, wv);
+            if (n_win > 1) stage_chunk<true, CODED>(P, l, a0, len, wv);
+            else stage_chunk<false, CODED>(P, l, a0, len, wv);
             __syncthreads();
-            accumulate_window(P, l, len, c0);
+            accumulate_window<CODED>(P, l, len);
             __syncthreads();
         }
         i32 nz;
@@ -491,7 +549,7 @@ __global__ __launch_bounds__(EX_T_WIN) void k_expand_window_pass(ExParams P, con
 
 __global__ __launch_bounds__(EX_T_CMP) void k_expand_window_finalize(ExParams P, const i32 *__restrict__ rows, i32 n_list) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ExLds l = ex_carve(smem, 0, 0);
+    const ExLds l = ex_carve(smem, 0, 0, 0, false);
     for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
         const i32 row = rows[li];
         finalize_row(P, l, row, P.n_win, P.s_run[row], &P.g_win_off[(size_t)row * P.n_win], &P.g_win_cnt[(size_t)row * P.n_win]);
@@ -501,7 +559,7 @@ __global__ __launch_bounds__(EX_T_CMP) void k_expand_window_finalize(ExParams P,
 
 __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ExLds l = ex_carve(smem, cap, W);
+    const ExLds l = ex_carve(smem, cap, W, MAX_WIN, false);
     const int tid = threadIdx.x;
     i64 nnzc = 0;
     for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
@@ -522,7 +580,7 @@ __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i
         i32 n_win = 0;
         for (i32 r0 = 0; r0 < nnz_row; r0 += cap, ++n_win) {      // rank windows (one for almost every row)
             const i32 rlen = min(cap, nnz_row - r0);
-            for (i32 t = tid; t < rlen; t += EX_T) l.acc[t] = 0;
+            for (i32 t = tid; t < rlen; t += EX_T) l.acc[t] = 0.0;
             __syncthreads();
             for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
                 const i32 len = min(STAGE, a_e - a0);
@@ -576,6 +634,14 @@ __global__ __launch_bounds__(256) void k_window_ptrs(i32 n_rows, const i32 *__re
     }
 }
 
+// ---- window-local 16-bit column offsets of B (the window kernel's operand stream) -------------------------
+__global__ __launch_bounds__(256) void k_local_cols(i64 nnz, const i32 *__restrict__ Bj, i32 cap, unsigned short *__restrict__ out) {
+    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (i64)gridDim.x * blockDim.x) {
+        const i32 c = Bj[p];
+        out[p] = (unsigned short)(c - (c / cap) * cap);
+    }
+}
+
 // ---- pack the bump-allocated rows into CSR order ---------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_rows(i32 n_rows, const i64 *__restrict__ row_off, const i32 *__restrict__ indptr,
                                                    const i32 *__restrict__ pool_col, const float *__restrict__ pool_val,
@@ -590,17 +656,24 @@ __global__ __launch_bounds__(256) void k_pack_rows(i32 n_rows, const i64 *__rest
 
 }  // namespace
 
-// C ABI --------------------------------------------------------------------------------------------
-extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int fx_shift, double inflation, double pruning,
-                                        hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
+// coded: B's entries as 16-bit link counts (same positions as b's) + the L1 row sums of the link matrix;
+// b itself still holds the float32 values (used by the light-row kernel and by the shape/size logic)
+struct CodedOperand {
+    const unsigned short *n16 = nullptr;
+    const double *row_sum = nullptr;
+};
+
+int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &coded, int fx_shift, double inflation, double pruning,
+                    hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
     if (!a || !b || !out) return fail("null pointer");
     if (a->n_cols != b->n_rows) return fail("expand shape mismatch");
     if (!(inflation > 0)) return fail("inflation must be positive");
-    if (fx_shift < 0 || fx_shift > 1000) fx_shift = 60;
+    if (fx_shift < 0 || fx_shift > 52) fx_shift = 52;        // the exact-double accumulation holds 52 fractional bits
     const i32 n_rows = a->n_rows, n_cols = b->n_cols;
     const i32 W = (n_cols + 31) / 32;
     // ---- plans
-    const size_t fixed_win = ex_fixed_bytes(0), fixed_cmp = ex_fixed_bytes(W);
+    const bool is_coded = coded.n16 != nullptr;
+    const size_t fixed_win = ex_fixed_bytes(0, 0, is_coded), fixed_cmp = ex_fixed_bytes(W, MAX_WIN, false);
     // window class: the column window must fit LDS (8 B per column).  Measured on MI355X (n = 100k, 330M
     // entries): the fewest, widest windows win — 6 windows 1.41 s, 13 windows 1.54 s, 27 windows 2.24 s —
     // because the per-segment cost grows faster than the Infinity Cache hit rate of a narrower column slice
@@ -626,7 +699,8 @@ extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int 
     const size_t lds_win = (size_t)cap_win * 8 + fixed_win, lds_cmp = (size_t)cap_cmp * 8 + fixed_cmp;
     static bool attr_set = false;
     if (!attr_set) {
-        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_expand_compact, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -643,6 +717,8 @@ extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int 
         s_run.alloc((size_t)n_rows + 1) || g_win_off.alloc((size_t)n_rows * n_win + 1) || g_win_cnt.alloc((size_t)n_rows * n_win + 1))
         return 1;
     DevBuf<i32> win_ptr;
+    DevBuf<unsigned short> c16;
+    if (cap_win > 65536) return fail("expand: column window wider than 16 bits");
     if (n_win > 1) {
         if (win_ptr.alloc((size_t)b->n_rows * (n_win + 1))) return 1;
         const i64 total = (i64)b->n_rows * (n_win + 1);
@@ -670,20 +746,30 @@ extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int 
         P.Ap = a->indptr.p; P.Aj = a->indices.p; P.Ax = a->data.p;
         P.Bp = b->indptr.p; P.Bj = b->indices.p; P.Bx = b->data.p;
         P.n_rows = n_rows; P.n_cols = n_cols;
-        P.scale = ldexp(1.0, fx_shift); P.inv_scale = ldexp(1.0, -fx_shift);
+        P.scale = ldexp(1.0, fx_shift - 52); P.inv_scale = ldexp(1.0, 52 - fx_shift);
         P.r = (double)(float)inflation; P.square = inflation == 2.0; P.thr = (float)pruning;
         P.cand_col = cand_col.p; P.cand_val = cand_val.p; P.cand_cap = cand_cap;
         P.out_col = out_col.p; P.out_val = out_val.p; P.out_cap = pool_cap;
         P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
         P.win_ptr = win_ptr.p; P.n_win = n_win;
         P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
+        P.Bc16 = nullptr; P.Bn16 = coded.n16; P.Bs = coded.row_sum;
         if (hc[0]) {
+            if (!c16.p) {                                 // 16-bit window-local columns of B, built once per call
+                if (c16.alloc((size_t)b->nnz)) return 1;
+                k_local_cols<<<(unsigned)std::max<i64>(1, std::min<i64>((b->nnz + 255) / 256, 65536)), 256, 0, g_stream>>>(
+                    b->nnz, b->indices.p, cap_win, c16.p);
+                HHX_LAUNCH_CHECK();
+            }
+            P.Bc16 = c16.p;
             KTimer kt("expand_window");
             const unsigned per_cu = lds_win > 80 * 1024 ? 1 : 2;
-            for (i32 wv = 0; wv < n_win; ++wv)
-                k_expand_window_pass<<<std::min<unsigned>(hc[0], 256 * per_cu), EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0],
-                                                                                                           cap_win, wv);
-            k_expand_window_finalize<<<std::min<unsigned>(hc[0], 256 * 8), EX_T_CMP, fixed_win, g_stream>>>(P, list_w.p, (i32)hc[0]);
+            const unsigned grid = std::min<unsigned>(hc[0], 256 * per_cu);
+            for (i32 wv = 0; wv < n_win; ++wv) {
+                if (is_coded) k_expand_window_pass<true><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
+                else k_expand_window_pass<false><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
+            }
+            k_expand_window_finalize<<<std::min<unsigned>(hc[0], 256 * 8), EX_T_CMP, ex_fixed_bytes(0, 0, false), g_stream>>>(P, list_w.p, (i32)hc[0]);
         }
         HHX_LAUNCH_CHECK();
         if (hc[1]) {
@@ -720,4 +806,17 @@ extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int 
         return 0;
     }
     return fail("expand: survivor pool kept overflowing");
+}
+
+extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int fx_shift, double inflation, double pruning,
+                                        hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
+    return hhx_expand_impl(a, b, CodedOperand(), fx_shift, inflation, pruning, out, n_products, nnz_expanded);
+}
+
+// b is the L1-normalised link matrix whose entry p equals float(n16[p] / row_sum[row]) (checked by the caller)
+int hhx_expand_coded(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
+                     double inflation, double pruning, hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
+    CodedOperand c;
+    c.n16 = n16; c.row_sum = row_sum;
+    return hhx_expand_impl(a, b, c, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
 }

@@ -32,14 +32,20 @@ struct LinkRun {
     }
 };
 
-struct DevTables {           // device-resident copies of hhx_ingest_config arrays
-    const i32 *ctg_rank;
-    const i64 *ctg_len;
-    const i32 *ctg_frag0;
-    const unsigned char *ctg_split;
-    const i32 *frag_rank;
-    const i64 *frag_len;
-    const unsigned char *frag_nx;
+// Per-contig / per-fragment facts packed into one 16-byte record: a read pair needs two 16-byte
+// gathers (four when contigs are split) instead of a dozen 1-8 byte ones.
+//   rank : lexical rank of the NAME (key orientation :1629 / :1720)
+//   aux  : contigs: id of the contig's first fragment; fragments: unused
+//   lenf : length | NX_BIT (fragment is in Nx_frag_set; for a contig: its only fragment is) | SPLIT_BIT
+constexpr i64 NX_BIT = (i64)1 << 61, SPLIT_BIT = (i64)1 << 62, LEN_MASK = ((i64)1 << 48) - 1;
+struct __attribute__((aligned(16))) UnitInfo {
+    i32 rank, aux;
+    i64 lenf;
+};
+
+struct DevTables {           // device-resident, built from hhx_ingest_config
+    const UnitInfo *ctg;     // [n_ctg]
+    const UnitInfo *frag;    // [n_frag]
     i32 n_ctg, n_frag;
     i64 bin_size, flank;
     i32 bins, skip_intra;
@@ -59,9 +65,7 @@ struct OrderedTables {
 
 struct hhx_ingest {
     hhx::DevTables t{};
-    hhx::DevBuf<i32> ctg_rank, ctg_frag0, frag_rank;
-    hhx::DevBuf<i64> ctg_len, frag_len;
-    hhx::DevBuf<unsigned char> ctg_split, frag_nx;
+    hhx::DevBuf<hhx::UnitInfo> ctg_info, frag_info;
     bool combined = true;                  // one table serves full and flank (no bins: fragment == contig)
     u64 ord_base = 0;                      // global ordinal of this handle's first pair (multi-GPU chunk offset)
     u64 n_pushed = 0;                      // pairs pushed so far

@@ -43,48 +43,63 @@ __device__ __forceinline__ bool is_flank(i64 coord, i64 length, i64 flank) {   /
 // ---- map: one read pair -> at most one record of stream `stream` ------------------------------------
 // stream 0: the contig-pair table (full_link_dict + HT_link_dict; also flank_link_dict when no contig is
 //           split, because fragment == contig then);  stream 1 (bins only): the fragment-pair flank table.
-__device__ __forceinline__ bool map_pair(const DevTables &t, int stream, bool combined, i32 r, i32 m, i32 p1, i32 p2, u64 &rec) {
+// COMBINED (no split contigs, parse_alignments_for_ctgs :1596-1655) is a compile-time variant: two
+// 16-byte gathers and no divisions per pair.
+template <bool COMBINED>
+__device__ __forceinline__ bool map_pair(const DevTables &t, int stream, i32 r, i32 m, i32 p1, i32 p2, u64 &rec) {
     if (t.skip_intra && r == m) return false;                                    // pairs_generator_inter_ctgs :1582
-    if (t.bins && r == m && (r < 0 || r >= t.n_ctg || !t.ctg_split[r])) return false;   // :1699
-    if (r < 0 || m < 0 || r >= t.n_ctg || m >= t.n_ctg) return false;           // :1625 / :1702
+    if ((u32)r >= (u32)t.n_ctg || (u32)m >= (u32)t.n_ctg) return false;         // :1625 / :1702 (name not in fa_dict)
+    UnitInfo a = t.ctg[r], b = t.ctg[m];
+    if (!COMBINED && t.bins && r == m && !(a.lenf & SPLIT_BIT)) return false;    // :1699
     i32 ci = r, cj = m;
     i64 xi = (i64)p1 + 1, xj = (i64)p2 + 1;                                      // 1-based, :1629
-    if (t.ctg_rank[r] > t.ctg_rank[m] || (r == m && xi > xj)) { ci = m; cj = r; const i64 tx = xi; xi = xj; xj = tx; }
-    i32 fi = t.ctg_frag0[ci], fj = t.ctg_frag0[cj];
-    i64 yi = xi, yj = xj;
-    if (t.bins) {                                                                // convert_frags :1662-1670
-        if (t.ctg_split[ci]) { const i64 nb = (xi + t.bin_size - 1) / t.bin_size; fi += (i32)(nb - 1); yi = xi - (nb - 1) * t.bin_size; }
-        if (t.ctg_split[cj]) { const i64 nb = (xj + t.bin_size - 1) / t.bin_size; fj += (i32)(nb - 1); yj = xj - (nb - 1) * t.bin_size; }
-        if (fi == fj) return false;                                              // :1715
-        if (t.frag_rank[fi] > t.frag_rank[fj]) { const i32 tf = fi; fi = fj; fj = tf; const i64 ty = yi; yi = yj; yj = ty; }   // :1719-1720
+    if (a.rank > b.rank || (r == m && xi > xj)) {
+        ci = m; cj = r;
+        const i64 tx = xi; xi = xj; xj = tx;
+        const UnitInfo tu = a; a = b; b = tu;
     }
-    const bool flank_ok = t.frag_nx[fi] && t.frag_nx[fj] && is_flank(yi, t.frag_len[fi], t.flank) &&
-                          is_flank(yj, t.frag_len[fj], t.flank);                 // :1636 / :1726
-    const bool full_ok = !(t.bins && r == m);                                    // :1736
-    const u64 ht = (u64)((xi * 2 > t.ctg_len[ci]) * 2 + (xj * 2 > t.ctg_len[cj]));   // :404-416
-    if (combined) {
+    const i64 li = a.lenf & LEN_MASK, lj = b.lenf & LEN_MASK;
+    const u64 ht = (u64)((xi * 2 > li) * 2 + (xj * 2 > lj));                     // :404-416
+    if (COMBINED) {
+        const bool flank_ok = (a.lenf & b.lenf & NX_BIT) && is_flank(xi, li, t.flank) && is_flank(xj, lj, t.flank);   // :1636
         rec = ((u64)(u32)ci << ID_BITS) | (u64)(u32)cj | (ht << HT_SHIFT) | FULL_BIT | (flank_ok ? FLANK_BIT : 0);
         return true;
     }
+    i32 fi = a.aux, fj = b.aux;
+    i64 yi = xi, yj = xj;
+    if (t.bins) {                                                                // convert_frags :1662-1670
+        if (a.lenf & SPLIT_BIT) { const i64 nb = (xi + t.bin_size - 1) / t.bin_size; fi += (i32)(nb - 1); yi = xi - (nb - 1) * t.bin_size; }
+        if (b.lenf & SPLIT_BIT) { const i64 nb = (xj + t.bin_size - 1) / t.bin_size; fj += (i32)(nb - 1); yj = xj - (nb - 1) * t.bin_size; }
+        if (fi == fj) return false;                                              // :1715
+    }
     if (stream == 0) {
-        if (!full_ok) return false;
+        if (t.bins && r == m) return false;                                      // :1736
         rec = ((u64)(u32)ci << ID_BITS) | (u64)(u32)cj | (ht << HT_SHIFT) | FULL_BIT;
         return true;
     }
-    if (!flank_ok) return false;
+    UnitInfo fa = t.frag[fi], fb = t.frag[fj];
+    if (t.bins && fa.rank > fb.rank) {                                           // :1719-1720
+        const i32 tf = fi; fi = fj; fj = tf;
+        const i64 ty = yi; yi = yj; yj = ty;
+        const UnitInfo tu = fa; fa = fb; fb = tu;
+    }
+    if (!((fa.lenf & fb.lenf & NX_BIT) && is_flank(yi, fa.lenf & LEN_MASK, t.flank) && is_flank(yj, fb.lenf & LEN_MASK, t.flank)))
+        return false;                                                            // :1726
     rec = ((u64)(u32)fi << ID_BITS) | (u64)(u32)fj | FLANK_BIT;
     return true;
 }
 
 // ---- record sources ---------------------------------------------------------------------------------
+template <bool COMBINED>
 struct SrcPairs {
     const i32 *id1, *pos1, *id2, *pos2;
     DevTables t;
-    int stream, combined;
+    int stream;
 };
-__device__ __forceinline__ bool src_get(const SrcPairs &s, i64 idx, u64 &rec, u32 &ord) {
+template <bool COMBINED>
+__device__ __forceinline__ bool src_get(const SrcPairs<COMBINED> &s, i64 idx, u64 &rec, u32 &ord) {
     ord = (u32)idx;
-    return map_pair(s.t, s.stream, s.combined != 0, s.id1[idx], s.id2[idx], s.pos1[idx], s.pos2[idx], rec);
+    return map_pair<COMBINED>(s.t, s.stream, s.id1[idx], s.id2[idx], s.pos1[idx], s.pos2[idx], rec);
 }
 struct SrcRecs {
     const u64 *rec;
@@ -405,7 +420,8 @@ int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, Link
         if (hist1.alloc(nb1 + 1) || cur1.alloc(nb1 + 1) || base1.alloc(nb1 + 2)) { delete run; return 1; }
         HHX_HIP(hipMemsetAsync(hist1.p, 0, sizeof(unsigned long long) * (nb1 + 1), g_stream));
         const PartLevel L1{total_bits, bits2, bits1};
-        k_part_count<Src><<<pgrid, PT, 0, g_stream>>>(src, n_items, L1, hist1.p);
+        { KTimer kt("part_count1");
+        k_part_count<Src><<<pgrid, PT, 0, g_stream>>>(src, n_items, L1, hist1.p); }
         HHX_LAUNCH_CHECK();
         i64 n_valid = 0;
         HHX_TRY(exclusive_scan_i64((const i64 *)hist1.p, base1.p, nb1, &n_valid));
@@ -414,7 +430,8 @@ int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, Link
         DevBuf<u32> ord1, ord2;
         if (rec1.alloc((size_t)n_valid) || ord1.alloc((size_t)n_valid)) { delete run; return 1; }
         k_u64_copy<<<grid_for(nb1 + 1), 256, 0, g_stream>>>((const unsigned long long *)base1.p, cur1.p, nb1 + 1);
-        k_part_scatter<Src><<<pgrid, PT, 0, g_stream>>>(src, n_items, L1, cur1.p, rec1.p, ord1.p);
+        { KTimer kt("part_scatter1");
+        k_part_scatter<Src><<<pgrid, PT, 0, g_stream>>>(src, n_items, L1, cur1.p, rec1.p, ord1.p); }
         HHX_LAUNCH_CHECK();
         const u64 *recs = rec1.p;
         const u32 *ords = ord1.p;
@@ -428,11 +445,13 @@ int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, Link
             const PartLevel L2{total_bits, 0, bits2};
             const SrcRecs s2{rec1.p, ord1.p};
             const unsigned g2 = (unsigned)std::max<i64>(1, std::min<i64>((n_valid + P_TILE - 1) / P_TILE, 256 * 4));
-            k_part_count<SrcRecs><<<g2, PT, 0, g_stream>>>(s2, n_valid, L2, hist2.p);
+            { KTimer kt("part_count2");
+            k_part_count<SrcRecs><<<g2, PT, 0, g_stream>>>(s2, n_valid, L2, hist2.p); }
             HHX_LAUNCH_CHECK();
             HHX_TRY(exclusive_scan_i64((const i64 *)hist2.p, base2.p, n_buckets, nullptr));
             k_u64_copy<<<grid_for(n_buckets + 1), 256, 0, g_stream>>>((const unsigned long long *)base2.p, cur2.p, n_buckets + 1);
-            k_part_scatter<SrcRecs><<<g2, PT, 0, g_stream>>>(s2, n_valid, L2, cur2.p, rec2.p, ord2.p);
+            { KTimer kt("part_scatter2");
+            k_part_scatter<SrcRecs><<<g2, PT, 0, g_stream>>>(s2, n_valid, L2, cur2.p, rec2.p, ord2.p); }
             HHX_LAUNCH_CHECK();
             recs = rec2.p; ords = ord2.p; base = base2.p;
         }
@@ -464,7 +483,8 @@ int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, Link
         HHX_HIP(hipStreamSynchronize(g_stream));
         if (ov) continue;                                       // a bucket held more distinct keys than LDS: more buckets
         if (run->alloc(n_keys)) { delete run; return 1; }
-        k_compact_run<<<n_wg, 256, 0, g_stream>>>(A, seg_off.p, run->key.p, run->ord_full.p, run->ord_flank.p, run->ht.p, run->fl.p);
+        { KTimer kt("compact");
+        k_compact_run<<<n_wg, 256, 0, g_stream>>>(A, seg_off.p, run->key.p, run->ord_full.p, run->ord_flank.p, run->ht.p, run->fl.p); }
         HHX_LAUNCH_CHECK();
         HHX_HIP(hipStreamSynchronize(g_stream));                // the gapped buffers are released on return
         *out = run;
@@ -635,21 +655,32 @@ extern "C" int hhx_ingest_create(const hhx_ingest_config *cfg, hhx_ingest **out)
     if (cfg->bins && cfg->bin_size <= 0) return fail("bins mode needs bin_size > 0");
     if ((i64)cfg->n_ctg >= ((i64)1 << ID_BITS) || (i64)cfg->n_frag >= ((i64)1 << ID_BITS))
         return fail("ingest: more than 2^29 contigs / fragments");
-    hhx_ingest *h = new hhx_ingest();
-    int rc = upload(h->ctg_rank, cfg->ctg_rank, (size_t)cfg->n_ctg) || upload(h->ctg_len, cfg->ctg_len, (size_t)cfg->n_ctg) ||
-             upload(h->ctg_frag0, cfg->ctg_frag0, (size_t)cfg->n_ctg) || upload(h->ctg_split, cfg->ctg_split, (size_t)cfg->n_ctg) ||
-             upload(h->frag_rank, cfg->frag_rank, (size_t)cfg->n_frag) || upload(h->frag_len, cfg->frag_len, (size_t)cfg->n_frag) ||
-             upload(h->frag_nx, cfg->frag_nx, (size_t)cfg->n_frag);
-    if (rc) { delete h; return 1; }
-    hipError_t e = hipStreamSynchronize(g_stream);
-    if (e != hipSuccess) { delete h; return fail("ingest_create: %s", hipGetErrorString(e)); }
-    h->t.ctg_rank = h->ctg_rank.p; h->t.ctg_len = h->ctg_len.p; h->t.ctg_frag0 = h->ctg_frag0.p; h->t.ctg_split = h->ctg_split.p;
-    h->t.frag_rank = h->frag_rank.p; h->t.frag_len = h->frag_len.p; h->t.frag_nx = h->frag_nx.p;
-    h->t.n_ctg = cfg->n_ctg; h->t.n_frag = cfg->n_frag; h->t.bin_size = cfg->bin_size; h->t.flank = cfg->flank;
-    h->t.bins = cfg->bins; h->t.skip_intra = cfg->skip_intra;
+    for (i32 c = 0; c < cfg->n_ctg; ++c)
+        if (cfg->ctg_len[c] < 0 || cfg->ctg_len[c] > LEN_MASK || cfg->ctg_frag0[c] < 0 || cfg->ctg_frag0[c] >= cfg->n_frag)
+            return fail("ingest: bad length / first fragment for contig %d", c);
     // one table serves both dicts when every contig is its own fragment (parse_alignments_for_ctgs)
     bool identity = !cfg->bins && cfg->n_ctg == cfg->n_frag;
-    for (i32 c = 0; identity && c < cfg->n_ctg; ++c) identity = cfg->ctg_frag0[c] == c;
+    for (i32 c = 0; identity && c < cfg->n_ctg; ++c)
+        identity = cfg->ctg_frag0[c] == c && cfg->frag_len[c] == cfg->ctg_len[c];
+    std::vector<UnitInfo> ci((size_t)cfg->n_ctg), fi((size_t)cfg->n_frag);
+    for (i32 f = 0; f < cfg->n_frag; ++f) {
+        fi[f].rank = cfg->frag_rank[f];
+        fi[f].aux = 0;
+        fi[f].lenf = (cfg->frag_len[f] & LEN_MASK) | (cfg->frag_nx[f] ? NX_BIT : 0);
+    }
+    for (i32 c = 0; c < cfg->n_ctg; ++c) {
+        ci[c].rank = cfg->ctg_rank[c];
+        ci[c].aux = cfg->ctg_frag0[c];
+        ci[c].lenf = cfg->ctg_len[c] | (cfg->ctg_split[c] ? SPLIT_BIT : 0) | (identity && cfg->frag_nx[c] ? NX_BIT : 0);
+    }
+    hhx_ingest *h = new hhx_ingest();
+    int rc = upload(h->ctg_info, ci.data(), ci.size()) || upload(h->frag_info, fi.data(), fi.size());
+    if (rc) { delete h; return 1; }
+    hipError_t e = hipStreamSynchronize(g_stream);               // the host vectors die at return
+    if (e != hipSuccess) { delete h; return fail("ingest_create: %s", hipGetErrorString(e)); }
+    h->t.ctg = h->ctg_info.p; h->t.frag = h->frag_info.p;
+    h->t.n_ctg = cfg->n_ctg; h->t.n_frag = cfg->n_frag; h->t.bin_size = cfg->bin_size; h->t.flank = cfg->flank;
+    h->t.bins = cfg->bins; h->t.skip_intra = cfg->skip_intra;
     h->combined = identity;
     *out = h;
     return 0;
@@ -677,11 +708,18 @@ extern "C" int hhx_ingest_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const
     }
     const u64 ord0 = h->ord_base + h->n_pushed;
     { KTimer kt("ingest");
-    for (int stream = 0; stream < (h->combined ? 1 : 2); ++stream) {
-        const SrcPairs sp{src[0], src[1], src[2], src[3], h->t, stream, h->combined ? 1 : 0};
+    if (h->combined) {
+        const SrcPairs<true> sp{src[0], src[1], src[2], src[3], h->t, 0};
         LinkRun *run = nullptr;
-        HHX_TRY((build_run<SrcPairs, 0>(sp, n_pairs, Payload(), ord0, &run)));
-        h->runs[stream].push_back(run);
+        HHX_TRY((build_run<SrcPairs<true>, 0>(sp, n_pairs, Payload(), ord0, &run)));
+        h->runs[0].push_back(run);
+    } else {
+        for (int stream = 0; stream < 2; ++stream) {
+            const SrcPairs<false> sp{src[0], src[1], src[2], src[3], h->t, stream};
+            LinkRun *run = nullptr;
+            HHX_TRY((build_run<SrcPairs<false>, 0>(sp, n_pairs, Payload(), ord0, &run)));
+            h->runs[stream].push_back(run);
+        }
     } }
     h->n_pushed += (u64)n_pairs;
     h->ord_limit = std::max<u64>(h->ord_limit, h->ord_base + h->n_pushed);

@@ -10,12 +10,14 @@
 using namespace hhx;
 
 int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
+int hhx_expand_coded(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
+                     double inflation, double pruning, hhx_csr **out, i64 *n_products, i64 *nnz_expanded);
 
 namespace {
 
-// Stochastic operands: every row of T sums to 1 and every entry is <= 1, so |C| <= 1 and a fixed
-// 2^60 scaling leaves 3 bits of headroom; no per-call bound reduction (and no host sync) is needed.
-constexpr int HHX_MCL_FX_SHIFT = 60;
+// Stochastic operands: every row of T sums to 1 and every entry is <= 1, so |C| <= 1 and products rounded on
+// the 2^-52 grid add exactly in a double (hhx_expand.hip: acc_add); no per-call bound reduction is needed.
+constexpr int HHX_MCL_FX_SHIFT = 52;
 
 constexpr int ROW_T = 256;                       // 4 waves per workgroup, one row per wave
 constexpr int ROW_WAVES = ROW_T / HHX_WAVE;
@@ -35,13 +37,14 @@ __device__ __forceinline__ float inflate_one(float x, double r, bool square) {
 
 // ---- L1 normalise in place ------------------------------------------------------------------
 __global__ __launch_bounds__(ROW_T) void k_normalize_l1(i32 n_rows, const i32 *__restrict__ indptr,
-                                                        float *__restrict__ data) {
+                                                        float *__restrict__ data, double *__restrict__ row_sum) {
     const int lane = lane_id();
     for (i32 row = blockIdx.x * ROW_WAVES + threadIdx.x / HHX_WAVE; row < n_rows; row += gridDim.x * ROW_WAVES) {
         const i32 b = indptr[row], e = indptr[row + 1];
         double s = 0.0;
         for (i32 p = b + lane; p < e; p += HHX_WAVE) s += fabs((double)data[p]);
         s = wave_sum_f64(s);
+        if (row_sum && lane == 0) row_sum[row] = s;
         if (s == 0.0) continue;
         for (i32 p = b + lane; p < e; p += HHX_WAVE) data[p] = (float)((double)data[p] / s);
     }
@@ -184,6 +187,25 @@ __global__ __launch_bounds__(ROW_T) void k_convergence(i32 n_rows, const i32 *__
     if (lane == 0 && best > 0.0f) atomicMax(out_bits, __float_as_uint(best));   // non-negative floats order as uints
 }
 
+// 16-bit link counts of a raw link matrix (:362-368: integer counts as float32, unit self loops); flags[0] is
+// raised if some entry is not an integer in [0, 65535] (e.g. after --normalize_by_nlinks)
+__global__ __launch_bounds__(256) void k_link_counts(i64 nnz, const float *__restrict__ data, unsigned short *__restrict__ n16,
+                                                     unsigned int *flags) {
+    bool bad = false;
+    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (i64)gridDim.x * blockDim.x) {
+        const float v = data[p];
+        const unsigned int c = (unsigned int)v;
+        if (!(v >= 0.0f && v <= 65535.0f) || (float)c != v) bad = true;
+        n16[p] = (unsigned short)c;
+    }
+    if (__any(bad) && lane_id() == 0) atomicExch(flags, 1u);
+}
+__global__ __launch_bounds__(256) void k_any_zero(i32 n, const double *__restrict__ v, unsigned int *flags) {
+    bool bad = false;
+    for (i32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bad |= !(v[i] > 0.0);
+    if (__any(bad) && lane_id() == 0) atomicExch(flags, 1u);
+}
+
 int inflate_prune_impl(hhx_csr *c, int mode, double inflation, double pruning, hhx_csr **out) {
     const i32 n = c->n_rows;
     DevBuf<i32> cnt, amax, optr;
@@ -217,7 +239,7 @@ int inflate_prune_impl(hhx_csr *c, int mode, double inflation, double pruning, h
 // ------------------------------------------------------------------ C ABI
 extern "C" int hhx_normalize_l1(hhx_csr *m) {
     if (!m) return fail("null matrix");
-    k_normalize_l1<<<row_grid(m->n_rows), ROW_T, 0, g_stream>>>(m->n_rows, m->indptr.p, m->data.p);
+    k_normalize_l1<<<row_grid(m->n_rows), ROW_T, 0, g_stream>>>(m->n_rows, m->indptr.p, m->data.p, nullptr);
     HHX_LAUNCH_CHECK();
     return 0;
 }
@@ -264,7 +286,8 @@ extern "C" int hhx_convergence_stat(const hhx_csr *m, const hhx_csr *last, float
 // pre_expanded == 0: `m` is the L1-normalised link matrix and the pre-expansion of :2146-2147 is
 // fused into iteration 0.  Every expansion that feeds an inflate+prune goes through the fused kernel.
 static int mcl_impl(const hhx_csr *m, int pre_expanded, int expansion, double inflation, int max_iter, double pruning,
-                    hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
+                    hhx_csr **out, int *n_iter, int *converged, i64 *stats, const unsigned short *n16 = nullptr,
+                    const double *row_sum = nullptr) {
     if (!m || !out || !n_iter || !converged) return fail("null pointer");
     if (m->n_rows != m->n_cols) return fail("mcl needs a square matrix");
     if (expansion < 1) return fail("expansion must be >= 1");
@@ -296,7 +319,10 @@ static int mcl_impl(const hhx_csr *m, int pre_expanded, int expansion, double in
             }
             if (!rc) {
                 i64 f = 0;
-                rc = hhx_expand_inflate_prune(run, src, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);   // :2030-2042
+                if (it == 0 && n16)   // iteration 0 right operand = the normalised link matrix itself: 4-byte count-coded stream
+                    rc = hhx_expand_coded(run, src, n16, row_sum, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);
+                else
+                    rc = hhx_expand_inflate_prune(run, src, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);   // :2030-2042
                 st_f += f;
             }
             if (run != src && run) hhx_csr_free(const_cast<hhx_csr *>(run));
@@ -331,6 +357,42 @@ extern "C" int hhx_mcl(const hhx_csr *pre, int expansion, double inflation, int 
 extern "C" int hhx_mcl_normalized(const hhx_csr *norm, int expansion, double inflation, int max_iter, double pruning,
                                   hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
     return mcl_impl(norm, 0, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats);
+}
+
+// run_mcl_clustering :2144-2158 for one inflation straight from the RAW link matrix of dict_to_matrix
+// (:362-368): L1 normalisation (:2144), pre-expansion (:2146-2147) fused into iteration 0, mcl().  When the
+// matrix holds integer link counts <= 65535 (always, unless --normalize_by_nlinks / GFA weights were applied)
+// iteration 0 streams its right operand as 16-bit counts.  `normalized_out` (optional) receives the
+// normalised matrix so that an inflation sweep can reuse it.
+extern "C" int hhx_mcl_links(const hhx_csr *links, int expansion, double inflation, int max_iter, double pruning,
+                             hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
+    if (!links || !out) return fail("null pointer");
+    hhx_csr *norm = nullptr;
+    HHX_TRY(hhx_csr_copy(links, &norm));
+    DevBuf<double> row_sum;
+    DevBuf<unsigned short> n16;
+    DevBuf<unsigned int> flags;
+    int rc = (row_sum.alloc((size_t)links->n_rows + 1) || n16.alloc((size_t)links->nnz) || flags.alloc(1)) ? 1 : 0;
+    unsigned int bad = 1;
+    if (!rc) {
+        hipError_t e = hipMemsetAsync(flags.p, 0, sizeof(unsigned int), g_stream);
+        k_normalize_l1<<<row_grid(norm->n_rows), ROW_T, 0, g_stream>>>(norm->n_rows, norm->indptr.p, norm->data.p, row_sum.p);
+        if (links->nnz)
+            k_link_counts<<<(unsigned)std::max<i64>(1, std::min<i64>((links->nnz + 255) / 256, 65536)), 256, 0, g_stream>>>(
+                links->nnz, links->data.p, n16.p, flags.p);
+        if (links->n_rows)
+            k_any_zero<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)links->n_rows + 255) / 256, 4096)), 256, 0, g_stream>>>(
+                links->n_rows, row_sum.p, flags.p);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, flags.p, sizeof bad, hipMemcpyDeviceToHost, g_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        if (e != hipSuccess) rc = fail("hhx_mcl_links: %s", hipGetErrorString(e));
+    }
+    if (!getenv("HHX_CODED")) bad = 1;      // opt-in: the 4-byte stream is ALU-bound on MI355X (hhx_expand.hip)
+    if (!rc) rc = mcl_impl(norm, 0, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats, bad ? nullptr : n16.p,
+                           bad ? nullptr : row_sum.p);
+    hhx_csr_free(norm);
+    return rc;
 }
 
 // interpret_result(), array half.  The final matrix holds ~n entries, so this is a host pass over a

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(SG_T) void k_spgemm_symbolic(i32 n_rows, const i32 
 
 // ---- numeric ---------------------------------------------------------------------------------
 __device__ __forceinline__ i64 to_fixed(float a, float b, double scale) {
-    return (i64)((double)a * (double)b * scale);        // exact product, exact power-of-two scaling, truncation
+    return __double2ll_rn((double)a * (double)b * scale);   // exact product, exact power-of-two scaling, round to nearest even
 }
 
 __global__ __launch_bounds__(SG_T) void k_spgemm_numeric(i32 n_rows, const i32 *__restrict__ Ap,

@@ -57,13 +57,13 @@ class HipEngine:
         return m.row_block(r0, r1)
 
     def spgemm(self, a, b):
-        return _lib.spgemm(a, b, fx_shift=60, want_products=True)
+        return _lib.spgemm(a, b, fx_shift=52, want_products=True)
 
     def inflate_prune(self, c, inflation, pruning):
         return _lib.inflate_prune(c, inflation, pruning)
 
     def expand_inflate_prune(self, a, b, inflation, pruning):
-        return _lib.expand_inflate_prune(a, b, inflation, pruning, fx_shift=60)
+        return _lib.expand_inflate_prune(a, b, inflation, pruning, fx_shift=52)
 
     def convergence_stat(self, m, last):
         return _lib.convergence_stat(m, last)

@@ -77,16 +77,18 @@ int hhx_inflate_prune(hhx_csr *c, double inflation, double pruning, hhx_csr **ou
  * sparse_dot_mkl.dot_product_mkl(A_csc, B_csc) :39-43, used by mkl_matrix_power :2017-2023.
  * On the CSC view out = A_csc * B_csc; in CSR(T) terms the caller passes (a = T_B, b = T_A), i.e.
  * out_T = T_B * T_A.  a may be a row block (n_local x k) of the left operand (multi-GPU shard).
- * Accumulation: each float32 product is formed exactly in double, converted to 64-bit fixed point
- * (2^fx_shift scaling chosen from ||a||_inf * max|b|) and summed with integer adds, so the result is
- * independent of summation order and of the GPU count; it is rounded to float32 once. */
+ * Accumulation: each float32 product is formed exactly in double, rounded to the nearest multiple of
+ * 2^-fx_shift (ties to even; shift chosen from ||a||_inf * max|b|) and summed exactly (64-bit integer adds),
+ * so the result is independent of summation order and of the GPU count; it is rounded to float32 once. */
 int hhx_spgemm(const hhx_csr *a, const hhx_csr *b, hhx_csr **out);
 /* same with an explicit fixed-point shift (tests); products counted into *n_products if non-NULL */
 int hhx_spgemm_ex(const hhx_csr *a, const hhx_csr *b, int fx_shift, hhx_csr **out, int64_t *n_products);
 
 /* One fused MCL iteration on the device, :2030-2042: out = prune(normalize(power(a * b, inflation))),
  * the expanded matrix a*b is consumed row by row in LDS and never written to HBM (at n = 100k the
- * un-pruned pre-expansion of :2147 has 10^10 entries).  a may be a row block.  fx_shift < 0: 60. */
+ * un-pruned pre-expansion of :2147 has 10^10 entries).  a may be a row block.  Operands must be
+ * stochastic (entries in [0,1], row sums <= 1): products are rounded on the 2^-fx_shift grid, fx_shift <= 52
+ * (default 52), and accumulated with exact float64 adds. */
 int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int fx_shift, double inflation, double pruning,
                              hhx_csr **out, int64_t *n_products, int64_t *nnz_expanded);
 
@@ -103,6 +105,14 @@ int hhx_mcl(const hhx_csr *pre_expanded, int expansion, double inflation, int ma
  * pre-expansion (:2146-2147) is fused into iteration 0 instead of being materialised. */
 int hhx_mcl_normalized(const hhx_csr *normalized, int expansion, double inflation, int max_iter, double pruning,
                        hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
+
+/* run_mcl_clustering :2144-2158 for one inflation straight from the RAW link matrix that dict_to_matrix
+ * returns (:362-368): the L1 normalisation (:2144), the pre-expansion (:2146-2147, fused into iteration 0) and
+ * mcl().  Same results as hhx_normalize_l1 + hhx_mcl_normalized; when the matrix holds integer link counts
+ * <= 65535 and HHX_CODED=1 is set, iteration 0 streams its right operand as 16-bit counts (4 B per product,
+ * bit-identical; off by default because it is ALU-bound on MI355X while the 6-byte stream is HBM-bound). */
+int hhx_mcl_links(const hhx_csr *links, int expansion, double inflation, int max_iter, double pruning,
+                  hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
 
 /* ---------------------------------------------------------------- a12: interpret_result :2065-2095
  * Array half: attractors (ascending) = rows with a non-zero diagonal; members of attractor a =

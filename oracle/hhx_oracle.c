@@ -58,9 +58,10 @@ void orc_power(i64 nnz, float *data, double r) {
  * k index in ascending order — bit-identical to scipy's csr_matmat (the SURVEY's MKL stand-in) on
  * canonical inputs.  Output rows are sorted by column.
  *   mode 0: float32 accumulation (reference-like).
- *   mode 1: the HIP kernel's specification — each product a*b formed exactly in double, converted
- *           to signed 64-bit fixed point with 2^fx_shift scaling (truncation toward zero), summed
- *           as integers (order independent), converted back once.  Used for bit-exact kernel checks.
+ *   mode 1: the HIP kernel's specification — each product a*b formed exactly in double, rounded to the
+ *           nearest multiple of 2^-fx_shift (ties to even), summed exactly (order independent: 64-bit
+ *           integers here, exact double adds in the fused HIP kernel), rounded to float32 once.
+ *           Used for bit-exact kernel checks.
  * Two-call pattern: pass Cj == NULL to get the row pointer only.
  * ---------------------------------------------------------------------------------------------- */
 static int cmp_i32(const void *a, const void *b) {
@@ -93,7 +94,7 @@ i64 orc_spgemm(i32 n_rows, i32 n_cols, const i32 *Ap, const i32 *Aj, const float
                 }
                 if (Cj) {
                     if (mode == 0) accf[j] += a * Bx[q];
-                    else acci[j] += (i64)((double)a * (double)Bx[q] * scale);
+                    else acci[j] += (i64)llrint((double)a * (double)Bx[q] * scale);
                 }
             }
         }

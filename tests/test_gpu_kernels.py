@@ -169,7 +169,7 @@ def test_mcl_whole(golden_mcl):
         want = {tuple(g[tag + '_clusters'][g[tag + '_clusters_ptr'][a]:g[tag + '_clusters_ptr'][a + 1]].tolist())
                 for a in range(len(g[tag + '_clusters_ptr']) - 1)}
         assert clusters_of(*_lib.interpret(res)) == want
-        o = orc.mcl(tri(g, tag + '_m2'), 2, infl, 200, 1e-4, spgemm_mode=1, fx_shift=60, want_stats=True)
+        o = orc.mcl(tri(g, tag + '_m2'), 2, infl, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True)
         assert np.array_equal(o[5], stats)      # nnz_A, nnz_C, nnz_P, F per iteration
         # not converging is not an error (:2058-2062)
         res2, n2, c2 = _lib.mcl(pre, 2, infl, 3, 1e-4)
@@ -178,13 +178,13 @@ def test_mcl_whole(golden_mcl):
 
 def test_mcl_deterministic_and_larger():
     A = clustered_stochastic(20000, 200, 30, 1, 11)
-    A2 = orc.spgemm(A, A, mode=1, fx_shift=60)
+    A2 = orc.spgemm(A, A, mode=1, fx_shift=52)
     pre = _lib.DeviceCSR.from_arrays(*A2)
     r1, n1, c1 = _lib.mcl(pre, 2, 2.0, 60, 1e-4)
     r2, n2, c2 = _lib.mcl(pre, 2, 2.0, 60, 1e-4)
     a1, a2 = r1.to_arrays(), r2.to_arrays()
     assert n1 == n2 and all(np.array_equal(x, y) for x, y in zip(a1, a2)), 'run-to-run bits differ'
-    o = orc.mcl(A2, 2, 2.0, 60, 1e-4, spgemm_mode=1, fx_shift=60)
+    o = orc.mcl(A2, 2, 2.0, 60, 1e-4, spgemm_mode=1, fx_shift=52)
     assert o[3] == n1 and o[4] == c1
     assert clusters_of(*_lib.interpret(r1)) == clusters_of(*orc.interpret(o[:3]))
 
@@ -304,7 +304,7 @@ def test_ingest_table_exchange_roundtrip():
         assert np.array_equal(got[k], o[k]), k
 
 
-def oracle_fused(A, B, infl, pruning=1e-4, shift=60):
+def oracle_fused(A, B, infl, pruning=1e-4, shift=52):
     c = orc.spgemm(A, B, n_cols=len(B[0]) - 1, mode=1, fx_shift=shift)
     x = orc.normalize_l1(c[0], orc.power(c[2], infl))
     return orc.prune((c[0], c[1], x), pruning), int(c[0][-1])
@@ -351,3 +351,51 @@ def test_mcl_normalized_fuses_pre_expansion(golden_mcl):
                 for a in range(len(g[tag + '_clusters_ptr']) - 1)}
         assert clusters_of(*_lib.interpret(res)) == want
         assert stats[0, 0] == len(g[tag + '_norm_j']) and stats[0, 1] == len(g[tag + '_m2_j']) and stats[0, 3] > 0
+
+
+def test_mcl_links_count_coded_iteration0():
+    """hhx_mcl_links (normalisation fused, iteration 0 streaming 16-bit link counts + 16-bit window-local
+    columns) must give exactly the bits of hhx_normalize_l1 + hhx_mcl_normalized, on a matrix wide enough
+    for several column windows; non-integer values must fall back to the generic stream."""
+    import torch
+    from haphic_amd import synth
+    gen = synth.make_genome(8, 60_000_000, 20_000, seed=8)          # ~24k contigs -> 2 column windows
+    n = gen.n
+    lex = gen.lexical_rank()
+    t = orc.FragTable(lex, gen.length, np.arange(n, dtype=np.int32), np.zeros(n, np.uint8), 0, lex, gen.length,
+                      np.ones(n, np.uint8))
+    id1, p1, id2, p2 = synth.sample_pairs(gen, 20_000_000, seed=9, device='cuda')
+    ing = _lib.Ingest(t, 500_000, bins=False, skip_intra=True)
+    ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+    torch.cuda.synchronize()
+    links, fidx, n_linked = ing.link_matrix(np.ones(n, np.uint8))
+    assert links.shape3[0] > 17_500
+    import os
+    os.environ['HHX_CODED'] = '1'                                # opt-in 4-byte stream (read at call time)
+    try:
+        r1, n1, c1, st1 = _lib.mcl(links, 2, 2.0, 200, 1e-4, want_stats=True, links=True)
+    finally:
+        del os.environ['HHX_CODED']
+    r0, n0, c0 = _lib.mcl(links, 2, 2.0, 200, 1e-4, links=True)     # default 6-byte stream
+    assert all(np.array_equal(x, y) for x, y in zip(r0.to_arrays(), r1.to_arrays()))
+    norm = links.copy()
+    _lib.normalize_l1(norm)
+    r2, n2, c2, st2 = _lib.mcl(norm, 2, 2.0, 200, 1e-4, want_stats=True, normalized=True)
+    assert (n1, c1) == (n2, c2) and np.array_equal(st1, st2)
+    assert all(np.array_equal(x, y) for x, y in zip(r1.to_arrays(), r2.to_arrays())), 'count-coded iteration 0 changed bits'
+    # one fused iteration against the oracle on a slice of rows (the oracle is too slow for all of them)
+    A = norm.to_arrays()
+    blk = norm.row_block(100, 140)
+    got = _lib.expand_inflate_prune(blk, norm, 2.0, 1e-4)[0].to_arrays()
+    lo, hi = A[0][100], A[0][140]
+    ref, _ = oracle_fused(((A[0][100:141] - lo).astype(np.int32), A[1][lo:hi], A[2][lo:hi]), A, 2.0)
+    assert_close_csr(got, ref, RTOL, 'windowed fused iteration vs oracle')
+    # values that are not integer counts: generic stream, same answer as the two-call path
+    p, j, x = links.to_arrays()
+    x2 = (x * np.float32(0.37)).astype(np.float32)
+    l2 = _lib.DeviceCSR.from_arrays(p, j, x2)
+    r3, n3, c3 = _lib.mcl(l2, 2, 2.0, 30, 1e-4, links=True)
+    nn = l2.copy()
+    _lib.normalize_l1(nn)
+    r4, n4, c4 = _lib.mcl(nn, 2, 2.0, 30, 1e-4, normalized=True)
+    assert (n3, c3) == (n4, c4) and all(np.array_equal(x, y) for x, y in zip(r3.to_arrays(), r4.to_arrays()))

@@ -34,7 +34,7 @@ class OracleEngine:
 
     def spgemm(self, a, b):
         lens = np.diff(b[0])
-        return orc.spgemm(a, b, n_cols=len(b[0]) - 1, mode=1, fx_shift=60), int(lens[a[1]].sum())
+        return orc.spgemm(a, b, n_cols=len(b[0]) - 1, mode=1, fx_shift=52), int(lens[a[1]].sum())
 
     def inflate_prune(self, c, inflation, pruning):
         x = orc.normalize_l1(c[0], orc.power(c[2], inflation))
@@ -128,8 +128,8 @@ def test_sharded_mcl_and_merge_world2():
         assert p.exitcode == 0
     # single-process truth
     T = stochastic(400, 6, 5)
-    pre = orc.spgemm(T, T, mode=1, fx_shift=60)
-    o = orc.mcl(pre, 2, 2.0, 100, 1e-4, spgemm_mode=1, fx_shift=60, want_stats=True)
+    pre = orc.spgemm(T, T, mode=1, fx_shift=52)
+    o = orc.mcl(pre, 2, 2.0, 100, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True)
     for rank, res, n_iter, conv, stats, merged in outs:
         assert (n_iter, conv) == (o[3], o[4])
         assert all(np.array_equal(x, y) for x, y in zip(res, o[:3])), 'sharded MCL is not bit-identical to 1 process'

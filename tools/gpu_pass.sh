@@ -11,6 +11,10 @@ for what in "$@"; do
     c3) timeout 900 python bench.py $C3 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/bench_c3.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3.log; grep "hhx expand" gpurun_out/bench_c3.log | head -3; python tools/bench_brief.py gpurun_out/bench_c3.log;;
     full) timeout 1200 python bench.py > gpurun_out/bench_full.log 2>&1; echo "rc=$?" >> gpurun_out/bench_full.log; tail -c 6000 gpurun_out/bench_full.log;;
     prof) rm -rf gpurun_out/prof; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof.log 2>&1; echo "rc=$?" >> gpurun_out/prof.log; ls -R gpurun_out/prof | head; tail -2 gpurun_out/prof.log | cut -c1-400;;
+    pmc:*) # pmc:NAME:COUNTER1,COUNTER2  -> one rocprofv3 --pmc pass of the default bench (1 step, no warmup)
+        spec="${what#pmc:}"; name="${spec%%:*}"; ctrs="${spec#*:}"; rm -rf gpurun_out/pmc_$name
+        timeout 900 rocprofv3 --kernel-trace --pmc ${ctrs//,/ } --output-format csv -d gpurun_out/pmc_$name -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline $PMC_ARGS > gpurun_out/pmc_$name.log 2>&1; echo "pmc $name rc=$?"; ls gpurun_out/pmc_$name | head -5;;
+    listpmc) rocprofv3 -L > gpurun_out/pmc_list.txt 2>&1; grep -c . gpurun_out/pmc_list.txt;;
     env:*) export "${what#env:}"; echo "set ${what#env:}";;
     *) echo "unknown $what";;
   esac
