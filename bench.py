@@ -146,55 +146,85 @@ def main():
         pairs_total = local_pairs * world * K
         value = pairs_total / t_ing
         stats = np.asarray(state['stats'])
-        # ---- roofline of the dominant kernel of the headline metric: k_ingest
-        ing_ms, ing_n = _lib.profile_get('ingest')
-        # 16 B read per pair + 12 B written per distinct key of each table + 4 B per fragment
-        alg_bytes = 16.0 * local_pairs + 12.0 * (state['n_full'] + state['n_flank']) + 4.0 * n
-        ach = alg_bytes / (ing_ms / max(ing_n, 1) * 1e-3) / 1e9 if ing_ms else None
-        roofline = {'kernel': 'k_ingest', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': (ach / HBM_PEAK_GBS) if ach else None, 'traffic': None,
-                    'alg_bytes_per_launch': alg_bytes, 'avg_launch_ms': ing_ms / max(ing_n, 1)}
-        # ---- MCL: expansion kernel roofline with SURVEY §8d's byte model, 8*(nnz_A + F) read + 8*nnz_C written
-        num_ms, num_n = _lib.profile_get('expand_window')
-        sym_ms, sym_n = _lib.profile_get('expand_compact')
-        infl_ms, _ = _lib.profile_get('inflate_stats')
-        prw_ms, _ = _lib.profile_get('prune_write')
-        cvg_ms, _ = _lib.profile_get('convergence')
-        # fused expand+inflate+prune launches: read 8 B per entry of A and per product (gather of B rows),
-        # write 8 B per surviving entry; the expanded matrix C never touches HBM
-        sp_bytes = float((8 * (stats[:, 0] + stats[:, 3]) + 8 * stats[:, 2]).sum()) if len(stats) else 0.0
-        sp_ach = sp_bytes * K / ((num_ms + sym_ms) * 1e-3) / 1e9 if (num_ms + sym_ms) else None
-        # B_iter of SURVEY §8d summed over the iterations of one mcl() call
-        b_iter = float((8 * (stats[:, 0] + stats[:, 3]) + 8 * stats[:, 1] + 8 * stats[:, 1] + 8 * stats[:, 2]
-                        + 16 * stats[:, 2] + 12 * n).sum()) if len(stats) else 0.0
+        pg = _lib.profile_get
+        # ---- dominant kernel of the step: k_expand_window_pass (the B-row stream of the fused expansion).
+        # Algorithmic bytes: SURVEY §8d's B_iter gather term with this kernel's stream format — 6 B per product
+        # (16-bit window-local column + float32 value; SURVEY counts 8 B for an int32 + float32 entry) + 16 B per
+        # staged A entry and window (column, value, two split pointers); survivors are written by the finalize
+        # kernel.  Time: HIP events on the launch stream around the n_win launches of every call.
+        win_ms, win_n = pg('expand_window')
+        F_w = _lib.profile_counter('expand_window_products')
+        A_w = _lib.profile_counter('expand_window_a_reads')
+        traffic = pmc_traffic(n, local_pairs)
+        roofline = None
+        if win_n:
+            alg = 6.0 * F_w + 16.0 * A_w
+            ach = alg / (win_ms * 1e-3) / 1e9
+            roofline = {'kernel': 'k_expand_window_pass', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': ach / HBM_PEAK_GBS, 'traffic': traffic.get('k_expand_window_pass<false>'),
+                        'alg_bytes_per_launch': alg / win_n, 'avg_launch_ms': win_ms / win_n, 'launches_per_step': win_n / K,
+                        'products_per_step': F_w / K, 'bytes_per_product': 6,
+                        'achieved_survey_8B_model': (8.0 * F_w + 16.0 * A_w) / (win_ms * 1e-3) / 1e9,
+                        'note': 'traffic = fabric bytes per launch from rocprofv3 PMC (profiles/), null if no profile matches this workload'}
+        # ---- ingest: the kernel that bounds `value` is the level-1 scatter of the group-by
+        sc_ms, sc_n = pg('part_scatter1')
+        ing_roofline = None
+        if sc_n:
+            n_rec = _lib.profile_counter('ingest_records') / K                 # pairs that survive the map (inter-contig, known contigs)
+            alg = 16.0 * local_pairs + 12.0 * n_rec                            # read a pair, write a 12-byte record
+            ach = alg / (sc_ms / sc_n * 1e-3) / 1e9
+            ing_roofline = {'kernel': 'k_part_scatter<SrcPairs>', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': ach / HBM_PEAK_GBS, 'traffic': traffic.get('k_part_scatter<SrcPairs<true> >'), 'alg_bytes_per_launch': alg,
+                            'avg_launch_ms': sc_ms / sc_n}
+        # whole link-matrix build against SURVEY §8d's B_ingest = 16 P + 12 (K_full + K_flank) + 4 n
+        b_ingest = 16.0 * local_pairs + 12.0 * (state['n_full'] + state['n_flank']) + 4.0 * n
+        cmp_ms, _ = pg('expand_compact')
+        fin_ms, _ = pg('expand_finalize')
+        cvg_ms, _ = pg('convergence')
+        # B_iter of SURVEY §8d summed over the iterations of one mcl() call (fused: C is never written or re-read)
+        b_iter = float((8 * (stats[:, 0] + stats[:, 3]) + 8 * stats[:, 2] + 16 * stats[:, 2] + 12 * n).sum()) if len(stats) else 0.0
         mcl = {'iters_per_s': iters / t_mcl if t_mcl else None, 'n': int(n), 'iterations': int(state['n_iter']),
                'converged': bool(state['conv']), 'inflation': args.inflation, 'ms_per_mcl': t_mcl / K * 1e3,
                'pre_expansion': 'fused into iteration 0', 'clusters': state.get('clusters'),
-               'alg_bytes_per_mcl': b_iter, 'alg_GBs': b_iter * K / t_mcl / 1e9 if t_mcl else None,
-               'frac_hbm': b_iter * K / t_mcl / 1e9 / HBM_PEAK_GBS if t_mcl else None,
+               'alg_bytes_per_mcl_survey': b_iter, 'alg_GBs_survey': b_iter * K / t_mcl / 1e9 if t_mcl else None,
                'stats_nnzA_nnzC_nnzP_F': stats.tolist(),
-               'kernel_ms_per_step': {'expand_compact': sym_ms / K, 'expand_window': num_ms / K, 'inflate_stats': infl_ms / K,
-                                      'prune_write': prw_ms / K, 'convergence': cvg_ms / K},
-               'roofline_expand': {'kernels': 'k_expand_window + k_expand_compact', 'bound': 'hbm', 'achieved': sp_ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                           'frac': sp_ach / HBM_PEAK_GBS if sp_ach else None, 'traffic': None,
-                                           'launches_per_step': (num_n + sym_n) / K}}
+               'kernel_ms_per_step': {'expand_window': win_ms / K, 'expand_finalize': fin_ms / K, 'expand_compact': cmp_ms / K,
+                                      'convergence': cvg_ms / K}}
+        ingest = {'pairs_per_s': value, 'ms_per_step': t_ing / K * 1e3, 'alg_bytes_survey': b_ingest,
+                  'alg_GBs_survey': b_ingest * K / t_ing / 1e9,
+                  'kernels_ms_per_step': {k: pg(k)[0] / K for k in ('ingest', 'part_count1', 'part_scatter1', 'part_count2',
+                                                                   'part_scatter2', 'aggregate', 'compact', 'ingest_merge', 'link_matrix')},
+                  'roofline': ing_roofline}
         out = {'metric': 'Hi-C pairs/s ingested (link-matrix build) + MCL iters/s', 'value': value, 'unit': 'pairs/s',
                'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': elapsed / K * 1e3,
-               'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int32 keys / u64 fixed-point + f32 values',
+               'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+               'dtype': 'u64 keys + u32 counts (ingest); f32 values, exact f64 accumulation (MCL)',
                'data': 'synthetic',
                'config': {'workload': '%d contigs / %d pairs (whole job, %d per GPU), %d chr, mean contig %d bp, inflation %.1f, dense-block off'
                                       % (n, local_pairs * world, local_pairs, args.nchrs, args.mean_len, args.inflation),
                           'contigs': int(n), 'pairs_per_gpu': local_pairs, 'full_keys': int(state['n_full']),
                           'flank_keys': int(state['n_flank']), 'link_matrix_nnz': int(state['nnz_link'])},
-               'ingest_ms_per_step': t_ing / K * 1e3,
-               'ingest_kernels_ms': {k: _lib.profile_get(k)[0] / K for k in ('ingest', 'part_count1', 'part_scatter1', 'part_count2', 'part_scatter2', 'aggregate', 'compact', 'ingest_merge', 'link_matrix')},
-               'mcl': mcl, 'roofline': roofline}
+               'mcl_iters_per_s': mcl['iters_per_s'], 'ingest': ingest, 'mcl': mcl, 'roofline': roofline}
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(n_contigs, pairs):
+    """HBM/fabric bytes per launch measured with rocprofv3 --pmc on this same command line (tools/pmc_summary.py
+    writes profiles/pmc_traffic.json); bench.py cannot read PMC counters itself."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    if d.get('contigs') != int(n_contigs) or d.get('pairs_per_gpu') != int(pairs):
+        return {}
+    return d.get('bytes_per_launch', {})
 
 
 def cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state):

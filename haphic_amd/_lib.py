@@ -40,6 +40,7 @@ SIGNATURES = {
     'hhx_profile_enable': (C.c_int, [C.c_int]),
     'hhx_profile_reset': (C.c_int, []),
     'hhx_profile_get': (C.c_int, [C.c_char_p, c_f64p, c_i64p]),
+    'hhx_profile_counter': (C.c_int, [C.c_char_p, c_i64p]),
     'hhx_csr_from_host': (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, c_vpp]),
     'hhx_csr_from_device': (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, c_vpp]),
     'hhx_csr_shape': (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i64p]),
@@ -128,6 +129,12 @@ def profile_get(kernel):
     ms, n = C.c_double(0), C.c_int64(0)
     check(load().hhx_profile_get(kernel.encode(), C.byref(ms), C.byref(n)))
     return ms.value, n.value
+
+
+def profile_counter(name):
+    v = C.c_int64(0)
+    check(load().hhx_profile_counter(name.encode(), C.byref(v)))
+    return v.value
 
 
 def ptr(a):

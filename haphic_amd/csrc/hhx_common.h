@@ -86,10 +86,16 @@ struct DevBuf {
 // RAII: records a HIP event pair on g_stream around the launches in its scope when profiling is on.
 struct KTimer {
     const char *name;
+    int launches;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    explicit KTimer(const char *n);
+    explicit KTimer(const char *n, int launches = 1);
     ~KTimer();
 };
+
+// named event counters (only while profiling is enabled): products / entries streamed by a kernel class, so that
+// bench.py can turn HIP-event times into achieved bytes per second
+void prof_count(const char *name, i64 v);
+bool prof_enabled();
 
 // ------------------------------------------------------------------ scans / reductions (hhx_scan.hip)
 // exclusive scan of n int32 counts into int32 offsets out[0..n] (out[n] = total); total returned

@@ -609,18 +609,22 @@ __global__ __launch_bounds__(256) void k_classify(i32 n_rows, const i32 *__restr
                                                   i32 *__restrict__ list_window, i32 *__restrict__ list_compact,
                                                   unsigned int *__restrict__ counts, unsigned long long *__restrict__ cursors) {
     const int lane = lane_id();
-    i64 total = 0;
+    i64 total = 0, total_w = 0, entries_w = 0;
     for (i32 row = blockIdx.x * 4 + threadIdx.x / HHX_WAVE; row < n_rows; row += gridDim.x * 4) {
         i64 f = 0;
         for (i32 p = Ap[row] + lane; p < Ap[row + 1]; p += HHX_WAVE) { const i32 k = Aj[p]; f += Bp[k + 1] - Bp[k]; }
         f = wave_sum_i64(f);
         if (lane == 0) {
             total += f;
-            if (f >= window_min_products) list_window[atomicAdd(&counts[0], 1u)] = row;
-            else list_compact[atomicAdd(&counts[1], 1u)] = row;
+            if (f >= window_min_products) {
+                list_window[atomicAdd(&counts[0], 1u)] = row;
+                total_w += f;
+                entries_w += Ap[row + 1] - Ap[row];
+            } else list_compact[atomicAdd(&counts[1], 1u)] = row;
         }
     }
     if (lane == 0 && total) atomicAdd(&cursors[4], (unsigned long long)total);
+    if (lane == 0 && total_w) { atomicAdd(&cursors[5], (unsigned long long)total_w); atomicAdd(&cursors[6], (unsigned long long)entries_w); }
 }
 
 // ---- split points of every B row at the column-window boundaries (window kernel, n_win > 1) -------------
@@ -762,13 +766,14 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 HHX_LAUNCH_CHECK();
             }
             P.Bc16 = c16.p;
-            KTimer kt("expand_window");
             const unsigned per_cu = lds_win > 80 * 1024 ? 1 : 2;
             const unsigned grid = std::min<unsigned>(hc[0], 256 * per_cu);
+            { KTimer kt("expand_window", n_win);            // one timer scope, n_win launches of k_expand_window_pass
             for (i32 wv = 0; wv < n_win; ++wv) {
                 if (is_coded) k_expand_window_pass<true><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
                 else k_expand_window_pass<false><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
-            }
+            } }
+            KTimer kt("expand_finalize");
             k_expand_window_finalize<<<std::min<unsigned>(hc[0], 256 * 8), EX_T_CMP, ex_fixed_bytes(0, 0, false), g_stream>>>(P, list_w.p, (i32)hc[0]);
         }
         HHX_LAUNCH_CHECK();
@@ -789,6 +794,10 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             if ((i64)cur[0] > cand_cap) cand_cap = std::max<i64>(cand_cap * 2, (i64)cur[0] + (i64)n_rows);
             if ((i64)cur[1] > pool_cap) pool_cap = std::max<i64>(pool_cap * 2, (i64)cur[1] + (i64)n_rows);
             continue;
+        }
+        if (prof_enabled() && hc[0]) {
+            prof_count("expand_window_products", (i64)cur[5]);
+            prof_count("expand_window_a_reads", (i64)cur[6] * n_win);
         }
         if (n_products) *n_products = (i64)cur[4];
         if (nnz_expanded) *nnz_expanded = (i64)cur[3];

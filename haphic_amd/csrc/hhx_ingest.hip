@@ -426,6 +426,7 @@ int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, Link
         i64 n_valid = 0;
         HHX_TRY(exclusive_scan_i64((const i64 *)hist1.p, base1.p, nb1, &n_valid));
         if (n_valid == 0) { *out = run; return run->alloc(0) ? (delete run, 1) : 0; }
+        if (MODE == 0 && attempt == 0) prof_count("ingest_records", n_valid);
         DevBuf<u64> rec1, rec2;
         DevBuf<u32> ord1, ord2;
         if (rec1.alloc((size_t)n_valid) || ord1.alloc((size_t)n_valid)) { delete run; return 1; }

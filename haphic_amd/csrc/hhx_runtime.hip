@@ -78,13 +78,13 @@ void pool_trim() {
 // ------------------------------------------------------------------ kernel timing
 namespace {
 bool g_prof_on = false;
-struct ProfRec { std::string name; hipEvent_t e0, e1; };
+struct ProfRec { std::string name; hipEvent_t e0, e1; int launches; };
 std::vector<ProfRec> g_prof_pending;
 std::map<std::string, std::pair<double, i64>> g_prof_total;
 std::mutex g_prof_mu;
 }  // namespace
 
-KTimer::KTimer(const char *n) : name(n) {
+KTimer::KTimer(const char *n, int l) : name(n), launches(l) {
     if (!g_prof_on) return;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
     (void)hipEventRecord(e0, g_stream);
@@ -93,8 +93,16 @@ KTimer::~KTimer() {
     if (!e0 || !e1) return;
     (void)hipEventRecord(e1, g_stream);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_pending.push_back({name, e0, e1});
+    g_prof_pending.push_back({name, e0, e1, launches});
 }
+namespace { std::map<std::string, i64> g_prof_counters; }
+void prof_count(const char *name, i64 v) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_counters[name] += v;
+}
+bool prof_enabled() { return g_prof_on; }
+
 static void prof_collect() {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &r : g_prof_pending) {
@@ -102,7 +110,7 @@ static void prof_collect() {
         if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
             auto &t = g_prof_total[r.name];
             t.first += ms;
-            t.second += 1;
+            t.second += r.launches;
         }
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);
@@ -239,6 +247,14 @@ extern "C" int hhx_profile_reset(void) {
     prof_collect();
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_total.clear();
+    g_prof_counters.clear();
+    return 0;
+}
+extern "C" int hhx_profile_counter(const char *name, i64 *value) {
+    if (!name || !value) return fail("null pointer");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    auto it = g_prof_counters.find(name);
+    *value = it == g_prof_counters.end() ? 0 : it->second;
     return 0;
 }
 extern "C" int hhx_profile_get(const char *kernel, double *total_ms, i64 *launches) {

@@ -46,6 +46,10 @@ int hhx_pool_trim(void);                       /* release cached device memory *
 int hhx_profile_enable(int on);
 int hhx_profile_reset(void);
 int hhx_profile_get(const char *kernel, double *total_ms, int64_t *launches);
+/* event counters gathered while profiling is on: "expand_window_products" (products streamed by
+ * k_expand_window_pass), "expand_window_a_reads" (entries of A staged, summed over the column windows),
+ * "ingest_records" (read pairs that survive the map stage) */
+int hhx_profile_counter(const char *name, int64_t *value);
 
 /* ---------------------------------------------------------------- matrices */
 /* build from / copy to host arrays (numpy: csc.indptr, csc.indices, csc.data) */

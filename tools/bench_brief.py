@@ -8,11 +8,17 @@ for line in open(sys.argv[1]):
             print(line.rstrip()[:300])
         continue
     d = json.loads(line)
-    m = d['mcl']
-    print('pairs/s %.3e  ingest_ms %.1f  k_ingest_ms %.1f | mcl it/s %.2f  ms_per_mcl %.1f iters %d  kernels %s | step ms %.1f' % (
-        d['value'], d['ingest_ms_per_step'], d['roofline']['avg_launch_ms'], m['iters_per_s'], m['ms_per_mcl'], m['iterations'],
-        {k: round(v, 1) for k, v in m['kernel_ms_per_step'].items()}, d['ms_per_step']))
-    if 'ingest_kernels_ms' in d:
-        print('ingest kernels ms/step', {k: round(v, 2) for k, v in d['ingest_kernels_ms'].items()})
+    m, g = d['mcl'], d['ingest']
+    print('pairs/s %.3e  ingest_ms %.1f | mcl it/s %.2f  ms_per_mcl %.1f iters %d | step ms %.1f' % (
+        d['value'], g['ms_per_step'], m['iters_per_s'], m['ms_per_mcl'], m['iterations'], d['ms_per_step']))
+    print('  mcl kernels ms/step', {k: round(v, 1) for k, v in m['kernel_ms_per_step'].items()})
+    print('  ingest kernels ms/step', {k: round(v, 2) for k, v in g['kernels_ms_per_step'].items()})
+    r = d['roofline']
+    if r:
+        print('  roofline %s: %.0f GB/s (frac %.3f) avg launch %.2f ms x %.0f/step, traffic %s' % (
+            r['kernel'], r['achieved'], r['frac'], r['avg_launch_ms'], r['launches_per_step'], r['traffic']))
+    r = g['roofline']
+    if r:
+        print('  ingest roofline %s: %.0f GB/s (frac %.3f) launch %.2f ms, traffic %s' % (r['kernel'], r['achieved'], r['frac'], r['avg_launch_ms'], r['traffic']))
     if 'cpu_baseline' in d:
-        print('cpu_baseline', d['cpu_baseline'])
+        print('  cpu_baseline', d['cpu_baseline'])
