@@ -603,28 +603,136 @@ __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i
     if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
 }
 
-// ---- classification: product count per row, row lists --------------------------------------------
+// ---- classification: product count per row, three row lists -----------------------------------------
+// A block takes 64 consecutive rows at a time: its waves count the products of one row each (coalesced),
+// then the first wave sorts the 64 rows into the class lists with ONE atomic per class and chunk (a
+// per-row atomicAdd on a single counter costs ~11 ns each: 1.1 ms for 100k rows, per iteration).
+constexpr int TINY_MAX = 32;        // rows with at most this many products go to the thread-per-row kernel
 __global__ __launch_bounds__(256) void k_classify(i32 n_rows, const i32 *__restrict__ Ap, const i32 *__restrict__ Aj,
                                                   const i32 *__restrict__ Bp, i64 window_min_products,
                                                   i32 *__restrict__ list_window, i32 *__restrict__ list_compact,
-                                                  unsigned int *__restrict__ counts, unsigned long long *__restrict__ cursors) {
-    const int lane = lane_id();
+                                                  i32 *__restrict__ list_tiny, unsigned int *__restrict__ counts,
+                                                  unsigned long long *__restrict__ cursors) {
+    __shared__ i64 fs[64];
+    const int lane = lane_id(), wave = threadIdx.x / HHX_WAVE;
     i64 total = 0, total_w = 0, entries_w = 0;
-    for (i32 row = blockIdx.x * 4 + threadIdx.x / HHX_WAVE; row < n_rows; row += gridDim.x * 4) {
-        i64 f = 0;
-        for (i32 p = Ap[row] + lane; p < Ap[row + 1]; p += HHX_WAVE) { const i32 k = Aj[p]; f += Bp[k + 1] - Bp[k]; }
-        f = wave_sum_i64(f);
-        if (lane == 0) {
-            total += f;
-            if (f >= window_min_products) {
-                list_window[atomicAdd(&counts[0], 1u)] = row;
-                total_w += f;
-                entries_w += Ap[row + 1] - Ap[row];
-            } else list_compact[atomicAdd(&counts[1], 1u)] = row;
+    for (i32 chunk = blockIdx.x * 64; chunk < n_rows; chunk += gridDim.x * 64) {
+        for (i32 r = wave; r < 64; r += 4) {
+            const i32 row = chunk + r;
+            i64 f = -1;
+            if (row < n_rows) {
+                f = 0;
+                for (i32 p = Ap[row] + lane; p < Ap[row + 1]; p += HHX_WAVE) { const i32 k = Aj[p]; f += Bp[k + 1] - Bp[k]; }
+                f = wave_sum_i64(f);
+            }
+            if (lane == 0) fs[r] = f;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const i64 f = fs[lane];
+            const i32 row = chunk + lane;
+            const int cls = f < 0 ? -1 : (f >= window_min_products ? 0 : (f <= TINY_MAX ? 2 : 1));
+            i32 *const lists[3] = {list_window, list_compact, list_tiny};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const u64 mask = __ballot(cls == c);
+                if (mask) {
+                    unsigned int base = 0;
+                    const int leader = __ffsll((unsigned long long)mask) - 1;
+                    if (lane == leader) base = atomicAdd(&counts[c], (unsigned int)__popcll(mask));
+                    base = __shfl(base, leader, HHX_WAVE);
+                    if (cls == c) lists[c][base + __popcll(mask & ((1ull << lane) - 1ull))] = row;
+                }
+            }
+            if (f > 0) total += f;
+            if (cls == 0) { total_w += f; entries_w += Ap[row + 1] - Ap[row]; }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        total = wave_sum_i64(total); total_w = wave_sum_i64(total_w); entries_w = wave_sum_i64(entries_w);
+        if (lane == 0 && total) atomicAdd(&cursors[4], (unsigned long long)total);
+        if (lane == 0 && total_w) { atomicAdd(&cursors[5], (unsigned long long)total_w); atomicAdd(&cursors[6], (unsigned long long)entries_w); }
+    }
+}
+
+// ---- tiny rows (<= TINY_MAX products): one THREAD per row ------------------------------------------------
+// After a few iterations almost every row of T has one to three entries; a workgroup per row then spends
+// its time clearing an n-bit bitmap.  Here a thread merges the row's products into a sorted local list
+// (exact grid-rounded double adds, same value as acc_add) and applies inflate / normalise / prune /
+// normalise sequentially, i.e. in the reference's own summation order (:2037-2042, :1987-2014).
+__global__ __launch_bounds__(256) void k_expand_tiny(ExParams P, const i32 *__restrict__ rows, i32 n_list) {
+    const int lane = lane_id();
+    i64 nnzc = 0;
+    for (i32 base_i = blockIdx.x * blockDim.x; base_i < n_list; base_i += gridDim.x * blockDim.x) {
+        const i32 li = base_i + threadIdx.x;
+        i32 cols[TINY_MAX];
+        double vals[TINY_MAX];
+        i32 cnt = 0, row = -1;
+        if (li < n_list) {
+            row = rows[li];
+            for (i32 p = P.Ap[row]; p < P.Ap[row + 1]; ++p) {
+                const i32 k = P.Aj[p];
+                const double da = (double)P.Ax[p] * P.scale;
+                for (i32 q = P.Bp[k]; q < P.Bp[k + 1]; ++q) {
+                    const i32 c = P.Bj[q];
+                    const double g = (da * (double)P.Bx[q] + 1.0) - 1.0;
+                    i32 pos = 0;
+                    while (pos < cnt && cols[pos] < c) ++pos;
+                    if (pos < cnt && cols[pos] == c) vals[pos] += g;
+                    else {
+                        for (i32 t = cnt; t > pos; --t) { cols[t] = cols[t - 1]; vals[t] = vals[t - 1]; }
+                        cols[pos] = c; vals[pos] = g;
+                        ++cnt;
+                    }
+                }
+            }
+        }
+        // inflate + first normalisation, first maximum, survivors
+        float pw[TINY_MAX];
+        double s1 = 0.0;
+        for (i32 t = 0; t < cnt; ++t) {
+            pw[t] = ex_inflate((float)(vals[t] * P.inv_scale), P.r, P.square);
+            s1 += fabs((double)pw[t]);
+        }
+        i32 am = -1, keep = 0;
+        float best = 0.f;
+        double s2 = 0.0;
+        for (i32 t = 0; t < cnt; ++t) {
+            if (s1 != 0.0) pw[t] = (float)((double)pw[t] / s1);
+            if (am < 0 || pw[t] > best) { am = t; best = pw[t]; }
+        }
+        for (i32 t = 0; t < cnt; ++t)
+            if (pw[t] >= P.thr || t == am) { ++keep; s2 += fabs((double)pw[t]); }
+        nnzc += cnt;
+        // one atomic per wave reserves the output rows of its 64 rows
+        i32 incl = keep;
+#pragma unroll
+        for (int o = 1; o < HHX_WAVE; o <<= 1) {
+            const i32 v = __shfl_up(incl, o, HHX_WAVE);
+            if (lane >= o) incl += v;
+        }
+        const i32 wave_total = __shfl(incl, HHX_WAVE - 1, HHX_WAVE);
+        unsigned long long wbase = 0;
+        if (lane == HHX_WAVE - 1 && wave_total) wbase = atomicAdd(&P.cursors[1], (unsigned long long)wave_total);
+        wbase = (unsigned long long)__shfl((long long)wbase, HHX_WAVE - 1, HHX_WAVE);
+        if (row >= 0) {
+            i64 o = (i64)wbase + incl - keep;
+            if ((i64)wbase + wave_total > P.out_cap) { atomicExch(&P.cursors[2], 1ull); P.row_off[row] = 0; P.row_cnt[row] = 0; }
+            else {
+                P.row_off[row] = o;
+                P.row_cnt[row] = keep;
+                for (i32 t = 0; t < cnt; ++t)
+                    if (pw[t] >= P.thr || t == am) {
+                        P.out_col[o] = cols[t];
+                        P.out_val[o] = s2 != 0.0 ? (float)((double)pw[t] / s2) : pw[t];
+                        ++o;
+                    }
+            }
         }
     }
-    if (lane == 0 && total) atomicAdd(&cursors[4], (unsigned long long)total);
-    if (lane == 0 && total_w) { atomicAdd(&cursors[5], (unsigned long long)total_w); atomicAdd(&cursors[6], (unsigned long long)entries_w); }
+    nnzc = wave_sum_i64(nnzc);
+    if (lane == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
 }
 
 // ---- split points of every B row at the column-window boundaries (window kernel, n_win > 1) -------------
@@ -711,13 +819,14 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     static const bool debug = getenv("HHX_DEBUG") != nullptr;
     // rows whose product count is well above the number of accumulator slots a dense sweep touches
     const i64 window_min = std::max<i64>(4096, (i64)n_cols / 2);
-    DevBuf<i32> list_w, list_c, row_cnt, indptr, g_win_cnt;
+    DevBuf<i32> list_w, list_c, list_t, row_cnt, indptr, g_win_cnt;
     DevBuf<i64> row_off, g_win_off;
     DevBuf<double> s_run;
     DevBuf<unsigned int> counts;
     DevBuf<unsigned long long> cursors;
-    if (list_w.alloc((size_t)n_rows + 1) || list_c.alloc((size_t)n_rows + 1) || row_cnt.alloc((size_t)n_rows + 1) ||
-        indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || counts.alloc(2) || cursors.alloc(8) ||
+    if (list_w.alloc((size_t)n_rows + 1) || list_c.alloc((size_t)n_rows + 1) || list_t.alloc((size_t)n_rows + 1) ||
+        row_cnt.alloc((size_t)n_rows + 1) ||
+        indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || counts.alloc(4) || cursors.alloc(8) ||
         s_run.alloc((size_t)n_rows + 1) || g_win_off.alloc((size_t)n_rows * n_win + 1) || g_win_cnt.alloc((size_t)n_rows * n_win + 1))
         return 1;
     DevBuf<i32> win_ptr;
@@ -738,12 +847,12 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         DevBuf<float> cand_val, out_val;
         if (cand_col.alloc((size_t)cand_cap) || cand_val.alloc((size_t)cand_cap) || out_col.alloc((size_t)pool_cap) ||
             out_val.alloc((size_t)pool_cap)) return 1;
-        HHX_HIP(hipMemsetAsync(counts.p, 0, 2 * sizeof(unsigned int), g_stream));
+        HHX_HIP(hipMemsetAsync(counts.p, 0, 4 * sizeof(unsigned int), g_stream));
         HHX_HIP(hipMemsetAsync(cursors.p, 0, 8 * sizeof(unsigned long long), g_stream));
-        k_classify<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 3) / 4, 4096)), 256, 0, g_stream>>>(
-            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, list_w.p, list_c.p, counts.p, cursors.p);
+        k_classify<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 63) / 64, 4096)), 256, 0, g_stream>>>(
+            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, list_w.p, list_c.p, list_t.p, counts.p, cursors.p);
         HHX_LAUNCH_CHECK();
-        unsigned int hc[2];
+        unsigned int hc[4];
         HHX_HIP(hipMemcpyAsync(hc, counts.p, sizeof hc, hipMemcpyDeviceToHost, g_stream));
         HHX_HIP(hipStreamSynchronize(g_stream));
         ExParams P;
@@ -775,6 +884,11 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             } }
             KTimer kt("expand_finalize");
             k_expand_window_finalize<<<std::min<unsigned>(hc[0], 256 * 8), EX_T_CMP, ex_fixed_bytes(0, 0, false), g_stream>>>(P, list_w.p, (i32)hc[0]);
+        }
+        HHX_LAUNCH_CHECK();
+        if (hc[2]) {
+            KTimer kt("expand_tiny");
+            k_expand_tiny<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)hc[2] + 255) / 256, 4096)), 256, 0, g_stream>>>(P, list_t.p, (i32)hc[2]);
         }
         HHX_LAUNCH_CHECK();
         if (hc[1]) {
