@@ -86,5 +86,5 @@ struct hhx_ingest {
 };
 
 // hhx_matrix.hip: dict_to_matrix on a run (flank rows, first-seen order taken from ord_flank)
-int hhx_link_matrix_from_run(const hhx::LinkRun *run, i32 n_frag, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,
+int hhx_link_matrix_from_run(const hhx::LinkRun *run, i32 n_frag, u64 ord_limit, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,
                              i32 *frag_index_host, i32 *n_linked_out, hhx_csr **out);

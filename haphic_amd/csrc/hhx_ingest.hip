@@ -23,6 +23,7 @@
 // Several pushes produce several aggregated runs; hhx_ingest_finalize merges them with the same
 // partition + aggregate pipeline (rows instead of pairs), which is also the multi-GPU exchange step.
 #include "hhx_ingest.h"
+#include "hhx_partition.h"
 
 using namespace hhx;
 
@@ -89,141 +90,32 @@ __device__ __forceinline__ bool map_pair(const DevTables &t, int stream, i32 r, 
     return true;
 }
 
-// ---- record sources ---------------------------------------------------------------------------------
+// ---- record sources (hhx_partition.h: get(idx, w0, w1)) --------------------------------------------------
 template <bool COMBINED>
 struct SrcPairs {
+    typedef u32 w1_t;
     const i32 *id1, *pos1, *id2, *pos2;
     DevTables t;
     int stream;
+    __device__ __forceinline__ bool get(i64 idx, u64 &rec, u32 &ord) const {
+        ord = (u32)idx;
+        return map_pair<COMBINED>(t, stream, id1[idx], id2[idx], pos1[idx], pos2[idx], rec);
+    }
 };
-template <bool COMBINED>
-__device__ __forceinline__ bool src_get(const SrcPairs<COMBINED> &s, i64 idx, u64 &rec, u32 &ord) {
-    ord = (u32)idx;
-    return map_pair<COMBINED>(s.t, s.stream, s.id1[idx], s.id2[idx], s.pos1[idx], s.pos2[idx], rec);
-}
-struct SrcRecs {
-    const u64 *rec;
-    const u32 *ord;
-};
-__device__ __forceinline__ bool src_get(const SrcRecs &s, i64 idx, u64 &rec, u32 &ord) {
-    rec = s.rec[idx];
-    ord = s.ord[idx];
-    return true;
-}
 struct SrcRows {            // table rows to be merged: the record is the bare key, the "ordinal" the row index
+    typedef u32 w1_t;
     const u64 *key;
-};
-__device__ __forceinline__ bool src_get(const SrcRows &s, i64 idx, u64 &rec, u32 &ord) {
-    rec = s.key[idx] & KEY_MASK;
-    ord = (u32)idx;
-    return true;
-}
-
-// ---- radix partition ------------------------------------------------------------------------------------
-constexpr int PT = 512, P_ITEMS = 8, P_TILE = PT * P_ITEMS, MAX_BINS = 2048;
-
-struct PartLevel {
-    int total_bits;     // bucket id = top total_bits of mix64(key)
-    int shift;          // digit of this level = bucket >> shift
-    int lds_bits;       // low lds_bits of the digit index the LDS histogram; the rest ("group") is constant
-                        // within a tile except where a tile straddles two level-1 buckets
-};
-
-template <class Src>
-__device__ __forceinline__ u32 tile_group(const Src &src, i64 first, i64 n, const PartLevel &L) {
-    if (L.shift + L.lds_bits >= L.total_bits) return 0;          // level 1: the LDS histogram spans the whole digit
-    u64 rec; u32 ord;
-    (void)src_get(src, first < n ? first : n - 1, rec, ord);     // level-2 sources have no invalid records
-    return (bucket_of(rec & KEY_MASK, L.total_bits) >> L.shift) >> L.lds_bits;
-}
-
-template <class Src>
-__global__ __launch_bounds__(PT) void k_part_count(Src src, i64 n, PartLevel L, unsigned long long *__restrict__ ghist) {
-    __shared__ u32 hist[MAX_BINS];
-    __shared__ u32 s_grp;
-    const int tid = threadIdx.x, nb = 1 << L.lds_bits;
-    for (int t = tid; t < nb; t += PT) hist[t] = 0;
-    u32 cur = 0xffffffffu;
-    const i64 n_tiles = (n + P_TILE - 1) / P_TILE;
-    for (i64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const i64 base = tile * P_TILE;
-        if (tid == 0) s_grp = tile_group(src, base, n, L);
-        __syncthreads();
-        const u32 tg = s_grp;
-        if (tg != cur) {                                         // flush the histogram of the previous group
-            if (cur != 0xffffffffu)
-                for (int t = tid; t < nb; t += PT) {
-                    if (hist[t]) atomicAdd(&ghist[((u64)cur << L.lds_bits) | (u64)t], (unsigned long long)hist[t]);
-                    hist[t] = 0;
-                }
-            cur = tg;
-            __syncthreads();
-        }
-#pragma unroll
-        for (int k = 0; k < P_ITEMS; ++k) {
-            const i64 idx = base + (i64)k * PT + tid;
-            u64 rec; u32 ord;
-            if (idx < n && src_get(src, idx, rec, ord)) {
-                const u32 d = bucket_of(rec & KEY_MASK, L.total_bits) >> L.shift;
-                if ((d >> L.lds_bits) == tg) atomicAdd(&hist[d & (u32)(nb - 1)], 1u);
-                else atomicAdd(&ghist[d], 1ull);
-            }
-        }
-        __syncthreads();
+    __device__ __forceinline__ bool get(i64 idx, u64 &rec, u32 &ord) const {
+        rec = key[idx] & KEY_MASK;
+        ord = (u32)idx;
+        return true;
     }
-    if (cur != 0xffffffffu)
-        for (int t = tid; t < nb; t += PT)
-            if (hist[t]) atomicAdd(&ghist[((u64)cur << L.lds_bits) | (u64)t], (unsigned long long)hist[t]);
-}
-
-template <class Src>
-__global__ __launch_bounds__(PT) void k_part_scatter(Src src, i64 n, PartLevel L, unsigned long long *__restrict__ cursor,
-                                                     u64 *__restrict__ out_rec, u32 *__restrict__ out_ord) {
-    __shared__ u32 hist[MAX_BINS];
-    __shared__ unsigned long long sbase[MAX_BINS];
-    __shared__ u32 s_grp;
-    const int tid = threadIdx.x, nb = 1 << L.lds_bits;
-    const i64 n_tiles = (n + P_TILE - 1) / P_TILE;
-    for (i64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const i64 base = tile * P_TILE;
-        for (int t = tid; t < nb; t += PT) hist[t] = 0;
-        if (tid == 0) s_grp = tile_group(src, base, n, L);
-        __syncthreads();
-        const u32 tg = s_grp;
-        u64 rec[P_ITEMS];
-        u32 ord[P_ITEMS], loc[P_ITEMS], rank[P_ITEMS];
-#pragma unroll
-        for (int k = 0; k < P_ITEMS; ++k) {
-            const i64 idx = base + (i64)k * PT + tid;
-            loc[k] = 0xffffffffu;
-            if (idx < n && src_get(src, idx, rec[k], ord[k])) {
-                const u32 d = bucket_of(rec[k] & KEY_MASK, L.total_bits) >> L.shift;
-                if ((d >> L.lds_bits) == tg) {
-                    loc[k] = d & (u32)(nb - 1);
-                    rank[k] = atomicAdd(&hist[loc[k]], 1u);
-                } else {                                         // straddling record: reserve its slot directly
-                    const unsigned long long pos = atomicAdd(&cursor[d], 1ull);
-                    out_rec[pos] = rec[k];
-                    out_ord[pos] = ord[k];
-                }
-            }
-        }
-        __syncthreads();
-        for (int t = tid; t < nb; t += PT) {
-            const u32 c = hist[t];
-            if (c) sbase[t] = atomicAdd(&cursor[((u64)tg << L.lds_bits) | (u64)t], (unsigned long long)c);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < P_ITEMS; ++k)
-            if (loc[k] != 0xffffffffu) {
-                const unsigned long long pos = sbase[loc[k]] + rank[k];
-                out_rec[pos] = rec[k];
-                out_ord[pos] = ord[k];
-            }
-        __syncthreads();
-    }
-}
+};
+// bucket of a record = top bits of the 64-bit mix of its key
+struct DigKeyHash {
+    int total_bits;
+    __device__ __forceinline__ u32 operator()(u64 w0) const { return bucket_of(w0 & KEY_MASK, total_bits); }
+};
 
 // ---- aggregation: LDS hash table per bucket -----------------------------------------------------------
 constexpr int AG_T = 512, AG_CAP = 2048;
@@ -233,6 +125,7 @@ struct AggParams {
     const u32 *ord;
     const unsigned long long *base;       // [n_buckets + 1]
     u32 n_buckets, buckets_per_wg;
+    int total_bits;                       // bucket = top total_bits of mix64(key); the next bits pick the sub-pass
     u64 ord_base;                         // MODE 0: global ordinal of pair 0 of the batch
     const u64 *in_ord_full, *in_ord_flank;   // MODE 1: payload rows, indexed by ord
     const u32 *in_ht, *in_fl;
@@ -270,8 +163,16 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
         const unsigned long long rb = A.base[b], re = A.base[b + 1];
         const u64 n = re - rb;
         if (n == 0) continue;
+        // A bucket holds ~8k records (read once from HBM, L2-resident afterwards); it is aggregated in 2^sbits
+        // SUB-PASSES over the same records, sub-pass s taking the keys whose next sbits hash bits equal s, so
+        // that each sub-pass sees ~1k records and fits the 2048-slot table.  (One more radix level would move
+        // every record through HBM again instead.)
+        int sbits = 0;
+        while ((n >> sbits) > 1024 && sbits < 4) ++sbits;
+        const u64 per_sub = (n >> sbits) + 1;
         u32 tsize = AG_CAP;
-        if (2 * n <= AG_CAP) { tsize = 64; while (tsize < 2 * n) tsize <<= 1; }
+        if (2 * per_sub <= AG_CAP) { tsize = 64; while (tsize < 2 * per_sub) tsize <<= 1; }
+        for (u32 sub = 0; sub < (1u << sbits); ++sub) {
         for (u32 s = tid; s < tsize; s += AG_T) {
             s_key[s] = EMPTY_KEY; s_of[s] = ORD_NONE; s_ok[s] = ORD_NONE;
 #pragma unroll
@@ -280,9 +181,11 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
         __syncthreads();
         for (u64 i = rb + tid; i < re; i += AG_T) {
             const u64 rec = A.rec[i];
-            const u32 ord = A.ord[i];
             const u64 key = rec & KEY_MASK;
-            u32 slot = (u32)mix64(key) & (tsize - 1);
+            const u64 h = mix64(key);
+            if (sbits && (u32)((h << A.total_bits) >> (64 - sbits)) != sub) continue;
+            const u32 ord = A.ord[i];
+            u32 slot = (u32)h & (tsize - 1);
             u32 probe = 0;
             for (; probe < tsize; ++probe) {
                 const u64 cur = *(volatile u64 *)&s_key[slot];
@@ -351,6 +254,7 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
         }
         out_pos += total;
         __syncthreads();
+        }   // sub-passes
     }
     if (tid == 0) A.seg_count[blockIdx.x] = out_pos - seg_start;
 }
@@ -385,10 +289,6 @@ inline unsigned grid_for(u64 n, unsigned per = 256) {
     return (unsigned)b;
 }
 
-__global__ __launch_bounds__(256) void k_u64_copy(const unsigned long long *src, unsigned long long *dst, i64 n) {
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-
 // ---- host driver: records from `src` (n items, some may be dropped by the map) -> one aggregated run ----
 struct Payload {            // MODE 1 only
     const u64 *ord_full = nullptr, *ord_flank = nullptr;
@@ -407,60 +307,27 @@ int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, Link
     if (n_items <= 0) { *out = run; return run->alloc(0) ? (delete run, 1) : 0; }
     if (n_items >= ((i64)1 << 32) - 1) { delete run; return fail("ingest: at most 2^32 - 2 pairs per push (got %lld)", (long long)n_items); }
     for (int attempt = 0; attempt < 4; ++attempt) {
-        // buckets of ~<= 1024 records: at most half of the 2048-slot LDS table even if every record is a new key
+        // buckets of ~<= 1k records (half of the 2048-slot LDS table even if every record is a new key; larger
+        // buckets are aggregated in sub-passes), radix levels of <= 7 bits: >= 32 records = 256 B per (tile, bucket)
+        // run.  Measured at 500 M pairs: 3 levels of 7+6+6 bits 34 ms, 2 levels of 8+8 bits + 8 sub-passes 40 ms.
+        static const i64 per_bucket = getenv("HHX_ING_BUCKET") ? atoll(getenv("HHX_ING_BUCKET")) : 1024;
+        static const int level_bits = getenv("HHX_ING_LBITS") ? atoi(getenv("HHX_ING_LBITS")) : 7;
         int total_bits = 0;
-        while ((n_items >> total_bits) > 1024 && total_bits < 22) ++total_bits;
-        total_bits = std::min(22, total_bits + 2 * attempt);
-        const int bits1 = total_bits <= 10 ? total_bits : (total_bits + 1) / 2, bits2 = total_bits - bits1;
-        const u32 nb1 = 1u << bits1, n_buckets = 1u << total_bits;
-        const unsigned pgrid = (unsigned)std::max<i64>(1, std::min<i64>((n_items + P_TILE - 1) / P_TILE, 256 * 4));
-        // ---- level 1
-        DevBuf<unsigned long long> hist1, cur1;
-        DevBuf<i64> base1;
-        if (hist1.alloc(nb1 + 1) || cur1.alloc(nb1 + 1) || base1.alloc(nb1 + 2)) { delete run; return 1; }
-        HHX_HIP(hipMemsetAsync(hist1.p, 0, sizeof(unsigned long long) * (nb1 + 1), g_stream));
-        const PartLevel L1{total_bits, bits2, bits1};
-        { KTimer kt("part_count1");
-        k_part_count<Src><<<pgrid, PT, 0, g_stream>>>(src, n_items, L1, hist1.p); }
-        HHX_LAUNCH_CHECK();
-        i64 n_valid = 0;
-        HHX_TRY(exclusive_scan_i64((const i64 *)hist1.p, base1.p, nb1, &n_valid));
+        while ((n_items >> total_bits) > per_bucket && total_bits < 24) ++total_bits;
+        total_bits = std::min(24, total_bits + 2 * attempt);
+        const DigKeyHash dig{total_bits};
+        Partitioned<u32> part;
+        { int rc = partition_records(src, dig, n_items, total_bits, level_bits, &part, "part"); if (rc) { delete run; return rc; } }
+        const i64 n_valid = part.n_valid;
         if (n_valid == 0) { *out = run; return run->alloc(0) ? (delete run, 1) : 0; }
         if (MODE == 0 && attempt == 0) prof_count("ingest_records", n_valid);
-        DevBuf<u64> rec1, rec2;
-        DevBuf<u32> ord1, ord2;
-        if (rec1.alloc((size_t)n_valid) || ord1.alloc((size_t)n_valid)) { delete run; return 1; }
-        k_u64_copy<<<grid_for(nb1 + 1), 256, 0, g_stream>>>((const unsigned long long *)base1.p, cur1.p, nb1 + 1);
-        { KTimer kt("part_scatter1");
-        k_part_scatter<Src><<<pgrid, PT, 0, g_stream>>>(src, n_items, L1, cur1.p, rec1.p, ord1.p); }
-        HHX_LAUNCH_CHECK();
-        const u64 *recs = rec1.p;
-        const u32 *ords = ord1.p;
-        DevBuf<unsigned long long> hist2, cur2;
-        DevBuf<i64> base2;
-        const i64 *base = base1.p;
-        if (bits2 > 0) {                                        // ---- level 2
-            if (hist2.alloc(n_buckets + 1) || cur2.alloc(n_buckets + 1) || base2.alloc((size_t)n_buckets + 2) ||
-                rec2.alloc((size_t)n_valid) || ord2.alloc((size_t)n_valid)) { delete run; return 1; }
-            HHX_HIP(hipMemsetAsync(hist2.p, 0, sizeof(unsigned long long) * (n_buckets + 1), g_stream));
-            const PartLevel L2{total_bits, 0, bits2};
-            const SrcRecs s2{rec1.p, ord1.p};
-            const unsigned g2 = (unsigned)std::max<i64>(1, std::min<i64>((n_valid + P_TILE - 1) / P_TILE, 256 * 4));
-            { KTimer kt("part_count2");
-            k_part_count<SrcRecs><<<g2, PT, 0, g_stream>>>(s2, n_valid, L2, hist2.p); }
-            HHX_LAUNCH_CHECK();
-            HHX_TRY(exclusive_scan_i64((const i64 *)hist2.p, base2.p, n_buckets, nullptr));
-            k_u64_copy<<<grid_for(n_buckets + 1), 256, 0, g_stream>>>((const unsigned long long *)base2.p, cur2.p, n_buckets + 1);
-            { KTimer kt("part_scatter2");
-            k_part_scatter<SrcRecs><<<g2, PT, 0, g_stream>>>(s2, n_valid, L2, cur2.p, rec2.p, ord2.p); }
-            HHX_LAUNCH_CHECK();
-            recs = rec2.p; ords = ord2.p; base = base2.p;
-        }
+        const u32 n_buckets = part.n_buckets;
         // ---- aggregate
         const u32 n_wg = std::min<u32>(n_buckets, 1024);
         AggParams A{};
-        A.rec = recs; A.ord = ords; A.base = (const unsigned long long *)base;
+        A.rec = part.w0.p; A.ord = part.w1.p; A.base = (const unsigned long long *)part.base.p;
         A.n_buckets = n_buckets; A.buckets_per_wg = (n_buckets + n_wg - 1) / n_wg;
+        A.total_bits = total_bits;
         A.ord_base = ord_base;
         A.in_ord_full = pl.ord_full; A.in_ord_flank = pl.ord_flank; A.in_ht = pl.ht; A.in_fl = pl.fl;
         DevBuf<u64> g_key, g_of, g_ok;
@@ -470,7 +337,6 @@ int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, Link
         DevBuf<unsigned int> overflow;
         if (g_key.alloc((size_t)n_valid) || g_of.alloc((size_t)n_valid) || g_ok.alloc((size_t)n_valid) || g_ht.alloc((size_t)n_valid * 4) ||
             g_fl.alloc((size_t)n_valid) || seg_count.alloc(n_wg + 1) || seg_off.alloc(n_wg + 2) || overflow.alloc(1)) { delete run; return 1; }
-        if (bits2 > 0) { rec1.release(); ord1.release(); }
         HHX_HIP(hipMemsetAsync(overflow.p, 0, sizeof(unsigned int), g_stream));
         A.o_key = g_key.p; A.o_ord_full = g_of.p; A.o_ord_flank = g_ok.p; A.o_ht = g_ht.p; A.o_fl = g_fl.p;
         A.seg_count = seg_count.p; A.overflow = overflow.p;
@@ -482,7 +348,7 @@ int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, Link
         unsigned int ov = 0;
         HHX_HIP(hipMemcpyAsync(&ov, overflow.p, sizeof ov, hipMemcpyDeviceToHost, g_stream));
         HHX_HIP(hipStreamSynchronize(g_stream));
-        if (ov) continue;                                       // a bucket held more distinct keys than LDS: more buckets
+        if (ov) continue;                                       // a sub-pass held more distinct keys than LDS: more buckets
         if (run->alloc(n_keys)) { delete run; return 1; }
         { KTimer kt("compact");
         k_compact_run<<<n_wg, 256, 0, g_stream>>>(A, seg_off.p, run->key.p, run->ord_full.p, run->ord_flank.p, run->ht.p, run->fl.p); }
@@ -816,7 +682,7 @@ extern "C" int hhx_ingest_link_matrix(hhx_ingest *h, const uint8_t *in_set_host,
                                       int32_t *frag_index_host, int32_t *n_linked, hhx_csr **out) {
     if (!h || !h->finalized) return fail("ingest handle not finalized");
     KTimer kt("link_matrix");
-    return hhx_link_matrix_from_run(h->table(1), h->t.n_frag, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked, out);
+    return hhx_link_matrix_from_run(h->table(1), h->t.n_frag, h->ord_limit, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked, out);
 }
 
 extern "C" int hhx_ingest_destroy(hhx_ingest *h) {

@@ -13,6 +13,7 @@
 // all-pairs count, no sort).  Rows are filled with atomic cursors and put in column order with an LDS
 // bitmap rank (columns of a row are unique).
 #include "hhx_ingest.h"
+#include "hhx_partition.h"
 
 using namespace hhx;
 
@@ -256,9 +257,191 @@ extern "C" int hhx_dict_to_matrix(i64 n_keys, const i32 *frag_i, const i32 *frag
     return build_matrix(vw, n_keys, n_frag, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked_out, out);
 }
 
-int hhx_link_matrix_from_run(const LinkRun *run, i32 n_frag, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,
+// ================================================================================================
+// Fast path of hhx_ingest_link_matrix: the matrix is built by PARTITIONING directed entries by row.
+// Every flank key (i, j, count, first ordinal) with both ends in frag_set yields two 16-byte entries
+//     w0 = row << 29 | column-fragment,   w1 = (2 * ordinal + side) << 31 | count
+// which the radix partition of hhx_partition.h groups by row (bucket = fragment id).  After that everything
+// is row-local and streaming: first position and length of a row are a wave reduction over its entries (no
+// per-fragment atomics), and a workgroup per row maps the column fragments to matrix indices, sorts them
+// with the LDS bitmap rank and writes the CSR row.  The generic path above needs 6 random-access passes with
+// L2 atomics over the keys (55 ms at 165 M keys; its scattered fill wrote 12x the bytes it stored).
+namespace {
+
+struct SrcDirected {
+    typedef u64 w1_t;
+    const u64 *key, *ord_flank;
+    const u32 *fl;
+    const unsigned char *in_set;
+    __device__ __forceinline__ bool get(i64 idx, u64 &w0, u64 &w1) const {
+        const i64 k = idx >> 1;
+        const u64 ord = ord_flank[k];
+        if (ord == NO_ORD) return false;
+        const u64 ky = key[k];
+        const u32 i = (u32)(ky >> ID_BITS), j = (u32)(ky & ID_MASK);
+        if (!in_set[i] || !in_set[j]) return false;
+        const u32 side = (u32)(idx & 1);
+        const u32 a = side ? j : i, b = side ? i : j;
+        w0 = ((u64)a << ID_BITS) | (u64)b;
+        w1 = ((2 * ord + side) << 31) | (u64)fl[k];
+        return true;
+    }
+};
+struct DigRow {
+    __device__ __forceinline__ u32 operator()(u64 w0) const { return (u32)(w0 >> ID_BITS); }
+};
+
+// first position (min over the row's entries) and length of every row; one wave per row
+__global__ __launch_bounds__(256) void k_row_first(i32 n_frag, const i64 *__restrict__ base, const u64 *__restrict__ w1,
+                                                   unsigned long long *__restrict__ first_pos, i32 *__restrict__ row_len) {
+    const int lane = lane_id();
+    for (i32 a = blockIdx.x * 4 + threadIdx.x / HHX_WAVE; a < n_frag; a += gridDim.x * 4) {
+        const i64 b = base[a], e = base[a + 1];
+        unsigned long long m = ~0ull;
+        for (i64 p = b + lane; p < e; p += HHX_WAVE) m = min(m, (unsigned long long)(w1[p] >> 31));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned long long)__shfl_down((long long)m, o, HHX_WAVE));
+        if (lane == 0) { first_pos[a] = m; row_len[a] = (i32)(e - b); }
+    }
+}
+__global__ __launch_bounds__(256) void k_len_by_index(i32 n_frag, const i32 *__restrict__ frag_index, const i32 *__restrict__ row_len,
+                                                      i32 *__restrict__ cnt) {
+    for (i32 f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frag; f += gridDim.x * blockDim.x)
+        if (frag_index[f] >= 0) cnt[frag_index[f]] += row_len[f];           // one writer per index
+}
+// one workgroup per linked fragment: CSR row in column order (LDS bitmap rank; columns of a row are unique)
+__global__ __launch_bounds__(256) void k_row_emit(i32 n_frag, i32 W, int self_loop, const i64 *__restrict__ base, const u64 *__restrict__ w0,
+                                                  const u64 *__restrict__ w1, const i32 *__restrict__ frag_index,
+                                                  const i32 *__restrict__ indptr, i32 *__restrict__ oj, float *__restrict__ ox) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32 *bitmap = (u32 *)smem, *prefix = bitmap + W, *scratch = prefix + W;
+    const int tid = threadIdx.x;
+    for (i32 a = blockIdx.x; a < n_frag; a += gridDim.x) {
+        const i32 r = frag_index[a];
+        if (r < 0) continue;
+        const i64 b = base[a], e = base[a + 1];
+        const i32 ob = indptr[r];
+        for (i32 w = tid; w < W; w += 256) bitmap[w] = 0;
+        __syncthreads();
+        for (i64 p = b + tid; p < e; p += 256) { const i32 c = frag_index[(u32)(w0[p] & ID_MASK)]; atomicOr(&bitmap[c >> 5], 1u << (c & 31)); }
+        if (self_loop && tid == 0) atomicOr(&bitmap[r >> 5], 1u << (r & 31));
+        __syncthreads();
+        const i32 per = (W + 255) / 256, wa = tid * per, wb = min(W, wa + per);
+        u32 local = 0;
+        for (i32 w = wa; w < wb; ++w) local += __popc(bitmap[w]);
+        scratch[tid] = local;
+        __syncthreads();
+        if (tid < 64) {
+            u32 v0 = scratch[tid * 4], v1 = scratch[tid * 4 + 1], v2 = scratch[tid * 4 + 2], v3 = scratch[tid * 4 + 3];
+            u32 s = v0 + v1 + v2 + v3, incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                u32 t = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += t;
+            }
+            u32 ex = incl - s;
+            scratch[tid * 4] = ex; scratch[tid * 4 + 1] = ex + v0; scratch[tid * 4 + 2] = ex + v0 + v1; scratch[tid * 4 + 3] = ex + v0 + v1 + v2;
+        }
+        __syncthreads();
+        u32 run = scratch[tid];
+        for (i32 w = wa; w < wb; ++w) { prefix[w] = run; run += __popc(bitmap[w]); }
+        __syncthreads();
+        for (i64 p = b + tid; p < e; p += 256) {
+            const i32 c = frag_index[(u32)(w0[p] & ID_MASK)];
+            const i32 k = (i32)(prefix[c >> 5] + __popc(bitmap[c >> 5] & ((1u << (c & 31)) - 1u)));
+            oj[ob + k] = c;
+            ox[ob + k] = (float)(u32)(w1[p] & 0x7fffffffu);
+        }
+        if (self_loop && tid == 0) {
+            const i32 k = (i32)(prefix[r >> 5] + __popc(bitmap[r >> 5] & ((1u << (r & 31)) - 1u)));
+            oj[ob + k] = r;
+            ox[ob + k] = 1.0f;                                  // self loops :362-364
+        }
+        __syncthreads();
+    }
+}
+// link-less members of frag_set: a unit self loop only
+__global__ __launch_bounds__(256) void k_rest_rows(i32 r0, i32 shape, const i32 *__restrict__ indptr, i32 *__restrict__ oj, float *__restrict__ ox) {
+    for (i32 r = r0 + blockIdx.x * blockDim.x + threadIdx.x; r < shape; r += gridDim.x * blockDim.x) { oj[indptr[r]] = r; ox[indptr[r]] = 1.0f; }
+}
+
+int link_matrix_partitioned(const LinkRun *run, i32 n_frag, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,
+                            i32 *frag_index_host, i32 *n_linked_out, hhx_csr **out) {
+    DevBuf<unsigned char> in_set;
+    if (in_set.alloc((size_t)n_frag)) return 1;
+    HHX_HIP(hipMemcpyAsync(in_set.p, in_set_host, (size_t)n_frag, hipMemcpyHostToDevice, g_stream));
+    int row_bits = 0;
+    while (((i64)1 << row_bits) < n_frag) ++row_bits;
+    const SrcDirected src{run->key.p, run->ord_flank.p, run->fl.p, in_set.p};
+    Partitioned<u64> part;
+    static const int level_bits = getenv("HHX_D2M_LBITS") ? atoi(getenv("HHX_D2M_LBITS")) : 9;
+    HHX_TRY(partition_records(src, DigRow(), 2 * run->n, row_bits, level_bits, &part, "d2m"));
+    DevBuf<unsigned long long> first_pos;
+    DevBuf<i32> frag_index, row_len;
+    DevBuf<unsigned int> nl;
+    if (first_pos.alloc((size_t)n_frag) || frag_index.alloc((size_t)n_frag) || row_len.alloc((size_t)n_frag) || nl.alloc(1)) return 1;
+    HHX_HIP(hipMemsetAsync(nl.p, 0, sizeof(unsigned int), g_stream));
+    if (part.n_valid == 0) {
+        HHX_HIP(hipMemsetAsync(first_pos.p, 0xff, sizeof(unsigned long long) * (size_t)n_frag, g_stream));
+        HHX_HIP(hipMemsetAsync(row_len.p, 0, sizeof(i32) * (size_t)n_frag, g_stream));
+    } else {
+        k_row_first<<<grid_for((u64)n_frag * 64), 256, 0, g_stream>>>(n_frag, part.base.p, part.w1.p, first_pos.p, row_len.p);
+        HHX_LAUNCH_CHECK();
+    }
+    k_rank_first<<<(unsigned)((n_frag + 255) / 256), 256, 0, g_stream>>>(n_frag, first_pos.p, frag_index.p, nl.p);
+    HHX_LAUNCH_CHECK();
+    unsigned int n_linked = 0;
+    HHX_HIP(hipMemcpyAsync(&n_linked, nl.p, sizeof n_linked, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    if (n_rest < 0) {
+        i64 members = 0;
+        for (i32 f = 0; f < n_frag; ++f) members += in_set_host[f] != 0;
+        n_rest = (i32)(members - (i64)n_linked);
+    }
+    const i64 shape64 = (i64)n_linked + n_rest;
+    if (shape64 > INT32_MAX) return fail("matrix order exceeds int32");
+    const i32 shape = (i32)shape64;
+    DevBuf<i32> cnt, indptr;
+    if (cnt.alloc((size_t)shape + 1) || indptr.alloc((size_t)shape + 2)) return 1;
+    k_init_counts<<<grid_for((u64)shape + 1), 256, 0, g_stream>>>(shape, cnt.p, add_self_loops ? 1 : 0);
+    k_len_by_index<<<grid_for((u64)n_frag), 256, 0, g_stream>>>(n_frag, frag_index.p, row_len.p, cnt.p);
+    HHX_LAUNCH_CHECK();
+    i64 nnz = 0;
+    HHX_TRY(exclusive_scan_i32(cnt.p, indptr.p, shape, &nnz));
+    hhx_csr *m = nullptr;
+    HHX_TRY(hhx_csr_alloc_internal(shape, shape, nnz, &m));
+    hipError_t e = hipMemcpyAsync(m->indptr.p, indptr.p, sizeof(i32) * ((size_t)shape + 1), hipMemcpyDeviceToDevice, g_stream);
+    const i32 W = (shape + 31) / 32;
+    const size_t lds = (size_t)W * 8 + 256 * 4;
+    if (lds > 160 * 1024) { hhx_csr_free(m); return fail("link matrix: order %d exceeds the LDS bitmap capacity", shape); }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_row_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (e == hipSuccess && part.n_valid)
+        k_row_emit<<<(unsigned)std::min<i64>(n_frag, 256 * 8), 256, lds, g_stream>>>(n_frag, W, add_self_loops, part.base.p, part.w0.p, part.w1.p,
+                                                                                  frag_index.p, indptr.p, m->indices.p, m->data.p);
+    if (e == hipSuccess && add_self_loops && shape > (i32)n_linked)
+        k_rest_rows<<<grid_for((u64)(shape - (i32)n_linked)), 256, 0, g_stream>>>((i32)n_linked, shape, indptr.p, m->indices.p, m->data.p);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess && frag_index_host)
+        e = hipMemcpyAsync(frag_index_host, frag_index.p, sizeof(i32) * (size_t)n_frag, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    if (e != hipSuccess) { hhx_csr_free(m); return fail("link matrix: %s", hipGetErrorString(e)); }
+    if (n_linked_out) *n_linked_out = (i32)n_linked;
+    *out = m;
+    return 0;
+}
+
+}  // namespace
+
+int hhx_link_matrix_from_run(const LinkRun *run, i32 n_frag, u64 ord_limit, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,
                              i32 *frag_index_host, i32 *n_linked_out, hhx_csr **out) {
     if (!out || !in_set_host || n_frag <= 0) return fail("hhx_ingest_link_matrix: bad argument");
+    // packed entries hold 2*ordinal+side in 33 bits and the count in 31: true whenever < 2^31 pairs were seen
+    if (run && run->n && n_frag <= (1 << 20) && ord_limit <= ((u64)1 << 31) && !getenv("HHX_D2M_GENERIC"))
+        return link_matrix_partitioned(run, n_frag, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked_out, out);
     const RunView vw{run ? run->key.p : nullptr, run ? run->ord_flank.p : nullptr, run ? run->fl.p : nullptr};
     return build_matrix(vw, run ? run->n : 0, n_frag, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked_out, out);
 }

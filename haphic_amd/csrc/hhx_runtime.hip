@@ -209,6 +209,10 @@ static int scan_total(const T *in, T *out, i64 n, i64 *total_host) {
     return 0;
 }
 
+void u64_copy_async(const unsigned long long *src, unsigned long long *dst, i64 n) {
+    (void)hipMemcpyAsync(dst, src, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToDevice, g_stream);
+}
+
 int exclusive_scan_i32(const i32 *in, i32 *out, i64 n, i64 *total_host) { return scan_total<i32>(in, out, n, total_host); }
 int exclusive_scan_i64(const i64 *in, i64 *out, i64 n, i64 *total_host) { return scan_total<i64>(in, out, n, total_host); }
 
