@@ -322,8 +322,22 @@ __global__ __launch_bounds__(256) void k_row_emit(i32 n_frag, i32 W, int self_lo
         const i64 b = base[a], e = base[a + 1];
         const i32 ob = indptr[r];
         for (i32 w = tid; w < W; w += 256) bitmap[w] = 0;
+        // the first EMIT_R entries of every thread stay in registers between the marking and the writing sweep
+        // (loads, then dependent index gathers, issued back to back); longer rows re-read the tail
+        constexpr int EMIT_R = 16;
+        i32 cc[EMIT_R];
+        float vv[EMIT_R];
+        u64 t0[EMIT_R];
+#pragma unroll
+        for (int u = 0; u < EMIT_R; ++u) { const i64 p = b + tid + (i64)u * 256; t0[u] = p < e ? w0[p] : 0; }
+#pragma unroll
+        for (int u = 0; u < EMIT_R; ++u) { const i64 p = b + tid + (i64)u * 256; vv[u] = p < e ? (float)(u32)(w1[p] & 0x7fffffffu) : 0.f; }
+#pragma unroll
+        for (int u = 0; u < EMIT_R; ++u) { const i64 p = b + tid + (i64)u * 256; cc[u] = p < e ? frag_index[(u32)(t0[u] & ID_MASK)] : -1; }
         __syncthreads();
-        for (i64 p = b + tid; p < e; p += 256) { const i32 c = frag_index[(u32)(w0[p] & ID_MASK)]; atomicOr(&bitmap[c >> 5], 1u << (c & 31)); }
+#pragma unroll
+        for (int u = 0; u < EMIT_R; ++u) if (cc[u] >= 0) atomicOr(&bitmap[cc[u] >> 5], 1u << (cc[u] & 31));
+        for (i64 p = b + tid + (i64)EMIT_R * 256; p < e; p += 256) { const i32 c = frag_index[(u32)(w0[p] & ID_MASK)]; atomicOr(&bitmap[c >> 5], 1u << (c & 31)); }
         if (self_loop && tid == 0) atomicOr(&bitmap[r >> 5], 1u << (r & 31));
         __syncthreads();
         const i32 per = (W + 255) / 256, wa = tid * per, wb = min(W, wa + per);
@@ -346,7 +360,15 @@ __global__ __launch_bounds__(256) void k_row_emit(i32 n_frag, i32 W, int self_lo
         u32 run = scratch[tid];
         for (i32 w = wa; w < wb; ++w) { prefix[w] = run; run += __popc(bitmap[w]); }
         __syncthreads();
-        for (i64 p = b + tid; p < e; p += 256) {
+#pragma unroll
+        for (int u = 0; u < EMIT_R; ++u)
+            if (cc[u] >= 0) {
+                const i32 c = cc[u];
+                const i32 k = (i32)(prefix[c >> 5] + __popc(bitmap[c >> 5] & ((1u << (c & 31)) - 1u)));
+                oj[ob + k] = c;
+                ox[ob + k] = vv[u];
+            }
+        for (i64 p = b + tid + (i64)EMIT_R * 256; p < e; p += 256) {
             const i32 c = frag_index[(u32)(w0[p] & ID_MASK)];
             const i32 k = (i32)(prefix[c >> 5] + __popc(bitmap[c >> 5] & ((1u << (c & 31)) - 1u)));
             oj[ob + k] = c;

@@ -276,8 +276,108 @@ def gen_pipeline(path):
     np.savez_compressed(path, **out)
 
 
+def _run_mcl_files(mat, bin_set, frag_len_dict, fidx, fa_dict, nchrs, infl_range, out):
+    """run the reference's run_mcl_clustering in a temp dir and freeze every file it writes"""
+    import logging
+    import tempfile
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        try:
+            H.logger.setLevel('INFO')
+            fh = logging.FileHandler('log.txt', 'w')
+            H.logger.addHandler(fh)
+            H.run_mcl_clustering(mat, bin_set, frag_len_dict, fidx, 2, infl_range[0], infl_range[1], infl_range[2], 200, 1e-4,
+                                 fa_dict, nchrs, False)
+            H.logger.removeHandler(fh)
+            fh.close()
+            H.logger.setLevel('WARNING')
+            infl = []
+            for d in sorted(os.listdir('.')):
+                if d.startswith('inflation_'):
+                    infl.append(d.split('_', 1)[1])
+                    out['clusters_txt_' + infl[-1]] = np.array(open('{0}/mcl_{0}.clusters.txt'.format(d)).read())
+                    groups = sorted(f for f in os.listdir(d) if f.startswith('group'))
+                    out['group_files_' + infl[-1]] = np.array(groups)
+                    out['group_txt_' + infl[-1]] = np.array([open(os.path.join(d, g)).read() for g in groups])
+            out['inflations'] = np.array(infl)
+            out['log_recommend'] = np.array([l.strip() for l in open('log.txt') if 'You could try' in l] or [''])
+        finally:
+            os.chdir(cwd)
+    return infl
+
+
+def gen_pipeline_bins(path):
+    """contigs longer than bin_size are split (parse_alignments :1658-1752, bin -> contig vote :2172-2194)"""
+    g = synth.make_genome(3, 2_000_000, 250_000, cv=0.5, min_len=20_000, seed=31)
+    rng = np.random.default_rng(32)
+    names = list(g.names)
+    fa_dict = {}
+    for nm, ln in zip(names, g.length):
+        seq = ''.join(rng.choice(list('ACGT'), int(ln)))
+        fa_dict[nm] = [seq, int(ln), H.count_RE_sites(seq, 'GATC') + 1]
+    _, bin_set, bin_size, frag_len_dict, Nx_frag_set, RE_site_dict, split_ctg_set = H.stat_fragments(
+        fa_dict, 'GATC', {}, set(), nchrs=3, flank=50, Nx=100, bin_size=100)
+    id1, p1, id2, p2 = [t.numpy() for t in synth.sample_pairs(g, 150_000, seed=33, cis=0.9)]
+    aln = ((names[a], names[b], int(x), int(y)) for a, x, b, y in zip(id1, p1, id2, p2))
+    args = Args()
+    args.flank = 50
+    args.remove_allelic_links = 0
+    args.remove_concentrated_links = False
+    args.max_read_pairs = 200
+    args.nwindows = 50
+    full, flank, HT, clm, frag_link, coord, _ = H.parse_alignments(
+        aln, fa_dict, args, bin_size, frag_len_dict, Nx_frag_set, split_ctg_set, 'int32', 'int32')
+    mat, fidx = H.dict_to_matrix(flank, Nx_frag_set, dense_matrix=False, add_self_loops=True)
+    frag_names = list(frag_len_dict)
+    out = dict(names=np.array(names), length=g.length, re_sites=np.array([fa_dict[n_][2] for n_ in names], np.int64),
+               bin_size=np.int64(bin_size), split=np.array([n_ in split_ctg_set for n_ in names], np.uint8),
+               frag_names=np.array(frag_names), frag_len=np.array([frag_len_dict[f] for f in frag_names], np.int64),
+               frag_nx=np.array([f in Nx_frag_set for f in frag_names], np.uint8),
+               frag_is_bin=np.array([f in bin_set for f in frag_names], np.uint8),
+               id1=id1.astype(np.int16), pos1=p1, id2=id2.astype(np.int16), pos2=p2,
+               frag_index=np.array([fidx.get(f, -1) for f in frag_names], np.int32), nchrs=np.int32(3),
+               n_full=np.int64(len(full)), n_flank=np.int64(len(flank)), full_total=np.int64(sum(full.values())))
+    for n_ in names:
+        fa_dict[n_][0] = None
+    infl = _run_mcl_files(mat, bin_set, frag_len_dict, fidx, fa_dict, 3, (1.2, 2.4, 0.4), out)
+    print('pipeline bins case: ctgs', len(names), 'frags', len(frag_names), 'split', len(split_ctg_set), 'pairs', len(id1),
+          'inflations', infl, 'matrix', mat.shape, mat.nnz, 'recommend:', out['log_recommend'])
+    np.savez_compressed(path, **out)
+
+
+def gen_pipeline_c1(path):
+    """BASELINE.json configs[0]: ~1k contigs (4 chr x 25 Mb, mean 100 kb), 1 M pairs, nchrs = 4.  The pairs are
+    NOT stored: the test regenerates them with synth.sample_pairs(seed) (torch CPU generator, same image)."""
+    g = synth.make_genome(4, 25_000_000, 100_000, cv=0.3, min_len=5000, seed=12345)
+    names = list(g.names)
+    fa_dict = {n_: [None, int(l), int(r)] for n_, l, r in zip(names, g.length, g.re_sites)}
+    id1, p1, id2, p2 = [t.numpy() for t in synth.sample_pairs(g, 1_000_000, seed=12345)]
+    keep = id1 != id2
+    aln = ((names[a], names[b], int(x), int(y)) for a, x, b, y in zip(id1[keep], p1[keep], id2[keep], p2[keep]))
+    args = Args()
+    args.flank = 500
+    args.remove_allelic_links = 0
+    args.remove_concentrated_links = False
+    args.max_read_pairs = 200
+    args.nwindows = 50
+    frag_len_dict = {n_: fa_dict[n_][1] for n_ in names}
+    Nx_set = set(names)
+    full, flank, HT, clm, frag_link, coord = H.parse_alignments_for_ctgs(aln, fa_dict, args, frag_len_dict, Nx_set, 'int32', 'int32')
+    mat, fidx = H.dict_to_matrix(flank, Nx_set, dense_matrix=False, add_self_loops=True)
+    out = dict(n_contigs=np.int64(len(names)), pairs_checksum=np.int64(int(id1.sum() + p1.sum() + id2.sum() + p2.sum())),
+               n_full=np.int64(len(full)), n_flank=np.int64(len(flank)), full_total=np.int64(sum(full.values())),
+               frag_index=np.array([fidx[n_] for n_ in names], np.int32), matrix_nnz=np.int64(mat.nnz), nchrs=np.int32(4))
+    infl = _run_mcl_files(mat, set(), frag_len_dict, fidx, fa_dict, 4, (1.4, 2.2, 0.4), out)
+    print('pipeline C1 case: ctgs', len(names), 'pairs', int(keep.sum()), 'keys', len(full), 'inflations', infl,
+          'matrix', mat.shape, mat.nnz, 'recommend:', out['log_recommend'])
+    np.savez_compressed(path, **out)
+
+
 if __name__ == '__main__':
     assert os.environ.get('PYTHONHASHSEED') == '0', 'run with PYTHONHASHSEED=0'
     gen_mcl(os.path.join(HERE, 'mcl_cases.npz'))
     gen_ingest(os.path.join(HERE, 'ingest_ctgs.npz'), os.path.join(HERE, 'ingest_bins.npz'))
     gen_pipeline(os.path.join(HERE, 'pipeline_toy.npz'))
+    gen_pipeline_bins(os.path.join(HERE, 'pipeline_bins.npz'))
+    gen_pipeline_c1(os.path.join(HERE, 'pipeline_c1.npz'))

@@ -96,3 +96,130 @@ def test_sharded_hip_engine_world1_nccl():
             assert np.array_equal(a[k], b[k]), k
     finally:
         dist.destroy_process_group()
+
+
+def _check_files(g, tmp_path, records):
+    for infl in g['inflations']:
+        infl = str(infl)
+        d = tmp_path / ('inflation_' + infl)
+        got = (d / 'mcl_inflation_{}.clusters.txt'.format(infl)).read_text()
+        assert got == str(g['clusters_txt_' + infl]), 'cluster file differs at inflation ' + infl
+        groups = sorted(f for f in os.listdir(d) if f.startswith('group'))
+        assert groups == [str(x) for x in g['group_files_' + infl]]
+        for name, want in zip(groups, g['group_txt_' + infl]):
+            assert (d / name).read_text() == str(want), name
+    want = str(g['log_recommend'][0])
+    if want:
+        assert want in records, (want, [m for m in records if 'You could try' in m])
+
+
+def _run_clustering(cluster, mat, bin_set, frag_len_dict, fidx, fa_dict, nchrs, infl, tmp_path):
+    records = []
+    handler = logging.Handler()
+    handler.emit = lambda rec: records.append(rec.getMessage())
+    cluster.logger.addHandler(handler)
+    cluster.logger.setLevel('INFO')
+    try:
+        cluster.run_mcl_clustering(mat, bin_set, frag_len_dict, fidx, 2, infl[0], infl[1], infl[2], 200, 1e-4, fa_dict, nchrs, False,
+                                   outdir_root=str(tmp_path))
+    finally:
+        cluster.logger.removeHandler(handler)
+    return records
+
+
+def test_cluster_files_with_split_contigs(tmp_path):
+    """parse_alignments (contigs split into bins, :1658-1752) -> dict_to_matrix -> run_mcl_clustering with the
+    bin -> contig vote (:2172-2194): files byte-identical to the reference's frozen run"""
+    from haphic_amd import cluster
+    from tests.conftest import load_golden
+    g = load_golden('pipeline_bins.npz')
+    names = [str(x) for x in g['names']]
+    fa_dict = {n: [None, int(l), int(r)] for n, l, r in zip(names, g['length'], g['re_sites'])}
+    frag_names = [str(x) for x in g['frag_names']]
+    frag_len_dict = {f: int(l) for f, l in zip(frag_names, g['frag_len'])}
+    Nx_frag_set = {f for f, x in zip(frag_names, g['frag_nx']) if x}
+    bin_set = {f for f, x in zip(frag_names, g['frag_is_bin']) if x}
+    split_ctg_set = {n for n, x in zip(names, g['split']) if x}
+    aln = ((names[a], names[b], int(x), int(y)) for a, x, b, y in zip(g['id1'], g['pos1'], g['id2'], g['pos2']))
+
+    class A(Args):
+        flank = 50
+    full, flank, HT, clm, frag_link, coord, _ = cluster.parse_alignments(
+        aln, fa_dict, A(), int(g['bin_size']), frag_len_dict, Nx_frag_set, split_ctg_set, 'int32', 'int32')
+    assert (len(full), len(flank), sum(full.values())) == (int(g['n_full']), int(g['n_flank']), int(g['full_total']))
+    mat, fidx = cluster.dict_to_matrix(flank, Nx_frag_set, dense_matrix=False, add_self_loops=True, _device=True)
+    assert [fidx.get(f, -1) for f in frag_names] == g['frag_index'].tolist()
+    records = _run_clustering(cluster, mat, bin_set, frag_len_dict, fidx, fa_dict, int(g['nchrs']), (1.2, 2.4, 0.4), tmp_path)
+    _check_files(g, tmp_path, records)
+
+
+def test_cluster_files_c1_config(tmp_path):
+    """BASELINE.json configs[0]: ~1k contigs / 1 M pairs / nchrs = 4 — the reference's own CPU-runnable case"""
+    from haphic_amd import cluster, synth
+    from tests.conftest import load_golden
+    g = load_golden('pipeline_c1.npz')
+    gen = synth.make_genome(4, 25_000_000, 100_000, cv=0.3, min_len=5000, seed=12345)
+    names = list(gen.names)
+    assert len(names) == int(g['n_contigs'])
+    id1, p1, id2, p2 = [t.numpy() for t in synth.sample_pairs(gen, 1_000_000, seed=12345)]
+    if int(id1.sum() + p1.sum() + id2.sum() + p2.sum()) != int(g['pairs_checksum']):
+        pytest.skip('torch CPU generator differs from the one that made the fixture')
+    fa_dict = {n: [None, int(l), int(r)] for n, l, r in zip(names, gen.length, gen.re_sites)}
+    keep = id1 != id2
+    aln = ((names[a], names[b], int(x), int(y)) for a, x, b, y in zip(id1[keep], p1[keep], id2[keep], p2[keep]))
+    frag_len_dict = {n: fa_dict[n][1] for n in names}
+    Nx_set = set(names)
+    full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(aln, fa_dict, Args(), frag_len_dict, Nx_set, 'int32', 'int32')
+    assert (len(full), len(flank), sum(full.values())) == (int(g['n_full']), int(g['n_flank']), int(g['full_total']))
+    mat, fidx = cluster.dict_to_matrix(flank, Nx_set, dense_matrix=False, add_self_loops=True, _device=True)
+    assert [fidx[n] for n in names] == g['frag_index'].tolist() and mat.nnz == int(g['matrix_nnz'])
+    records = _run_clustering(cluster, mat, set(), frag_len_dict, fidx, fa_dict, 4, (1.4, 2.2, 0.4), tmp_path)
+    _check_files(g, tmp_path, records)
+
+
+def test_edge_cases():
+    """empty stream, every pair dropped, a single key, link-less fragments only, unknown names"""
+    from haphic_amd import _lib
+    from oracle import oracle as orc
+    n = 7
+    rank = np.arange(n, dtype=np.int32)[::-1].copy()
+    length = np.full(n, 10_000, np.int64)
+    t = orc.FragTable(rank, length, np.arange(n, dtype=np.int32), np.zeros(n, np.uint8), 0, rank, length, np.ones(n, np.uint8))
+    z = np.zeros(0, np.int32)
+    ing = _lib.Ingest(t, 0, bins=False, skip_intra=True)
+    ing.push(z, z, z, z)                                               # empty batch
+    assert ing.finalize() == (0, 0)
+    out = ing.fetch()
+    assert out['full_i'].size == 0 and out['flank_cnt'].size == 0 and not out['frag_links'].any()
+    m, fidx, nl = ing.link_matrix(np.ones(n, np.uint8))
+    p, j, x = m.to_arrays()
+    assert nl == 0 and (fidx == -1).all() and np.array_equal(p, np.arange(n + 1)) and np.array_equal(j, np.arange(n)) and (x == 1).all()
+    res, n_iter, conv = _lib.mcl(m, 2, 2.0, 50, 1e-4, links=True)      # identity: n singleton clusters
+    att, ptr, mem = _lib.interpret(res)
+    assert conv and len(att) == n and np.array_equal(mem, np.arange(n))
+    # every pair dropped: intra-contig, unknown names (-1), id out of range
+    ing = _lib.Ingest(t, 0, bins=False, skip_intra=True)
+    ing.push(np.array([1, -1, 3, 99], np.int32), np.array([5, 5, 5, 5], np.int32), np.array([1, 2, -1, 0], np.int32), np.array([9, 9, 9, 9], np.int32))
+    assert ing.finalize() == (0, 0)
+    # one key hit many times from both orientations, in two pushes
+    ing = _lib.Ingest(t, 0, bins=False, skip_intra=True)
+    a = np.array([2, 5] * 500, np.int32)
+    b = np.array([5, 2] * 500, np.int32)
+    pos = np.arange(1000, dtype=np.int32)
+    ing.push(a[:300], pos[:300], b[:300], pos[:300])
+    ing.push(a[300:], pos[300:], b[300:], pos[300:])
+    assert ing.finalize() == (1, 1)
+    out = ing.fetch()
+    ref = orc.ingest(t, a, pos.astype(np.int64), b, pos.astype(np.int64), 0)
+    for k in ('full_i', 'full_j', 'full_cnt', 'ht_cnt', 'flank_i', 'flank_j', 'flank_cnt', 'frag_links'):
+        assert np.array_equal(out[k], ref[k]), k
+    in_set = np.ones(n, np.uint8)
+    m, fidx, nl = ing.link_matrix(in_set)
+    rp, rj, rx, ridx, rl = orc.dict_to_matrix(ref['flank_i'], ref['flank_j'], ref['flank_cnt'].astype(np.float64), n, in_set, n - 2)
+    assert nl == rl == 2 and np.array_equal(fidx, ridx)
+    assert all(np.array_equal(u, v) for u, v in zip(m.to_arrays(), (rp, rj, rx)))
+    # a fragment of the only key is not in frag_set: nothing is linked
+    in2 = in_set.copy()
+    in2[5] = 0
+    m2, fidx2, nl2 = ing.link_matrix(in2)
+    assert nl2 == 0 and m2.shape3[0] == n - 1 and m2.nnz == n - 1
