@@ -161,7 +161,7 @@ def main():
             alg = 6.0 * F_w + 16.0 * A_w
             ach = alg / (win_ms * 1e-3) / 1e9
             roofline = {'kernel': 'k_expand_window_pass', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': ach / HBM_PEAK_GBS, 'traffic': traffic.get('k_expand_window_pass<false>'),
+                        'frac': ach / HBM_PEAK_GBS, 'traffic': pick(traffic, 'k_expand_window_pass'),
                         'alg_bytes_per_launch': alg / win_n, 'avg_launch_ms': win_ms / win_n, 'launches_per_step': win_n / K,
                         'products_per_step': F_w / K, 'bytes_per_product': 6,
                         'achieved_survey_8B_model': (8.0 * F_w + 16.0 * A_w) / (win_ms * 1e-3) / 1e9,
@@ -174,7 +174,7 @@ def main():
             alg = 16.0 * local_pairs + 12.0 * n_rec                            # read a pair, write a 12-byte record
             ach = alg / (sc_ms / sc_n * 1e-3) / 1e9
             ing_roofline = {'kernel': 'k_part_scatter<SrcPairs>', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                            'frac': ach / HBM_PEAK_GBS, 'traffic': traffic.get('k_part_scatter<SrcPairs<true> >'), 'alg_bytes_per_launch': alg,
+                            'frac': ach / HBM_PEAK_GBS, 'traffic': pick(traffic, 'k_part_scatter', 'SrcPairs'), 'alg_bytes_per_launch': alg,
                             'avg_launch_ms': sc_ms / sc_n}
         # whole link-matrix build against SURVEY §8d's B_ingest = 16 P + 12 (K_full + K_flank) + 4 n
         b_ingest = 16.0 * local_pairs + 12.0 * (state['n_full'] + state['n_flank']) + 4.0 * n
@@ -225,6 +225,14 @@ def pmc_traffic(n_contigs, pairs):
     if d.get('contigs') != int(n_contigs) or d.get('pairs_per_gpu') != int(pairs):
         return {}
     return d.get('bytes_per_launch', {})
+
+
+def pick(traffic, *needles):
+    """bytes per launch of the profiled kernel whose name contains every needle"""
+    for name, v in traffic.items():
+        if all(x in name for x in needles):
+            return v
+    return None
 
 
 def cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state):

@@ -138,9 +138,10 @@ def mkl_matrix_power(matrix, n):
 
 
 # ------------------------------------------------------------------ S2: mcl
-def mcl_device(pre_expanded, expansion, inflation, iters, pruning):
-    """mcl() on a device-resident pre-expanded matrix; logs like the reference (:2047 :2058)."""
-    res, n_iter, converged = _lib.mcl(pre_expanded, expansion, inflation, iters, pruning)
+def mcl_device(pre_expanded, expansion, inflation, iters, pruning, links=False):
+    """mcl() on a device-resident pre-expanded matrix (links=True: on the raw link matrix, normalisation and
+    pre-expansion fused into iteration 0); logs like the reference (:2047 :2058)."""
+    res, n_iter, converged = _lib.mcl(pre_expanded, expansion, inflation, iters, pruning, links=links)
     if converged:
         logger.info('The matrix has converged after {} rounds of iterations '
                     '(expansion: {}, inflation: {}, maximum iterations: {}, pruning threshold: {})'.format(
@@ -368,17 +369,31 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
     index_frag = {i: f for f, i in frag_index_dict.items()}
     own = not isinstance(link_matrix, _lib.DeviceCSR)
     m = _to_device(link_matrix) if own else link_matrix.copy()
-    _lib.normalize_l1(m)                                             # :2144
-    pre = m
-    for _ in range(2, expansion + 1):                                # :2146-2147
-        nxt = _lib.spgemm(pre, m)
-        if pre is not m:
-            pre.free()
-        pre = nxt
+    n = m.shape3[0]
+    # The reference pre-expands once (:2146-2147) and restarts every inflation from that matrix.  M^e is
+    # nearly dense: it is materialised only while it is guaranteed to fit scipy's int32 index range
+    # (n^2 < 2^31); beyond that every inflation starts from the link matrix and the pre-expansion is fused
+    # into its iteration 0 (hhx_mcl_links) — same results, the n^2-entry matrix never exists.
+    materialise = expansion > 1 and n * n < 2 ** 31
+    pre = None
+    if materialise:
+        _lib.normalize_l1(m)                                         # :2144
+        pre = m
+        for _ in range(2, expansion + 1):                            # :2146-2147
+            nxt = _lib.spgemm(pre, m, fx_shift=52)
+            if pre is not m:
+                pre.free()
+            pre = nxt
+    elif expansion <= 1:
+        _lib.normalize_l1(m)
+        pre = m
     result_clusters_list = []
     mcl_nrounds = 0
     for inflation in _inflation_values(min_inflation, max_inflation, inflation_step):
-        res = mcl_device(pre, expansion, float(inflation), max_iter, pruning)
+        if pre is not None:
+            res = mcl_device(pre, expansion, float(inflation), max_iter, pruning)
+        else:
+            res = mcl_device(m, expansion, float(inflation), max_iter, pruning, links=True)
         mcl_nrounds += 1
         clusters = interpret_result_device(res)
         res.free()
@@ -414,7 +429,7 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
                 for ctg in ctgs:
                     fout.write('{}\t{}\t{}\n'.format(ctg, fa_dict[ctg][2], fa_dict[ctg][1]))
         result_clusters_list.append((inflation, result_clusters))
-    if pre is not m:
+    if pre is not None and pre is not m:
         pre.free()
     m.free()
     max_nclusters = max([len(rc) for _, rc in result_clusters_list])
