@@ -66,6 +66,7 @@ SIGNATURES = {
     'hhx_interpret': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i32p]),
     'hhx_dict_to_matrix': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_void_p,
                                      C.c_int32, C.c_int, C.c_void_p, c_i32p, c_vpp]),
+    'hhx_count_re_sites': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'hhx_ingest_create': (C.c_int, [C.POINTER(IngestConfig), c_vpp]),
     'hhx_ingest_push': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     'hhx_ingest_finalize': (C.c_int, [C.c_void_p, c_i64p, c_i64p]),
@@ -315,6 +316,19 @@ def dict_to_matrix(frag_i, frag_j, value, n_frag, in_set, n_rest, add_self_loops
     check(load().hhx_dict_to_matrix(nk, a, b, v, int(on_device), int(n_frag), ptr(in_set), int(n_rest),
                                     int(add_self_loops), ptr(frag_index), C.byref(n_linked), C.byref(out)))
     return DeviceCSR(out), frag_index[:n_frag], n_linked.value
+
+
+def count_re_sites(seq, seg_off, seg_len, sites):
+    """seq: bytes-like / uint8 array; sites: list of bytes patterns (already N-expanded).  Returns int64 counts."""
+    buf = np.frombuffer(seq, np.uint8) if not isinstance(seq, np.ndarray) else np.ascontiguousarray(seq, np.uint8)
+    off = np.ascontiguousarray(seg_off, np.int64)
+    ln = np.ascontiguousarray(seg_len, np.int64)
+    pats = np.frombuffer(b''.join(sites), np.uint8) if sites else np.zeros(1, np.uint8)
+    plen = np.array([len(x) for x in sites], np.int32) if sites else np.zeros(1, np.int32)
+    out = np.zeros(max(off.size, 1), np.int64)
+    check(load().hhx_count_re_sites(ptr(buf) if buf.size else None, buf.size, off.size, ptr(off), ptr(ln), len(sites), ptr(pats),
+                                    ptr(plen), ptr(out)))
+    return out[:off.size]
 
 
 class Ingest:

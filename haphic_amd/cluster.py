@@ -82,6 +82,142 @@ class FragTable:
                    [frag_len_dict[f] for f in frag_names], [f in Nx_frag_set for f in frag_names])
 
 
+# ------------------------------------------------------------------ a5: restriction sites, fragment statistics
+def parse_RE_sites(sites):
+    """parse_RE_sites() :56-72 — expands every N into A/T/C/G"""
+    output_sites = []
+    for site in sites:
+        if 'N' in site:
+            for base in 'ATCG':
+                output_sites.append(site.replace('N', base, 1))
+        else:
+            output_sites.append(site)
+    if 'N' not in ''.join(output_sites):
+        return output_sites
+    return parse_RE_sites(output_sites)
+
+
+def _sites_of(RE):
+    sites = [site.strip().upper() for site in RE.split(',') if site.strip()]
+    return [x.encode() for x in parse_RE_sites(sites)]
+
+
+def count_RE_sites(seq, RE):
+    """count_RE_sites() :75-84 on one sequence (str or bytes)"""
+    buf = seq.encode() if isinstance(seq, str) else bytes(seq)
+    return int(_lib.count_re_sites(buf, [0], [len(buf)], _sites_of(RE))[0])
+
+
+def parse_fasta(fasta, RE='GATC', keep_letter_case=False, logger=logger):
+    """parse_fasta() :87-113 — fa_dict[ctg] = [seq, len, RE sites + 1]; the RE sites of all contigs are
+    counted in one device pass over the genome bytes"""
+    logger.info('Parsing input FASTA file...')
+    fa_dict = dict()
+    with open(fasta) as f:
+        for line in f:
+            if not line.strip():
+                continue
+            if line.startswith('>'):
+                ctg = line.split()[0][1:]
+                fa_dict[ctg] = list()
+            else:
+                fa_dict[ctg].append(line.strip() if keep_letter_case else line.strip().upper())
+    seqs = {ctg: ''.join(seq_list) for ctg, seq_list in fa_dict.items()}
+    lens = np.fromiter((len(x) for x in seqs.values()), np.int64, len(seqs))
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64) if len(lens) else np.zeros(0, np.int64)
+    counts = _lib.count_re_sites(''.join(seqs.values()).encode(), offs, lens, _sites_of(RE)) if len(lens) else []
+    for k, (ctg, seq) in enumerate(seqs.items()):
+        fa_dict[ctg] = [seq, len(seq), int(counts[k]) + 1]       # pseudo-count of 1 (:110)
+    return fa_dict
+
+
+def stat_fragments(fa_dict, RE, read_depth_dict, whitelist, nchrs=0, flank=0, Nx=100, bin_size=0, logger=logger):
+    """stat_fragments() :188-296.  The bin table, the seeded shuffle (:273) and the Nx set are the reference's
+    own Python; every RE-site count (:192-199 flank-only counting, :245-256 bins) comes from ONE device call."""
+    import random
+    from math import inf
+    logger.info('Making some statistics of fragments (contigs / bins)')
+    flank *= 1000
+    total_len = sum([ctg_info[1] for ctg_info in fa_dict.values()])
+    if not bin_size:
+        logger.info('bin_size is set to {}, no fragments will be split'.format(bin_size))
+        bin_size = inf
+    elif bin_size < 0:
+        bin_size = max(min(int(total_len / nchrs / 30), 2000000), 100000)
+        logger.info('bin_size is calculated to be {} bp'.format(bin_size))
+    else:
+        bin_size *= 1000
+        logger.info('bin_size is manually designated to {} bp'.format(bin_size))
+    frags = list()
+    bin_set = set()
+    split_ctg_set = set()
+    RE_site_dict, frag_len_dict = dict(), dict()
+    # segments to count: (fragment, offset in the genome buffer, length); a fragment may own two (flanks)
+    pieces, seg_frag, seg_off, seg_len = [], [], [], []
+    cursor = 0
+
+    def want(frag, start, length):
+        # count_flank_RE_sites :190-199 on the slice [start, start + length) of the current contig
+        if not flank or length <= 2 * flank:
+            seg_frag.append(frag); seg_off.append(cursor + start); seg_len.append(length)
+        else:
+            seg_frag.append(frag); seg_off.append(cursor + start); seg_len.append(flank)
+            seg_frag.append(frag); seg_off.append(cursor + start + length - flank); seg_len.append(flank)
+
+    for ctg, (seq, ctg_len, RE_sites) in fa_dict.items():
+        need_seq = False
+        if ctg_len > bin_size:
+            split_ctg_set.add(ctg)
+            nbins = ceil(ctg_len / bin_size)
+            for m in range(nbins):
+                bin_ = '{}_bin{}'.format(ctg, m + 1)
+                assert bin_ not in fa_dict
+                frags.append(bin_)
+                bin_set.add(bin_)
+                bin_len = bin_size if m + 1 < nbins else ctg_len - m * bin_size
+                want(bin_, m * bin_size, bin_len)
+                need_seq = True
+                frag_len_dict[bin_] = bin_len
+                if read_depth_dict:
+                    read_depth_dict[bin_] = read_depth_dict[ctg]
+            if read_depth_dict:
+                del read_depth_dict[ctg]
+        else:
+            frags.append(ctg)
+            frag_len_dict[ctg] = ctg_len
+            if not flank or ctg_len <= 2 * flank:
+                RE_site_dict[ctg] = RE_sites
+            else:
+                want(ctg, 0, ctg_len)
+                need_seq = True
+        if need_seq:
+            pieces.append(seq)
+            cursor += ctg_len
+        fa_dict[ctg][0] = None                                   # :266 the sequences are not needed any more
+    if seg_frag:
+        counts = _lib.count_re_sites(''.join(pieces).encode(), seg_off, seg_len, _sites_of(RE))
+        for frag, c in zip(seg_frag, counts.tolist()):
+            RE_site_dict[frag] = RE_site_dict.get(frag, 1) + c     # + 1 pseudo-count once per fragment (:193 :199)
+    # bins were appended to RE_site_dict after the unsplit contigs: restore the reference's insertion order
+    RE_site_dict = {frag: RE_site_dict[frag] for frag in frags}
+    random.seed(12345)
+    random.shuffle(frags)
+    sorted_frag_list = sorted([(frag, frag_len_dict[frag]) for frag in frags], key=lambda x: x[1], reverse=True)
+    len_sum = 0
+    Nx_frag_set = set()
+    for frag, frag_len in sorted_frag_list:
+        len_sum += frag_len
+        if len_sum / total_len * 100 < Nx or Nx == 100:
+            Nx_frag_set.add(frag)
+    if Nx != 100:
+        Nx_frag_set.add(sorted_frag_list[len(Nx_frag_set)][0])
+    if whitelist:
+        for frag, _ in sorted_frag_list:
+            if frag.rsplit('_bin', 1)[0] in whitelist:
+                Nx_frag_set.add(frag)
+    return sorted_frag_list, bin_set, bin_size, frag_len_dict, Nx_frag_set, RE_site_dict, split_ctg_set
+
+
 # ------------------------------------------------------------------ S1 / S3: matrix-level seams
 def _to_device(matrix):
     return _lib.DeviceCSR.from_scipy_csc(matrix)

@@ -16,6 +16,9 @@ SEAMS = {
     'prune': ('HapHiC_cluster.py:1987-2014', cluster.prune),                            # S3
     'interpret_result': ('HapHiC_cluster.py:2065-2095', cluster.interpret_result),      # a12
     'run_mcl_clustering': ('HapHiC_cluster.py:2132-2242', cluster.run_mcl_clustering),  # S6
+    'count_RE_sites': ('HapHiC_cluster.py:75-84', cluster.count_RE_sites),              # a5
+    'parse_fasta': ('HapHiC_cluster.py:87-113', cluster.parse_fasta),                   # a5
+    'stat_fragments': ('HapHiC_cluster.py:188-296', cluster.stat_fragments),            # a5
 }
 # S4/S5 are opt-in: dict_to_matrix is also called in dense mode by the filters (:603 :868), and the
 # device ingest does not produce the CLM distance lists / coordinate records yet.

@@ -197,16 +197,29 @@ def gather_tables(engine, tensors, dist):
     return [torch.cat(_all_gather_var(t.contiguous(), dist, torch)).contiguous() for t in tensors]
 
 
-def merge_flank_and_build(ing, table, flank, bins, in_set, dist, device):
+def merge_flank_and_build(ing, table, flank, bins, in_set, dist, device, full_tables=False):
     """exchange step of the sharded ingest + dict_to_matrix on the merged table (replicated on every rank).
-    `ing`: this rank's finalized Ingest (ordinal base = number of pairs held by lower ranks)."""
+    `ing`: this rank's finalized Ingest (ordinal base = number of pairs held by lower ranks).
+    full_tables=False exchanges only what the link matrix needs — key, first flank ordinal, flank count
+    (20 B per row instead of 44): the contig-pair table (full_link_dict / HT counts) stays per rank and is
+    merged only when a caller wants the host dicts (full_tables=True)."""
     eng = HipEngine(device)
+    t = eng.torch
     merged = _lib.Ingest(table, flank, bins=bins)
-    for which in ((0,) if not bins else (0, 1)):
+    for which in ((1,) if not full_tables else ((0,) if not bins else (0, 1))):
         n, *ptrs = ing.table_device(which)
-        g = gather_tables(eng, eng.table_tensors(n, ptrs), dist)
-        eng.torch.cuda.current_stream(eng.device).synchronize()
-        merged.push_table(which, g[0].numel(), *[t.data_ptr() for t in g])
+        cols = eng.table_tensors(n, ptrs)
+        if full_tables:
+            g = gather_tables(eng, cols, dist)
+        else:
+            key, _of, ok, _ht, fl = cols
+            if n:                                            # rows that never entered flank_link_dict are not needed
+                keep = ok != -1                              # NO_ORD == 2^64 - 1 == -1 as int64
+                key, ok, fl = key[keep], ok[keep], fl[keep]
+            gk, gok, gfl = gather_tables(eng, [key, ok, fl], dist)
+            g = [gk, t.full_like(gk, -1), gok, t.zeros(4 * gk.numel(), dtype=t.int32, device=gk.device), gfl]
+        t.cuda.current_stream(eng.device).synchronize()
+        merged.push_table(which, g[0].numel(), *[x.data_ptr() for x in g])
     merged.finalize()
     m, fidx, n_linked = merged.link_matrix(in_set)
     return m, n_linked, merged

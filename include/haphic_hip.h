@@ -134,6 +134,16 @@ int hhx_dict_to_matrix(int64_t n_keys, const int32_t *frag_i, const int32_t *fra
                        int on_device, int32_t n_frag, const uint8_t *in_set_host, int32_t n_rest,
                        int add_self_loops, int32_t *frag_index_host, int32_t *n_linked, hhx_csr **out);
 
+/* ---------------------------------------------------------------- a5: restriction-site counts
+ * count_RE_sites :75-84 for many segments of one sequence buffer (host bytes, letter case as the caller's
+ * parse_fasta :87-113 leaves it): counts[s] = sum over sites of seq[off[s] : off[s]+len[s]].count(site),
+ * Python str.count semantics (non-overlapping, leftmost first).  `sites` holds the n_sites patterns after
+ * parse_RE_sites' N expansion (:56-72), concatenated; site_len their lengths (<= 32).  Segments may overlap:
+ * stat_fragments :188-296 asks for whole contigs, bins and the flank prefix / suffix of either. */
+int hhx_count_re_sites(const uint8_t *seq_host, int64_t seq_len, int64_t n_seg, const int64_t *seg_off,
+                       const int64_t *seg_len, int32_t n_sites, const uint8_t *sites, const int32_t *site_len,
+                       int64_t *counts_host);
+
 /* ---------------------------------------------------------------- S5: ingest
  * parse_alignments_for_ctgs :1596-1655 (bins = 0) and parse_alignments :1658-1752 (bins = 1) on
  * integer ids.  The Python shim maps names to ids once (haphic_amd/cluster.py: FragTable):

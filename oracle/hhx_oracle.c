@@ -578,3 +578,25 @@ i64 orc_dict_to_matrix(i64 n_keys, const i32 *fi, const i32 *fj, const double *v
     free(ent); free(cur); free(cnt);
     return nnz;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * count_RE_sites(), :75-84, over segments: counts[s] = sum over sites of seq[off:off+len].count(site).
+ * Python str.count counts NON-overlapping occurrences, scanning from the left and resuming after each
+ * match.  sites are concatenated, each site_len[k] bytes (after parse_RE_sites' N expansion :56-72).
+ * ---------------------------------------------------------------------------------------------- */
+void orc_count_re_sites(const unsigned char *seq, i64 n_seg, const i64 *seg_off, const i64 *seg_len, i32 n_sites,
+                        const unsigned char *sites, const i32 *site_len, i64 *counts) {
+    for (i64 s = 0; s < n_seg; ++s) {
+        i64 total = 0;
+        const unsigned char *pat = sites;
+        for (i32 k = 0; k < n_sites; ++k) {
+            const i32 L = site_len[k];
+            const i64 a = seg_off[s], e = a + seg_len[s];
+            for (i64 p = a; p + L <= e;) {
+                if (memcmp(seq + p, pat, (size_t)L) == 0) { ++total; p += L; } else ++p;
+            }
+            pat += L;
+        }
+        counts[s] = total;
+    }
+}

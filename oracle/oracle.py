@@ -67,6 +67,8 @@ def lib():
         L.orc_dict_to_matrix.argtypes = [C.c_int64, _i32p, _i32p, _f64p, C.c_int32, _u8p, C.c_int32, C.c_int,
                                          _i32p, C.POINTER(C.c_int32), _i32p, C.c_void_p, C.c_void_p]
         L.orc_dict_to_matrix.restype = C.c_int64
+        L.orc_count_re_sites.argtypes = [_u8p, C.c_int64, _i64p, _i64p, C.c_int32, _u8p, _i32p, _i64p]
+        L.orc_count_re_sites.restype = None
         _lib = L
     return _lib
 
@@ -224,3 +226,18 @@ def dict_to_matrix(fi, fj, val, n_frag, in_set, n_rest, add_self_loops=True):
     L.orc_dict_to_matrix(fi.size, fi, fj, val, n_frag, in_set, n_rest, int(add_self_loops), frag_index,
                          C.byref(n_linked), indptr, indices.ctypes.data, data.ctypes.data)
     return indptr[:shape + 1].copy(), indices[:nnz], data[:nnz], frag_index[:n_frag], n_linked.value
+
+
+def count_re_sites(seq, seg_off, seg_len, sites):
+    """count_RE_sites :75-84 over segments of a byte buffer; sites = list of bytes (N-expanded)"""
+    buf = np.ascontiguousarray(np.frombuffer(seq, np.uint8) if not isinstance(seq, np.ndarray) else seq, np.uint8)
+    if buf.size == 0:
+        buf = np.zeros(1, np.uint8)
+    off = np.ascontiguousarray(seg_off, np.int64)
+    ln = np.ascontiguousarray(seg_len, np.int64)
+    pats = np.ascontiguousarray(np.frombuffer(b''.join(sites) or b'\0', np.uint8))
+    plen = np.array([len(x) for x in sites] or [0], np.int32)
+    out = np.zeros(max(off.size, 1), np.int64)
+    lib().orc_count_re_sites(buf, off.size, off if off.size else np.zeros(1, np.int64), ln if ln.size else np.zeros(1, np.int64),
+                             len(sites), pats, plen, out)
+    return out[:off.size]

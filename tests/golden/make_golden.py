@@ -374,6 +374,51 @@ def gen_pipeline_c1(path):
     np.savez_compressed(path, **out)
 
 
+def gen_resites(path):
+    """count_RE_sites (:75-84) on slices, and stat_fragments (:188-296) on a small assembly"""
+    rng = np.random.default_rng(77)
+    parts = [''.join(rng.choice(list('ACGT'), 30_000)), 'A' * 1003, 'GC' * 777, ''.join(rng.choice(list('ACGTN'), 5000)),
+             'GATC' * 500, ''.join(rng.choice(list('AG'), 4000)), 'GANTCGAATC' * 50, ''.join(rng.choice(list('ACGT'), 9000))]
+    seq = ''.join(parts)
+    n = len(seq)
+    off = rng.integers(0, n, 400)
+    ln = np.minimum(rng.integers(0, 9000, 400), n - off)
+    off = np.concatenate([off, [0, 0, n - 3, n, 5]]).astype(np.int64)
+    ln = np.concatenate([ln, [n, 0, 3, 0, 4097]]).astype(np.int64)
+    out = dict(seq=np.frombuffer(seq.encode(), np.uint8), seg_off=off, seg_len=ln)
+    res = []
+    for RE in ('GATC', 'GATC,GANTC', 'AAGCTT', 'GCGC', 'AAAA,GATC', 'A', 'GANNTC', 'ACGTACGTACGTACGTACGTACGTACGTACGT'):
+        res.append(RE)
+        out['counts_' + RE] = np.array([H.count_RE_sites(seq[a:a + l], RE) for a, l in zip(off, ln)], np.int64)
+        out['sites_' + RE] = np.array(H.parse_RE_sites([x.strip().upper() for x in RE.split(',') if x.strip()]))
+    out['REs'] = np.array(res)
+    # stat_fragments: 14 contigs, flank-only counting, bins, Nx < 100, whitelist
+    fa = {}
+    names = []
+    for i in range(14):
+        L = int(rng.integers(3000, 90_000))
+        sq = ''.join(rng.choice(list('ACGT'), L))
+        nm = 'ptg%03dl' % i
+        names.append(nm)
+        fa[nm] = [sq, L, H.count_RE_sites(sq, 'GATC,GANTC') + 1]
+    out['sf_names'] = np.array(names)
+    out['sf_seq'] = np.frombuffer(''.join(fa[n_][0] for n_ in names).encode(), np.uint8)
+    out['sf_len'] = np.array([fa[n_][1] for n_ in names], np.int64)
+    out['sf_re'] = np.array([fa[n_][2] for n_ in names], np.int64)
+    r = H.stat_fragments(fa, 'GATC,GANTC', {}, {'ptg003l'}, nchrs=2, flank=4, Nx=70, bin_size=20)
+    out['sf_sorted'] = np.array([f for f, _ in r[0]])
+    out['sf_bin_size'] = np.int64(r[2])
+    out['sf_frags'] = np.array(list(r[3]))
+    out['sf_frag_len'] = np.array(list(r[3].values()), np.int64)
+    out['sf_nx'] = np.array(sorted(r[4]))
+    out['sf_re_frags'] = np.array(list(r[5]))
+    out['sf_re_counts'] = np.array(list(r[5].values()), np.int64)
+    out['sf_split'] = np.array(sorted(r[6]))
+    out['sf_bins'] = np.array(sorted(r[1]))
+    print('resites case: seq', n, 'segments', len(off), 'REs', res, 'stat_fragments frags', len(r[3]), 'bins', len(r[1]))
+    np.savez_compressed(path, **out)
+
+
 if __name__ == '__main__':
     assert os.environ.get('PYTHONHASHSEED') == '0', 'run with PYTHONHASHSEED=0'
     gen_mcl(os.path.join(HERE, 'mcl_cases.npz'))
@@ -381,3 +426,4 @@ if __name__ == '__main__':
     gen_pipeline(os.path.join(HERE, 'pipeline_toy.npz'))
     gen_pipeline_bins(os.path.join(HERE, 'pipeline_bins.npz'))
     gen_pipeline_c1(os.path.join(HERE, 'pipeline_c1.npz'))
+    gen_resites(os.path.join(HERE, 'resites.npz'))

@@ -87,13 +87,16 @@ def test_sharded_hip_engine_world1_nccl():
         torch.cuda.synchronize()
         ing.finalize()
         in_set = np.ones(n, np.uint8)
-        m, n_linked, merged = sharded.merge_flank_and_build(ing, t, 3000, False, in_set, dist, 'cuda:0')
         m1, fidx, nl1 = ing.link_matrix(in_set)
-        assert merged.n_flank == ing.n_flank and nl1 == n_linked
-        assert all(np.array_equal(x, y) for x, y in zip(m.to_arrays(), m1.to_arrays()))
-        a, b = merged.fetch(), ing.fetch()
-        for k in a:
-            assert np.array_equal(a[k], b[k]), k
+        b = ing.fetch()
+        for full_tables in (False, True):
+            m, n_linked, merged = sharded.merge_flank_and_build(ing, t, 3000, False, in_set, dist, 'cuda:0', full_tables=full_tables)
+            assert merged.n_flank == ing.n_flank and nl1 == n_linked
+            assert all(np.array_equal(x, y) for x, y in zip(m.to_arrays(), m1.to_arrays()))
+            a = merged.fetch()
+            for k in a:
+                if full_tables or k.startswith('flank') or k == 'frag_links':
+                    assert np.array_equal(a[k], b[k]), k
     finally:
         dist.destroy_process_group()
 
@@ -223,3 +226,32 @@ def test_edge_cases():
     in2[5] = 0
     m2, fidx2, nl2 = ing.link_matrix(in2)
     assert nl2 == 0 and m2.shape3[0] == n - 1 and m2.nnz == n - 1
+
+
+def test_re_sites_and_stat_fragments():
+    """a5: count_RE_sites (:75-84, non-overlapping str.count semantics incl. self-overlapping sites) and
+    stat_fragments (:188-296: bins, flank-only counting, seeded shuffle, Nx set, whitelist) against the reference"""
+    from haphic_amd import _lib, cluster
+    from tests.conftest import load_golden
+    g = load_golden('resites.npz')
+    for RE in g['REs']:
+        RE = str(RE)
+        sites = [str(x).encode() for x in g['sites_' + RE]]
+        assert [x.decode() for x in cluster._sites_of(RE)] == [str(x) for x in g['sites_' + RE]]
+        got = _lib.count_re_sites(g['seq'], g['seg_off'], g['seg_len'], sites)
+        assert np.array_equal(got, g['counts_' + RE]), RE
+    assert cluster.count_RE_sites('GATCGATC' + 'AAAAA', 'GATC,AAAA') == 3
+    names = [str(x) for x in g['sf_names']]
+    seq = bytes(g['sf_seq']).decode()
+    fa, pos = {}, 0
+    for n, L, re_ in zip(names, g['sf_len'], g['sf_re']):
+        fa[n] = [seq[pos:pos + int(L)], int(L), int(re_)]
+        pos += int(L)
+    assert all(cluster.count_RE_sites(v[0], 'GATC,GANTC') + 1 == v[2] for v in fa.values())
+    r = cluster.stat_fragments(fa, 'GATC,GANTC', {}, {'ptg003l'}, nchrs=2, flank=4, Nx=70, bin_size=20)
+    assert [f for f, _ in r[0]] == [str(x) for x in g['sf_sorted']]
+    assert r[2] == int(g['sf_bin_size']) and sorted(r[1]) == [str(x) for x in g['sf_bins']] and sorted(r[6]) == [str(x) for x in g['sf_split']]
+    assert list(r[3]) == [str(x) for x in g['sf_frags']] and list(r[3].values()) == g['sf_frag_len'].tolist()
+    assert sorted(r[4]) == [str(x) for x in g['sf_nx']]
+    assert list(r[5]) == [str(x) for x in g['sf_re_frags']] and list(r[5].values()) == g['sf_re_counts'].tolist()
+    assert all(v[0] is None for v in fa.values())

@@ -114,3 +114,13 @@ def test_dict_to_matrix(golden_ingest):
     val = g['flank_cnt'] / (fl[g['flank_i']] * fl[g['flank_j']]) ** 0.5
     x2 = orc.dict_to_matrix(g['flank_i'], g['flank_j'], val, len(in_set), in_set, n_rest)[2]
     assert np.array_equal(x2, g['d2m_nlinks_x'])
+
+
+def test_count_re_sites(request):
+    from tests.conftest import load_golden
+    g = load_golden('resites.npz')
+    for RE in g['REs']:
+        RE = str(RE)
+        sites = [str(x).encode() for x in g['sites_' + RE]]
+        got = orc.count_re_sites(g['seq'], g['seg_off'], g['seg_len'], sites)
+        assert np.array_equal(got, g['counts_' + RE]), RE
