@@ -67,6 +67,7 @@ SIGNATURES = {
     'hhx_dict_to_matrix': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_void_p,
                                      C.c_int32, C.c_int, C.c_void_p, c_i32p, c_vpp]),
     'hhx_count_re_sites': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'hhx_rank_sums': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'hhx_ingest_create': (C.c_int, [C.POINTER(IngestConfig), c_vpp]),
     'hhx_ingest_push': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     'hhx_ingest_finalize': (C.c_int, [C.c_void_p, c_i64p, c_i64p]),
@@ -316,6 +317,13 @@ def dict_to_matrix(frag_i, frag_j, value, n_frag, in_set, n_rest, add_self_loops
     check(load().hhx_dict_to_matrix(nk, a, b, v, int(on_device), int(n_frag), ptr(in_set), int(n_rest),
                                     int(add_self_loops), ptr(frag_index), C.byref(n_linked), C.byref(out)))
     return DeviceCSR(out), frag_index[:n_frag], n_linked.value
+
+
+def rank_sums(m, topN):
+    """filter_fragments' rank-sum statistic of every row of the (self-loop free) link matrix"""
+    out = np.zeros(max(m.shape3[0], 1), np.int64)
+    check(load().hhx_rank_sums(m.h, int(topN), ptr(out)))
+    return out[:m.shape3[0]]
 
 
 def count_re_sites(seq, seg_off, seg_len, sites):

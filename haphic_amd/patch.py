@@ -19,6 +19,7 @@ SEAMS = {
     'count_RE_sites': ('HapHiC_cluster.py:75-84', cluster.count_RE_sites),              # a5
     'parse_fasta': ('HapHiC_cluster.py:87-113', cluster.parse_fasta),                   # a5
     'stat_fragments': ('HapHiC_cluster.py:188-296', cluster.stat_fragments),            # a5
+    'filter_fragments': ('HapHiC_cluster.py:741-940', cluster.filter_fragments),        # f1 (rank sums on the device)
 }
 # S4/S5 are opt-in: dict_to_matrix is also called in dense mode by the filters (:603 :868), and the
 # device ingest does not produce the CLM distance lists / coordinate records yet.

@@ -144,6 +144,13 @@ int hhx_count_re_sites(const uint8_t *seq_host, int64_t seq_len, int64_t n_seg, 
                        const int64_t *seg_len, int32_t n_sites, const uint8_t *sites, const int32_t *site_len,
                        int64_t *counts_host);
 
+/* ---------------------------------------------------------------- f1: filter_fragments rank sums :866-892
+ * m: the link matrix WITHOUT self loops (dict_to_matrix(flank_link_dict, filtered_frags) :868).  The reference
+ * ranks the fragments of every dense row by links descending (stable: ties and link-less fragments by index),
+ * takes the topN of fragment f and sums min(rank_a(b), rank_b(a)) over the unordered pairs of that top list.
+ * rank_sum_host[n]: the statistic for every row, computed on the sparse rows (no dense matrix, no sort). */
+int hhx_rank_sums(const hhx_csr *m, int topN, int64_t *rank_sum_host);
+
 /* ---------------------------------------------------------------- S5: ingest
  * parse_alignments_for_ctgs :1596-1655 (bins = 0) and parse_alignments :1658-1752 (bins = 1) on
  * integer ids.  The Python shim maps names to ids once (haphic_amd/cluster.py: FragTable):

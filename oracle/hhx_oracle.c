@@ -600,3 +600,39 @@ void orc_count_re_sites(const unsigned char *seq, i64 n_seg, const i64 *seg_off,
         counts[s] = total;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * filter_fragments(), rank-sum statistic :866-892, on CSR rows of the symmetric link matrix without
+ * self loops.  The reference sorts every DENSE row by links descending (stable: ties by index, :874-878),
+ * takes the first topN fragments and sums min(rank_a(b), rank_b(a)) over combinations(top, 2) (:884-887).
+ * Restated literally with a dense scratch row (n small in tests).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float v; i32 i; } rk_t;
+static int cmp_rk(const void *a, const void *b) {
+    const rk_t *x = (const rk_t *)a, *y = (const rk_t *)b;
+    if (x->v != y->v) return x->v > y->v ? -1 : 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+void orc_rank_sums(i32 n, const i32 *indptr, const i32 *indices, const float *data, int topN, i64 *out) {
+    i32 *rank = (i32 *)malloc(sizeof(i32) * (size_t)n * (size_t)n);    /* rank[a*n + x] = position of x in the ranking of a */
+    i32 *order = (i32 *)malloc(sizeof(i32) * (size_t)n * (size_t)n);
+    rk_t *row = (rk_t *)malloc(sizeof(rk_t) * (size_t)n);
+    for (i32 a = 0; a < n; ++a) {
+        for (i32 i = 0; i < n; ++i) { row[i].v = 0.0f; row[i].i = i; }
+        for (i32 p = indptr[a]; p < indptr[a + 1]; ++p) row[indices[p]].v = data[p];
+        qsort(row, (size_t)n, sizeof(rk_t), cmp_rk);
+        for (i32 r = 0; r < n; ++r) { order[(size_t)a * n + r] = row[r].i; rank[(size_t)a * n + row[r].i] = r; }
+    }
+    for (i32 f = 0; f < n; ++f) {
+        const int t = topN < n ? topN : n;
+        i64 s = 0;
+        for (int i = 0; i < t; ++i)
+            for (int j = i + 1; j < t; ++j) {
+                const i32 a = order[(size_t)f * n + i], b = order[(size_t)f * n + j];
+                const i32 r1 = rank[(size_t)a * n + b], r2 = rank[(size_t)b * n + a];
+                s += r1 < r2 ? r1 : r2;
+            }
+        out[f] = s;
+    }
+    free(rank); free(order); free(row);
+}

@@ -67,6 +67,8 @@ def lib():
         L.orc_dict_to_matrix.argtypes = [C.c_int64, _i32p, _i32p, _f64p, C.c_int32, _u8p, C.c_int32, C.c_int,
                                          _i32p, C.POINTER(C.c_int32), _i32p, C.c_void_p, C.c_void_p]
         L.orc_dict_to_matrix.restype = C.c_int64
+        L.orc_rank_sums.argtypes = [C.c_int32, _i32p, _i32p, _f32p, C.c_int, _i64p]
+        L.orc_rank_sums.restype = None
         L.orc_count_re_sites.argtypes = [_u8p, C.c_int64, _i64p, _i64p, C.c_int32, _u8p, _i32p, _i64p]
         L.orc_count_re_sites.restype = None
         _lib = L
@@ -241,3 +243,12 @@ def count_re_sites(seq, seg_off, seg_len, sites):
     lib().orc_count_re_sites(buf, off.size, off if off.size else np.zeros(1, np.int64), ln if ln.size else np.zeros(1, np.int64),
                              len(sites), pats, plen, out)
     return out[:off.size]
+
+
+def rank_sums(A, topN):
+    """filter_fragments rank-sum statistic :866-892 for every row of the (self-loop free) link matrix"""
+    ap, aj, ax = _csr(*A)
+    n = len(ap) - 1
+    out = np.zeros(max(n, 1), np.int64)
+    lib().orc_rank_sums(n, ap, aj if aj.size else np.zeros(1, np.int32), ax if ax.size else np.zeros(1, np.float32), int(topN), out)
+    return out[:n]

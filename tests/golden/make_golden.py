@@ -419,6 +419,45 @@ def gen_resites(path):
     np.savez_compressed(path, **out)
 
 
+def gen_filter(path):
+    """filter_fragments (:741-940) on a 230-contig assembly with some link-poor / promiscuous contigs"""
+    g = synth.make_genome(4, 1_600_000, 28_000, cv=0.4, min_len=4000, seed=41)
+    names = list(g.names)
+    rng = np.random.default_rng(42)
+    fa_dict = {n_: [None, int(l), int(r)] for n_, l, r in zip(names, g.length, g.re_sites)}
+    id1, p1, id2, p2 = [t.numpy() for t in synth.sample_pairs(g, 90_000, seed=43, cis=0.75)]
+    keep = id1 != id2
+    id1, p1, id2, p2 = id1[keep], p1[keep], id2[keep], p2[keep]
+    aln = ((names[a], names[b], int(x), int(y)) for a, x, b, y in zip(id1, p1, id2, p2))
+    args = Args()
+    args.flank = 500
+    args.remove_allelic_links = 0
+    args.remove_concentrated_links = False
+    args.max_read_pairs = 200
+    args.nwindows = 50
+    frag_len_dict = {n_: fa_dict[n_][1] for n_ in names}
+    Nx_set = set(names[:-7])                                   # a few contigs outside the Nx set
+    full, flank, HT, clm, frag_link, coord = H.parse_alignments_for_ctgs(aln, fa_dict, args, frag_len_dict, Nx_set, 'int32', 'int32')
+    RE_site_dict = {n_: fa_dict[n_][2] for n_ in names}
+    cid = {n_: i for i, n_ in enumerate(names)}
+    out = dict(names=np.array(names), nx=np.array([n_ in Nx_set for n_ in names], np.uint8),
+               re_sites=np.array([RE_site_dict[n_] for n_ in names], np.int64),
+               frag_links=np.array([frag_link.get(n_, -1) for n_ in names], np.int64),
+               flank_i=np.array([cid[k[0]] for k in flank], np.int32), flank_j=np.array([cid[k[1]] for k in flank], np.int32),
+               flank_cnt=np.array(list(flank.values()), np.int64))
+    cases = [(5, '0.2X', '1.9X', 10, '1.5X', 0, None), (3, '0.1X', '3X', 5, '0.5X', 0, {names[3], names[40]}),
+             (5, '0.2X', '1.9X', 10, '3X', 600, None), (0, '0X', '100X', 10, '100X', 0, None)]
+    H.logger.setLevel('WARNING')
+    for k, (cut, lo, up, topn, rsu, hard, wl) in enumerate(cases):
+        res = H.filter_fragments(set(Nx_set), RE_site_dict, cut, frag_link, lo, up, topn, rsu, hard, flank, {}, '1.5X', wl)
+        out['case%d_params' % k] = np.array([str(cut), lo, up, str(topn), rsu, str(hard)])
+        out['case%d_whitelist' % k] = np.array(sorted(wl) if wl else [], dtype=str)
+        out['case%d_kept' % k] = np.array(sorted(res))
+        print('filter case', k, 'kept', len(res), 'of', len(Nx_set))
+    out['n_cases'] = np.int32(len(cases))
+    np.savez_compressed(path, **out)
+
+
 if __name__ == '__main__':
     assert os.environ.get('PYTHONHASHSEED') == '0', 'run with PYTHONHASHSEED=0'
     gen_mcl(os.path.join(HERE, 'mcl_cases.npz'))
@@ -427,3 +466,4 @@ if __name__ == '__main__':
     gen_pipeline_bins(os.path.join(HERE, 'pipeline_bins.npz'))
     gen_pipeline_c1(os.path.join(HERE, 'pipeline_c1.npz'))
     gen_resites(os.path.join(HERE, 'resites.npz'))
+    gen_filter(os.path.join(HERE, 'filter.npz'))

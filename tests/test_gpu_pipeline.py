@@ -255,3 +255,35 @@ def test_re_sites_and_stat_fragments():
     assert sorted(r[4]) == [str(x) for x in g['sf_nx']]
     assert list(r[5]) == [str(x) for x in g['sf_re_frags']] and list(r[5].values()) == g['sf_re_counts'].tolist()
     assert all(v[0] is None for v in fa.values())
+
+
+def test_filter_fragments_and_rank_sums():
+    """f1: filter_fragments (:741-940) with the rank-sum statistic on the device, against the reference's kept sets;
+    hhx_rank_sums against the oracle on rows with fewer links than topN, ties, and n < topN"""
+    from haphic_amd import _lib, cluster
+    from oracle import oracle as orc
+    from tests.conftest import load_golden
+    from tests.test_oracle_golden import _filter_inputs
+    g = load_golden('filter.npz')
+    names, Nx_set, RE_site_dict, frag_link, flank = _filter_inputs(g)
+    cluster.logger.setLevel('WARNING')
+    for k in range(int(g['n_cases'])):
+        cut, lo, up, topn, rsu, hard = [str(x) for x in g['case%d_params' % k]]
+        wl = {str(x) for x in g['case%d_whitelist' % k]} or None
+        kept = cluster.filter_fragments(set(Nx_set), RE_site_dict, int(cut), frag_link, lo, up, int(topn), rsu, int(hard), flank, {}, '1.5X', wl)
+        assert sorted(kept) == [str(x) for x in g['case%d_kept' % k]], k
+    rng = np.random.default_rng(3)
+    for n, deg, topn in ((300, 4, 10), (500, 40, 10), (7, 2, 10), (64, 1, 3), (200, 0, 5)):
+        iu = rng.integers(0, n, n * deg)
+        ju = rng.integers(0, n, n * deg)
+        ok = iu != ju
+        key = np.unique(np.minimum(iu, ju)[ok] * n + np.maximum(iu, ju)[ok])
+        a, b = key // n, key % n
+        v = rng.integers(1, 4, key.size).astype(np.float32)            # few distinct values: many ties
+        rows = np.concatenate([a, b]); cols = np.concatenate([b, a]); vals = np.concatenate([v, v])
+        order = np.lexsort((cols, rows))
+        indptr = np.zeros(n + 1, np.int32)
+        np.add.at(indptr, rows + 1, 1)
+        A = (np.cumsum(indptr).astype(np.int32), cols[order].astype(np.int32), vals[order])
+        m = _lib.DeviceCSR.from_arrays(*A)
+        assert np.array_equal(_lib.rank_sums(m, topn), orc.rank_sums(A, topn)), (n, deg, topn)

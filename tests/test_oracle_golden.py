@@ -124,3 +124,58 @@ def test_count_re_sites(request):
         sites = [str(x).encode() for x in g['sites_' + RE]]
         got = orc.count_re_sites(g['seq'], g['seg_off'], g['seg_len'], sites)
         assert np.array_equal(got, g['counts_' + RE]), RE
+
+
+def _filter_inputs(g):
+    names = [str(x) for x in g['names']]
+    Nx_set = {n for n, x in zip(names, g['nx']) if x}
+    RE_site_dict = {n: int(r) for n, r in zip(names, g['re_sites'])}
+    frag_link = {n: int(c) for n, c in zip(names, g['frag_links']) if c >= 0}
+    flank = {(names[i], names[j]): int(c) for i, j, c in zip(g['flank_i'], g['flank_j'], g['flank_cnt'])}
+    return names, Nx_set, RE_site_dict, frag_link, flank
+
+
+def test_rank_sums_pin_filter_fragments(monkeypatch):
+    """the oracle's rank-sum statistic, pinned through the reference's filter_fragments outputs: the host mirror
+    (haphic_amd/cluster.py:filter_fragments) is run with the oracle standing in for the two device calls"""
+    from haphic_amd import cluster, _lib
+    from tests.conftest import load_golden
+    g = load_golden('filter.npz')
+    names, Nx_set, RE_site_dict, frag_link, flank = _filter_inputs(g)
+
+    class HostMatrix:
+        def __init__(self, tri):
+            self.tri = tri
+
+        def free(self):
+            pass
+
+    def d2m(link_dict, frag_set, dense_matrix=True, add_self_loops=False, _device=False):
+        ids = {}
+        fi, fj, fv = [], [], []
+        for (a, b), v in link_dict.items():
+            fi.append(ids.setdefault(a, len(ids))); fj.append(ids.setdefault(b, len(ids))); fv.append(v)
+        for f in frag_set:
+            ids.setdefault(f, len(ids))
+        id_names = list(ids)
+        in_set = np.array([f in frag_set for f in id_names], np.uint8)
+        fi, fj = np.array(fi, np.int32), np.array(fj, np.int32)
+        ok = in_set[fi].astype(bool) & in_set[fj].astype(bool)
+        linked = np.zeros(len(id_names), bool)
+        linked[fi[ok]] = True
+        linked[fj[ok]] = True
+        rest = [f for f in frag_set if not linked[ids[f]]]
+        p, j, x, fidx, nl = orc.dict_to_matrix(fi, fj, np.array(fv, np.float64), len(id_names), in_set, len(rest), add_self_loops)
+        frag_index = {id_names[i]: int(fidx[i]) for i in np.flatnonzero(linked)}
+        for k, f in enumerate(rest):
+            frag_index[f] = nl + k
+        return HostMatrix((p, j, x)), frag_index
+
+    monkeypatch.setattr(cluster, 'dict_to_matrix', d2m)
+    monkeypatch.setattr(_lib, 'rank_sums', lambda m, topN: orc.rank_sums(m.tri, topN))
+    cluster.logger.setLevel('WARNING')
+    for k in range(int(g['n_cases'])):
+        cut, lo, up, topn, rsu, hard = [str(x) for x in g['case%d_params' % k]]
+        wl = {str(x) for x in g['case%d_whitelist' % k]} or None
+        kept = cluster.filter_fragments(set(Nx_set), RE_site_dict, int(cut), frag_link, lo, up, int(topn), rsu, int(hard), flank, {}, '1.5X', wl)
+        assert sorted(kept) == [str(x) for x in g['case%d_kept' % k]], k
