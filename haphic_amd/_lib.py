@@ -75,6 +75,8 @@ SIGNATURES = {
     'hhx_ingest_flank_device': (C.c_int, [C.c_void_p, c_vpp, c_vpp, c_vpp]),
     'hhx_ingest_flank_count_device': (C.c_int, [C.c_void_p, c_vpp]),
     'hhx_ingest_destroy': (C.c_int, [C.c_void_p]),
+    'hhx_ingest_keep_pairs': (C.c_int, [C.c_void_p, C.c_int]),
+    'hhx_ingest_fetch_pairs': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'hhx_ingest_set_ordinal_base': (C.c_int, [C.c_void_p, C.c_int64]),
     'hhx_ingest_link_matrix': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, c_i32p, c_vpp]),
     'hhx_ingest_table_device': (C.c_int, [C.c_void_p, C.c_int, c_i64p, c_vpp, c_vpp, c_vpp, c_vpp, c_vpp]),
@@ -396,6 +398,22 @@ class Ingest:
         c = C.c_void_p()
         check(load().hhx_ingest_flank_count_device(self.h, C.byref(c)))
         return c.value or 0
+
+    def keep_pairs(self, on=True):
+        """also keep the oriented coordinates of every counted pair (CLM / coordinate side products)"""
+        check(load().hhx_ingest_keep_pairs(self.h, int(on)))
+
+    def fetch_pairs(self, max_read_pairs, full_cnt):
+        """(clm_ptr, clm, crd_ptr, crd) in dict insertion order; clm_ptr counts READ PAIRS (x 4 values each)"""
+        nf = len(full_cnt)
+        total = int(np.sum(full_cnt))
+        capped = int(np.minimum(full_cnt, max_read_pairs).sum()) if max_read_pairs > 0 else 0
+        clm_ptr = np.zeros(nf + 1, np.int64)
+        crd_ptr = np.zeros(nf + 1, np.int64)
+        clm = np.zeros(max(4 * total, 1), np.int64)
+        crd = np.zeros(max(2 * capped, 1), np.int64)
+        check(load().hhx_ingest_fetch_pairs(self.h, int(max_read_pairs), ptr(clm_ptr), ptr(clm), ptr(crd_ptr), ptr(crd)))
+        return clm_ptr, clm[:4 * total], crd_ptr, crd[:2 * capped]
 
     def set_ordinal_base(self, base):
         """global stream ordinal of this handle's first pair (multi-GPU chunk offset); before the first push"""

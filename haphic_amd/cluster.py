@@ -543,22 +543,50 @@ def _ids_from_alignments(alignments, cid, chunk):
         yield b1[:k], p1[:k], b2[:k], p2[:k], k
 
 
-def ingest_links(alignments, table, flank, bins, chunk=1 << 22, expected_keys=0):
+def ingest_links(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False, max_read_pairs=0):
     """Feed an alignment iterator (name tuples, as the reference's generators :1539-1593 yield them)
-    through the device ingest; returns the insertion-ordered tables as numpy arrays."""
+    through the device ingest; returns the insertion-ordered tables as numpy arrays (+ the CLM distances and
+    the first coordinates of every contig pair when want_pairs)."""
     cid = {n: i for i, n in enumerate(table.ctg_names)}
-    ing = _lib.Ingest(table, flank, bins=bins, skip_intra=False, expected_keys=expected_keys)
+    ing = _lib.Ingest(table, flank, bins=bins, skip_intra=False)
     try:
+        if want_pairs:
+            ing.keep_pairs()
         for b1, p1, b2, p2, k in _ids_from_alignments(alignments, cid, chunk):
-            if not bins:
-                # ref == mref never reaches parse_alignments_for_ctgs from run() (:2862-2865) but the
-                # function itself accepts it; negative ids (unknown names) are filtered on the device
-                pass
-            ing.push(b1, p1, b2, p2)
+            ing.push(b1, p1, b2, p2)         # unknown names (-1) and intra-contig pairs are filtered on the device
         ing.finalize()
-        return ing.fetch()
+        out = ing.fetch()
+        if want_pairs:
+            out['clm_ptr'], out['clm'], out['crd_ptr'], out['crd'] = ing.fetch_pairs(max_read_pairs, out['full_cnt'])
+        return out
     finally:
         ing.destroy()
+
+
+def cal_concordance_ratio(coord_list, shorter_len, nwindows):
+    """cal_concordance_ratio() :419-428 (host statistics on <= max_read_pairs coordinates, stays Python)"""
+    from scipy.stats import mode
+    bin_width = shorter_len // nwindows
+    npairs = len(coord_list) // 2
+    y_minus_x_list = [(coord_list[2 * n + 1] - coord_list[2 * n]) // bin_width for n in range(npairs)]
+    y_plus_x_list = [(coord_list[2 * n + 1] + coord_list[2 * n]) // bin_width for n in range(npairs)]
+    return max(mode(y_minus_x_list, keepdims=False)[1] / npairs, mode(y_plus_x_list, keepdims=False)[1] / npairs)
+
+
+def cal_concentration_adj_ratio(coord_list, bin_width=10000):
+    """cal_concentration_adj_ratio() :431-451"""
+    from numpy import median
+    npairs = len(coord_list) // 2
+    x_bin_dict, y_bin_dict = defaultdict(int), defaultdict(int)
+    for n in range(npairs):
+        x_bin_dict[coord_list[2 * n] // bin_width] += 1
+        y_bin_dict[coord_list[2 * n + 1] // bin_width] += 1
+    x_bin_list, y_bin_list = x_bin_dict.values(), y_bin_dict.values()
+    x_bin_median = median([links for links in x_bin_list if links])
+    y_bin_median = median([links for links in y_bin_list if links])
+    concentration_ratio_x = sum([links for links in x_bin_list if links >= 10 * x_bin_median]) / npairs
+    concentration_ratio_y = sum([links for links in y_bin_list if links >= 10 * y_bin_median]) / npairs
+    return (1 - concentration_ratio_x) * (1 - concentration_ratio_y)
 
 
 def _link_dicts(out, table):
@@ -581,25 +609,68 @@ def _link_dicts(out, table):
     return full, flank, HT, frag_link
 
 
+def _pair_dicts(out, table, fa_dict, args, pos_int_type, dist_int_type):
+    """clm_dict (update_clm_dict :395-401) and ctg_coord_dict (record_coord_pairs :454-471) from the device lists"""
+    from array import array
+    cn = table.ctg_names
+    dist_code, dist_np = ('i', np.int32) if dist_int_type == 'int32' else ('l', np.int64)
+    pos_code, pos_np = ('i', np.int32) if pos_int_type == 'int32' else ('l', np.int64)
+    clm_dict = defaultdict(lambda: array(dist_code))
+    ctg_coord_dict = defaultdict(lambda: array(pos_code))
+    record = bool(args.remove_allelic_links or args.remove_concentrated_links)
+    clm = out['clm'].astype(dist_np)
+    crd = out['crd'].astype(pos_np)
+    cp, kp = out['clm_ptr'].tolist(), out['crd_ptr'].tolist()
+    for k, (i, j) in enumerate(zip(out['full_i'].tolist(), out['full_j'].tolist())):
+        pair = (cn[i], cn[j])
+        a = array(dist_code)
+        a.frombytes(clm[4 * cp[k]:4 * cp[k + 1]].tobytes())
+        clm_dict[pair] = a
+        if record:
+            c = array(pos_code)
+            c.frombytes(crd[2 * kp[k]:2 * kp[k + 1]].tobytes())
+            ctg_coord_dict[pair] = c
+            if len(c) >= args.max_read_pairs * 2:                                     # :460-471
+                if args.remove_allelic_links:
+                    shorter_len = min(fa_dict[pair[0]][1], fa_dict[pair[1]][1])
+                    ctg_coord_dict[pair] = [cal_concordance_ratio(c, shorter_len, args.nwindows), 1]
+                if args.remove_concentrated_links:
+                    adj_ratio = cal_concentration_adj_ratio(c)
+                    if args.remove_allelic_links:
+                        ctg_coord_dict[pair][1] = adj_ratio
+                    else:
+                        ctg_coord_dict[pair] = [0, adj_ratio]
+    return clm_dict, ctg_coord_dict
+
+
 def parse_alignments_for_ctgs(alignments, fa_dict, args, ctg_len_dict, Nx_ctg_set, pos_int_type, dist_int_type):
-    """parse_alignments_for_ctgs() :1596-1655 — link tables from the device.  The CLM distance lists and
-    the per-pair coordinate records (:1643, :1652) are SURVEY §8f "next" rows: they are returned empty
-    here and the caller keeps the reference's own Python loop when it needs them."""
+    """parse_alignments_for_ctgs() :1596-1655 — all six containers from the device: link tables, HT counts, the
+    CLM distance lists and the first coordinates of every contig pair."""
     logger.info('Parsing input alignments...')
     table = FragTable.from_reference(fa_dict, ctg_len_dict, Nx_ctg_set)
-    out = ingest_links(alignments, table, int(args.flank * 1000), bins=False)
+    record = bool(args.remove_allelic_links or args.remove_concentrated_links)
+    out = ingest_links(alignments, table, int(args.flank * 1000), bins=False, want_pairs=True,
+                       max_read_pairs=int(args.max_read_pairs) if record else 0)
     full, flank, HT, frag_link = _link_dicts(out, table)
-    return full, flank, HT, defaultdict(list), frag_link, defaultdict(list)
+    clm_dict, ctg_coord_dict = _pair_dicts(out, table, fa_dict, args, pos_int_type, dist_int_type)
+    return full, flank, HT, clm_dict, frag_link, ctg_coord_dict
 
 
 def parse_alignments(alignments, fa_dict, args, bin_size, frag_len_dict, Nx_frag_set, split_ctg_set, pos_int_type,
                      dist_int_type):
-    """parse_alignments() :1658-1752 (some contigs split into bins); see parse_alignments_for_ctgs."""
+    """parse_alignments() :1658-1752 (some contigs split into bins).  ctg_pair_to_frag (:1731-1732, only used with
+    --remove_allelic_links on split contigs) is returned empty."""
+    if args.remove_allelic_links:
+        raise NotImplementedError('parse_alignments on split contigs with --remove_allelic_links needs ctg_pair_to_frag '
+                                  '(:1731-1732), which the device ingest does not produce: keep the reference function')
     logger.info('Parsing input alignments...')
     table = FragTable.from_reference(fa_dict, frag_len_dict, Nx_frag_set, split_ctg_set, bin_size)
-    out = ingest_links(alignments, table, int(args.flank * 1000), bins=True)
+    record = bool(args.remove_allelic_links or args.remove_concentrated_links)
+    out = ingest_links(alignments, table, int(args.flank * 1000), bins=True, want_pairs=True,
+                       max_read_pairs=int(args.max_read_pairs) if record else 0)
     full, flank, HT, frag_link = _link_dicts(out, table)
-    return full, flank, HT, defaultdict(list), frag_link, defaultdict(list), defaultdict(set)
+    clm_dict, ctg_coord_dict = _pair_dicts(out, table, fa_dict, args, pos_int_type, dist_int_type)
+    return full, flank, HT, clm_dict, frag_link, ctg_coord_dict, defaultdict(set)
 
 
 # ------------------------------------------------------------------ S6: run_mcl_clustering

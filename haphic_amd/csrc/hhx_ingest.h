@@ -51,6 +51,63 @@ struct DevTables {           // device-resident, built from hhx_ingest_config
     i32 bins, skip_intra;
 };
 
+#ifdef __HIPCC__
+// ---- map: one read pair -> at most one record of stream `stream` (shared by the group-by and the side records)
+__device__ __forceinline__ bool is_flank(i64 coord, i64 length, i64 flank) {   // :299-307
+    return flank == 0 || coord <= flank || coord > length - flank;
+}
+
+// stream 0: the contig-pair table (full_link_dict + HT_link_dict; also flank_link_dict when no contig is
+//           split, because fragment == contig then);  stream 1 (bins only): the fragment-pair flank table.
+// COMBINED (no split contigs, parse_alignments_for_ctgs :1596-1655) is a compile-time variant: two
+// 16-byte gathers and no divisions per pair.
+template <bool COMBINED>
+__device__ __forceinline__ bool map_pair(const DevTables &t, int stream, i32 r, i32 m, i32 p1, i32 p2, u64 &rec, u64 *xy = nullptr) {
+    if (t.skip_intra && r == m) return false;                                    // pairs_generator_inter_ctgs :1582
+    if ((u32)r >= (u32)t.n_ctg || (u32)m >= (u32)t.n_ctg) return false;         // :1625 / :1702 (name not in fa_dict)
+    UnitInfo a = t.ctg[r], b = t.ctg[m];
+    if (!COMBINED && t.bins && r == m && !(a.lenf & SPLIT_BIT)) return false;    // :1699
+    i32 ci = r, cj = m;
+    i64 xi = (i64)p1 + 1, xj = (i64)p2 + 1;                                      // 1-based, :1629
+    if (a.rank > b.rank || (r == m && xi > xj)) {
+        ci = m; cj = r;
+        const i64 tx = xi; xi = xj; xj = tx;
+        const UnitInfo tu = a; a = b; b = tu;
+    }
+    const i64 li = a.lenf & LEN_MASK, lj = b.lenf & LEN_MASK;
+    if (xy) *xy = ((u64)(u32)xi << 32) | (u64)(u32)xj;                           // oriented 1-based contig coordinates
+    const u64 ht = (u64)((xi * 2 > li) * 2 + (xj * 2 > lj));                     // :404-416
+    if (COMBINED) {
+        const bool flank_ok = (a.lenf & b.lenf & NX_BIT) && is_flank(xi, li, t.flank) && is_flank(xj, lj, t.flank);   // :1636
+        rec = ((u64)(u32)ci << ID_BITS) | (u64)(u32)cj | (ht << HT_SHIFT) | FULL_BIT | (flank_ok ? FLANK_BIT : 0);
+        return true;
+    }
+    i32 fi = a.aux, fj = b.aux;
+    i64 yi = xi, yj = xj;
+    if (t.bins) {                                                                // convert_frags :1662-1670
+        if (a.lenf & SPLIT_BIT) { const i64 nb = (xi + t.bin_size - 1) / t.bin_size; fi += (i32)(nb - 1); yi = xi - (nb - 1) * t.bin_size; }
+        if (b.lenf & SPLIT_BIT) { const i64 nb = (xj + t.bin_size - 1) / t.bin_size; fj += (i32)(nb - 1); yj = xj - (nb - 1) * t.bin_size; }
+        if (fi == fj) return false;                                              // :1715
+    }
+    if (stream == 0) {
+        if (t.bins && r == m) return false;                                      // :1736
+        rec = ((u64)(u32)ci << ID_BITS) | (u64)(u32)cj | (ht << HT_SHIFT) | FULL_BIT;
+        return true;
+    }
+    UnitInfo fa = t.frag[fi], fb = t.frag[fj];
+    if (t.bins && fa.rank > fb.rank) {                                           // :1719-1720
+        const i32 tf = fi; fi = fj; fj = tf;
+        const i64 ty = yi; yi = yj; yj = ty;
+        const UnitInfo tu = fa; fa = fb; fb = tu;
+    }
+    if (!((fa.lenf & fb.lenf & NX_BIT) && is_flank(yi, fa.lenf & LEN_MASK, t.flank) && is_flank(yj, fb.lenf & LEN_MASK, t.flank)))
+        return false;                                                            // :1726
+    rec = ((u64)(u32)fi << ID_BITS) | (u64)(u32)fj | FLANK_BIT;
+    return true;
+}
+
+#endif
+
 // Insertion-ordered views (Python dict order), materialised on demand from a run.
 struct OrderedTables {
     bool ready = false;
@@ -74,6 +131,11 @@ struct hhx_ingest {
     bool finalized = false;
     i64 n_full = 0, n_flank = 0;
     hhx::OrderedTables ordered;
+    // optional side product (hhx_ingest_keep_pairs): the oriented 1-based coordinates of every read pair counted in
+    // full_link_dict, in stream order — what update_clm_dict :395-401 and record_coord_pairs :454-471 consume
+    bool keep_pairs = false;
+    std::vector<hhx::DevBuf<u64>> side_key, side_xy;     // one pair of arrays per push: key, (xi << 32 | xj)
+    i64 n_side = 0;
     hhx::DevBuf<i32> stage[4];             // staging for host-side inputs
     ~hhx_ingest() {
         for (auto &v : runs)
@@ -84,6 +146,9 @@ struct hhx_ingest {
         return v.empty() ? nullptr : v[0];
     }
 };
+
+// hhx_pairs.hip: stable compaction of the side records of one push; CLM / coordinate lists from them
+int hhx_side_records_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const i32 *pos1, const i32 *id2, const i32 *pos2);
 
 // hhx_matrix.hip: dict_to_matrix on a run (flank rows, first-seen order taken from ord_flank)
 int hhx_link_matrix_from_run(const hhx::LinkRun *run, i32 n_frag, u64 ord_limit, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,

@@ -37,59 +37,6 @@ __device__ __forceinline__ u32 bucket_of(u64 key, int total_bits) {
     return total_bits ? (u32)(mix64(key) >> (64 - total_bits)) : 0u;
 }
 
-__device__ __forceinline__ bool is_flank(i64 coord, i64 length, i64 flank) {   // :299-307
-    return flank == 0 || coord <= flank || coord > length - flank;
-}
-
-// ---- map: one read pair -> at most one record of stream `stream` ------------------------------------
-// stream 0: the contig-pair table (full_link_dict + HT_link_dict; also flank_link_dict when no contig is
-//           split, because fragment == contig then);  stream 1 (bins only): the fragment-pair flank table.
-// COMBINED (no split contigs, parse_alignments_for_ctgs :1596-1655) is a compile-time variant: two
-// 16-byte gathers and no divisions per pair.
-template <bool COMBINED>
-__device__ __forceinline__ bool map_pair(const DevTables &t, int stream, i32 r, i32 m, i32 p1, i32 p2, u64 &rec) {
-    if (t.skip_intra && r == m) return false;                                    // pairs_generator_inter_ctgs :1582
-    if ((u32)r >= (u32)t.n_ctg || (u32)m >= (u32)t.n_ctg) return false;         // :1625 / :1702 (name not in fa_dict)
-    UnitInfo a = t.ctg[r], b = t.ctg[m];
-    if (!COMBINED && t.bins && r == m && !(a.lenf & SPLIT_BIT)) return false;    // :1699
-    i32 ci = r, cj = m;
-    i64 xi = (i64)p1 + 1, xj = (i64)p2 + 1;                                      // 1-based, :1629
-    if (a.rank > b.rank || (r == m && xi > xj)) {
-        ci = m; cj = r;
-        const i64 tx = xi; xi = xj; xj = tx;
-        const UnitInfo tu = a; a = b; b = tu;
-    }
-    const i64 li = a.lenf & LEN_MASK, lj = b.lenf & LEN_MASK;
-    const u64 ht = (u64)((xi * 2 > li) * 2 + (xj * 2 > lj));                     // :404-416
-    if (COMBINED) {
-        const bool flank_ok = (a.lenf & b.lenf & NX_BIT) && is_flank(xi, li, t.flank) && is_flank(xj, lj, t.flank);   // :1636
-        rec = ((u64)(u32)ci << ID_BITS) | (u64)(u32)cj | (ht << HT_SHIFT) | FULL_BIT | (flank_ok ? FLANK_BIT : 0);
-        return true;
-    }
-    i32 fi = a.aux, fj = b.aux;
-    i64 yi = xi, yj = xj;
-    if (t.bins) {                                                                // convert_frags :1662-1670
-        if (a.lenf & SPLIT_BIT) { const i64 nb = (xi + t.bin_size - 1) / t.bin_size; fi += (i32)(nb - 1); yi = xi - (nb - 1) * t.bin_size; }
-        if (b.lenf & SPLIT_BIT) { const i64 nb = (xj + t.bin_size - 1) / t.bin_size; fj += (i32)(nb - 1); yj = xj - (nb - 1) * t.bin_size; }
-        if (fi == fj) return false;                                              // :1715
-    }
-    if (stream == 0) {
-        if (t.bins && r == m) return false;                                      // :1736
-        rec = ((u64)(u32)ci << ID_BITS) | (u64)(u32)cj | (ht << HT_SHIFT) | FULL_BIT;
-        return true;
-    }
-    UnitInfo fa = t.frag[fi], fb = t.frag[fj];
-    if (t.bins && fa.rank > fb.rank) {                                           // :1719-1720
-        const i32 tf = fi; fi = fj; fj = tf;
-        const i64 ty = yi; yi = yj; yj = ty;
-        const UnitInfo tu = fa; fa = fb; fb = tu;
-    }
-    if (!((fa.lenf & fb.lenf & NX_BIT) && is_flank(yi, fa.lenf & LEN_MASK, t.flank) && is_flank(yj, fb.lenf & LEN_MASK, t.flank)))
-        return false;                                                            // :1726
-    rec = ((u64)(u32)fi << ID_BITS) | (u64)(u32)fj | FLANK_BIT;
-    return true;
-}
-
 // ---- record sources (hhx_partition.h: get(idx, w0, w1)) --------------------------------------------------
 template <bool COMBINED>
 struct SrcPairs {
@@ -560,6 +507,13 @@ extern "C" int hhx_ingest_set_ordinal_base(hhx_ingest *h, int64_t base) {
     return 0;
 }
 
+extern "C" int hhx_ingest_keep_pairs(hhx_ingest *h, int on) {
+    if (!h) return fail("null handle");
+    if (h->n_pushed) return fail("hhx_ingest_keep_pairs: call before the first push");
+    h->keep_pairs = on != 0;
+    return 0;
+}
+
 extern "C" int hhx_ingest_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const i32 *pos1, const i32 *id2, const i32 *pos2,
                                int on_device) {
     if (!h) return fail("null handle");
@@ -588,6 +542,7 @@ extern "C" int hhx_ingest_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const
             h->runs[stream].push_back(run);
         }
     } }
+    if (h->keep_pairs) HHX_TRY(hhx_side_records_push(h, n_pairs, src[0], src[1], src[2], src[3]));
     h->n_pushed += (u64)n_pairs;
     h->ord_limit = std::max<u64>(h->ord_limit, h->ord_base + h->n_pushed);
     return 0;
@@ -659,6 +614,13 @@ extern "C" int hhx_ingest_fetch(hhx_ingest *h, i32 *full_i, i32 *full_j, i64 *fu
     if (flank_cnt && nk) HHX_HIP(hipMemcpyAsync(flank_cnt, o.flank_cnt.p, 8 * nk, hipMemcpyDeviceToHost, g_stream));
     if (frag_links) HHX_HIP(hipMemcpyAsync(frag_links, o.frag_links.p, 8 * (size_t)h->t.n_frag, hipMemcpyDeviceToHost, g_stream));
     HHX_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+int hhx_ingest_ordered_full_device(hhx_ingest *h, const i32 **fi, const i32 **fj) {
+    HHX_TRY(materialize(h));
+    *fi = h->ordered.full_i.p;
+    *fj = h->ordered.full_j.p;
     return 0;
 }
 

@@ -21,8 +21,9 @@ SEAMS = {
     'stat_fragments': ('HapHiC_cluster.py:188-296', cluster.stat_fragments),            # a5
     'filter_fragments': ('HapHiC_cluster.py:741-940', cluster.filter_fragments),        # f1 (rank sums on the device)
 }
-# S4/S5 are opt-in: dict_to_matrix is also called in dense mode by the filters (:603 :868), and the
-# device ingest does not produce the CLM distance lists / coordinate records yet.
+# S4/S5: dict_to_matrix is also called in dense mode by the filters (:603) — the mirror returns `.toarray()` then;
+# the device ingest returns all of the reference's containers (link tables, HT counts, CLM distance lists, first
+# coordinates) except ctg_pair_to_frag (:1731, split contigs + --remove_allelic_links), where it raises.
 OPTIONAL = {
     'dict_to_matrix': ('HapHiC_cluster.py:310-373', cluster.dict_to_matrix),
     'parse_alignments_for_ctgs': ('HapHiC_cluster.py:1596-1655', cluster.parse_alignments_for_ctgs),
@@ -30,7 +31,7 @@ OPTIONAL = {
 }
 
 
-def patch_reference(H, ingest=False, matrix_build=False):
+def patch_reference(H, ingest=True, matrix_build=True):
     """H: the imported reference module (HapHiC_cluster).  Returns {name: original} so the caller can undo."""
     from . import _lib
     _lib.load()                          # fail loudly here if the HIP library is missing

@@ -200,6 +200,16 @@ int hhx_ingest_flank_count_device(hhx_ingest *h, void **dev_count_i64);   /* sam
  * decided by the Python caller). */
 int hhx_ingest_link_matrix(hhx_ingest *h, const uint8_t *in_set_host, int32_t n_rest, int add_self_loops,
                            int32_t *frag_index_host, int32_t *n_linked, hhx_csr **out);
+/* Side products that need the read pairs themselves.  hhx_ingest_keep_pairs(h, 1) before the first
+ * push keeps, for every pair counted in full_link_dict, its oriented 1-based contig coordinates.  After finalize,
+ * hhx_ingest_fetch_pairs returns, per contig pair in dict insertion order (the order of hhx_ingest_fetch):
+ *   clm[4 * n]: update_clm_dict :395-401, four distances per read pair, read pairs in stream order;
+ *               clm_ptr[k] .. clm_ptr[k+1] are the READ PAIRS of key k (multiply by 4 for the array offset);
+ *   crd[2 * m]: record_coord_pairs :454-459, the first max_read_pairs (coord_i, coord_j) of every key.
+ * Host buffers: clm_ptr, crd_ptr [n_full + 1]; clm [4 * sum(full_cnt)]; crd [2 * sum(min(full_cnt, max))]. */
+int hhx_ingest_keep_pairs(hhx_ingest *h, int on);
+int hhx_ingest_fetch_pairs(hhx_ingest *h, int64_t max_read_pairs, int64_t *clm_ptr, int64_t *clm, int64_t *crd_ptr,
+                           int64_t *crd);
 int hhx_ingest_destroy(hhx_ingest *h);
 
 /* Multi-GPU exchange step (ingest).  The aggregated table of a finalized handle, device

@@ -208,6 +208,24 @@ def test_ingest_golden(golden_ingest, chunk):
         assert np.array_equal(out[k], g[k]), k
 
 
+@pytest.mark.parametrize('chunk', [None, 7001])
+def test_ingest_pairs_side_products_golden(golden_ingest, chunk):
+    """f2: CLM distances (update_clm_dict :395-401) and first coordinates (record_coord_pairs :454-459) per contig
+    pair, in dict insertion order and stream order, single push and several pushes"""
+    g = golden_ingest
+    t = table_of(g)
+    ing = _lib.Ingest(t, int(g['flank']), bins=bool(g['bins']))
+    ing.keep_pairs()
+    n = len(g['id1'])
+    step = chunk or n
+    for s in range(0, n, step):
+        ing.push(g['id1'][s:s + step], g['pos1'][s:s + step], g['id2'][s:s + step], g['pos2'][s:s + step])
+    out = ing.fetch()
+    clm_ptr, clm, crd_ptr, crd = ing.fetch_pairs(int(g['max_read_pairs']), out['full_cnt'])
+    assert np.array_equal(4 * clm_ptr, g['clm_ptr']) and np.array_equal(clm, g['clm'])
+    assert np.array_equal(2 * crd_ptr, g['crd_ptr']) and np.array_equal(crd, g['crd'])
+
+
 def test_dict_to_matrix_golden(golden_ingest):
     g = golden_ingest
     in_set = g['d2m_in_set']
