@@ -167,14 +167,14 @@ def main():
                         'achieved_survey_8B_model': (8.0 * F_w + 16.0 * A_w) / (win_ms * 1e-3) / 1e9,
                         'note': 'traffic = fabric bytes per launch from rocprofv3 PMC (profiles/), null if no profile matches this workload'}
         # ---- ingest: the kernel that bounds `value` is the level-1 scatter of the group-by
-        sc_ms, sc_n = pg('part_scatter1')
+        sc_ms, sc_n = pg('map')
         ing_roofline = None
         if sc_n:
             n_rec = _lib.profile_counter('ingest_records') / K                 # pairs that survive the map (inter-contig, known contigs)
-            alg = 16.0 * local_pairs + 12.0 * n_rec                            # read a pair, write a 12-byte record
+            alg = 16.0 * local_pairs + 8.0 * local_pairs                        # read a pair, write an 8-byte record slot
             ach = alg / (sc_ms / sc_n * 1e-3) / 1e9
-            ing_roofline = {'kernel': 'k_part_scatter<SrcPairs>', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                            'frac': ach / HBM_PEAK_GBS, 'traffic': pick(traffic, 'k_part_scatter', 'SrcPairs'), 'alg_bytes_per_launch': alg,
+            ing_roofline = {'kernel': 'k_map_records', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': ach / HBM_PEAK_GBS, 'traffic': pick(traffic, 'k_map_records'), 'alg_bytes_per_launch': alg,
                             'avg_launch_ms': sc_ms / sc_n}
         # whole link-matrix build against SURVEY §8d's B_ingest = 16 P + 12 (K_full + K_flank) + 4 n
         b_ingest = 16.0 * local_pairs + 12.0 * (state['n_full'] + state['n_flank']) + 4.0 * n
@@ -192,8 +192,9 @@ def main():
                                       'convergence': cvg_ms / K}}
         ingest = {'pairs_per_s': value, 'ms_per_step': t_ing / K * 1e3, 'alg_bytes_survey': b_ingest,
                   'alg_GBs_survey': b_ingest * K / t_ing / 1e9,
-                  'kernels_ms_per_step': {k: pg(k)[0] / K for k in ('ingest', 'part_count1', 'part_scatter1', 'part_count2',
-                                                                   'part_scatter2', 'aggregate', 'compact', 'ingest_merge', 'link_matrix')},
+                  'kernels_ms_per_step': {k: pg(k)[0] / K for k in ('ingest', 'map', 'part_count1', 'part_scatter1', 'part_count2',
+                                                                   'part_scatter2', 'part_count3', 'part_scatter3', 'aggregate', 'compact',
+                                                                   'ingest_merge', 'link_matrix')},
                   'roofline': ing_roofline}
         out = {'metric': 'Hi-C pairs/s ingested (link-matrix build) + MCL iters/s', 'value': value, 'unit': 'pairs/s',
                'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': elapsed / K * 1e3,

@@ -818,7 +818,8 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     }
     static const bool debug = getenv("HHX_DEBUG") != nullptr;
     // rows whose product count is well above the number of accumulator slots a dense sweep touches
-    const i64 window_min = std::max<i64>(4096, (i64)n_cols / 2);
+    static const double wfac = getenv("HHX_WINDOW_FACTOR") ? atof(getenv("HHX_WINDOW_FACTOR")) : 0.5;
+    const i64 window_min = std::max<i64>(4096, (i64)((double)n_cols * wfac));
     DevBuf<i32> list_w, list_c, list_t, row_cnt, indptr, g_win_cnt;
     DevBuf<i64> row_off, g_win_off;
     DevBuf<double> s_run;

