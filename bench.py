@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--mean-len', type=int, default=30_000)
     ap.add_argument('--inflation', type=float, default=2.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-sharded', action='store_true', help='take the multi-GPU code path on one rank (1-rank nccl group)')
     ap.add_argument('--cpu-sample-pairs', type=int, default=20_000_000)
     return ap.parse_args()
 
@@ -62,8 +63,14 @@ def main():
     torch.cuda.set_device(local_rank)
     _lib.check(_lib.load().hhx_set_device(local_rank))
     dev = 'cuda:%d' % local_rank
-    if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device(dev))
+    sharded_path = world > 1 or args.force_sharded
+    if sharded_path:
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(dev))
+        else:
+            dist.init_process_group('nccl', device_id=torch.device(dev))
 
     per_chr = max(1, args.contigs // args.nchrs)
     gen = synth.make_genome(args.nchrs, per_chr * args.mean_len, args.mean_len, seed=12345)
@@ -77,7 +84,7 @@ def main():
     torch.cuda.synchronize()
     in_set = np.ones(n, np.uint8)
 
-    if world > 1:
+    if sharded_path:
         from haphic_amd import sharded
     state = {}
 
@@ -87,7 +94,7 @@ def main():
         ing.set_ordinal_base(rank * local_pairs)
         ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
         n_full, n_flank = ing.finalize()
-        if world > 1:
+        if sharded_path:
             m, n_linked, merged = sharded.merge_flank_and_build(ing, table, flank, False, in_set, dist, dev)
             n_full, n_flank = merged.n_full, merged.n_flank
             merged.destroy()
@@ -100,7 +107,7 @@ def main():
         ing.destroy()
         # ---- run_mcl_clustering :2144-2158 at one inflation
         t2 = time.perf_counter()
-        if world > 1:
+        if sharded_path:
             _lib.normalize_l1(m)                                                # :2144
             res, n_iter, conv, stats = sharded.mcl_sharded(m, 2, args.inflation, 200, 1e-4, dist, dev)
         else:
@@ -118,7 +125,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded_path:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -137,7 +144,7 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.profile_enable(False)
     tm = torch.tensor([elapsed, t_ing, t_mcl, t_pre], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharded_path:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     elapsed, t_ing, t_mcl, t_pre = tm.tolist()
 
@@ -209,7 +216,7 @@ def main():
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state)
         print(json.dumps(out))
-    if world > 1:
+    if sharded_path:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -714,9 +714,11 @@ def recommend_inflation(result_stat, nchrs, len_ratio):
 
 def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, expansion, min_inflation,
                        max_inflation, inflation_step, max_iter, pruning, fa_dict, nchrs, dense_matrix=False,
-                       outdir_root='.'):
+                       outdir_root='.', dist=None):
     """run_mcl_clustering() :2132-2242.  link_matrix: scipy CSC or a DeviceCSR.  The normalised,
-    pre-expanded matrix is built once and stays in HBM for the whole inflation sweep."""
+    pre-expanded matrix is built once and stays in HBM for the whole inflation sweep.  With a torch.distributed
+    group (`dist`, one process per GPU, every rank holding the link matrix) the inflations are dealt round-robin
+    to the ranks (sharded.inflation_sweep); every rank gets all results, rank 0 writes the files."""
     if dense_matrix:
         raise ValueError('dense_matrix mode is not on the MI355X path; use the reference function')
     logger.info('Performing Markov clustering...')
@@ -743,14 +745,29 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
         pre = m
     result_clusters_list = []
     mcl_nrounds = 0
-    for inflation in _inflation_values(min_inflation, max_inflation, inflation_step):
+    inflations = _inflation_values(min_inflation, max_inflation, inflation_step)
+
+    def run_one(inflation):
         if pre is not None:
             res = mcl_device(pre, expansion, float(inflation), max_iter, pruning)
         else:
             res = mcl_device(m, expansion, float(inflation), max_iter, pruning, links=True)
+        try:
+            return _lib.interpret(res) + (res.shape3[0],)
+        finally:
+            res.free()
+
+    if dist is not None and dist.get_world_size() > 1:
+        from . import sharded
+        attractor_arrays = sharded.inflation_sweep(run_one, inflations, dist)
+        write_files = dist.get_rank() == 0
+    else:
+        attractor_arrays = None
+        write_files = True
+    for k_infl, inflation in enumerate(inflations):
+        att, att_ptr, members, shape = attractor_arrays[k_infl] if attractor_arrays is not None else run_one(inflation)
         mcl_nrounds += 1
-        clusters = interpret_result_device(res)
-        res.free()
+        clusters = _clusters_from_arrays(att, att_ptr, members, shape)
         if not clusters:
             logger.info('Some fragments are missing / redundant, result of inflation {} will NOT be output'.format(inflation))
             continue
@@ -771,6 +788,11 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
             groups[best][1] += fa_dict[ctg][1]
         result_clusters = sorted(tuple(groups.values()), key=lambda g: g[1], reverse=True)   # stable, :2197
         outdir = os.path.join(outdir_root, 'inflation_{}'.format(inflation))
+        if not write_files:
+            for ctgs, group_len in result_clusters:
+                ctgs.sort(key=lambda c: fa_dict[c][1], reverse=True)
+            result_clusters_list.append((inflation, result_clusters))
+            continue
         os.makedirs(outdir, exist_ok=True)
         with open(os.path.join(outdir, 'mcl_inflation_{}.clusters.txt'.format(inflation)), 'w') as fout:
             fout.write('#Group\tnContigs\tContigs\n')

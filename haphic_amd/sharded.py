@@ -223,3 +223,20 @@ def merge_flank_and_build(ing, table, flank, bins, in_set, dist, device, full_ta
     merged.finalize()
     m, fidx, n_linked = merged.link_matrix(in_set)
     return m, n_linked, merged
+
+
+# ------------------------------------------------------------------ inflation sweep: replicas, no data-path collective
+def inflation_sweep(run_one, inflations, dist):
+    """run_mcl_clustering :2155-2165 restarts every inflation from the same matrix, so the sweep is embarrassingly
+    parallel (SURVEY §8e): rank r runs inflations[r::world] with `run_one(inflation) -> picklable result` (e.g. the
+    attractor arrays of hhx_interpret) on its own replica of the matrix; ONE all_gather_object of the small results
+    at the end.  Returns the results in the order of `inflations` on every rank."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = [(k, run_one(inflations[k])) for k in range(rank, len(inflations), world)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    out = [None] * len(inflations)
+    for part in gathered:
+        for k, res in part:
+            out[k] = res
+    return out

@@ -100,7 +100,8 @@ def _worker(rank, world, port, q):
         np.minimum.at(first, inv, go)
         order = np.argsort(first, kind='stable')
         merged = (len(uniq), (uniq[order] >> 29).astype(np.int32), (uniq[order] & ((1 << 29) - 1)).astype(np.int32), cnt[order])
-        q.put((rank, res, n_iter, conv, stats, merged))
+        sweep = sharded.inflation_sweep(lambda infl: (round(infl * 10), rank), [1.2, 1.4, 1.6, 1.8, 2.0], dist)
+        q.put((rank, res, n_iter, conv, stats, merged, sweep))
     finally:
         dist.destroy_process_group()
 
@@ -130,7 +131,8 @@ def test_sharded_mcl_and_merge_world2():
     T = stochastic(400, 6, 5)
     pre = orc.spgemm(T, T, mode=1, fx_shift=52)
     o = orc.mcl(pre, 2, 2.0, 100, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True)
-    for rank, res, n_iter, conv, stats, merged in outs:
+    for rank, res, n_iter, conv, stats, merged, sweep in outs:
+        assert sweep == [(12, 0), (14, 1), (16, 0), (18, 1), (20, 0)]      # inflations dealt round-robin, results in order
         assert (n_iter, conv) == (o[3], o[4])
         assert all(np.array_equal(x, y) for x, y in zip(res, o[:3])), 'sharded MCL is not bit-identical to 1 process'
         # iteration 0 of the sharded driver includes the fused pre-expansion: nnz entering = nnz(T), F > 0
@@ -143,7 +145,7 @@ def test_sharded_mcl_and_merge_world2():
     id1, p1, id2, p2 = [a.numpy() for a in synth.sample_pairs(gen, 40_000, seed=3)]
     keep = id1 != id2
     whole = orc.ingest(t, id1[keep], p1[keep].astype(np.int64), id2[keep], p2[keep].astype(np.int64), 3000)
-    for rank, *_rest, (k, mi, mj, mc) in outs:
+    for rank, _res, _n, _c, _st, (k, mi, mj, mc), _sw in outs:
         assert k == len(whole['flank_i'])
         assert np.array_equal(mi, whole['flank_i']) and np.array_equal(mj, whole['flank_j']) and np.array_equal(mc, whole['flank_cnt'])
 
