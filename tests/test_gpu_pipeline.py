@@ -287,3 +287,77 @@ def test_filter_fragments_and_rank_sums():
         A = (np.cumsum(indptr).astype(np.int32), cols[order].astype(np.int32), vals[order])
         m = _lib.DeviceCSR.from_arrays(*A)
         assert np.array_equal(_lib.rank_sums(m, topn), orc.rank_sums(A, topn)), (n, deg, topn)
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[1] at full size (10k contigs / 50 M pairs — the oracle cannot finish this in seconds),
+    checked through size-independent properties: count conservation, chunked == whole (the exchange step), symmetry
+    and structure of the link matrix, stochastic rows, a valid partition, idempotence of the converged matrix, and
+    bit-identical results across repeated runs and across the sharded (row-block) driver."""
+    import torch
+    from haphic_amd import _lib, synth
+    from haphic_amd.cluster import FragTable, _clusters_from_arrays
+    gen = synth.make_genome(16, 624 * 50_000, 50_000, seed=12345)
+    n = gen.n
+    table = FragTable.for_contigs(gen.lexical_rank(), gen.length, np.ones(n, np.uint8))
+    P = 50_000_000
+    id1, p1, id2, p2 = synth.sample_pairs(gen, P, seed=12345, device='cuda:0')
+    kept = int((id1 != id2).sum().item())
+    whole = _lib.Ingest(table, 500_000, bins=False, skip_intra=True)
+    whole.push_device(P, id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+    torch.cuda.synchronize()
+    n_full, n_flank = whole.finalize()
+    # the same stream in three uneven chunks, each aggregated on its own, then merged (multi-GPU exchange on one GPU)
+    cuts = [0, 17_000_003, 40_000_000, P]
+    merged = _lib.Ingest(table, 500_000, bins=False, skip_intra=True)
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = _lib.Ingest(table, 500_000, bins=False, skip_intra=True)
+        part.set_ordinal_base(lo)
+        a = [x[lo:hi] for x in (id1, p1, id2, p2)]
+        part.push_device(hi - lo, *[x.data_ptr() for x in a])
+        torch.cuda.synchronize()
+        part.finalize()
+        parts.append(part)
+        merged.push_table(0, *part.table_device(0))
+    assert merged.finalize() == (n_full, n_flank)
+    a, b = whole.fetch(), merged.fetch()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k                      # incl. dict insertion order
+    assert int(a['full_cnt'].sum()) == kept and int(a['ht_cnt'].sum()) == kept        # every kept pair counted once
+    assert int(a['frag_links'].sum()) == 2 * int(a['flank_cnt'].sum())
+    assert (a['full_i'] != a['full_j']).all() and len(np.unique(a['full_i'].astype(np.int64) * n + a['full_j'])) == n_full
+    in_set = np.ones(n, np.uint8)
+    m, fidx, n_linked = whole.link_matrix(in_set)
+    m2, fidx2, _ = merged.link_matrix(in_set)
+    ip, ix, dx = m.to_arrays()
+    assert all(np.array_equal(u, v) for u, v in zip((ip, ix, dx), m2.to_arrays())) and np.array_equal(fidx, fidx2)
+    import scipy.sparse as sp
+    M = sp.csr_matrix((dx, ix, ip), shape=(len(ip) - 1,) * 2)
+    assert (M != M.T).nnz == 0 and (M.diagonal() == 1).all() and M.nnz == 2 * n_flank + M.shape[0]
+    assert np.array_equal(np.sort(fidx[fidx >= 0]), np.arange(n_linked))
+    rows = np.repeat(np.arange(M.shape[0]), np.diff(ip))
+    assert (np.diff(ix)[np.diff(rows) == 0] > 0).all()            # rows sorted by column, no duplicates
+    # MCL: stochastic, valid partition, idempotent, reproducible, shard-invariant
+    res, n_iter, conv = _lib.mcl(m, 2, 2.0, 200, 1e-4, links=True)
+    assert conv
+    rp, rj, rx = res.to_arrays()
+    sums = np.add.reduceat(rx.astype(np.float64), rp[:-1])
+    assert np.abs(sums - 1).max() < 1e-6
+    att, ptr, mem = _lib.interpret(res)
+    clusters = _clusters_from_arrays(att, ptr, mem, res.shape3[0])
+    assert clusters is not None and sum(len(c) for c in clusters) == res.shape3[0]
+    again, _, _ = _lib.expand_inflate_prune(res, res, 2.0, 1e-4)   # one more iteration of a converged matrix
+    np.testing.assert_allclose(again.to_arrays()[2], rx, rtol=1e-5)
+    assert np.array_equal(again.to_arrays()[1], rj)
+    res2, n2, c2 = _lib.mcl(m, 2, 2.0, 200, 1e-4, links=True)
+    assert n2 == n_iter and all(np.array_equal(u, v) for u, v in zip(res2.to_arrays(), (rp, rj, rx)))
+    norm = m.copy()
+    _lib.normalize_l1(norm)
+    r0, r1 = 3000, 5200                                           # a row block, as a GPU of a sharded run computes it
+    blk, _, _ = _lib.expand_inflate_prune(norm.row_block(r0, r1), norm, 2.0, 1e-4)
+    full, _, _ = _lib.expand_inflate_prune(norm, norm, 2.0, 1e-4)
+    fp, fj, fx = full.to_arrays()
+    bp, bj, bx = blk.to_arrays()
+    lo, hi = fp[r0], fp[r1]
+    assert np.array_equal(bp, fp[r0:r1 + 1] - lo) and np.array_equal(bj, fj[lo:hi]) and np.array_equal(bx, fx[lo:hi])
