@@ -51,6 +51,7 @@ struct ExParams {
     i32 n_rows, n_cols;
     double scale, inv_scale;        // 2^(shift-52), 2^(52-shift): products are rounded on the 2^-52 grid of [1,2)
     double r; int square; float thr;
+    int raw;                        // 1: plain product C = A * B (hhx_spgemm): every non-zero entry is written, nothing else
     // candidate + survivor pools (col, value) and the per-row table
     i32 *cand_col; float *cand_val; i64 cand_cap;
     i32 *out_col; float *out_val; i64 out_cap;
@@ -350,7 +351,7 @@ __device__ __forceinline__ double window_power_sum(const ExParams &P, const ExLd
         float p = -1.0f;
         if (COMPACT || a != 0.0) {
             const float x = (float)(a * P.inv_scale);
-            p = ex_inflate(x, P.r, P.square);
+            p = P.raw ? x : ex_inflate(x, P.r, P.square);
             s += (double)p;
             ++nz;
         }
@@ -383,7 +384,7 @@ __device__ __forceinline__ void window_emit_candidates(const ExParams &P, const 
     i32 cnt = 0;
     for (i32 t = s0; t < s1; ++t) {
         const float p = ((float *)&l.acc[t])[0];
-        if (p >= 0.0f && (t == bs || (float)((double)p / s_run) >= P.thr)) ++cnt;
+        if (p >= 0.0f && (P.raw || t == bs || (float)((double)p / s_run) >= P.thr)) ++cnt;
     }
     i32 total;
     i32 off = block_excl_scan_i32(cnt, l.red_i, &total);
@@ -419,7 +420,7 @@ __device__ __forceinline__ void window_emit_candidates(const ExParams &P, const 
             bits &= bits - 1;
         } else col = c0 + t;
         const float p = ((float *)&l.acc[t])[0];
-        if (p >= 0.0f && (t == bs || (float)((double)p / s_run) >= P.thr)) {
+        if (p >= 0.0f && (P.raw || t == bs || (float)((double)p / s_run) >= P.thr)) {
             P.cand_col[o] = col;
             P.cand_val[o] = p;
             ++o;
@@ -431,6 +432,7 @@ __device__ __forceinline__ void window_emit_candidates(const ExParams &P, const 
 __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, i32 row, i32 n_win, double s1,
                                              const i64 *win_off, const i32 *win_cnt) {
     const int tid = threadIdx.x;
+    if (P.raw) s1 = 0.0;                              // plain product: q = p, every candidate is kept, no normalisation
     __threadfence_block();
     __syncthreads();
     // pass A: first row maximum of q = float(p / S)
@@ -458,7 +460,7 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
             if (t < cnt) {
                 const float p = P.cand_val[base + t];
                 const float q = s1 != 0.0 ? (float)((double)p / s1) : p;
-                if (q >= P.thr || P.cand_col[base + t] == bc) { ++keep; v = (double)q; }
+                if (P.raw || q >= P.thr || P.cand_col[base + t] == bc) { ++keep; v = (double)q; }
             }
             s2 += block_sum_f64(v, l.red_d);        // chunk sums added in order: deterministic
         }
@@ -492,13 +494,13 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
                 const float p = P.cand_val[base + t];
                 q = s1 != 0.0 ? (float)((double)p / s1) : p;
                 c = P.cand_col[base + t];
-                k = (q >= P.thr) || (c == bc);
+                k = P.raw || (q >= P.thr) || (c == bc);
             }
             i32 tot;
             const i32 pos = block_excl_scan_i32(k ? 1 : 0, l.red_i, &tot);
             if (k) {
                 P.out_col[o + pos] = c;
-                P.out_val[o + pos] = s2 != 0.0 ? (float)((double)q / s2) : q;
+                P.out_val[o + pos] = (s2 != 0.0 && !P.raw) ? (float)((double)q / s2) : q;
             }
             o += tot;
             __syncthreads();
@@ -692,9 +694,11 @@ __global__ __launch_bounds__(256) void k_expand_tiny(ExParams P, const i32 *__re
         float pw[TINY_MAX];
         double s1 = 0.0;
         for (i32 t = 0; t < cnt; ++t) {
-            pw[t] = ex_inflate((float)(vals[t] * P.inv_scale), P.r, P.square);
+            const float x = (float)(vals[t] * P.inv_scale);
+            pw[t] = P.raw ? x : ex_inflate(x, P.r, P.square);
             s1 += fabs((double)pw[t]);
         }
+        if (P.raw) s1 = 0.0;
         i32 am = -1, keep = 0;
         float best = 0.f;
         double s2 = 0.0;
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(256) void k_expand_tiny(ExParams P, const i32 *__re
             if (am < 0 || pw[t] > best) { am = t; best = pw[t]; }
         }
         for (i32 t = 0; t < cnt; ++t)
-            if (pw[t] >= P.thr || t == am) { ++keep; s2 += fabs((double)pw[t]); }
+            if (P.raw || pw[t] >= P.thr || t == am) { ++keep; s2 += fabs((double)pw[t]); }
         nnzc += cnt;
         // one atomic per wave reserves the output rows of its 64 rows
         i32 incl = keep;
@@ -723,9 +727,9 @@ __global__ __launch_bounds__(256) void k_expand_tiny(ExParams P, const i32 *__re
                 P.row_off[row] = o;
                 P.row_cnt[row] = keep;
                 for (i32 t = 0; t < cnt; ++t)
-                    if (pw[t] >= P.thr || t == am) {
+                    if (P.raw || pw[t] >= P.thr || t == am) {
                         P.out_col[o] = cols[t];
-                        P.out_val[o] = s2 != 0.0 ? (float)((double)pw[t] / s2) : pw[t];
+                        P.out_val[o] = (s2 != 0.0 && !P.raw) ? (float)((double)pw[t] / s2) : pw[t];
                         ++o;
                     }
             }
@@ -773,6 +777,7 @@ __global__ __launch_bounds__(256) void k_pack_rows(i32 n_rows, const i64 *__rest
 struct CodedOperand {
     const unsigned short *n16 = nullptr;
     const double *row_sum = nullptr;
+    int raw = 0;                        // plain product (no inflation / pruning): hhx_spgemm's fast path
 };
 
 int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &coded, int fx_shift, double inflation, double pruning,
@@ -843,6 +848,10 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     // candidate pool: early windows test against a partial row sum and admit more than finally survive
     i64 pool_cap = std::max<i64>(4 * a->nnz + 16 * (i64)n_rows, (i64)1 << 22);
     i64 cand_cap = n_win > 1 ? 2 * pool_cap : pool_cap;
+    if (coded.raw) {                    // the product of two sparse matrices is at most dense
+        const i64 dense = (i64)n_rows * n_cols;
+        pool_cap = cand_cap = std::min<i64>(dense, std::max<i64>(pool_cap, 32 * a->nnz)) + n_rows;
+    }
     for (int attempt = 0; attempt < 6; ++attempt) {
         DevBuf<i32> cand_col, out_col;
         DevBuf<float> cand_val, out_val;
@@ -862,6 +871,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         P.n_rows = n_rows; P.n_cols = n_cols;
         P.scale = ldexp(1.0, fx_shift - 52); P.inv_scale = ldexp(1.0, 52 - fx_shift);
         P.r = (double)(float)inflation; P.square = inflation == 2.0; P.thr = (float)pruning;
+        P.raw = coded.raw;
         P.cand_col = cand_col.p; P.cand_val = cand_val.p; P.cand_cap = cand_cap;
         P.out_col = out_col.p; P.out_val = out_val.p; P.out_cap = pool_cap;
         P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
@@ -943,4 +953,12 @@ int hhx_expand_coded(const hhx_csr *a, const hhx_csr *b, const unsigned short *n
     CodedOperand c;
     c.n16 = n16; c.row_sum = row_sum;
     return hhx_expand_impl(a, b, c, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
+}
+
+// C = A * B for stochastic-like operands (entries in [0, 1], row sums of A <= 1): the fused kernels in plain-product mode
+int hhx_expand_raw(const hhx_csr *a, const hhx_csr *b, int fx_shift, hhx_csr **out, i64 *n_products) {
+    CodedOperand c;
+    c.raw = 1;
+    i64 nnzc = 0;
+    return hhx_expand_impl(a, b, c, fx_shift, 2.0, 0.0, out, n_products, &nnzc);
 }

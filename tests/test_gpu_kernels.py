@@ -86,10 +86,18 @@ def test_spgemm_bit_exact_vs_fixed_point_spec(golden_mcl):
 def test_spgemm_random(n, deg, seed):
     A = random_stochastic(n, deg, seed)
     d = _lib.DeviceCSR.from_arrays(*A)
-    c, f = _lib.spgemm(d, d, fx_shift=60, want_products=True)
+    c, f = _lib.spgemm(d, d, fx_shift=60, want_products=True)          # generic kernels (64-bit integer accumulation)
     ref = orc.spgemm(A, A, mode=1, fx_shift=60)
     got = c.to_arrays()
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    c52, f52 = _lib.spgemm(d, d, fx_shift=52, want_products=True)      # stochastic operands: fused kernels, plain-product mode
+    ref52 = orc.spgemm(A, A, mode=1, fx_shift=52)
+    assert f52 == f and all(np.array_equal(x, y) for x, y in zip(c52.to_arrays(), ref52))
+    # operands outside [0, 1] take the generic kernels at any shift
+    A2 = (A[0], A[1], (A[2] * np.float32(-3.0)).astype(np.float32))
+    d2 = _lib.DeviceCSR.from_arrays(*A2)
+    g2 = _lib.spgemm(d2, d2, fx_shift=40).to_arrays()
+    assert all(np.array_equal(x, y) for x, y in zip(g2, orc.spgemm(A2, A2, mode=1, fx_shift=40)))
     lens = np.diff(A[0])
     assert f == int(lens[A[1]].sum())
     ref0 = orc.spgemm(A, A, mode=0)
