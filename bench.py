@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--mean-len', type=int, default=30_000)
     ap.add_argument('--inflation', type=float, default=2.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pushes', type=int, default=1, help='hand the pairs over in this many batches (streaming ingest: one aggregated run per batch, merged at finalize)')
     ap.add_argument('--force-sharded', action='store_true', help='take the multi-GPU code path on one rank (1-rank nccl group)')
     ap.add_argument('--cpu-sample-pairs', type=int, default=20_000_000)
     return ap.parse_args()
@@ -92,7 +93,9 @@ def main():
         t0 = time.perf_counter()
         ing = _lib.Ingest(table, flank, bins=False, skip_intra=True)
         ing.set_ordinal_base(rank * local_pairs)
-        ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+        bounds = [local_pairs * k // args.pushes for k in range(args.pushes + 1)]
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            ing.push_device(hi - lo, id1[lo:hi].data_ptr(), p1[lo:hi].data_ptr(), id2[lo:hi].data_ptr(), p2[lo:hi].data_ptr())
         n_full, n_flank = ing.finalize()
         if sharded_path:
             m, n_linked, merged = sharded.merge_flank_and_build(ing, table, flank, False, in_set, dist, dev)

@@ -244,124 +244,81 @@ def check_param(param, string, suffix, true_suffix=''):
     raise RuntimeError('Parameter check failed')
 
 
+def _cut(sorted_values, string, flag, scale, offset=0.0, strict=True):
+    """Index at which an ascending list is cut by a "0.2"-style (fraction of the list) or "0.2X"-style (multiple of
+    `scale`, plus `offset`) parameter — the two modes of the reference's thresholds (:779-810, :841-854, :911-923).
+    strict: first value > limit (upper cuts); otherwise first value >= limit (the lower density cut)."""
+    from bisect import bisect_left, bisect_right
+    num, mode = check_param(flag, string, {'X', 'x'})
+    if mode:
+        limit = offset + num * scale
+        return (bisect_right if strict else bisect_left)(sorted_values, limit)
+    return int(len(sorted_values) * float(string))
+
+
 def filter_fragments(Nx_frag_set, RE_site_dict, RE_site_cutoff, frag_link_dict, density_lower, density_upper,
                      topN, rank_sum_upper, rank_sum_hard_cutoff, flank_link_dict, read_depth_dict, read_depth_upper, whitelist):
-    """filter_fragments() :741-940.  Steps (1)-(4) (Nx / RE sites / link density / read depth) are the reference's
-    own list logic on O(n) items.  Step (5), the rank-sum statistic (:866-892) — a dense n x n matrix and O(n^2)
-    Python sorting in the reference — is computed on the device from the sparse link matrix (hhx_rank_sums)."""
+    """filter_fragments() :741-940.  The Nx / RE-site / link-density / read-depth steps are O(n) list work on the
+    host; the rank-sum statistic (:866-892) — a dense n x n matrix and O(n^2 log n) Python sorting in the
+    reference — is computed on the device from the sparse link matrix (hhx_rank_sums)."""
     from numpy import quantile
     logger.info('Filtering fragments...')
-    frags_in_whitelist = set()
-    frag_density_list = list()
-    total_links = 0
-    total_RE_sites = 1
-    for frag in Nx_frag_set:                                                  # (1) (2)
-        RE_sites = RE_site_dict[frag]
-        if RE_sites > RE_site_cutoff:
-            if frag in frag_link_dict:
-                frag_links = frag_link_dict[frag]
-                total_links += frag_links
-                total_RE_sites += RE_sites - 1
-                frag_density_list.append((frag, frag_links / RE_sites))
+    # (1) Nx set, (2) RE sites: link density = flank links / RE sites (:753-765); set iteration order, then a stable sort
+    density, total_links, total_RE_sites = [], 0, 1
+    for frag in Nx_frag_set:
+        sites = RE_site_dict[frag]
+        if sites > RE_site_cutoff:
+            links = frag_link_dict.get(frag) if frag in frag_link_dict else None
+            if links is None:
+                density.append((frag, 0))
             else:
-                frag_density_list.append((frag, 0))
-        if whitelist and frag.rsplit('_bin', 1)[0] in whitelist:
-            frags_in_whitelist.add(frag)
-    Nx_frag_num = len(Nx_frag_set)
-    logger.info('[Nx filtering] {} fragments kept'.format(Nx_frag_num))
-    logger.info('[RE sites filtering] {} fragments removed, {} fragments kept'.format(
-        Nx_frag_num - len(frag_density_list), len(frag_density_list)))
-    frag_density_list.sort(key=lambda x: x[1])                                # (3)
-    param_density_lower = check_param('--density_lower', density_lower, {'X', 'x'})
-    param_density_upper = check_param('--density_upper', density_upper, {'X', 'x'})
-    remaining_nfrags = len(frag_density_list)
-    average_density = total_links / total_RE_sites
-    if param_density_lower[-1] in {'X', 'x'}:
-        for lower, (frag, density) in enumerate(frag_density_list):
-            if density >= average_density * param_density_lower[0]:
-                break
+                total_links += links
+                total_RE_sites += sites - 1
+                density.append((frag, links / sites))
+    whitelisted = {f for f in Nx_frag_set if whitelist and f.rsplit('_bin', 1)[0] in whitelist}
+    logger.info('[RE sites filtering] {} of {} Nx fragments kept'.format(len(density), len(Nx_frag_set)))
+    # (3) link density between density_lower and density_upper (:767-823)
+    density.sort(key=lambda x: x[1])
+    values = [d for _, d in density]
+    average = total_links / total_RE_sites
+    lower = _cut(values, density_lower, '--density_lower', average, strict=False)
+    upper = _cut(values, density_upper, '--density_upper', average)
+    unfiltered = density
+    density = density[lower:upper]
+    kept = {frag for frag, _ in density}
+    logger.info('[link density filtering] {} fragments kept'.format(len(kept)))
+    # (4) read depth: Q3 + k * IQR over ALL density-ranked fragments (:825-863)
+    if read_depth_dict:
+        depth = sorted(((frag, read_depth_dict[frag][1]) for frag, _ in unfiltered), key=lambda x: x[1])
+        q1, _m, q3 = quantile([d for _, d in depth], (0.25, 0.5, 0.75))
+        num, mode = check_param('--read_depth_upper', read_depth_upper, {'X', 'x'})
+        if mode:
+            from bisect import bisect_right
+            cut = bisect_right([d for _, d in depth], q3 + num * (q3 - q1))
         else:
-            lower += 1
-    else:
-        lower = int(remaining_nfrags * float(density_lower))
-    if param_density_upper[-1] in {'X', 'x'}:
-        for upper, (frag, density) in enumerate(frag_density_list):
-            if density > average_density * param_density_upper[0]:
-                break
-        else:
-            upper += 1
-    else:
-        upper = int(remaining_nfrags * float(density_upper))
-    filtered_frags = {frag for frag, density in frag_density_list[lower:upper]}
-    nfiltered_frags = len(filtered_frags)
-    logger.info('[link density filtering] {} fragments removed, {} fragments kept'.format(
-        remaining_nfrags - nfiltered_frags, nfiltered_frags))
-    frag_density_list_unfiltered = frag_density_list
-    frag_density_list = frag_density_list[lower:upper]
-    if read_depth_dict:                                                       # (4)
-        read_depth_list = [(frag, read_depth_dict[frag][1]) for frag, density in frag_density_list_unfiltered]
-        read_depth_list.sort(key=lambda x: x[1])
-        param_read_depth_upper = check_param('--read_depth_upper', read_depth_upper, {'X', 'x'})
-        q1, m, q3 = quantile([read_depth for frag, read_depth in read_depth_list], (0.25, 0.5, 0.75))
-        iqr = q3 - q1
-        logger.info('[read depth filtering] Q1={}, median={}, Q3={}, IQR=Q3-Q1={}'.format(q1, m, q3, iqr))
-        if param_read_depth_upper[-1]:
-            read_depth_upper_limit = q3 + param_read_depth_upper[0] * iqr
-            for upper, (frag, read_depth) in enumerate(read_depth_list):
-                if read_depth > read_depth_upper_limit:
-                    break
-            else:
-                upper += 1
-        else:
-            upper = int(remaining_nfrags * float(read_depth_upper))
-        filtered_frags &= {frag for frag, read_depth in read_depth_list[:upper]}
-        nfiltered_frags = len(filtered_frags)
-        frag_density_list = [(frag, density) for frag, density in frag_density_list if frag in filtered_frags]
-    # (5) rank sums between the topN strongest neighbours, :866-892
-    m_dev, frag_index_dict = dict_to_matrix(flank_link_dict, filtered_frags, dense_matrix=False, add_self_loops=False, _device=True)
+            cut = int(len(unfiltered) * float(read_depth_upper))
+        kept &= {frag for frag, _ in depth[:cut]}
+        density = [(frag, d) for frag, d in density if frag in kept]
+        logger.info('[read depth filtering] {} fragments kept'.format(len(kept)))
+    # (5) rank sums between the topN strongest neighbours (:866-892), on the device
+    m_dev, frag_index_dict = dict_to_matrix(flank_link_dict, kept, dense_matrix=False, add_self_loops=False, _device=True)
     try:
         rs = _lib.rank_sums(m_dev, topN)
     finally:
         m_dev.free()
-    rank_sum_list = list()
-    hard_filtered_nfrags = 0
-    for frag, _ in frag_density_list:
-        rank_sum = int(rs[frag_index_dict[frag]])
-        if rank_sum_hard_cutoff and rank_sum > rank_sum_hard_cutoff:
-            hard_filtered_nfrags += 1
-            continue
-        rank_sum_list.append((frag, rank_sum))
-    rank_sum_list.sort(key=lambda x: x[1])
-    remaining_nfrags = len(rank_sum_list)
+    ranked = [(frag, int(rs[frag_index_dict[frag]])) for frag, _ in density]
     if rank_sum_hard_cutoff:
-        logger.info('[rank sum filtering] {} fragments removed by hard filtering, {} fragments kept'.format(
-            hard_filtered_nfrags, remaining_nfrags))
-    param_rank_sum_upper = check_param('--rank_sum_upper', rank_sum_upper, {'X', 'x'})
-    q1, m, q3 = quantile([rank_sum for _, rank_sum in rank_sum_list], (0.25, 0.5, 0.75))
-    iqr = q3 - q1
-    logger.info('[rank sum filtering] Q1={}, median={}, Q3={}, IQR=Q3-Q1={}'.format(q1, m, q3, iqr))
-    if param_rank_sum_upper[-1]:
-        rank_sum_upper_limit = q3 + param_rank_sum_upper[0] * iqr
-        for upper, (frag, rank_sum) in enumerate(rank_sum_list):
-            if rank_sum > rank_sum_upper_limit:
-                break
-        else:
-            upper += 1
-    else:
-        upper = int(remaining_nfrags * float(rank_sum_upper))
-    filtered_frags = {frag for frag, rank_sum in rank_sum_list[:upper]}
-    nfiltered_frags = len(filtered_frags)
-    logger.info('[rank sum filtering] {} fragments removed, {} fragments kept'.format(
-        len(rank_sum_list) - nfiltered_frags, nfiltered_frags))
-    if frags_in_whitelist:
-        n = 0
-        for frag in frags_in_whitelist:
-            if frag in filtered_frags:
-                continue
-            n += 1
-            filtered_frags.add(frag)
-        logger.info('[rank sum filtering] {} fragments added, {} fragments are used to perform Markov clustering'.format(
-            n, len(filtered_frags)))
+        ranked = [x for x in ranked if x[1] <= rank_sum_hard_cutoff]
+    ranked.sort(key=lambda x: x[1])
+    sums = [r for _, r in ranked]
+    q1, _m, q3 = quantile(sums, (0.25, 0.5, 0.75))
+    logger.info('[rank sum filtering] Q1={}, Q3={}, IQR={}'.format(q1, q3, q3 - q1))
+    cut = _cut(sums, rank_sum_upper, '--rank_sum_upper', q3 - q1, offset=q3)
+    filtered_frags = {frag for frag, _ in ranked[:cut]}
+    logger.info('[rank sum filtering] {} fragments kept'.format(len(filtered_frags)))
+    if whitelisted:
+        filtered_frags |= whitelisted
+        logger.info('[rank sum filtering] {} fragments are used to perform Markov clustering'.format(len(filtered_frags)))
     return filtered_frags
 
 
