@@ -190,6 +190,7 @@ def main():
         b_ingest = 16.0 * local_pairs + 12.0 * (state['n_full'] + state['n_flank']) + 4.0 * n
         cmp_ms, _ = pg('expand_compact')
         fin_ms, _ = pg('expand_finalize')
+        tiny_ms, _ = pg('expand_tiny')
         cvg_ms, _ = pg('convergence')
         # B_iter of SURVEY §8d summed over the iterations of one mcl() call (fused: C is never written or re-read)
         b_iter = float((8 * (stats[:, 0] + stats[:, 3]) + 8 * stats[:, 2] + 16 * stats[:, 2] + 12 * n).sum()) if len(stats) else 0.0
@@ -199,6 +200,7 @@ def main():
                'alg_bytes_per_mcl_survey': b_iter, 'alg_GBs_survey': b_iter * K / t_mcl / 1e9 if t_mcl else None,
                'stats_nnzA_nnzC_nnzP_F': stats.tolist(),
                'kernel_ms_per_step': {'expand_window': win_ms / K, 'expand_finalize': fin_ms / K, 'expand_compact': cmp_ms / K,
+                                      'expand_tiny': tiny_ms / K,
                                       'convergence': cvg_ms / K}}
         ingest = {'pairs_per_s': value, 'ms_per_step': t_ing / K * 1e3, 'alg_bytes_survey': b_ingest,
                   'alg_GBs_survey': b_ingest * K / t_ing / 1e9,
