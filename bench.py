@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--pushes', type=int, default=1, help='hand the pairs over in this many batches (streaming ingest: one aggregated run per batch, merged at finalize)')
     ap.add_argument('--force-sharded', action='store_true', help='take the multi-GPU code path on one rank (1-rank nccl group)')
     ap.add_argument('--cpu-sample-pairs', type=int, default=20_000_000)
+    ap.add_argument('--text-lines', type=int, default=1_000_000, help='a1 leg: lines of .pairs text formatted on the host (0 = skip)')
+    ap.add_argument('--text-tile', type=int, default=16, help='a1 leg: copies of that text concatenated in HBM')
     return ap.parse_args()
 
 
@@ -218,12 +220,57 @@ def main():
                           'contigs': int(n), 'pairs_per_gpu': local_pairs, 'full_keys': int(state['n_full']),
                           'flank_keys': int(state['n_flank']), 'link_matrix_nnz': int(state['nnz_link'])},
                'mcl_iters_per_s': mcl['iters_per_s'], 'ingest': ingest, 'mcl': mcl, 'roofline': roofline}
+        if world == 1 and args.text_lines:
+            out['ingest']['text'] = text_leg(args, gen, id1, p1, id2, p2, dev)
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state)
         print(json.dumps(out))
     if sharded_path:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def text_leg(args, gen, id1, p1, id2, p2, dev):
+    """a1 beside the headline: .pairs TEXT already in HBM -> id / position arrays (hhx_pairs_parse), with and without
+    the alignments.bed bytes.  The text is text_lines real lines of this workload, tiled to text_tile copies."""
+    import torch
+    from haphic_amd import _lib
+    k = min(args.text_lines, id1.numel())
+    names = list(gen.names)
+    h = [a[:k].cpu().numpy() for a in (id1, p1, id2, p2)]
+    raw = ''.join('r%d\t%s\t%d\t%s\t%d\t+\t-\n' % (i, names[a], x + 1, names[b], y + 1)
+                  for i, (a, x, b, y) in enumerate(zip(*[v.tolist() for v in h]))).encode()
+    text = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev).repeat(args.text_tile)
+    n_bytes, n_lines = text.numel(), k * args.text_tile
+    ps = _lib.PairsParser(names)
+    res = {'lines': n_lines, 'bytes': n_bytes, 'bytes_per_line': n_bytes / n_lines}
+    for tag, bed in (('parse', False), ('parse_bed', True)):
+        best = None
+        for _ in range(3):
+            _lib.check(_lib.load().hhx_synchronize())
+            t0 = time.perf_counter()
+            assert ps.parse(None, want_bed=bed, device_ptr=text.data_ptr(), n_bytes=n_bytes) == n_lines
+            _lib.check(_lib.load().hhx_synchronize())
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        res[tag] = {'ms': best * 1e3, 'text_GBs': n_bytes / best / 1e9, 'pairs_per_s': n_lines / best}
+        if bed:
+            res[tag]['bed_bytes'] = ps.bed_bytes
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    ps.parse(None, want_bed=True, device_ptr=text.data_ptr(), n_bytes=n_bytes)
+    _lib.check(_lib.load().hhx_synchronize())
+    _lib.profile_enable(False)
+    res['kernel_ms'] = {kname: _lib.profile_get(kname)[0] for kname in ('text_breaks', 'text_starts', 'text_parse', 'text_bed')}
+    # algorithmic bytes of the parse kernel: the text once + 16 B of arrays per line
+    res['roofline'] = {'kernel': 'k_parse_lines', 'bound': 'hbm', 'achieved': (n_bytes + 16 * n_lines) / (res['kernel_ms']['text_parse'] * 1e-3) / 1e9,
+                       'peak': 8000.0, 'unit': 'GB/s'}
+    res['roofline']['frac'] = res['roofline']['achieved'] / 8000.0
+    out = ps.fetch()                                 # every tile must reproduce the sample it was formatted from
+    for c in range(4):
+        assert np.array_equal(out[c].reshape(args.text_tile, k), np.broadcast_to(h[c], (args.text_tile, k))), 'text leg mismatch'
+    ps.destroy()
+    return res
 
 
 def pmc_traffic(n_contigs, pairs):

@@ -76,6 +76,13 @@ SIGNATURES = {
     'hhx_ingest_flank_count_device': (C.c_int, [C.c_void_p, c_vpp]),
     'hhx_ingest_destroy': (C.c_int, [C.c_void_p]),
     'hhx_ingest_keep_pairs': (C.c_int, [C.c_void_p, C.c_int]),
+    'hhx_pairs_parser_create': (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    'hhx_pairs_parse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, c_i64p, c_i64p]),
+    'hhx_pairs_parser_arrays': (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5),
+    'hhx_pairs_parser_fetch': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
+    'hhx_pairs_parser_destroy': (C.c_int, [C.c_void_p]),
+    'hhx_ingest_keep_frag_pairs': (C.c_int, [C.c_void_p, C.c_int]),
+    'hhx_ingest_fetch_frag_pairs': (C.c_int, [C.c_void_p, c_i64p, C.c_void_p, C.c_void_p]),
     'hhx_ingest_fetch_pairs': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'hhx_ingest_set_ordinal_base': (C.c_int, [C.c_void_p, C.c_int64]),
     'hhx_ingest_link_matrix': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, c_i32p, c_vpp]),
@@ -341,6 +348,60 @@ def count_re_sites(seq, seg_off, seg_len, sites):
     return out[:off.size]
 
 
+class PairsParser:
+    """hhx_pairs_parser: .pairs text chunks -> device id / position arrays (+ the alignments.bed bytes)."""
+
+    def __init__(self, names):
+        enc = [n.encode() for n in names]
+        off = np.zeros(len(enc) + 1, np.int64)
+        if enc:
+            off[1:] = np.cumsum([len(b) for b in enc])
+        blob = np.frombuffer(b''.join(enc) or b'\0', np.uint8)
+        self.h = C.c_void_p()
+        check(load().hhx_pairs_parser_create(len(enc), ptr(blob), ptr(off), C.byref(self.h)))
+        self.n_lines = self.bed_bytes = 0
+
+    def parse(self, text, want_bed=False, device_ptr=None, n_bytes=None):
+        """text: bytes-like holding whole lines (or device_ptr + n_bytes); raises IndexError / ValueError like
+        the reference's cols[k] / int() do"""
+        nl, nb = C.c_int64(0), C.c_int64(0)
+        if device_ptr is None:
+            buf = np.frombuffer(text, np.uint8)
+            rc = load().hhx_pairs_parse(self.h, ptr(buf) if buf.size else None, buf.size, 0, int(want_bed), C.byref(nl), C.byref(nb))
+        else:
+            rc = load().hhx_pairs_parse(self.h, C.c_void_p(device_ptr), int(n_bytes), 1, int(want_bed), C.byref(nl), C.byref(nb))
+        if rc:
+            msg = load().hhx_last_error().decode('utf-8', 'replace')
+            kind = {'IndexError': IndexError, 'ValueError': ValueError}.get(msg.split(':', 1)[0])
+            if kind:
+                raise kind(msg.split(': ', 1)[1])
+            raise RuntimeError('libhaphic_hip: ' + msg)
+        self.n_lines, self.bed_bytes = nl.value, nb.value
+        return self.n_lines
+
+    def device_arrays(self):
+        p = [C.c_void_p() for _ in range(5)]
+        check(load().hhx_pairs_parser_arrays(self.h, *[C.byref(x) for x in p]))
+        return [x.value for x in p]
+
+    def fetch(self, want_bed=False):
+        out = [np.empty(self.n_lines, np.int32) for _ in range(4)]
+        bed = np.empty(self.bed_bytes if want_bed else 0, np.uint8)
+        check(load().hhx_pairs_parser_fetch(self.h, *[ptr(a) for a in out], ptr(bed) if bed.size else None))
+        return out + [bed.tobytes()]
+
+    def destroy(self):
+        if self.h is not None and self.h.value:
+            load().hhx_pairs_parser_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class Ingest:
     """hhx_ingest handle: push batches of (id1, pos1, id2, pos2), then finalize/fetch."""
 
@@ -414,6 +475,18 @@ class Ingest:
         crd = np.zeros(max(2 * capped, 1), np.int64)
         check(load().hhx_ingest_fetch_pairs(self.h, int(max_read_pairs), ptr(clm_ptr), ptr(clm), ptr(crd_ptr), ptr(crd)))
         return clm_ptr, clm[:4 * total], crd_ptr, crd[:2 * capped]
+
+    def keep_frag_pairs(self, on=True):
+        check(load().hhx_ingest_keep_frag_pairs(self.h, int(on)))
+
+    def fetch_frag_pairs(self):
+        """every distinct oriented fragment pair of the stream (ctg_pair_to_frag :1731): (frag_i, frag_j) arrays"""
+        n = C.c_int64(0)
+        check(load().hhx_ingest_fetch_frag_pairs(self.h, C.byref(n), None, None))
+        fi, fj = np.empty(n.value, np.int32), np.empty(n.value, np.int32)
+        if n.value:
+            check(load().hhx_ingest_fetch_frag_pairs(self.h, C.byref(n), ptr(fi), ptr(fj)))
+        return fi, fj
 
     def set_ordinal_base(self, base):
         """global stream ordinal of this handle's first pair (multi-GPU chunk offset); before the first push"""

@@ -481,6 +481,115 @@ def dict_to_matrix(link_dict, frag_set, dense_matrix=True, add_self_loops=False,
     return (csc.toarray() if dense_matrix else csc), frag_index_dict
 
 
+# ------------------------------------------------------------------ a1: .pairs text
+class PairsText:
+    """What pairs_generator / pairs_generator_inter_ctgs (:1539-1583) return here: the .pairs file, tokenised on the
+    device one chunk of whole lines at a time (hhx_pairs_parse).  parse_alignments* take it as is and push the
+    device arrays straight into the ingest; iterating it yields the reference's (ref, mref, pos, mpos) tuples for
+    any other consumer.  alignments.bed is written in the working directory as the reference does (:1549)."""
+
+    def __init__(self, pairs, aln_format, inter_only, chunk_bytes=256 << 20, bed_path='alignments.bed'):
+        assert aln_format in ('pairs', 'bgzipped_pairs')
+        self.path, self.aln_format, self.inter_only = pairs, aln_format, inter_only
+        self.chunk_bytes, self.bed_path = chunk_bytes, bed_path
+
+    def _chunks(self):
+        """byte chunks holding whole lines (cut after the last '\n'; the tail of the file goes as it is).  A plain
+        .pairs file is memory-mapped and handed to the device copy without passing through Python bytes objects."""
+        if self.aln_format == 'pairs':
+            import mmap
+            size = os.path.getsize(self.path)
+            if size == 0:
+                return
+            with open(self.path, 'rb') as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+                at = 0
+                while at < size:
+                    end = min(at + self.chunk_bytes, size)
+                    cut = end if end == size else mm.rfind(b'\n', at, end) + 1
+                    while cut <= at:                             # a line longer than the chunk
+                        end = min(end + self.chunk_bytes, size)
+                        cut = end if end == size else mm.rfind(b'\n', at, end) + 1
+                    view = np.frombuffer(mm, np.uint8, cut - at, at)
+                    yield view
+                    del view                                     # the map cannot close while a view is alive
+                    at = cut
+            return
+        import gzip
+        with gzip.open(self.path, 'rb') as f:
+            carry = b''
+            while True:
+                block = f.read(self.chunk_bytes)
+                if not block:
+                    break
+                cut = block.rfind(b'\n') + 1
+                if cut == 0:
+                    carry += block
+                    continue
+                yield carry + block[:cut]
+                carry = block[cut:]
+            if carry:
+                yield carry
+
+    def batches(self, names):
+        """per chunk: (parser, n_lines) with the id / position arrays of the chunk on the device; the BED bytes of
+        the chunk go to alignments.bed through a writer thread while the next chunk is parsed"""
+        import queue
+        import threading
+        parser = _lib.PairsParser(names)
+        fbed = open(self.bed_path, 'wb') if self.bed_path else None
+        todo = queue.Queue(maxsize=2)
+        failed = []
+
+        def writer():
+            while True:
+                buf = todo.get()
+                if buf is None:
+                    return
+                try:
+                    if not failed:
+                        fbed.write(memoryview(buf))
+                except Exception as e:                           # surfaced on the caller's thread below
+                    failed.append(e)
+        th = threading.Thread(target=writer, daemon=True) if fbed is not None else None
+        if th:
+            th.start()
+        try:
+            for chunk in self._chunks():
+                n = parser.parse(chunk, want_bed=fbed is not None)
+                del chunk
+                if fbed is not None and parser.bed_bytes:
+                    bed = np.empty(parser.bed_bytes, np.uint8)
+                    _lib.check(_lib.load().hhx_pairs_parser_fetch(parser.h, None, None, None, None, _lib.ptr(bed)))
+                    todo.put(bed)
+                if failed:
+                    raise failed[0]
+                yield parser, n
+        finally:
+            if th:
+                todo.put(None)
+                th.join()
+            if fbed is not None:
+                fbed.close()
+            parser.destroy()
+        if failed:
+            raise failed[0]
+
+    def __iter__(self):
+        # name tuples would mean tokenising on the host; patch_reference binds these generators only together with S5
+        raise TypeError('PairsText is consumed by haphic_amd.cluster.parse_alignments / parse_alignments_for_ctgs; '
+                        'patch_reference(H, ingest=False) keeps the reference generators')
+
+
+def pairs_generator(pairs, aln_format):
+    """pairs_generator() :1539-1559"""
+    return PairsText(pairs, aln_format, inter_only=False)
+
+
+def pairs_generator_inter_ctgs(pairs, aln_format):
+    """pairs_generator_inter_ctgs() :1562-1583"""
+    return PairsText(pairs, aln_format, inter_only=True)
+
+
 # ------------------------------------------------------------------ S5: ingest
 def _ids_from_alignments(alignments, cid, chunk):
     """(ref, mref, pos, mpos) iterator -> int32 arrays, `chunk` pairs at a time"""
@@ -500,21 +609,31 @@ def _ids_from_alignments(alignments, cid, chunk):
         yield b1[:k], p1[:k], b2[:k], p2[:k], k
 
 
-def ingest_links(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False, max_read_pairs=0):
+def ingest_links(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False, max_read_pairs=0, want_frag_pairs=False):
     """Feed an alignment iterator (name tuples, as the reference's generators :1539-1593 yield them)
     through the device ingest; returns the insertion-ordered tables as numpy arrays (+ the CLM distances and
     the first coordinates of every contig pair when want_pairs)."""
-    cid = {n: i for i, n in enumerate(table.ctg_names)}
-    ing = _lib.Ingest(table, flank, bins=bins, skip_intra=False)
+    text = isinstance(alignments, PairsText)
+    ing = _lib.Ingest(table, flank, bins=bins, skip_intra=text and alignments.inter_only)      # :1582
     try:
         if want_pairs:
             ing.keep_pairs()
-        for b1, p1, b2, p2, k in _ids_from_alignments(alignments, cid, chunk):
-            ing.push(b1, p1, b2, p2)         # unknown names (-1) and intra-contig pairs are filtered on the device
+        if want_frag_pairs:
+            ing.keep_frag_pairs()
+        if text:                             # a1 on the device: text chunk -> id arrays -> ingest, nothing returns to the host
+            for parser, k in alignments.batches(table.ctg_names):
+                if k:
+                    ing.push_device(k, *parser.device_arrays()[:4])
+        else:
+            cid = {n: i for i, n in enumerate(table.ctg_names)}
+            for b1, p1, b2, p2, k in _ids_from_alignments(alignments, cid, chunk):
+                ing.push(b1, p1, b2, p2)     # unknown names (-1) and intra-contig pairs are filtered on the device
         ing.finalize()
         out = ing.fetch()
         if want_pairs:
             out['clm_ptr'], out['clm'], out['crd_ptr'], out['crd'] = ing.fetch_pairs(max_read_pairs, out['full_cnt'])
+        if want_frag_pairs:
+            out['fp_i'], out['fp_j'] = ing.fetch_frag_pairs()
         return out
     finally:
         ing.destroy()
@@ -615,19 +734,23 @@ def parse_alignments_for_ctgs(alignments, fa_dict, args, ctg_len_dict, Nx_ctg_se
 
 def parse_alignments(alignments, fa_dict, args, bin_size, frag_len_dict, Nx_frag_set, split_ctg_set, pos_int_type,
                      dist_int_type):
-    """parse_alignments() :1658-1752 (some contigs split into bins).  ctg_pair_to_frag (:1731-1732, only used with
-    --remove_allelic_links on split contigs) is returned empty."""
-    if args.remove_allelic_links:
-        raise NotImplementedError('parse_alignments on split contigs with --remove_allelic_links needs ctg_pair_to_frag '
-                                  '(:1731-1732), which the device ingest does not produce: keep the reference function')
+    """parse_alignments() :1658-1752 (some contigs split into bins): all seven containers from the device."""
     logger.info('Parsing input alignments...')
     table = FragTable.from_reference(fa_dict, frag_len_dict, Nx_frag_set, split_ctg_set, bin_size)
     record = bool(args.remove_allelic_links or args.remove_concentrated_links)
     out = ingest_links(alignments, table, int(args.flank * 1000), bins=True, want_pairs=True,
-                       max_read_pairs=int(args.max_read_pairs) if record else 0)
+                       max_read_pairs=int(args.max_read_pairs) if record else 0, want_frag_pairs=bool(args.remove_allelic_links))
     full, flank, HT, frag_link = _link_dicts(out, table)
     clm_dict, ctg_coord_dict = _pair_dicts(out, table, fa_dict, args, pos_int_type, dist_int_type)
-    return full, flank, HT, clm_dict, frag_link, ctg_coord_dict, defaultdict(set)
+    ctg_pair_to_frag = defaultdict(set)                         # :1731-1733
+    if args.remove_allelic_links:
+        fn, cn = table.frag_names, table.ctg_names
+        ci = np.searchsorted(table.ctg_frag0, out['fp_i'], side='right') - 1     # fragment id -> its contig
+        cj = np.searchsorted(table.ctg_frag0, out['fp_j'], side='right') - 1
+        for fi, fj, a, b in zip(out['fp_i'].tolist(), out['fp_j'].tolist(), ci.tolist(), cj.tolist()):
+            ca, cb = cn[a], cn[b]
+            ctg_pair_to_frag[(ca, cb) if ca <= cb else (cb, ca)].add((fn[fi], fn[fj]))
+    return full, flank, HT, clm_dict, frag_link, ctg_coord_dict, ctg_pair_to_frag
 
 
 # ------------------------------------------------------------------ S6: run_mcl_clustering

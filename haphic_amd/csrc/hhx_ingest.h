@@ -89,6 +89,14 @@ __device__ __forceinline__ bool map_pair(const DevTables &t, int stream, i32 r, 
         if (b.lenf & SPLIT_BIT) { const i64 nb = (xj + t.bin_size - 1) / t.bin_size; fj += (i32)(nb - 1); yj = xj - (nb - 1) * t.bin_size; }
         if (fi == fj) return false;                                              // :1715
     }
+    if (stream == 2) {                                                           // ctg_pair_to_frag :1731-1733: every pair that got here
+        if (t.bins) {
+            const UnitInfo fa = t.frag[fi], fb = t.frag[fj];
+            if (fa.rank > fb.rank) { const i32 tf = fi; fi = fj; fj = tf; }
+        }
+        rec = ((u64)(u32)fi << ID_BITS) | (u64)(u32)fj | FLANK_BIT;
+        return true;
+    }
     if (stream == 0) {
         if (t.bins && r == m) return false;                                      // :1736
         rec = ((u64)(u32)ci << ID_BITS) | (u64)(u32)cj | (ht << HT_SHIFT) | FULL_BIT;
@@ -127,7 +135,9 @@ struct hhx_ingest {
     u64 ord_base = 0;                      // global ordinal of this handle's first pair (multi-GPU chunk offset)
     u64 n_pushed = 0;                      // pairs pushed so far
     u64 ord_limit = 0;                     // 1 + largest ordinal that can occur (pairs and pushed tables)
-    std::vector<hhx::LinkRun *> runs[2];   // [0] full (or combined) table, [1] flank table (bins mode only)
+    std::vector<hhx::LinkRun *> runs[3];   // [0] full (or combined) table, [1] flank table (bins mode only),
+                                           // [2] every fragment pair seen (ctg_pair_to_frag :1731, on request)
+    bool keep_frag_pairs = false;
     bool finalized = false;
     i64 n_full = 0, n_flank = 0;
     hhx::OrderedTables ordered;

@@ -533,6 +533,28 @@ extern "C" int hhx_ingest_keep_pairs(hhx_ingest *h, int on) {
     return 0;
 }
 
+extern "C" int hhx_ingest_keep_frag_pairs(hhx_ingest *h, int on) {
+    if (!h) return fail("null handle");
+    if (h->n_pushed) return fail("hhx_ingest_keep_frag_pairs: call before the first push");
+    h->keep_frag_pairs = on != 0;
+    return 0;
+}
+
+// every distinct (frag_i, frag_j) the stream produced (ctg_pair_to_frag :1731-1733), in no particular order
+extern "C" int hhx_ingest_fetch_frag_pairs(hhx_ingest *h, i64 *n_pairs, i32 *frag_i, i32 *frag_j) {
+    if (!h || !h->finalized) return fail("ingest handle not finalized");
+    if (!h->keep_frag_pairs) return fail("hhx_ingest_fetch_frag_pairs: hhx_ingest_keep_frag_pairs was not requested");
+    const LinkRun *r = h->runs[2].empty() ? nullptr : h->runs[2][0];
+    const i64 n = r ? r->n : 0;
+    if (n_pairs) *n_pairs = n;
+    if (!frag_i || !frag_j || !n) return 0;
+    std::vector<u64> keys((size_t)n);
+    HHX_HIP(hipMemcpyAsync(keys.data(), r->key.p, 8 * (size_t)n, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    for (i64 k = 0; k < n; ++k) { frag_i[k] = (i32)(keys[(size_t)k] >> ID_BITS); frag_j[k] = (i32)(keys[(size_t)k] & ID_MASK); }
+    return 0;
+}
+
 extern "C" int hhx_ingest_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const i32 *pos1, const i32 *id2, const i32 *pos2,
                                int on_device) {
     if (!h) return fail("null handle");
@@ -551,9 +573,11 @@ extern "C" int hhx_ingest_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const
     DevBuf<u64> mapped;
     if (mapped.alloc((size_t)n_pairs)) return 1;
     const unsigned mgrid = (unsigned)std::max<i64>(1, std::min<i64>((n_pairs + 255) / 256, 256 * 32));
-    for (int stream = 0; stream < (h->combined ? 1 : 2); ++stream) {
+    for (int stream = 0; stream < 3; ++stream) {
+        if (stream == 1 && h->combined) continue;
+        if (stream == 2 && !h->keep_frag_pairs) continue;
         { KTimer kt2("map");
-        if (h->combined) k_map_records<true><<<mgrid, 256, 0, g_stream>>>(SrcPairs<true>{src[0], src[1], src[2], src[3], h->t, 0}, n_pairs, mapped.p);
+        if (h->combined && stream == 0) k_map_records<true><<<mgrid, 256, 0, g_stream>>>(SrcPairs<true>{src[0], src[1], src[2], src[3], h->t, 0}, n_pairs, mapped.p);
         else k_map_records<false><<<mgrid, 256, 0, g_stream>>>(SrcPairs<false>{src[0], src[1], src[2], src[3], h->t, stream}, n_pairs, mapped.p); }
         HHX_LAUNCH_CHECK();
         LinkRun *run = nullptr;
@@ -590,7 +614,8 @@ extern "C" int hhx_ingest_finalize(hhx_ingest *h, i64 *n_full_keys, i64 *n_flank
     if (!h->finalized) {
         { KTimer kt("ingest_merge");
         HHX_TRY(merge_runs(h->runs[0]));
-        HHX_TRY(merge_runs(h->runs[1])); }
+        HHX_TRY(merge_runs(h->runs[1]));
+        HHX_TRY(merge_runs(h->runs[2])); }
         i64 a = 0, b = 0, c = 0, d = 0;
         HHX_TRY(run_stats(h->table(0), &a, &b, &h->ord_limit));
         if (!h->combined) HHX_TRY(run_stats(h->table(1), &c, &d, &h->ord_limit));

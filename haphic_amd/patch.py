@@ -23,11 +23,13 @@ SEAMS = {
 }
 # S4/S5: dict_to_matrix is also called in dense mode by the filters (:603) — the mirror returns `.toarray()` then;
 # the device ingest returns all of the reference's containers (link tables, HT counts, CLM distance lists, first
-# coordinates) except ctg_pair_to_frag (:1731, split contigs + --remove_allelic_links), where it raises.
+# coordinates, ctg_pair_to_frag :1731 for split contigs + --remove_allelic_links).
 OPTIONAL = {
     'dict_to_matrix': ('HapHiC_cluster.py:310-373', cluster.dict_to_matrix),
     'parse_alignments_for_ctgs': ('HapHiC_cluster.py:1596-1655', cluster.parse_alignments_for_ctgs),
     'parse_alignments': ('HapHiC_cluster.py:1658-1752', cluster.parse_alignments),
+    'pairs_generator': ('HapHiC_cluster.py:1539-1559', cluster.pairs_generator),                      # a1
+    'pairs_generator_inter_ctgs': ('HapHiC_cluster.py:1562-1583', cluster.pairs_generator_inter_ctgs),
 }
 
 
@@ -42,6 +44,8 @@ def patch_reference(H, ingest=True, matrix_build=True):
     if ingest:
         seams['parse_alignments_for_ctgs'] = OPTIONAL['parse_alignments_for_ctgs']
         seams['parse_alignments'] = OPTIONAL['parse_alignments']
+        seams['pairs_generator'] = OPTIONAL['pairs_generator']                # a1: only together with S5, which consumes it
+        seams['pairs_generator_inter_ctgs'] = OPTIONAL['pairs_generator_inter_ctgs']
     for name, (_cite, fn) in seams.items():
         saved[name] = getattr(H, name, None)
         setattr(H, name, fn)

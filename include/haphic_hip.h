@@ -210,6 +210,28 @@ int hhx_ingest_link_matrix(hhx_ingest *h, const uint8_t *in_set_host, int32_t n_
 int hhx_ingest_keep_pairs(hhx_ingest *h, int on);
 int hhx_ingest_fetch_pairs(hhx_ingest *h, int64_t max_read_pairs, int64_t *clm_ptr, int64_t *clm, int64_t *crd_ptr,
                            int64_t *crd);
+/* ------------------------------------------------------------------ a1: .pairs text -> id / position arrays
+ * pairs_generator :1539-1559 and pairs_generator_inter_ctgs :1562-1583: skip blank and '#' lines, split on
+ * whitespace, (ref, pos, mref, mpos) = (cols[1], int(cols[2]) - 1, cols[3], int(cols[4]) - 1), and the two
+ * alignments.bed records per line (:1557).  Names are resolved against the FASTA names given at creation
+ * (n_names strings, concatenated, name_off[n_names + 1]); a name that is not among them, and every skipped
+ * line, yields id -1 — which hhx_ingest_push drops (:1610 / :1702) — so line k of the chunk is element k of
+ * the arrays.  A chunk must hold whole lines.  A line with fewer than 5 columns or a malformed integer fails
+ * the call with "IndexError: ..." / "ValueError: ..." in hhx_last_error(), as the reference raises.  The
+ * arrays (device pointers, int32) stay valid until the next parse on the same parser. */
+typedef struct hhx_pairs_parser hhx_pairs_parser;
+int hhx_pairs_parser_create(int32_t n_names, const uint8_t *names, const int64_t *name_off, hhx_pairs_parser **out);
+int hhx_pairs_parse(hhx_pairs_parser *p, const uint8_t *text, int64_t n_bytes, int on_device, int want_bed,
+                    int64_t *n_lines, int64_t *bed_bytes);
+int hhx_pairs_parser_arrays(hhx_pairs_parser *p, void **id1, void **pos1, void **id2, void **pos2, void **bed);
+int hhx_pairs_parser_fetch(hhx_pairs_parser *p, int32_t *id1, int32_t *pos1, int32_t *id2, int32_t *pos2, uint8_t *bed);
+int hhx_pairs_parser_destroy(hhx_pairs_parser *p);
+
+/* ctg_pair_to_frag :1731-1733 (split contigs + --remove_allelic_links): every distinct oriented fragment pair the
+ * stream produced, whatever its flank / Nx status.  Request before the first push; fetch after finalize (call with
+ * NULL arrays for the size). */
+int hhx_ingest_keep_frag_pairs(hhx_ingest *h, int on);
+int hhx_ingest_fetch_frag_pairs(hhx_ingest *h, int64_t *n_pairs, int32_t *frag_i, int32_t *frag_j);
 int hhx_ingest_destroy(hhx_ingest *h);
 
 /* Multi-GPU exchange step (ingest).  The aggregated table of a finalized handle, device

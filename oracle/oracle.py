@@ -209,6 +209,53 @@ def ingest(table, id1, pos1, id2, pos2, flank, bins=False, want_clm=False, max_r
     return out
 
 
+def parse_pairs_text(text, names):
+    """pairs_generator (scripts/HapHiC_cluster.py:1539-1559) on a bytes object: one (id1, pos1, id2, pos2) row per
+    LINE (skipped lines and unknown names -> id -1, so that rows stay aligned with lines) and the alignments.bed
+    bytes (:1557).  Pure-Python restatement, small inputs only."""
+    import io
+    cid = {n: i for i, n in enumerate(names)}
+    rows, bed = [], []
+    for line in io.TextIOWrapper(io.BytesIO(bytes(text)), encoding='utf-8', newline=None):   # 'rt': universal newlines
+        if not line.strip() or line.startswith('#'):                                           # :1552
+            rows.append((-1, 0, -1, 0))
+            continue
+        cols = line.split()                                                                    # :1554
+        ref, pos, mref, mpos = cols[1], int(cols[2]) - 1, cols[3], int(cols[4]) - 1            # :1556
+        bed.append('{0}\t{1}\t{2}\t{3}/1\t255\t.\n{4}\t{5}\t{6}\t{3}/2\t255\t.\n'.format(ref, pos, pos, cols[0], mref, mpos, mpos))
+        rows.append((cid.get(ref, -1), pos, cid.get(mref, -1), mpos))
+    a = np.array(rows, np.int64).reshape(-1, 4)
+    return a[:, 0].astype(np.int32), a[:, 1].astype(np.int32), a[:, 2].astype(np.int32), a[:, 3].astype(np.int32), ''.join(bed).encode()
+
+
+def frag_pairs(table, id1, pos1, id2, pos2):
+    """ctg_pair_to_frag (scripts/HapHiC_cluster.py:1696-1733): the distinct oriented fragment pairs of a stream on
+    split contigs, whatever their flank / Nx status.  numpy restatement; returns sorted (frag_i, frag_j) rows."""
+    id1, pos1, id2, pos2 = (np.asarray(a, np.int64) for a in (id1, pos1, id2, pos2))
+    ok = (id1 >= 0) & (id2 >= 0)                                                   # :1702 not in the fasta
+    id1, pos1, id2, pos2 = id1[ok], pos1[ok], id2[ok], pos2[ok]
+    split = table.ctg_split.astype(bool)
+    keep = (id1 != id2) | split[id1]                                               # :1698
+    id1, pos1, id2, pos2 = id1[keep], pos1[keep], id2[keep], pos2[keep]
+    c1, c2 = pos1 + 1, pos2 + 1
+    r1, r2 = table.ctg_rank[id1].astype(np.int64), table.ctg_rank[id2].astype(np.int64)
+    sw = (r1 > r2) | ((r1 == r2) & (c1 > c2))                                      # :1706 sorted((name, coord))
+    ci, cj = np.where(sw, id2, id1), np.where(sw, id1, id2)
+    xi, xj = np.where(sw, c2, c1), np.where(sw, c1, c2)
+
+    def conv(c, x):                                                                # convert_frags :1665-1673
+        b = split[c]
+        return table.ctg_frag0[c].astype(np.int64) + np.where(b, (x - 1) // max(table.bin_size, 1), 0), b
+    fi, bi = conv(ci, xi)
+    fj, bj = conv(cj, xj)
+    ne = fi != fj                                                                  # :1714
+    fi, fj, anyb = fi[ne], fj[ne], (bi | bj)[ne]
+    sw = anyb & (table.frag_rank[fi] > table.frag_rank[fj])                        # :1718-1719
+    fi, fj = np.where(sw, fj, fi), np.where(sw, fi, fj)
+    u = np.unique(np.stack([fi, fj], 1), axis=0) if len(fi) else np.zeros((0, 2), np.int64)
+    return u[:, 0].astype(np.int32), u[:, 1].astype(np.int32)
+
+
 def dict_to_matrix(fi, fj, val, n_frag, in_set, n_rest, add_self_loops=True):
     """Array half of dict_to_matrix() :310-373.  Returns (indptr, indices, data, frag_index, n_linked)."""
     L = lib()

@@ -135,9 +135,10 @@ def ingest_case(nchrs, chr_len, mean_len, npairs, flank_kb, Nx, bin_size_kb, see
     H.cal_concordance_ratio = lambda coord_list, shorter_len, nwindows: tuple(coord_list)
     try:
         if split_ctg_set:
-            full, flank, HT, clm, frag_link, coord, _ = H.parse_alignments(
+            full, flank, HT, clm, frag_link, coord, c2f = H.parse_alignments(
                 iter(aln), fa_dict, args, bin_size, frag_len_dict, Nx_frag_set, split_ctg_set, 'int32', 'int32')
         else:
+            c2f = None
             full, flank, HT, clm, frag_link, coord = H.parse_alignments_for_ctgs(
                 iter(aln), fa_dict, args, frag_len_dict, Nx_frag_set, 'int32', 'int32')
     finally:
@@ -198,6 +199,9 @@ def ingest_case(nchrs, chr_len, mean_len, npairs, flank_kb, Nx, bin_size_kb, see
             crd_ptr.append(len(crd_all))
         out['crd_ptr'] = np.array(crd_ptr, np.int64)
         out['crd'] = np.array(crd_all, np.int64)
+    if c2f is not None:      # ctg_pair_to_frag :1731-1733 -> (ctg_i, ctg_j, frag_i, frag_j) rows, sorted
+        rows = sorted((cid[ck[0]], cid[ck[1]], fid[fk[0]], fid[fk[1]]) for ck, fs in c2f.items() for fk in fs)
+        out['c2f'] = np.array(rows, np.int32).reshape(-1, 4)
     # ---- dict_to_matrix on a filtered fragment set (drop ~15 % of the Nx set, keep some link-less)
     fset = set(f for f in Nx_frag_set if rng.random() > 0.15)
     mat, fidx = H.dict_to_matrix(flank, fset, dense_matrix=False, add_self_loops=True)
@@ -458,6 +462,76 @@ def gen_filter(path):
     np.savez_compressed(path, **out)
 
 
+def gen_pairs_text(path):
+    """a1: pairs_generator / pairs_generator_inter_ctgs (:1539-1583) on a .pairs text with every line shape the
+    tokeniser has to get right: header and blank lines, CRLF and lone-CR line ends, space / tab / \\x0b / \\x1c
+    separators, leading whitespace, extra columns, names that are not in the FASTA, signs, zero padding and
+    underscores in the integers, no newline at the end.  Frozen: the text, the names, the yielded tuples (as ids)
+    and the bytes of alignments.bed."""
+    import tempfile
+    rng = np.random.default_rng(77)
+    names = ['ctg%d' % k for k in range(40)] + ['Chr1_7_100_200_+_100', 'a', 'ab', 'ctg1x', 'utg000001l|arrow']
+    pool = names + ['unplaced_scaffold', 'ctg', 'ctg400', 'A']
+    lines = ['## pairs format v1.0', '#columns: readID chr1 pos1 chr2 pos2 strand1 strand2', '']
+    for k in range(3000):
+        a, b = pool[rng.integers(len(pool))], pool[rng.integers(len(pool))]
+        if rng.random() < 0.2:
+            b = a
+        x, y = int(rng.integers(1, 2_000_000_000)), int(rng.integers(1, 5_000_000))
+        sx, sy = str(x), str(y)
+        r = rng.random()
+        if r < 0.03:
+            sx = '+' + sx
+        elif r < 0.06:
+            sx = '00' + sx
+        elif r < 0.09 and len(sy) > 3:
+            sy = sy[:2] + '_' + sy[2:]
+        elif r < 0.10:
+            sx = '0'                              # -> pos -1
+        elif r < 0.11:
+            sx = '-12'
+        sep = '\t' if rng.random() < 0.9 else [' ', '  ', '\t ', '\x0b', '\x1c', '\x0c'][rng.integers(6)]
+        cols = ['read%d' % k, a, sx, b, sy]
+        if rng.random() < 0.7:
+            cols += ['+', '-']
+        if rng.random() < 0.05:
+            cols += ['extra col']
+        line = sep.join(cols)
+        if rng.random() < 0.03:
+            line = '  ' + line
+        if rng.random() < 0.03:
+            line += ' \t'
+        lines.append(line)
+        if rng.random() < 0.02:
+            lines.append(['', '   ', '#comment in the middle', '\t'][rng.integers(4)])
+    text = ''
+    for ln in lines:
+        r = rng.random()
+        text += ln + ('\r\n' if r < 0.1 else '\r' if r < 0.13 else '\n')
+    text += 'lastread\tctg3\t77\tctg9\t99'     # no line end at EOF
+    raw = text.encode()
+    out = dict(text=np.frombuffer(raw, np.uint8), names=np.array(names))
+    cid = {n_: i for i, n_ in enumerate(names)}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        try:
+            with open('in.pairs', 'wb') as f:
+                f.write(raw)
+            for tag, gen in (('all', H.pairs_generator), ('inter', H.pairs_generator_inter_ctgs)):
+                tuples = list(gen('in.pairs', 'pairs'))
+                out[tag] = np.array([(cid.get(a, -1), x, cid.get(b, -1), y) for a, b, x, y in tuples], np.int64)
+                out[tag + '_known'] = np.array([(a in cid) * 1 + (b in cid) * 2 for a, b, x, y in tuples], np.uint8)
+                with open('alignments.bed', 'rb') as f:
+                    out['bed_' + tag] = np.frombuffer(f.read(), np.uint8)
+        finally:
+            os.chdir(cwd)
+    assert np.array_equal(out['bed_all'], out['bed_inter'])
+    del out['bed_inter']
+    print('pairs text case: bytes', len(raw), 'tuples', len(out['all']), 'inter', len(out['inter']), 'bed bytes', len(out['bed_all']))
+    np.savez_compressed(path, **out)
+
+
 if __name__ == '__main__':
     assert os.environ.get('PYTHONHASHSEED') == '0', 'run with PYTHONHASHSEED=0'
     gen_mcl(os.path.join(HERE, 'mcl_cases.npz'))
@@ -467,3 +541,4 @@ if __name__ == '__main__':
     gen_pipeline_c1(os.path.join(HERE, 'pipeline_c1.npz'))
     gen_resites(os.path.join(HERE, 'resites.npz'))
     gen_filter(os.path.join(HERE, 'filter.npz'))
+    gen_pairs_text(os.path.join(HERE, 'pairs_text.npz'))

@@ -234,6 +234,151 @@ def test_ingest_pairs_side_products_golden(golden_ingest, chunk):
     assert np.array_equal(2 * crd_ptr, g['crd_ptr']) and np.array_equal(crd, g['crd'])
 
 
+def _random_bins_case(npairs, seed):
+    """contigs above 60 kb split into 25 kb bins, names ranked lexically as the reference's sorted() would"""
+    from haphic_amd import synth
+    gen = synth.make_genome(3, 1_500_000, 40_000, cv=0.8, min_len=3000, seed=seed)
+    names = list(gen.names)
+    bin_size = 25_000
+    frag_names, frag0, split, frag_len = [], [], [], []
+    for nm, ln in zip(names, gen.length.tolist()):
+        frag0.append(len(frag_names))
+        if ln > 60_000:
+            nb = -(-ln // bin_size)
+            split.append(1)
+            frag_names += ['{}_bin{}'.format(nm, k + 1) for k in range(nb)]
+            frag_len += [bin_size] * (nb - 1) + [ln - bin_size * (nb - 1)]
+        else:
+            split.append(0)
+            frag_names.append(nm)
+            frag_len.append(ln)
+
+    def rank(lst):
+        order = sorted(range(len(lst)), key=lst.__getitem__)
+        r = np.empty(len(lst), np.int32)
+        r[order] = np.arange(len(lst), dtype=np.int32)
+        return r
+    t = orc.FragTable(rank(names), gen.length, np.array(frag0, np.int32), np.array(split, np.uint8), bin_size,
+                      rank(frag_names), np.array(frag_len, np.int64), (np.arange(len(frag_names)) % 5 != 0).astype(np.uint8))
+    id1, p1, id2, p2 = [x.numpy() for x in synth.sample_pairs(gen, npairs, seed=seed + 1, cis=0.9)]
+    return t, id1.astype(np.int32), p1.astype(np.int64), id2.astype(np.int32), p2.astype(np.int64)
+
+
+@pytest.mark.parametrize('chunk', [None, 7001])
+def test_ingest_frag_pairs_golden(chunk):
+    """ctg_pair_to_frag (:1731-1733): the distinct fragment pairs, single push and several pushes; the other
+    tables are unaffected by the extra stream"""
+    from tests.conftest import load_golden
+    g = load_golden('ingest_bins.npz')
+    ing = _lib.Ingest(table_of(g), int(g['flank']), bins=True)
+    ing.keep_frag_pairs()
+    n = len(g['id1'])
+    step = chunk or n
+    for s in range(0, n, step):
+        ing.push(g['id1'][s:s + step], g['pos1'][s:s + step], g['id2'][s:s + step], g['pos2'][s:s + step])
+    out = ing.fetch()
+    for k in ('full_i', 'full_j', 'full_cnt', 'ht_cnt', 'flank_i', 'flank_j', 'flank_cnt', 'frag_links'):
+        assert np.array_equal(out[k], g[k]), k
+    fi, fj = ing.fetch_frag_pairs()
+    got = np.unique(np.stack([fi, fj], 1), axis=0)
+    assert len(got) == len(fi)                              # distinct
+    assert np.array_equal(got, np.unique(g['c2f'][:, 2:], axis=0))
+    # larger random stream against the oracle's restatement
+    t, id1, p1, id2, p2 = _random_bins_case(40000, seed=77)
+    ing = _lib.Ingest(t, 3000, bins=True)
+    ing.keep_frag_pairs()
+    ing.push(id1, p1, id2, p2)
+    ing.fetch()
+    fi, fj = ing.fetch_frag_pairs()
+    wi, wj = orc.frag_pairs(t, id1, p1, id2, p2)
+    assert np.array_equal(np.unique(np.stack([fi, fj], 1), axis=0), np.stack([wi, wj], 1)) and len(fi) == len(wi)
+
+
+def test_pairs_text_tokeniser_golden():
+    """a1 on the device: line k of the chunk -> row k (skipped lines and unknown names -1), BED bytes identical to
+    the reference's alignments.bed; whole text and cut into chunks of whole lines"""
+    from tests.conftest import load_golden
+    g = load_golden('pairs_text.npz')
+    names = [str(x) for x in g['names']]
+    raw = g['text'].tobytes()
+    w1, wp1, w2, wp2, wbed = orc.parse_pairs_text(raw, names)
+    ps = _lib.PairsParser(names)
+    assert ps.parse(raw, want_bed=True) == len(w1)
+    i1, p1, i2, p2, bed = ps.fetch(want_bed=True)
+    assert all(np.array_equal(a, b) for a, b in zip((i1, p1, i2, p2), (w1, wp1, w2, wp2)))
+    assert bed == g['bed_all'].tobytes() == wbed
+    # chunks: cut after a '\n' every ~5 KB
+    got, beds, at = [], [], 0
+    while at < len(raw):
+        cut = raw.rfind(b'\n', at, at + 5000) + 1
+        if cut <= at:
+            cut = len(raw)
+        ps.parse(raw[at:cut], want_bed=True)
+        out = ps.fetch(want_bed=True)
+        got.append(np.stack(out[:4], 1))
+        beds.append(out[4])
+        at = cut
+    assert b''.join(beds) == wbed
+    rows = np.concatenate(got)
+    live = ~((rows[:, 0] == -1) & (rows[:, 2] == -1) & (rows[:, 1] == 0) & (rows[:, 3] == 0))
+    assert np.array_equal(rows[live], g['all'])            # a lone '\r' before a cut is a line end in both
+    # no BED wanted, empty input, a text without any line end
+    assert ps.parse(b'') == 0
+    assert ps.parse(b'r1 ctg1 5 ctg2 9') == 1
+    assert [a.tolist() for a in ps.fetch()[:4]] == [[1], [4], [2], [8]]
+    # malformed lines raise what the reference raises
+    with pytest.raises(IndexError):
+        ps.parse(b'r1\tctg1\t5\tctg2\n')
+    with pytest.raises(ValueError):
+        ps.parse(b'r1\tctg1\t5x\tctg2\t7\n')
+    with pytest.raises(ValueError):
+        ps.parse(b'#h\n\nr1\tctg1\t5\tctg2\t7_\n')
+    ps.destroy()
+
+
+def test_pairs_text_through_ingest(tmp_path, monkeypatch):
+    """.pairs file -> cluster.pairs_generator_inter_ctgs -> cluster.parse_alignments_for_ctgs: the dicts equal the
+    oracle's on the tuples the reference generator yielded; alignments.bed byte-identical; plain and gzipped,
+    one chunk and many"""
+    import gzip
+    from haphic_amd import cluster
+    from tests.conftest import load_golden
+    g = load_golden('pairs_text.npz')
+    names = [str(x) for x in g['names']]
+    raw = g['text'].tobytes()
+    (tmp_path / 'in.pairs').write_bytes(raw)
+    with gzip.open(tmp_path / 'in.pairs.gz', 'wb') as f:
+        f.write(raw)
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(5)
+    lens = rng.integers(3_000_000, 6_000_000, len(names))
+    fa_dict = {n: [None, int(l), 0] for n, l in zip(names, lens)}
+    frag_len_dict = {n: fa_dict[n][1] for n in names}
+    order = sorted(range(len(names)), key=names.__getitem__)
+    rank = np.empty(len(names), np.int32)
+    rank[order] = np.arange(len(names), dtype=np.int32)
+    t = orc.FragTable(rank, lens, np.arange(len(names), dtype=np.int32), np.zeros(len(names), np.uint8), 0, rank, lens,
+                      np.ones(len(names), np.uint8))
+    ok = g['inter'][:, 1] >= 0                              # the oracle takes 0-based positions like the generator's
+    want = orc.ingest(t, *[g['inter'][:, c] for c in range(4)], 500_000)
+
+    class A:
+        flank = 500
+        remove_allelic_links = 0
+        remove_concentrated_links = False
+        max_read_pairs = 200
+        nwindows = 50
+    for fname, fmt, chunk in (('in.pairs', 'pairs', 256 << 20), ('in.pairs', 'pairs', 3000), ('in.pairs.gz', 'bgzipped_pairs', 10000)):
+        aln = cluster.pairs_generator_inter_ctgs(fname, fmt)
+        aln.chunk_bytes = chunk
+        full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(aln, fa_dict, A(), frag_len_dict, set(names),
+                                                                                   'int32', 'int32')
+        assert list(full.items()) == [((names[i], names[j]), c) for i, j, c in zip(want['full_i'], want['full_j'], want['full_cnt'].tolist())]
+        assert list(flank.items()) == [((names[i], names[j]), c) for i, j, c in zip(want['flank_i'], want['flank_j'], want['flank_cnt'].tolist())]
+        assert (tmp_path / 'alignments.bed').read_bytes() == g['bed_all'].tobytes()
+    assert ok.any()
+
+
 def test_dict_to_matrix_golden(golden_ingest):
     g = golden_ingest
     in_set = g['d2m_in_set']

@@ -156,6 +156,53 @@ def test_cluster_files_with_split_contigs(tmp_path):
     _check_files(g, tmp_path, records)
 
 
+def test_parse_alignments_seven_containers_allelic(monkeypatch):
+    """parse_alignments with --remove_allelic_links on split contigs (:1658-1752): all seven containers — link
+    tables, HT, CLM, frag link counts, the first max_read_pairs coordinates handed to cal_concordance_ratio
+    (:454-471) and ctg_pair_to_frag (:1731-1733) — equal to the reference's frozen output, dict order included"""
+    from haphic_amd import cluster
+    from tests.conftest import load_golden
+    g = load_golden('ingest_bins.npz')
+    names = [str(x) for x in g['names']]
+    frag_names = [str(x) for x in g['frag_names']]
+    fa_dict = {n: [None, int(l), 0] for n, l in zip(names, g['ctg_len'])}
+    frag_len_dict = {f: int(l) for f, l in zip(frag_names, g['frag_len'])}
+    Nx_frag_set = {f for f, x in zip(frag_names, g['frag_nx']) if x}
+    split_ctg_set = {n for n, x in zip(names, g['ctg_split']) if x}
+
+    def nm(i):
+        return names[i] if i >= 0 else 'unplaced_scaffold'
+    aln = ((nm(a), nm(b), int(x), int(y)) for a, x, b, y in zip(g['id1'], g['pos1'], g['id2'], g['pos2']))
+
+    class A(Args):
+        flank = int(g['flank']) // 1000
+        remove_allelic_links = 4
+        max_read_pairs = int(g['max_read_pairs'])
+        nwindows = 50
+    monkeypatch.setattr(cluster, 'cal_concordance_ratio', lambda coord_list, shorter_len, nwindows: tuple(coord_list))
+    full, flank, HT, clm, frag_link, coord, c2f = cluster.parse_alignments(
+        aln, fa_dict, A(), int(g['bin_size']), frag_len_dict, Nx_frag_set, split_ctg_set, 'int32', 'int32')
+    assert list(full.items()) == [((names[i], names[j]), c) for i, j, c in zip(g['full_i'], g['full_j'], g['full_cnt'].tolist())]
+    assert list(flank.items()) == [((frag_names[i], frag_names[j]), c)
+                                   for i, j, c in zip(g['flank_i'], g['flank_j'], g['flank_cnt'].tolist())]
+    assert [frag_link.get(f, 0) for f in frag_names] == g['frag_links'].tolist()
+    cp, kp = g['clm_ptr'].tolist(), g['crd_ptr'].tolist()
+    for k, pair in enumerate(full):
+        assert list(clm[pair]) == g['clm'][cp[k]:cp[k + 1]].tolist()
+        v = coord[pair]
+        v = list(v[0]) if isinstance(v, list) else list(v)
+        assert v == g['crd'][kp[k]:kp[k + 1]].tolist()
+        if kp[k + 1] - kp[k] >= 2 * A.max_read_pairs:
+            assert isinstance(coord[pair], list) and coord[pair][1] == 1
+        ht = g['ht_cnt'][k]
+        for q, (a, b) in enumerate((('H', 'H'), ('H', 'T'), ('T', 'H'), ('T', 'T'))):
+            assert HT.get((pair[0] + '_' + a, pair[1] + '_' + b), 0) == ht[q]
+    want = {}
+    for ci, cj, fi, fj in g['c2f'].tolist():
+        want.setdefault((names[ci], names[cj]), set()).add((frag_names[fi], frag_names[fj]))
+    assert dict(c2f) == want
+
+
 def test_cluster_files_c1_config(tmp_path):
     """BASELINE.json configs[0]: ~1k contigs / 1 M pairs / nchrs = 4 — the reference's own CPU-runnable case"""
     from haphic_amd import cluster, synth

@@ -95,6 +95,32 @@ def test_ingest(golden_ingest):
             assert np.array_equal(out[k], g[k]), k
 
 
+def _text_rows(g, which):
+    return g[which][:, 0], g[which][:, 1], g[which][:, 2], g[which][:, 3]
+
+
+def test_pairs_text_restatement_pinned():
+    """a1: the tuples pairs_generator (:1539-1559) yields and the alignments.bed it writes, frozen from the
+    reference on a text with headers, blank lines, CR / CRLF ends, odd separators and odd integers"""
+    from tests.conftest import load_golden
+    g = load_golden('pairs_text.npz')
+    names = [str(x) for x in g['names']]
+    i1, p1, i2, p2, bed = orc.parse_pairs_text(g['text'].tobytes(), names)
+    live = ~((i1 == -1) & (i2 == -1) & (p1 == 0) & (p2 == 0))
+    assert np.array_equal(np.stack([i1, p1, i2, p2], 1)[live], g['all'])
+    assert bed == g['bed_all'].tobytes()
+
+
+def test_frag_pairs_restatement_pinned():
+    """ctg_pair_to_frag (:1731-1733), frozen from the reference's parse_alignments on split contigs"""
+    from tests.conftest import load_golden
+    g = load_golden('ingest_bins.npz')
+    fi, fj = orc.frag_pairs(table_of(g), g['id1'], g['pos1'], g['id2'], g['pos2'])
+    want = np.unique(g['c2f'][:, 2:], axis=0)
+    assert len(want) == len(g['c2f'])                      # a fragment pair belongs to exactly one contig pair
+    assert np.array_equal(np.stack([fi, fj], 1), want)
+
+
 def test_dict_to_matrix(golden_ingest):
     g = golden_ingest
     in_set = g['d2m_in_set']

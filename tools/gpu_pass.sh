@@ -11,6 +11,11 @@ for what in "$@"; do
     c3) timeout 900 python bench.py $C3 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/bench_c3.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3.log; grep "hhx expand" gpurun_out/bench_c3.log | head -3; python tools/bench_brief.py gpurun_out/bench_c3.log;;
     sharded1) timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --force-sharded > gpurun_out/bench_sh.log 2>&1; echo "rc=$?" >> gpurun_out/bench_sh.log; python tools/bench_brief.py gpurun_out/bench_sh.log; tail -3 gpurun_out/bench_sh.log | cut -c1-300;;
     pushes4) timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --pushes 4 > gpurun_out/bench_p4.log 2>&1; echo "rc=$?" >> gpurun_out/bench_p4.log; python tools/bench_brief.py gpurun_out/bench_p4.log | head -4;;
+    text) timeout 600 python -m pytest tests -m gpu -x -q -k "pairs_text" 2>&1 | tail -3; timeout 600 python bench.py --contigs 10000 --pairs 20000000 --nchrs 16 --mean-len 50000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/bench_text.log 2>&1; echo "rc=$?"; python -c "
+import json
+for l in open('gpurun_out/bench_text.log'):
+    if l.startswith('{'): print(json.dumps(json.loads(l)['ingest'].get('text')))
+";;
     pcie) timeout 600 python tools/pcie_rate.py 100000000 2>&1 | tail -4;;
     full) timeout 1200 python bench.py > gpurun_out/bench_full.log 2>&1; echo "rc=$?" >> gpurun_out/bench_full.log; tail -c 6000 gpurun_out/bench_full.log;;
     prof) rm -rf gpurun_out/prof; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof.log 2>&1; echo "rc=$?" >> gpurun_out/prof.log; ls -R gpurun_out/prof | head; tail -2 gpurun_out/prof.log | cut -c1-400;;
