@@ -462,6 +462,33 @@ def gen_filter(path):
     np.savez_compressed(path, **out)
 
 
+def gen_coord_stats(path):
+    """cal_concordance_ratio :419-428 and cal_concentration_adj_ratio :431-451 on random coordinate lists (the host
+    statistics behind --remove_allelic_links / --remove_concentrated_links; host mirrors in cluster.py)"""
+    from array import array
+    rng = np.random.default_rng(91)
+    lists, lens, conc, adj = [], [], [], []
+    for k in range(60):
+        npairs = int(rng.integers(3, 400))
+        shorter = int(rng.integers(20_000, 3_000_000))
+        if k % 3 == 0:      # collinear (allelic-looking) pairs with noise
+            x = rng.integers(0, shorter, npairs)
+            y = np.clip(x + rng.integers(-shorter // 40, shorter // 40 + 1, npairs), 0, None)
+        elif k % 3 == 1:    # concentrated in one bin
+            x = rng.integers(0, shorter, npairs); y = rng.integers(0, shorter, npairs)
+            x[: npairs // 2] = x[0] // 10000 * 10000 + rng.integers(0, 10000, npairs // 2)
+        else:
+            x = rng.integers(0, shorter, npairs); y = rng.integers(0, shorter, npairs)
+        c = np.stack([x, y], 1).reshape(-1).astype(np.int32)
+        lists.append(c); lens.append(shorter)
+        conc.append(float(H.cal_concordance_ratio(array('i', c.tolist()), shorter, 50)))
+        adj.append(float(H.cal_concentration_adj_ratio(array('i', c.tolist()))))
+    ptr = np.cumsum([0] + [len(c) for c in lists])
+    np.savez_compressed(path, ptr=ptr, coords=np.concatenate(lists), shorter=np.array(lens, np.int64),
+                        concordance=np.array(conc), adj=np.array(adj))
+    print('coord stats case:', len(lists), 'lists')
+
+
 def gen_pairs_text(path):
     """a1: pairs_generator / pairs_generator_inter_ctgs (:1539-1583) on a .pairs text with every line shape the
     tokeniser has to get right: header and blank lines, CRLF and lone-CR line ends, space / tab / \\x0b / \\x1c
@@ -542,3 +569,4 @@ if __name__ == '__main__':
     gen_resites(os.path.join(HERE, 'resites.npz'))
     gen_filter(os.path.join(HERE, 'filter.npz'))
     gen_pairs_text(os.path.join(HERE, 'pairs_text.npz'))
+    gen_coord_stats(os.path.join(HERE, 'coord_stats.npz'))

@@ -205,3 +205,16 @@ def test_rank_sums_pin_filter_fragments(monkeypatch):
         wl = {str(x) for x in g['case%d_whitelist' % k]} or None
         kept = cluster.filter_fragments(set(Nx_set), RE_site_dict, int(cut), frag_link, lo, up, int(topn), rsu, int(hard), flank, {}, '1.5X', wl)
         assert sorted(kept) == [str(x) for x in g['case%d_kept' % k]], k
+
+
+def test_coordinate_statistics_mirrors_pinned():
+    """the host statistics of --remove_allelic_links / --remove_concentrated_links (cal_concordance_ratio :419-428,
+    cal_concentration_adj_ratio :431-451): cluster.py's mirrors return the reference's floats exactly"""
+    from array import array
+    from haphic_amd import cluster
+    from tests.conftest import load_golden
+    g = load_golden('coord_stats.npz')
+    for k in range(len(g['shorter'])):
+        c = array('i', g['coords'][g['ptr'][k]:g['ptr'][k + 1]].tolist())
+        assert float(cluster.cal_concordance_ratio(c, int(g['shorter'][k]), 50)) == g['concordance'][k]
+        assert float(cluster.cal_concentration_adj_ratio(c)) == g['adj'][k]
