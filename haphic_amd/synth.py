@@ -102,3 +102,29 @@ def sample_pairs(genome, npairs, seed=12345, cis=0.85, device='cpu', min_dist=10
     id1, p1 = locate(c1, x1)
     id2, p2 = locate(c2, x2)
     return id1, p1, id2, p2
+
+
+def make_polyploid(base, ploidy):
+    """`ploidy` collinear copies of `base` (simulation/sim_haplotypes.py without the divergence: same contig
+    layout on every haplotype), contig k of haplotype h = id h * base.n + k, named 'hap{h+1}_' + base name."""
+    names = ['hap{}_{}'.format(h + 1, nm) for h in range(ploidy) for nm in base.names]
+    tile = lambda a: np.concatenate([a] * ploidy)
+    chrom = np.concatenate([base.chrom + h * base.nchrs for h in range(ploidy)]).astype(np.int32)
+    return Genome(names, tile(base.length), chrom, tile(base.start), tile(base.rev), tile(base.re_sites), base.chr_len,
+                  base.nchrs * ploidy)
+
+
+def add_allelic_pairs(genome, n_base, ploidy, id1, p1, id2, p2, frac, seed, jitter=2000):
+    """turn a fraction of the pairs into allelic contacts: the mate lands on the same contig of
+    another haplotype at the homologous position +- jitter.  numpy arrays in, numpy arrays out."""
+    rng = np.random.default_rng(seed)
+    id1, p1, id2, p2 = (np.array(a) for a in (id1, p1, id2, p2))
+    n = len(id1)
+    pick = rng.random(n) < frac
+    hop = rng.integers(1, ploidy, n)
+    k, h = id1 % n_base, id1 // n_base
+    mate = ((h + hop) % ploidy) * n_base + k
+    pos = np.clip(p1 + rng.integers(-jitter, jitter + 1, n), 0, genome.length[mate] - 1)
+    id2 = np.where(pick, mate, id2).astype(id2.dtype)
+    p2 = np.where(pick, pos, p2).astype(p2.dtype)
+    return id1, p1, id2, p2

@@ -378,6 +378,67 @@ def gen_pipeline_c1(path):
     np.savez_compressed(path, **out)
 
 
+C4 = dict(nchrs=3, chr_len=3_000_000, mean_len=60_000, ploidy=4, npairs=400_000, allelic=0.08, seed=4040)
+
+
+def c4_inputs():
+    """BASELINE.json configs[3] at test scale: autotetraploid (4 collinear haplotypes), cis power-law pairs inside a
+    haplotype + 8 % allelic contacts between homologous positions; shared by the generator and the GPU test"""
+    base = synth.make_genome(C4['nchrs'], C4['chr_len'], C4['mean_len'], cv=0.3, min_len=8000, seed=C4['seed'])
+    g = synth.make_polyploid(base, C4['ploidy'])
+    id1, p1, id2, p2 = [t.numpy() for t in synth.sample_pairs(g, C4['npairs'], seed=C4['seed'] + 1, cis=0.9)]
+    id1, p1, id2, p2 = synth.add_allelic_pairs(g, base.n, C4['ploidy'], id1, p1, id2, p2, C4['allelic'], C4['seed'] + 2)
+    keep = id1 != id2                                   # run() feeds the inter-contig generator (:2865)
+    return g, id1[keep], p1[keep], id2[keep], p2[keep]
+
+
+def gen_pipeline_c4(path):
+    """--remove_allelic_links 4 on an autotetraploid: parse_alignments_for_ctgs -> remove_allelic_HiC_links (:474-689,
+    networkx cliques + Hungarian matching, stays the reference's Python) -> dict_to_matrix -> run_mcl_clustering.
+    Frozen: ctg_coord_dict as remove_allelic_HiC_links receives it (key order, collapsed [ratio, 1] entries,
+    raw coordinate lists), which keys and fragments it removed, and the cluster files."""
+    g, id1, p1, id2, p2 = c4_inputs()
+    names = list(g.names)
+    fa_dict = {n_: [None, int(l), int(r)] for n_, l, r in zip(names, g.length, g.re_sites)}
+    aln = ((names[a], names[b], int(x), int(y)) for a, x, b, y in zip(id1, p1, id2, p2))
+    args = Args()
+    args.flank = 500
+    args.remove_allelic_links = 4
+    args.remove_concentrated_links = False
+    args.max_read_pairs = 40
+    args.min_read_pairs = 20
+    args.concordance_ratio_cutoff = 0.2
+    args.nwindows = 50
+    frag_len_dict = {n_: fa_dict[n_][1] for n_ in names}
+    Nx_set = set(names)
+    full, flank, HT, clm, frag_link, coord = H.parse_alignments_for_ctgs(aln, fa_dict, args, frag_len_dict, Nx_set, 'int32', 'int32')
+    cid = {n_: i for i, n_ in enumerate(names)}
+    ckeys = list(coord)
+    collapsed = np.array([isinstance(coord[k], list) for k in ckeys], bool)
+    ratio = np.array([coord[k][0] if isinstance(coord[k], list) else -1.0 for k in ckeys], np.float64)
+    raw_ptr, raw = [0], []
+    for k in ckeys:
+        if not isinstance(coord[k], list):
+            raw += list(coord[k])
+        raw_ptr.append(len(raw))
+    pre_full, pre_flank = list(full), list(flank)
+    remaining = H.remove_allelic_HiC_links(fa_dict, coord, full, args, flank, set(names))
+    out = dict(pairs_checksum=np.int64(int(id1.sum() + p1.sum() + id2.sum() + p2.sum())), n_contigs=np.int64(len(names)),
+               coord_i=np.array([cid[k[0]] for k in ckeys], np.int32), coord_j=np.array([cid[k[1]] for k in ckeys], np.int32),
+               coord_collapsed=collapsed, coord_ratio=ratio, coord_raw_ptr=np.array(raw_ptr, np.int64), coord_raw=np.array(raw, np.int64),
+               n_full=np.int64(len(pre_full)), n_flank=np.int64(len(pre_flank)),
+               full_removed=np.array([k not in full for k in pre_full], bool),
+               flank_removed=np.array([k not in flank for k in pre_flank], bool),
+               remaining=np.array([n_ in remaining for n_ in names], bool), nchrs=np.int32(C4['nchrs'] * C4['ploidy']))
+    mat, fidx = H.dict_to_matrix(flank, remaining, dense_matrix=False, add_self_loops=True)
+    out['frag_index'] = np.array([fidx.get(n_, -1) for n_ in names], np.int32)
+    infl = _run_mcl_files(mat, set(), frag_len_dict, fidx, fa_dict, int(out['nchrs']), (1.4, 2.6, 0.4), out)
+    print('pipeline c4 case: ctgs', len(names), 'pairs', len(id1), 'coord keys', len(ckeys), 'collapsed', int(collapsed.sum()),
+          'full removed', int(out['full_removed'].sum()), 'flank removed', int(out['flank_removed'].sum()),
+          'fragments kept', int(out['remaining'].sum()), 'matrix', mat.shape, mat.nnz, 'recommend:', out['log_recommend'])
+    np.savez_compressed(path, **out)
+
+
 def gen_resites(path):
     """count_RE_sites (:75-84) on slices, and stat_fragments (:188-296) on a small assembly"""
     rng = np.random.default_rng(77)
@@ -570,3 +631,4 @@ if __name__ == '__main__':
     gen_filter(os.path.join(HERE, 'filter.npz'))
     gen_pairs_text(os.path.join(HERE, 'pairs_text.npz'))
     gen_coord_stats(os.path.join(HERE, 'coord_stats.npz'))
+    gen_pipeline_c4(os.path.join(HERE, 'pipeline_c4.npz'))

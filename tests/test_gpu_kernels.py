@@ -379,6 +379,43 @@ def test_pairs_text_through_ingest(tmp_path, monkeypatch):
     assert ok.any()
 
 
+@pytest.mark.parametrize('seed,flank,npairs,chunk', [(101, 0, 5000, None), (102, 1000, 60000, 9973), (103, 30000, 200000, None),
+                                                      (104, 7000, 1, None), (105, 12000, 300000, 65536)])
+def test_ingest_bins_randomised_vs_oracle(seed, flank, npairs, chunk):
+    """split contigs, random flank widths (0 = every position is flank :299-307), single pairs, ragged pushes: every
+    table, the CLM distances, the first coordinates and the fused link matrix against the oracle"""
+    t, id1, p1, id2, p2 = _random_bins_case(npairs, seed)
+    rng = np.random.default_rng(seed)
+    id1 = id1.copy()
+    id1[rng.random(npairs) < 0.02] = -1                      # names that are not in the FASTA
+    want = orc.ingest(t, id1, p1, id2, p2, flank, bins=True, want_clm=True, max_read_pairs=7)
+    ing = _lib.Ingest(t, flank, bins=True)
+    ing.keep_pairs()
+    step = chunk or npairs
+    for s in range(0, npairs, step):
+        ing.push(id1[s:s + step], p1[s:s + step], id2[s:s + step], p2[s:s + step])
+    out = ing.fetch()
+    for k in ('full_i', 'full_j', 'full_cnt', 'ht_cnt', 'flank_i', 'flank_j', 'flank_cnt', 'frag_links'):
+        assert np.array_equal(out[k], want[k]), k
+    clm_ptr, clm, crd_ptr, crd = ing.fetch_pairs(7, out['full_cnt'])
+    assert np.array_equal(4 * clm_ptr, want['clm_ptr']) and np.array_equal(clm, want['clm'])
+    assert np.array_equal(2 * crd_ptr, want['crd_ptr']) and np.array_equal(crd, want['crd'])
+    in_set = t.frag_nx.copy()
+    in_set[rng.random(len(in_set)) < 0.1] = 0                # a filtered fragment set (filter_fragments' output)
+    m, fidx, n_linked = ing.link_matrix(in_set)
+    ok = in_set[want['flank_i']].astype(bool) & in_set[want['flank_j']].astype(bool)
+    linked = np.zeros(len(in_set), bool)
+    linked[want['flank_i'][ok]] = True
+    linked[want['flank_j'][ok]] = True
+    n_rest = int(in_set.sum() - linked.sum())
+    rp, rj, rx, ridx, rl = orc.dict_to_matrix(want['flank_i'], want['flank_j'], want['flank_cnt'].astype(np.float64), len(in_set),
+                                              in_set, n_rest)
+    assert n_linked == rl and np.array_equal(fidx, ridx)
+    assert all(np.array_equal(a, b) for a, b in zip(m.to_arrays(), (rp, rj, rx)))
+    m.free()
+    ing.destroy()
+
+
 def test_dict_to_matrix_golden(golden_ingest):
     g = golden_ingest
     in_set = g['d2m_in_set']

@@ -227,6 +227,59 @@ def test_cluster_files_c1_config(tmp_path):
     _check_files(g, tmp_path, records)
 
 
+def test_cluster_files_c4_allele_aware(tmp_path):
+    """BASELINE.json configs[3] at test scale: autotetraploid, --remove_allelic_links 4.  The device ingest must hand
+    remove_allelic_HiC_links (:474-689, the reference's own Python: cliques + Hungarian matching) exactly the
+    ctg_coord_dict the reference loop builds — key order, concordance ratios of the collapsed entries (:460-465, host
+    statistic on the first max_read_pairs coordinates), raw coordinate lists; with its frozen verdict applied (which
+    contig pairs and fragments go), dict_to_matrix + the inflation sweep write byte-identical cluster files"""
+    from haphic_amd import cluster, synth
+    from tests.conftest import load_golden
+    g = load_golden('pipeline_c4.npz')
+    base = synth.make_genome(3, 3_000_000, 60_000, cv=0.3, min_len=8000, seed=4040)
+    gen = synth.make_polyploid(base, 4)
+    id1, p1, id2, p2 = [t.numpy() for t in synth.sample_pairs(gen, 400_000, seed=4041, cis=0.9)]
+    id1, p1, id2, p2 = synth.add_allelic_pairs(gen, base.n, 4, id1, p1, id2, p2, 0.08, 4042)
+    keep = id1 != id2
+    id1, p1, id2, p2 = id1[keep], p1[keep], id2[keep], p2[keep]
+    if int(id1.sum() + p1.sum() + id2.sum() + p2.sum()) != int(g['pairs_checksum']):
+        pytest.skip('torch CPU generator differs from the one that made the fixture')
+    names = list(gen.names)
+    assert len(names) == int(g['n_contigs'])
+    fa_dict = {n: [None, int(l), int(r)] for n, l, r in zip(names, gen.length, gen.re_sites)}
+    aln = ((names[a], names[b], int(x), int(y)) for a, x, b, y in zip(id1, p1, id2, p2))
+
+    class A(Args):
+        remove_allelic_links = 4
+        max_read_pairs = 40
+        min_read_pairs = 20
+        concordance_ratio_cutoff = 0.2
+    frag_len_dict = {n: fa_dict[n][1] for n in names}
+    full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(aln, fa_dict, A(), frag_len_dict, set(names), 'int32', 'int32')
+    assert (len(full), len(flank)) == (int(g['n_full']), int(g['n_flank']))
+    # ctg_coord_dict == the reference's, entry by entry and in order
+    assert [(names[i], names[j]) for i, j in zip(g['coord_i'], g['coord_j'])] == list(coord)
+    rp = g['coord_raw_ptr'].tolist()
+    for k, pair in enumerate(coord):
+        v = coord[pair]
+        if g['coord_collapsed'][k]:
+            assert isinstance(v, list) and v[1] == 1 and float(v[0]) == g['coord_ratio'][k], pair
+        else:
+            assert list(v) == g['coord_raw'][rp[k]:rp[k + 1]].tolist(), pair
+    # the reference's remove_allelic_HiC_links verdict, applied to OUR dicts
+    for k, gone in zip(list(full), g['full_removed']):
+        if gone:
+            del full[k]
+    for k, gone in zip(list(flank), g['flank_removed']):
+        if gone:
+            del flank[k]
+    remaining = {n for n, r in zip(names, g['remaining']) if r}
+    mat, fidx = cluster.dict_to_matrix(flank, remaining, dense_matrix=False, add_self_loops=True, _device=True)
+    assert [fidx.get(n, -1) for n in names] == g['frag_index'].tolist()
+    records = _run_clustering(cluster, mat, set(), frag_len_dict, fidx, fa_dict, int(g['nchrs']), (1.4, 2.6, 0.4), tmp_path)
+    _check_files(g, tmp_path, records)
+
+
 def test_edge_cases():
     """empty stream, every pair dropped, a single key, link-less fragments only, unknown names"""
     from haphic_amd import _lib

@@ -6,7 +6,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 C3="--contigs 100000 --pairs 500000000 --nchrs 24 --mean-len 30000"
 for what in "$@"; do
   case $what in
-    tests) timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; tail -4 gpurun_out/pytest_gpu.log;;
+    tests) timeout 900 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; grep -A8 "slowest" gpurun_out/pytest_gpu.log | head -9; tail -2 gpurun_out/pytest_gpu.log;;
     c2) timeout 600 python bench.py --contigs 10000 --pairs 50000000 --nchrs 16 --mean-len 50000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_c2.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c2.log; python tools/bench_brief.py gpurun_out/bench_c2.log;;
     c3) timeout 900 python bench.py $C3 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/bench_c3.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3.log; grep "hhx expand" gpurun_out/bench_c3.log | head -3; python tools/bench_brief.py gpurun_out/bench_c3.log;;
     sharded1) timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --force-sharded > gpurun_out/bench_sh.log 2>&1; echo "rc=$?" >> gpurun_out/bench_sh.log; python tools/bench_brief.py gpurun_out/bench_sh.log; tail -3 gpurun_out/bench_sh.log | cut -c1-300;;
