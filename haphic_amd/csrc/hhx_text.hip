@@ -167,6 +167,42 @@ __device__ __forceinline__ int first_tokens(const RD &rd, i64 a, i64 e, Tok tok[
     return n;
 }
 
+// whitespace bytes of an 8-byte word as an 8-bit mask.  Per byte, with the high bit forced on, (x - n) keeps the
+// high bit iff the low 7 bits are >= n (n <= 0x80: no borrow crosses a byte), so two range tests give is_ws()
+// exactly; the flags are gathered with one multiply (distinct (byte, shift) pairs never collide).
+__device__ __forceinline__ u32 ws_mask8(u64 w) {
+    constexpr u64 H = 0x8080808080808080ull, L = 0x0101010101010101ull;
+    const u64 x = w | H;
+    const u64 m = (((x - 9 * L) & ~(x - 14 * L)) | ((x - 0x1c * L) & ~(x - 0x21 * L))) & H & ~w;
+    return (u32)((m * 0x0002040810204081ull) >> 56);
+}
+
+// first_tokens on the LDS-staged text: token boundaries from the whitespace masks of the aligned 8-byte words
+__device__ __forceinline__ int first_tokens(const LdsText &rd, i64 a, i64 e, Tok tok[5]) {
+    const u32 ao = (u32)(a - rd.bias), eo = (u32)(e - rd.bias);
+    int n = 0;
+    u32 ts = 0, in_tok = 0;
+    for (u32 wi = ao >> 3; (wi << 3) < eo && n < 5; ++wi) {
+        const i32 lo = (i32)ao - (i32)(wi << 3), hi = (i32)eo - (i32)(wi << 3);
+        u32 valid = 0xffu;                                       // bytes outside [a, e) count as whitespace
+        if (lo > 0) valid &= 0xffu << lo;
+        if (hi < 8) valid &= (1u << hi) - 1;
+        const u32 tokb = ~ws_mask8(rd.l64[wi]) & valid;          // bytes that belong to a token
+        const u32 prev = (tokb << 1) | in_tok;
+        const u32 starts = tokb & ~prev;
+        u32 ev = (starts | (~tokb & prev)) & 0xffu;              // a token starts at / has ended before byte k
+        while (ev && n < 5) {
+            const int k = __ffs(ev) - 1;
+            ev &= ev - 1;
+            if ((starts >> k) & 1) ts = (wi << 3) + k;
+            else { tok[n].s = rd.bias + ts; tok[n].len = (i32)((wi << 3) + k - ts); ++n; }
+        }
+        in_tok = (tokb >> 7) & 1;
+    }
+    if (n < 5 && in_tok) { tok[n].s = rd.bias + ts; tok[n].len = (i32)(eo - ts); ++n; }
+    return n;
+}
+
 struct NameTable {
     const u64 *names;                                            // every name padded with zeros to whole 8-byte words
     const i64 *name_off;                                         // in words; name_len in bytes
@@ -270,7 +306,7 @@ __device__ __forceinline__ void parse_one(const RD &rd, i64 k, i64 a, i64 e, con
             o2 = lookup(T, rd, tok[3]);
             q1 = (i32)(v1 - 1);
             q2 = (i32)(v2 - 1);
-            blen = tok[1].len + tok[3].len + 2 * (i64)tok[0].len + 2 * dec_len(v1 - 1) + 2 * dec_len(v2 - 1) + 24;
+            if (O.bed_len) blen = tok[1].len + tok[3].len + 2 * (i64)tok[0].len + 2 * dec_len(v1 - 1) + 2 * dec_len(v2 - 1) + 24;
         }
     }
     O.id1[k] = o1; O.pos1[k] = q1; O.id2[k] = o2; O.pos2[k] = q2;
