@@ -19,6 +19,8 @@
 // in HBM; when the row sum is final the candidates are tested exactly as the reference does
 // (q = float(p / S) >= float32(pruning), first row maximum restored, second L1 normalisation) and the
 // survivors are bump-allocated; a final pass packs the rows into CSR order.
+#include <chrono>
+
 #include "hhx_common.h"
 
 using namespace hhx;
@@ -51,6 +53,7 @@ struct ExParams {
     i32 n_rows, n_cols;
     double scale, inv_scale;        // 2^(shift-52), 2^(52-shift): products are rounded on the 2^-52 grid of [1,2)
     double r; int square; float thr;
+    int fake_decode;                // probe only (HHX_CODED_FAKE): skip the count decode, results are garbage
     int raw;                        // 1: plain product C = A * B (hhx_spgemm): every non-zero entry is written, nothing else
     // candidate + survivor pools (col, value) and the per-row table
     i32 *cand_col; float *cand_val; i64 cand_cap;
@@ -179,7 +182,7 @@ __device__ __forceinline__ void stage_chunk(const ExParams &P, const ExLds &l, i
             qb = wp[0]; qe = wp[1];
         } else { qb = P.Bp[k]; qe = P.Bp[k + 1]; }
         l.st_da[t] = (double)P.Ax[a0 + t] * P.scale;
-        if (CODED) l.st_s[t] = P.Bs[k];
+        if (CODED) l.st_s[t] = P.fake_decode ? -1.0 : P.Bs[k];
         l.st_qb[t] = qb;
         l.st_qe[t] = qe;
     }
@@ -223,6 +226,7 @@ struct Tile {
 // quotient, so both round to the same float unless a float rounding boundary (a double whose low 29 mantissa
 // bits are 1000...0) lies that close — then, about once per 10^8 entries, the exact division is done.
 __device__ __forceinline__ float coded_value(u32 cnt, double s, double r) {
+    if (s < 0.0) return (float)cnt * 1e-6f;
     const double q = (double)cnt * r;
     const u32 low = (u32)__double_as_longlong(q) & 0x1fffffffu;
     if (__builtin_expect(low - 0x0ffffffcu <= 8u, 0)) return (float)((double)cnt / s);
@@ -253,16 +257,20 @@ __device__ __forceinline__ void tile_fetch(const ExParams &P, const ExLds &l, Se
         if (c.q >= c.qe) { c.e += EX_WAVES; seg_open<CODED>(l, c, len); }
     }
 }
-template <bool CODED>
-__device__ __forceinline__ void tile_consume(const ExLds &l, const Tile &t) {
+// PROBE (HHX_PROBE, measurement only — results are garbage): 1 = no LDS operation per product (register sink),
+// 2 = a plain ds_write_b64 instead of the atomic add
+template <bool CODED, int PROBE = 0>
+__device__ __forceinline__ void tile_consume(const ExLds &l, const Tile &t, double &sink) {
 #pragma unroll
     for (int u = 0; u < TILE_U; ++u)
         if (t.j[u] != 0xffffffffu) {
             const float b = CODED ? coded_value(t.v[u], t.s, t.r) : __uint_as_float(t.v[u]);
-            acc_add(&l.acc[t.j[u]], t.da * (double)b);
+            if (PROBE == 1) sink += (t.da * (double)b + 1.0) - 1.0;
+            else if (PROBE == 2) l.acc[t.j[u]] = (t.da * (double)b + 1.0) - 1.0;
+            else acc_add(&l.acc[t.j[u]], t.da * (double)b);
         }
 }
-template <bool CODED>
+template <bool CODED, int PROBE = 0>
 __device__ __forceinline__ void accumulate_window(const ExParams &P, const ExLds &l, i32 len) {
     SegCursor c;
     c.e = threadIdx.x / HHX_WAVE;
@@ -270,14 +278,16 @@ __device__ __forceinline__ void accumulate_window(const ExParams &P, const ExLds
     seg_open<CODED>(l, c, len);
     Tile ta, tb;
     tile_fetch<CODED>(P, l, c, len, ta);
+    double sink = 0.0;
     for (;;) {
         tile_fetch<CODED>(P, l, c, len, tb);
-        tile_consume<CODED>(l, ta);
+        tile_consume<CODED, PROBE>(l, ta, sink);
         if (!tb.valid) break;
         tile_fetch<CODED>(P, l, c, len, ta);
-        tile_consume<CODED>(l, tb);
+        tile_consume<CODED, PROBE>(l, tb, sink);
         if (!ta.valid) break;
     }
+    if (PROBE == 1 && sink == 123.456) l.acc[0] = sink;
 }
 // compact mode: mark, then acc[rank(c)] += fixed(a * b)
 __device__ __forceinline__ void mark_compact(const ExParams &P, const ExLds &l, i32 len) {
@@ -514,7 +524,7 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
 // B[:, w] (nnz_B / n_win entries), which raises the Infinity Cache / L2 hit rate of the B-row stream
 // compared with a row-outer nest (measured at n = 100k, 6 windows: 1.59 s vs 1.76 s before tile
 // pipelining), and the per-row epilogue (finalize) becomes its own uniform launch.
-template <bool CODED>
+template <bool CODED, int PROBE = 0>
 __global__ __launch_bounds__(EX_T_WIN) void k_expand_window_pass(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap,
                                                                  i32 wv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -533,7 +543,7 @@ __global__ __launch_bounds__(EX_T_WIN) void k_expand_window_pass(ExParams P, con
             if (n_win > 1) stage_chunk<true, CODED>(P, l, a0, len, wv);
             else stage_chunk<false, CODED>(P, l, a0, len, wv);
             __syncthreads();
-            accumulate_window<CODED>(P, l, len);
+            accumulate_window<CODED, PROBE>(P, l, len);
             __syncthreads();
         }
         i32 nz;
@@ -786,6 +796,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     if (a->n_cols != b->n_rows) return fail("expand shape mismatch");
     if (!(inflation > 0)) return fail("inflation must be positive");
     if (fx_shift < 0 || fx_shift > 52) fx_shift = 52;        // the exact-double accumulation holds 52 fractional bits
+    const auto t_enter = std::chrono::steady_clock::now();
     const i32 n_rows = a->n_rows, n_cols = b->n_cols;
     const i32 W = (n_cols + 31) / 32;
     // ---- plans
@@ -818,10 +829,13 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     if (!attr_set) {
         HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_expand_compact, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     static const bool debug = getenv("HHX_DEBUG") != nullptr;
+    static const int probe = getenv("HHX_PROBE") ? atoi(getenv("HHX_PROBE")) : 0;
     // rows whose product count is well above the number of accumulator slots a dense sweep touches
     static const double wfac = getenv("HHX_WINDOW_FACTOR") ? atof(getenv("HHX_WINDOW_FACTOR")) : 0.5;
     const i64 window_min = std::max<i64>(4096, (i64)((double)n_cols * wfac));
@@ -878,6 +892,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         P.win_ptr = win_ptr.p; P.n_win = n_win;
         P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
         P.Bc16 = nullptr; P.Bn16 = coded.n16; P.Bs = coded.row_sum;
+        P.fake_decode = getenv("HHX_CODED_FAKE") != nullptr;
         if (hc[0]) {
             if (!c16.p) {                                 // 16-bit window-local columns of B, built once per call
                 if (c16.alloc((size_t)b->nnz)) return 1;
@@ -891,6 +906,8 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             { KTimer kt("expand_window", n_win);            // one timer scope, n_win launches of k_expand_window_pass
             for (i32 wv = 0; wv < n_win; ++wv) {
                 if (is_coded) k_expand_window_pass<true><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
+                else if (probe == 1) k_expand_window_pass<false, 1><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
+                else if (probe == 2) k_expand_window_pass<false, 2><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
                 else k_expand_window_pass<false><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
             } }
             KTimer kt("expand_finalize");
@@ -913,8 +930,9 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         HHX_HIP(hipStreamSynchronize(g_stream));
         if (debug)
             fprintf(stderr, "[hhx expand] %d x %d, nnzA %lld nnzB %lld: window rows %u (n_win %d x %d cols, lds %zu), compact rows %u; "
-                    "candidates %llu / %lld, survivors %llu / %lld%s\n", n_rows, n_cols, (long long)a->nnz, (long long)b->nnz, hc[0], n_win,
-                    cap_win, lds_win, hc[1], cur[0], (long long)cand_cap, cur[1], (long long)pool_cap, cur[2] ? "  OVERFLOW -> retry" : "");
+                    "candidates %llu / %lld, survivors %llu / %lld, %.1f ms since entry%s\n", n_rows, n_cols, (long long)a->nnz, (long long)b->nnz, hc[0], n_win,
+                    cap_win, lds_win, hc[1], cur[0], (long long)cand_cap, cur[1], (long long)pool_cap,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count(), cur[2] ? "  OVERFLOW -> retry" : "");
         if (cur[2]) {                                  // a pool overflowed: grow and redo the launches
             if ((i64)cur[0] > cand_cap) cand_cap = std::max<i64>(cand_cap * 2, (i64)cur[0] + (i64)n_rows);
             if ((i64)cur[1] > pool_cap) pool_cap = std::max<i64>(pool_cap * 2, (i64)cur[1] + (i64)n_rows);
