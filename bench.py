@@ -100,9 +100,9 @@ def main():
             ing.push_device(hi - lo, id1[lo:hi].data_ptr(), p1[lo:hi].data_ptr(), id2[lo:hi].data_ptr(), p2[lo:hi].data_ptr())
         n_full, n_flank = ing.finalize()
         if sharded_path:
-            m, n_linked, merged = sharded.merge_flank_and_build(ing, table, flank, False, in_set, dist, dev)
-            n_full, n_flank = merged.n_full, merged.n_flank
-            merged.destroy()
+            # all-reduce(min) of the first positions + all-to-all(v) of the matrix entries by row owner: every rank ends
+            # up with ITS row block of the link matrix (no rank ever holds another rank's table)
+            m, _fi, n_linked, shape = sharded.build_link_matrix_sharded(sharded.HipEngine(dev), ing, in_set, dist)
         else:
             # dict_to_matrix fused onto the device-resident table; link-less contigs get trailing indices
             m, fidx, n_linked = ing.link_matrix(in_set)
@@ -113,8 +113,8 @@ def main():
         # ---- run_mcl_clustering :2144-2158 at one inflation
         t2 = time.perf_counter()
         if sharded_path:
-            _lib.normalize_l1(m)                                                # :2144
-            res, n_iter, conv, stats = sharded.mcl_sharded(m, 2, args.inflation, 200, 1e-4, dist, dev)
+            _lib.normalize_l1(m)                                                # :2144, row-local
+            res, n_iter, conv, stats = sharded.mcl_sharded(None, 2, args.inflation, 200, 1e-4, dist, dev, local_block=m, n=shape)
         else:
             # normalisation (:2144) and pre-expansion (:2146-2147) fused into iteration 0: the 10^8..10^10-entry
             # M^2 never exists, and iteration 0 streams the link matrix as 16-bit counts

@@ -56,24 +56,25 @@ __global__ __launch_bounds__(256) void k_first_pos(View vw, i64 n_keys, const un
 // 2 * ordinal + side are distinct (a position names one side of one read pair) but sparse in
 // [0, 2 * #pairs), so they are ranked by a tiled all-pairs count over the n_frag values (LDS broadcast
 // tiles; 10^10 compares at n = 100k, a fraction of a millisecond on 256 CUs) instead of a bitmap.
+// `none` marks a fragment without entries: ~0 here, INT64_MAX in the multi-GPU build (its all-reduce(min) is signed)
 __global__ __launch_bounds__(256) void k_rank_first(i32 n_frag, const unsigned long long *__restrict__ first_pos,
-                                                    i32 *__restrict__ frag_index, unsigned int *n_linked) {
+                                                    i32 *__restrict__ frag_index, unsigned int *n_linked, unsigned long long none = ~0ull) {
     __shared__ unsigned long long tile[1024];
     const i32 f = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long mine = f < n_frag ? first_pos[f] : ~0ull;
+    const unsigned long long mine = f < n_frag ? first_pos[f] : none;
     i32 rank = 0;
     for (i32 t0 = 0; t0 < n_frag; t0 += 1024) {
-        for (i32 t = threadIdx.x; t < 1024; t += blockDim.x) tile[t] = (t0 + t < n_frag) ? first_pos[t0 + t] : ~0ull;
+        for (i32 t = threadIdx.x; t < 1024; t += blockDim.x) tile[t] = (t0 + t < n_frag) ? first_pos[t0 + t] : none;
         __syncthreads();
-        if (mine != ~0ull) {
+        if (mine != none) {
 #pragma unroll 8
             for (i32 t = 0; t < 1024; ++t) rank += tile[t] < mine;
         }
         __syncthreads();
     }
     if (f < n_frag) {
-        frag_index[f] = mine == ~0ull ? -1 : rank;
-        if (mine != ~0ull) atomicAdd(n_linked, 1u);
+        frag_index[f] = mine == none ? -1 : rank;
+        if (mine != none) atomicAdd(n_linked, 1u);
     }
 }
 template <class View>
@@ -466,4 +467,265 @@ int hhx_link_matrix_from_run(const LinkRun *run, i32 n_frag, u64 ord_limit, cons
         return link_matrix_partitioned(run, n_frag, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked_out, out);
     const RunView vw{run ? run->key.p : nullptr, run ? run->ord_flank.p : nullptr, run ? run->fl.p : nullptr};
     return build_matrix(vw, run ? run->n : 0, n_frag, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked_out, out);
+}
+
+// ================================================================================================
+// Multi-GPU build of the link matrix (haphic_amd/sharded.py: build_link_matrix_sharded).  Every rank holds the
+// aggregated table of ITS chunk of the pair stream (ordinals are global stream ordinals).  dict_to_matrix's index of
+// a fragment is the rank of its first position 2 * ordinal + side over the whole stream, and a first position is a
+// minimum — so the ranks all-reduce(min) one int64 per fragment, rank it identically, and then exchange matrix
+// ENTRIES (row index, column index, count) by row owner instead of gathering every rank's whole table:
+//   hhx_shard_create     this rank's directed entries partitioned by row fragment (same pipeline as the 1-GPU build)
+//   hhx_shard_first      first position of every fragment in this chunk (INT64_MAX: none)      -> all-reduce(min)
+//   hhx_rank_first       matrix index of every fragment from the reduced positions (replicated)
+//   hhx_shard_emit       the entries rewritten as (row << 29 | column, count), sorted by matrix row -> all-to-all(v)
+//   hhx_rows_from_entries  the owner groups what it received by row, adds up the counts of equal (row, column)
+//                        coming from different chunks, and writes its CSR row block (self loops, link-less rows)
+struct hhx_shard {
+    i32 n_frag = 0;
+    hhx::Partitioned<u64> part;
+    hhx::DevBuf<long long> first;          // [n_frag]
+    hhx::DevBuf<i32> row_len;              // [n_frag] entries of the fragment in this chunk
+    hhx::DevBuf<u64> out_w0, out_w1;
+    hhx::DevBuf<unsigned char> in_set;
+};
+
+namespace {
+
+constexpr long long SHARD_NONE = INT64_MAX;
+
+__global__ __launch_bounds__(256) void k_first_signed(i32 n_frag, const unsigned long long *__restrict__ first_pos, long long *__restrict__ out) {
+    for (i32 f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frag; f += gridDim.x * blockDim.x)
+        out[f] = first_pos[f] == ~0ull ? SHARD_NONE : (long long)first_pos[f];
+}
+__global__ __launch_bounds__(256) void k_len_by_row(i32 n_frag, const i32 *__restrict__ frag_index, const i32 *__restrict__ row_len,
+                                                    i64 *__restrict__ len_by_row) {
+    for (i32 f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frag; f += gridDim.x * blockDim.x)
+        if (frag_index[f] >= 0) len_by_row[frag_index[f]] = row_len[f];             // one writer per row
+}
+// one wave per fragment: its entries move to the slot of its matrix row, fragment ids become matrix indices
+__global__ __launch_bounds__(256) void k_emit_by_row(i32 n_frag, const i64 *__restrict__ base, const u64 *__restrict__ w0, const u64 *__restrict__ w1,
+                                                     const i32 *__restrict__ frag_index, const i64 *__restrict__ row_off,
+                                                     u64 *__restrict__ o0, u64 *__restrict__ o1) {
+    const int lane = lane_id();
+    for (i32 a = blockIdx.x * 4 + threadIdx.x / HHX_WAVE; a < n_frag; a += gridDim.x * 4) {
+        const i32 r = frag_index[a];
+        const i64 b = base[a], e = base[a + 1];
+        if (r < 0 || b == e) continue;
+        const i64 d = row_off[r];
+        for (i64 p = b + lane; p < e; p += HHX_WAVE) {
+            o0[d + (p - b)] = ((u64)(u32)r << ID_BITS) | (u64)(u32)frag_index[(u32)(w0[p] & ID_MASK)];
+            o1[d + (p - b)] = w1[p] & 0x7fffffffull;
+        }
+    }
+}
+struct DigLocalRow {
+    u32 r0;
+    __device__ __forceinline__ u32 operator()(u64 w0) const { return (u32)(w0 >> ID_BITS) - r0; }
+};
+// LDS bitmap of the distinct columns of one row; returns nothing, leaves bitmap[] filled (all threads must call)
+__device__ __forceinline__ void mark_columns(u32 *bitmap, i32 W, const u64 *__restrict__ w0, i64 b, i64 e, i32 self_col) {
+    for (i32 w = threadIdx.x; w < W; w += 256) bitmap[w] = 0;
+    __syncthreads();
+    for (i64 p = b + threadIdx.x; p < e; p += 256) { const u32 c = (u32)(w0[p] & ID_MASK); atomicOr(&bitmap[c >> 5], 1u << (c & 31)); }
+    if (self_col >= 0 && threadIdx.x == 0) atomicOr(&bitmap[self_col >> 5], 1u << (self_col & 31));
+    __syncthreads();
+}
+// distinct columns per local row (+ the self loop)
+__global__ __launch_bounds__(256) void k_rows_distinct(i32 n_local, i32 r0, i32 W, int self_loop, const i64 *__restrict__ base, const u64 *__restrict__ w0,
+                                                       i32 *__restrict__ cnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32 *bitmap = (u32 *)smem;
+    i32 *wsum = (i32 *)(bitmap + W);                             // no static LDS: the 160 KB attribute needs it all dynamic
+    for (i32 a = blockIdx.x; a < n_local; a += gridDim.x) {
+        const i64 b = base ? base[a] : 0, e = base ? base[a + 1] : 0;
+        if (b == e) { if (threadIdx.x == 0) cnt[a] = self_loop ? 1 : 0; continue; }
+        mark_columns(bitmap, W, w0, b, e, self_loop ? r0 + a : -1);
+        i32 c = 0;
+        for (i32 w = threadIdx.x; w < W; w += 256) c += __popc(bitmap[w]);
+        c = wave_sum_i32(c);
+        if (lane_id() == 0) wsum[threadIdx.x / HHX_WAVE] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) cnt[a] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
+// CSR row block: columns in order (bitmap rank), counts of equal columns added up as integers, then cast to float
+__global__ __launch_bounds__(256) void k_rows_merge_emit(i32 n_local, i32 r0, i32 W, int self_loop, const i64 *__restrict__ base, const u64 *__restrict__ w0,
+                                                         const u64 *__restrict__ w1, const i32 *__restrict__ indptr, i32 *__restrict__ oj,
+                                                         float *__restrict__ ox) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32 *bitmap = (u32 *)smem, *prefix = bitmap + W, *scratch = prefix + W;
+    const int tid = threadIdx.x;
+    u32 *oxu = reinterpret_cast<u32 *>(ox);
+    for (i32 a = blockIdx.x; a < n_local; a += gridDim.x) {
+        const i64 b = base ? base[a] : 0, e = base ? base[a + 1] : 0;
+        const i32 ob = indptr[a], oe = indptr[a + 1], r = r0 + a;
+        if (b == e) {                                            // link-less row: the unit self loop only
+            if (tid == 0 && oe > ob) { oj[ob] = r; ox[ob] = 1.0f; }
+            continue;
+        }
+        mark_columns(bitmap, W, w0, b, e, self_loop ? r : -1);
+        const i32 per = (W + 255) / 256, wa = tid * per, wb = min(W, wa + per);
+        u32 local = 0;
+        for (i32 w = wa; w < wb; ++w) local += __popc(bitmap[w]);
+        scratch[tid] = local;
+        for (i32 k = ob + tid; k < oe; k += 256) oxu[k] = 0;
+        __syncthreads();
+        if (tid == 0) { u32 run = 0; for (int t = 0; t < 256; ++t) { const u32 v = scratch[t]; scratch[t] = run; run += v; } }
+        __syncthreads();
+        u32 run = scratch[tid];
+        for (i32 w = wa; w < wb; ++w) { prefix[w] = run; run += __popc(bitmap[w]); }
+        __syncthreads();
+        for (i64 p = b + tid; p < e; p += 256) {
+            const u32 c = (u32)(w0[p] & ID_MASK);
+            const i32 k = ob + (i32)(prefix[c >> 5] + __popc(bitmap[c >> 5] & ((1u << (c & 31)) - 1u)));
+            oj[k] = (i32)c;
+            atomicAdd(&oxu[k], (u32)w1[p]);
+        }
+        __syncthreads();
+        for (i32 k = ob + tid; k < oe; k += 256) ox[k] = (float)atomicOr(&oxu[k], 0u);   // read at L2; int -> float32, the cast of :368
+        __syncthreads();
+        if (self_loop && tid == 0) {
+            const i32 k = ob + (i32)(prefix[r >> 5] + __popc(bitmap[r >> 5] & ((1u << (r & 31)) - 1u)));
+            oj[k] = r;
+            ox[k] = 1.0f;                                        // :362-364 (a flank key never has i == j)
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int hhx_shard_create(hhx_ingest *h, const uint8_t *in_set_host, hhx_shard **out) {
+    if (!h || !h->finalized || !in_set_host || !out) return fail("hhx_shard_create: bad argument (finalize the ingest first)");
+    if (h->ord_limit > ((u64)1 << 31)) return fail("hhx_shard_create: more than 2^31 read pairs in the stream");
+    const LinkRun *run = h->table(1);
+    const i32 n_frag = h->t.n_frag;
+    if (n_frag > (1 << 20)) return fail("hhx_shard_create: more than 2^20 fragments");
+    auto *s = new hhx_shard();
+    s->n_frag = n_frag;
+    DevBuf<unsigned long long> first_pos;
+    if (s->in_set.alloc((size_t)n_frag) || s->first.alloc((size_t)n_frag) || s->row_len.alloc((size_t)n_frag) || first_pos.alloc((size_t)n_frag)) { delete s; return 1; }
+    int rc = 0;
+    do {
+        if (hipMemcpyAsync(s->in_set.p, in_set_host, (size_t)n_frag, hipMemcpyHostToDevice, g_stream) != hipSuccess) { rc = fail("hhx_shard_create: copy failed"); break; }
+        int row_bits = 0;
+        while (((i64)1 << row_bits) < n_frag) ++row_bits;
+        if (run && run->n) {
+            const SrcDirected src{run->key.p, run->ord_flank.p, run->fl.p, s->in_set.p};
+            if ((rc = partition_records(src, DigRow(), 2 * run->n, row_bits, 9, &s->part, "d2m"))) break;
+        }
+        if (s->part.n_valid == 0) {
+            (void)hipMemsetAsync(first_pos.p, 0xff, sizeof(unsigned long long) * (size_t)n_frag, g_stream);
+            (void)hipMemsetAsync(s->row_len.p, 0, sizeof(i32) * (size_t)n_frag, g_stream);
+        } else {
+            k_row_first<<<grid_for((u64)n_frag * 64), 256, 0, g_stream>>>(n_frag, s->part.base.p, s->part.w1.p, first_pos.p, s->row_len.p);
+        }
+        k_first_signed<<<grid_for((u64)n_frag), 256, 0, g_stream>>>(n_frag, first_pos.p, s->first.p);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(g_stream) != hipSuccess) { rc = fail("hhx_shard_create: kernel failed"); break; }
+    } while (0);
+    if (rc) { delete s; return rc; }
+    *out = s;
+    return 0;
+}
+
+extern "C" int hhx_shard_first(hhx_shard *s, void **first_dev) {
+    if (!s || !first_dev) return fail("hhx_shard_first: null argument");
+    *first_dev = s->first.p;
+    return 0;
+}
+
+extern "C" int hhx_rank_first(i32 n_frag, const void *first_dev, void *frag_index_dev, i32 *n_linked) {
+    if (n_frag <= 0 || !first_dev || !frag_index_dev) return fail("hhx_rank_first: bad argument");
+    DevBuf<unsigned int> nl;
+    if (nl.alloc(1)) return 1;
+    HHX_HIP(hipMemsetAsync(nl.p, 0, sizeof(unsigned int), g_stream));
+    k_rank_first<<<(unsigned)((n_frag + 255) / 256), 256, 0, g_stream>>>(n_frag, (const unsigned long long *)first_dev, (i32 *)frag_index_dev, nl.p,
+                                                                        (unsigned long long)SHARD_NONE);
+    HHX_LAUNCH_CHECK();
+    unsigned int v = 0;
+    HHX_HIP(hipMemcpyAsync(&v, nl.p, sizeof v, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    if (n_linked) *n_linked = (i32)v;
+    return 0;
+}
+
+extern "C" int hhx_shard_emit(hhx_shard *s, const void *frag_index_dev, i32 n_bounds, const i32 *bounds, void **w0_dev, void **w1_dev, i64 *counts) {
+    if (!s || !frag_index_dev || n_bounds < 2 || !bounds || !w0_dev || !w1_dev || !counts) return fail("hhx_shard_emit: bad argument");
+    const i32 shape = bounds[n_bounds - 1];
+    const i64 n = s->part.n_valid;
+    DevBuf<i64> len_by_row, row_off;
+    if (len_by_row.alloc((size_t)shape + 1) || row_off.alloc((size_t)shape + 2)) return 1;
+    HHX_HIP(hipMemsetAsync(len_by_row.p, 0, sizeof(i64) * ((size_t)shape + 1), g_stream));
+    k_len_by_row<<<grid_for((u64)s->n_frag), 256, 0, g_stream>>>(s->n_frag, (const i32 *)frag_index_dev, s->row_len.p, len_by_row.p);
+    HHX_LAUNCH_CHECK();
+    i64 total = 0;
+    HHX_TRY(exclusive_scan_i64(len_by_row.p, row_off.p, shape, &total));
+    if (total != n) return fail("hhx_shard_emit: %lld entries but the ranked fragments hold %lld (fragment index does not cover this chunk)", (long long)n, (long long)total);
+    if (s->out_w0.alloc((size_t)n + 1) || s->out_w1.alloc((size_t)n + 1)) return 1;
+    if (n) {
+        k_emit_by_row<<<grid_for((u64)s->n_frag * 64), 256, 0, g_stream>>>(s->n_frag, s->part.base.p, s->part.w0.p, s->part.w1.p, (const i32 *)frag_index_dev,
+                                                                           row_off.p, s->out_w0.p, s->out_w1.p);
+        HHX_LAUNCH_CHECK();
+    }
+    std::vector<i64> at((size_t)n_bounds);
+    for (i32 k = 0; k < n_bounds; ++k) {
+        if (bounds[k] < 0 || bounds[k] > shape || (k && bounds[k] < bounds[k - 1])) return fail("hhx_shard_emit: bad row bounds");
+        HHX_HIP(hipMemcpyAsync(&at[(size_t)k], row_off.p + bounds[k], sizeof(i64), hipMemcpyDeviceToHost, g_stream));
+    }
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    for (i32 k = 0; k + 1 < n_bounds; ++k) counts[k] = at[(size_t)k + 1] - at[(size_t)k];
+    *w0_dev = s->out_w0.p;
+    *w1_dev = s->out_w1.p;
+    return 0;
+}
+
+extern "C" int hhx_shard_destroy(hhx_shard *s) {
+    delete s;
+    return 0;
+}
+
+extern "C" int hhx_rows_from_entries(i64 n, const void *w0_dev, const void *w1_dev, i32 r0, i32 r1, i32 shape, int add_self_loops, hhx_csr **out) {
+    if (n < 0 || r0 < 0 || r1 < r0 || r1 > shape || !out || (n && (!w0_dev || !w1_dev))) return fail("hhx_rows_from_entries: bad argument");
+    const i32 n_local = r1 - r0;
+    const i32 W = (shape + 31) / 32;
+    const size_t lds = (size_t)W * 8 + 256 * 4;
+    if (lds > 160 * 1024) return fail("hhx_rows_from_entries: order %d exceeds the LDS bitmap capacity", shape);
+    Partitioned<u64> part;
+    if (n && n_local) {
+        int row_bits = 0;
+        while (((i64)1 << row_bits) < n_local) ++row_bits;
+        const SrcRecs<u64> src{(const u64 *)w0_dev, (const u64 *)w1_dev};
+        HHX_TRY(partition_records(src, DigLocalRow{(u32)r0}, n, row_bits, 9, &part, "rows"));
+    } else if (n) {
+        return fail("hhx_rows_from_entries: entries for an empty row block");
+    }
+    const bool any = part.n_valid > 0;
+    DevBuf<i32> cnt, indptr;
+    if (cnt.alloc((size_t)n_local + 1) || indptr.alloc((size_t)n_local + 2)) return 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HHX_HIP(hipFuncSetAttribute((const void *)k_rows_distinct, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_rows_merge_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(n_local, 256 * 8));
+    if (n_local) {
+        k_rows_distinct<<<grid, 256, (size_t)W * 4 + 16, g_stream>>>(n_local, r0, W, add_self_loops, any ? part.base.p : nullptr, any ? part.w0.p : nullptr, cnt.p);
+        HHX_LAUNCH_CHECK();
+    }
+    i64 nnz = 0;
+    HHX_TRY(exclusive_scan_i32(cnt.p, indptr.p, n_local, &nnz));
+    hhx_csr *m = nullptr;
+    HHX_TRY(hhx_csr_alloc_internal(n_local, shape, nnz, &m));
+    hipError_t e = hipMemcpyAsync(m->indptr.p, indptr.p, sizeof(i32) * ((size_t)n_local + 1), hipMemcpyDeviceToDevice, g_stream);
+    if (e == hipSuccess && n_local)
+        k_rows_merge_emit<<<grid, 256, lds, g_stream>>>(n_local, r0, W, add_self_loops, any ? part.base.p : nullptr, any ? part.w0.p : nullptr,
+                                                        any ? part.w1.p : nullptr, indptr.p, m->indices.p, m->data.p);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    if (e != hipSuccess) { hhx_csr_free(m); return fail("hhx_rows_from_entries: %s", hipGetErrorString(e)); }
+    *out = m;
+    return 0;
 }

@@ -77,6 +77,48 @@ class HipEngine:
     def sync(self):
         _lib.check(_lib.load().hhx_synchronize())
 
+    # ---- sharded link-matrix build (hhx_shard_*): `src` is this rank's finalized _lib.Ingest
+    def shard_open(self, src, in_set):
+        in_set = np.ascontiguousarray(in_set, np.uint8)
+        h = _lib.C.c_void_p()
+        _lib.check(_lib.load().hhx_shard_create(src.h, _lib.ptr(in_set), _lib.C.byref(h)))
+        return {'h': h, 'n_frag': src.n_frag}
+
+    def shard_first(self, st):
+        p = _lib.C.c_void_p()
+        _lib.check(_lib.load().hhx_shard_first(st['h'], _lib.C.byref(p)))
+        return self.view(p.value, st['n_frag'], '<i8', self.torch.int64)
+
+    def rank_first(self, first):
+        fidx = self.torch.empty(first.numel(), dtype=self.torch.int32, device=self.device)
+        nl = _lib.C.c_int32(0)
+        self.torch.cuda.current_stream(self.device).synchronize()
+        _lib.check(_lib.load().hhx_rank_first(first.numel(), _lib.C.c_void_p(first.data_ptr()), _lib.C.c_void_p(fidx.data_ptr()), _lib.C.byref(nl)))
+        return fidx, nl.value
+
+    def shard_emit(self, st, fidx, bounds):
+        b = np.ascontiguousarray(bounds, np.int32)
+        counts = np.zeros(len(b) - 1, np.int64)
+        w0, w1 = _lib.C.c_void_p(), _lib.C.c_void_p()
+        _lib.check(_lib.load().hhx_shard_emit(st['h'], _lib.C.c_void_p(fidx.data_ptr()), len(b), b.ctypes.data_as(_lib.c_i32p), _lib.C.byref(w0),
+                                              _lib.C.byref(w1), counts.ctypes.data_as(_lib.c_i64p)))
+        n = int(counts.sum())
+        return self.view(w0.value, n, '<i8', self.torch.int64), self.view(w1.value, n, '<i8', self.torch.int64), counts.tolist()
+
+    def shard_close(self, st):
+        _lib.load().hhx_shard_destroy(st['h'])
+
+    def rows_from_entries(self, w0, w1, r0, r1, shape):
+        self.torch.cuda.current_stream(self.device).synchronize()
+        out = _lib.C.c_void_p()
+        _lib.check(_lib.load().hhx_rows_from_entries(int(w0.numel()), _lib.C.c_void_p(w0.data_ptr()), _lib.C.c_void_p(w1.data_ptr()), int(r0), int(r1),
+                                                     int(shape), 1, _lib.C.byref(out)))
+        return _lib.DeviceCSR(out)
+
+    def normalize_l1(self, m):
+        _lib.normalize_l1(m)
+        return m
+
     def table_tensors(self, n, ptrs):
         """torch views (int64 / int32 bit patterns) of an aggregated ingest table: key, ord_full, ord_flank, ht, fl"""
         t = self.torch
@@ -86,20 +128,61 @@ class HipEngine:
 
 
 # ------------------------------------------------------------------ collectives on variable-size blocks
+MAX_MESSAGE_BYTES = 1 << 30     # one collective call never moves more than this per peer: a 2.6 GB all-to-all was
+                                # observed to come back truncated (32-bit byte counts somewhere below torch.distributed)
+
+
 def _all_gather_var(t, dist, torch):
-    """all-gather of 1-D tensors of different lengths (RCCL has no all-gather-v): gather the lengths,
-    pad to the maximum, one all_gather_into_tensor, then slice.  Returns the list of per-rank tensors."""
+    """all-gather of 1-D tensors of different lengths (RCCL has no all-gather-v): gather the lengths, then rounds of
+    all_gather_into_tensor on slices padded to the round's longest piece.  Returns the list of per-rank tensors."""
     world = dist.get_world_size()
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = torch.empty(world, dtype=torch.int64, device=t.device)
     dist.all_gather_into_tensor(sizes, n)
     sizes = sizes.tolist()
-    mx = max(max(sizes), 1)
-    buf = torch.zeros(mx, dtype=t.dtype, device=t.device)
-    buf[:t.numel()] = t
-    out = torch.empty(world * mx, dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, buf)
-    return [out[r * mx:r * mx + sizes[r]] for r in range(world)]
+    step = max(1, MAX_MESSAGE_BYTES // t.element_size())
+    outs = [torch.empty(sizes[r], dtype=t.dtype, device=t.device) for r in range(world)]
+    for lo in range(0, max(max(sizes), 1), step):
+        mx = max(1, min(step, max(sizes) - lo))
+        buf = torch.zeros(mx, dtype=t.dtype, device=t.device)
+        mine = t[lo:lo + mx]
+        buf[:mine.numel()] = mine
+        out = torch.empty(world * mx, dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, buf)
+        for r in range(world):
+            k = max(0, min(mx, sizes[r] - lo))
+            if k:
+                outs[r][lo:lo + k] = out[r * mx:r * mx + k]
+    return outs
+
+
+def _all_to_all_var(t, send_counts, dist, torch):
+    """all-to-all(v) of a 1-D tensor laid out as [to rank 0 | to rank 1 | ...]: exchange the counts, then rounds of
+    all_to_all_single in which every (sender, receiver) pair moves at most MAX_MESSAGE_BYTES.  Returns the received
+    tensor laid out as [from rank 0 | from rank 1 | ...] and the per-source counts."""
+    world = dist.get_world_size()
+    send_n = torch.tensor(send_counts, dtype=torch.int64, device=t.device)
+    recv_n = torch.empty(world, dtype=torch.int64, device=t.device)
+    dist.all_to_all_single(recv_n, send_n)
+    recv_counts = recv_n.tolist()
+    longest = torch.tensor([max(max(send_counts), max(recv_counts), 0)], dtype=torch.int64, device=t.device)
+    dist.all_reduce(longest, op=dist.ReduceOp.MAX)                    # every rank runs the same number of rounds
+    step = max(1, MAX_MESSAGE_BYTES // t.element_size())
+    out = torch.empty(int(sum(recv_counts)), dtype=t.dtype, device=t.device)
+    s_off = np.concatenate([[0], np.cumsum(send_counts)]).tolist()
+    r_off = np.concatenate([[0], np.cumsum(recv_counts)]).tolist()
+    for lo in range(0, max(int(longest.item()), 1), step):
+        s_k = [max(0, min(step, c - lo)) for c in send_counts]
+        r_k = [max(0, min(step, c - lo)) for c in recv_counts]
+        piece = torch.cat([t[s_off[p] + lo:s_off[p] + lo + s_k[p]] for p in range(world)]) if sum(s_k) else t[:0]
+        got = torch.empty(int(sum(r_k)), dtype=t.dtype, device=t.device)
+        dist.all_to_all_single(got, piece.contiguous(), output_split_sizes=r_k, input_split_sizes=s_k)
+        at = 0
+        for p in range(world):
+            if r_k[p]:
+                out[r_off[p] + lo:r_off[p] + lo + r_k[p]] = got[at:at + r_k[p]]
+                at += r_k[p]
+    return out, recv_counts
 
 
 def row_ranges(n, world):
@@ -126,20 +209,24 @@ def allgather_rows(engine, local, n_cols, dist):
     return engine.from_tensors(n_rows, n_cols, indptr, torch.cat(ix_all).contiguous(), torch.cat(dx_all).contiguous())
 
 
-def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, dist):
+def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, dist, local_block=None, n=None):
     """run_mcl_clustering's pre-expansion (:2146-2147) + mcl() (:2026-2062) with T sharded by row block.
-    full_norm: the L1-normalised link matrix, replicated.  The pre-expansion is fused into iteration 0
-    (the expanded rows are consumed in LDS, never materialised).  Returns (full result, n_iter,
-    converged, stats)."""
+    full_norm: the L1-normalised link matrix, replicated — or None with local_block = this rank's rows
+    [row_ranges(n)[rank], ...) of it (build_link_matrix_sharded + normalize_l1): the right operand of iteration 0 is
+    then all-gathered once.  The pre-expansion is fused into iteration 0 (the expanded rows are consumed in LDS,
+    never materialised).  Returns (full result, n_iter, converged, stats)."""
     torch = engine.torch
-    n = engine.shape(full_norm)[0]
     world, rank = dist.get_world_size(), dist.get_rank()
+    own_full = False
+    if full_norm is None:
+        full_norm = allgather_rows(engine, local_block, n, dist)         # n: order of the matrix
+        own_full = True
+    n = engine.shape(full_norm)[0]
     b = row_ranges(n, world)
     r0, r1 = b[rank], b[rank + 1]
     stats = []
-    cur_local = engine.row_block(full_norm, r0, r1)   # this rank's rows of the current matrix
+    cur_local = engine.row_block(full_norm, r0, r1) if local_block is None else engine.copy(local_block)
     cur_full = full_norm                              # all rows: right operand of the expansion
-    own_full = False
     converged = False
     n_iter = 0
     for it in range(iters):
@@ -186,9 +273,9 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
 
 
 # ------------------------------------------------------------------ product entry points (HIP engine)
-def mcl_sharded(full_norm, expansion, inflation, iters, pruning, dist, device):
+def mcl_sharded(full_norm, expansion, inflation, iters, pruning, dist, device, local_block=None, n=None):
     eng = HipEngine(device)
-    return mcl_sharded_engine(eng, full_norm, expansion, inflation, iters, pruning, dist)
+    return mcl_sharded_engine(eng, full_norm, expansion, inflation, iters, pruning, dist, local_block=local_block, n=n)
 
 
 def gather_tables(engine, tensors, dist):
@@ -223,6 +310,36 @@ def merge_flank_and_build(ing, table, flank, bins, in_set, dist, device, full_ta
     merged.finalize()
     m, fidx, n_linked = merged.link_matrix(in_set)
     return m, n_linked, merged
+
+
+def build_link_matrix_sharded(engine, src, in_set, dist):
+    """dict_to_matrix (:310-373, add_self_loops) over a pair stream that is split across the ranks: `src` is this rank's
+    finalized ingest of its chunk (global ordinals, hhx_ingest_set_ordinal_base).  One all-reduce(min) of the first
+    positions (8 B per fragment) fixes every fragment's matrix index on all ranks; one all-to-all(v) moves each matrix
+    entry to the owner of its row; the owner adds the counts of the chunks.  Returns (this rank's CSR row block of the
+    link matrix [row_ranges(shape)[rank], ...), fragment -> matrix index array (int32 numpy, -1 = not in the matrix...
+    link-less members of in_set take the trailing indices like the reference's `frag_set - frags_in_dict`), n_linked,
+    shape)."""
+    torch = engine.torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    in_set = np.ascontiguousarray(in_set, np.uint8)
+    st = engine.shard_open(src, in_set)
+    try:
+        first = engine.shard_first(st).clone()
+        dist.all_reduce(first, op=dist.ReduceOp.MIN)                       # exchange 1: first positions
+        fidx, n_linked = engine.rank_first(first)
+        shape = int(in_set.sum())                                          # every member of frag_set gets a row (linked ones first)
+        bounds = row_ranges(shape, world)
+        w0, w1, counts = engine.shard_emit(st, fidx, bounds)
+        e0, _recv = _all_to_all_var(w0, counts, dist, torch)                # exchange 2: the entries, to their row owners
+        e1, _recv = _all_to_all_var(w1, counts, dist, torch)
+        block = engine.rows_from_entries(e0, e1, bounds[rank], bounds[rank + 1], shape)
+    finally:
+        engine.shard_close(st)
+    fi = fidx.cpu().numpy().astype(np.int32)
+    rest = np.flatnonzero((in_set != 0) & (fi < 0))                        # link-less members: trailing indices, id order
+    fi[rest] = n_linked + np.arange(len(rest), dtype=np.int32)
+    return block, fi, n_linked, shape
 
 
 # ------------------------------------------------------------------ inflation sweep: replicas, no data-path collective

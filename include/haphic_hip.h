@@ -210,6 +210,24 @@ int hhx_ingest_link_matrix(hhx_ingest *h, const uint8_t *in_set_host, int32_t n_
 int hhx_ingest_keep_pairs(hhx_ingest *h, int on);
 int hhx_ingest_fetch_pairs(hhx_ingest *h, int64_t max_read_pairs, int64_t *clm_ptr, int64_t *clm, int64_t *crd_ptr,
                            int64_t *crd);
+/* ------------------------------------------------------------------ multi-GPU build of the link matrix
+ * dict_to_matrix :310-373 over a pair stream that is split into per-rank chunks.  The matrix index of a fragment is
+ * the rank of its first position (2 * first ordinal + side) over the WHOLE stream — a minimum, so the ranks
+ * all-reduce(min) hhx_shard_first's array, rank it with hhx_rank_first (same result everywhere), and exchange matrix
+ * entries by row owner (all-to-all(v) of hhx_shard_emit's arrays, counts[] entries for each owner) instead of whole
+ * tables; hhx_rows_from_entries adds up the counts of equal (row, column) received from different chunks and writes
+ * the owner's CSR row block [r0, r1) x shape (self loops :362-364, link-less rows :357-359 at the tail).
+ * Entries: w0 = row << 29 | column, w1 = count (uint64 each).  first: int64[n_frag], INT64_MAX = no entry here. */
+typedef struct hhx_shard hhx_shard;
+int hhx_shard_create(hhx_ingest *h, const uint8_t *in_set, hhx_shard **out);           /* after hhx_ingest_finalize */
+int hhx_shard_first(hhx_shard *s, void **first_dev);
+int hhx_rank_first(int32_t n_frag, const void *first_dev, void *frag_index_dev, int32_t *n_linked);
+int hhx_shard_emit(hhx_shard *s, const void *frag_index_dev, int32_t n_bounds, const int32_t *row_bounds,
+                   void **w0_dev, void **w1_dev, int64_t *counts);
+int hhx_rows_from_entries(int64_t n, const void *w0_dev, const void *w1_dev, int32_t r0, int32_t r1, int32_t shape,
+                          int add_self_loops, hhx_csr **out);
+int hhx_shard_destroy(hhx_shard *s);
+
 /* ------------------------------------------------------------------ a1: .pairs text -> id / position arrays
  * pairs_generator :1539-1559 and pairs_generator_inter_ctgs :1562-1583: skip blank and '#' lines, split on
  * whitespace, (ref, pos, mref, mpos) = (cols[1], int(cols[2]) - 1, cols[3], int(cols[4]) - 1), and the two

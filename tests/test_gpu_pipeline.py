@@ -97,8 +97,74 @@ def test_sharded_hip_engine_world1_nccl():
             for k in a:
                 if full_tables or k.startswith('flank') or k == 'frag_links':
                     assert np.array_equal(a[k], b[k]), k
+        # row-owner build (all-reduce(min) of first positions + all-to-all(v) of matrix entries), world 1
+        in_set[::13] = 0
+        m1, fidx1, nl1 = ing.link_matrix(in_set)
+        eng = sharded.HipEngine('cuda:0')
+        block, fi, n_linked, shape = sharded.build_link_matrix_sharded(eng, ing, in_set, dist)
+        assert (n_linked, shape) == (nl1, m1.shape3[0]) and np.array_equal(fi[fidx1 >= 0], fidx1[fidx1 >= 0])
+        assert all(np.array_equal(x, y) for x, y in zip(block.to_arrays(), m1.to_arrays()))
+        # ... and MCL started from the row block == MCL on the replicated matrix
+        _lib.normalize_l1(block)
+        r_b, it_b, cv_b, _ = sharded.mcl_sharded(None, 2, 2.0, 100, 1e-4, dist, 'cuda:0', local_block=block, n=shape)
+        _lib.normalize_l1(m1)
+        r_f, it_f, cv_f, _ = sharded.mcl_sharded(m1, 2, 2.0, 100, 1e-4, dist, 'cuda:0')
+        assert (it_b, cv_b) == (it_f, cv_f) and all(np.array_equal(x, y) for x, y in zip(r_b.to_arrays(), r_f.to_arrays()))
     finally:
         dist.destroy_process_group()
+
+
+def test_row_owner_build_two_chunks_one_gpu():
+    """the device half of the multi-GPU link-matrix build with TWO chunks of a stream on one GPU: per-chunk first
+    positions reduced with min, one ranking, per-owner entry slices swapped by hand (what all-to-all(v) does), and
+    the owners' row blocks stacked == the link matrix of the whole stream (counts of keys seen in both chunks add up)"""
+    import torch
+    from haphic_amd import _lib, sharded, synth
+    from oracle import oracle as orc
+    gen = synth.make_genome(4, 600_000, 9_000, seed=8)
+    n = gen.n
+    lex = gen.lexical_rank()
+    t = orc.FragTable(lex, gen.length, np.arange(n, dtype=np.int32), np.zeros(n, np.uint8), 0, lex, gen.length, np.ones(n, np.uint8))
+    id1, p1, id2, p2 = synth.sample_pairs(gen, 300_000, seed=9, device='cuda:0')
+    torch.cuda.synchronize()
+    in_set = np.ones(n, np.uint8)
+    in_set[::7] = 0
+    whole = _lib.Ingest(t, 4000, bins=False, skip_intra=True)
+    whole.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+    whole.finalize()
+    want, widx, wl = whole.link_matrix(in_set)
+    cut = 131_071
+    chunks = []
+    for lo, hi in ((0, cut), (cut, id1.numel())):
+        ing = _lib.Ingest(t, 4000, bins=False, skip_intra=True)
+        ing.set_ordinal_base(lo)
+        ing.push_device(hi - lo, id1[lo:hi].data_ptr(), p1[lo:hi].data_ptr(), id2[lo:hi].data_ptr(), p2[lo:hi].data_ptr())
+        ing.finalize()
+        chunks.append(ing)
+    eng = sharded.HipEngine('cuda:0')
+    states = [eng.shard_open(c, in_set) for c in chunks]
+    first = torch.minimum(eng.shard_first(states[0]), eng.shard_first(states[1]))
+    fidx, n_linked = eng.rank_first(first)
+    shape = int(in_set.sum())
+    assert n_linked == wl and np.array_equal(fidx.cpu().numpy()[widx >= 0], widx[widx >= 0])
+    for bounds in ([0, shape // 3, shape], [0, 0, shape], [0, shape, shape]):
+        sent = [eng.shard_emit(st, fidx, bounds) for st in states]
+        blocks = []
+        for owner in range(2):
+            parts0, parts1 = [], []
+            for w0, w1, counts in sent:
+                off = sum(counts[:owner])
+                parts0.append(w0[off:off + counts[owner]])
+                parts1.append(w1[off:off + counts[owner]])
+            blocks.append(eng.rows_from_entries(torch.cat(parts0).contiguous(), torch.cat(parts1).contiguous(), bounds[owner], bounds[owner + 1], shape))
+        a, b = [x.to_arrays() for x in blocks]
+        wp, wj, wx = want.to_arrays()
+        assert np.array_equal(np.concatenate([a[0][:-1], b[0] + a[0][-1]]), wp)
+        assert np.array_equal(np.concatenate([a[1], b[1]]), wj) and np.array_equal(np.concatenate([a[2], b[2]]), wx)
+        for x in blocks:
+            x.free()
+    for st in states:
+        eng.shard_close(st)
 
 
 def _check_files(g, tmp_path, records):

@@ -56,6 +56,50 @@ class OracleEngine:
     def sync(self):
         pass
 
+    def normalize_l1(self, m):
+        return (m[0], m[1], orc.normalize_l1(m[0], m[2]))
+
+    # ---- sharded link-matrix build: numpy stand-ins of hhx_shard_* (src: this chunk's flank table with ordinals)
+    def shard_open(self, src, in_set):
+        ok = in_set[src['i']].astype(bool) & in_set[src['j']].astype(bool)
+        return {'i': src['i'][ok], 'j': src['j'][ok], 'cnt': src['cnt'][ok], 'ord': src['ord'][ok], 'n_frag': len(in_set)}
+
+    def shard_first(self, st):
+        first = np.full(st['n_frag'], np.iinfo(np.int64).max, np.int64)
+        np.minimum.at(first, st['i'], 2 * st['ord'])
+        np.minimum.at(first, st['j'], 2 * st['ord'] + 1)
+        return torch.from_numpy(first)
+
+    def rank_first(self, first):
+        f = first.numpy()
+        linked = f != np.iinfo(np.int64).max
+        fidx = np.full(len(f), -1, np.int32)
+        order = np.flatnonzero(linked)[np.argsort(f[linked], kind='stable')]
+        fidx[order] = np.arange(len(order), dtype=np.int32)
+        return torch.from_numpy(fidx), int(linked.sum())
+
+    def shard_emit(self, st, fidx, bounds):
+        fx = fidx.numpy().astype(np.int64)
+        row = np.concatenate([fx[st['i']], fx[st['j']]])
+        col = np.concatenate([fx[st['j']], fx[st['i']]])
+        cnt = np.concatenate([st['cnt'], st['cnt']]).astype(np.int64)
+        o = np.argsort(row, kind='stable')
+        row, col, cnt = row[o], col[o], cnt[o]
+        counts = [int(((row >= bounds[k]) & (row < bounds[k + 1])).sum()) for k in range(len(bounds) - 1)]
+        return torch.from_numpy((row << 29) | col), torch.from_numpy(cnt), counts
+
+    def shard_close(self, st):
+        pass
+
+    def rows_from_entries(self, w0, w1, r0, r1, shape):
+        import scipy.sparse as sp
+        w0, w1 = w0.numpy(), w1.numpy()
+        row, col = (w0 >> 29) - r0, w0 & ((1 << 29) - 1)
+        m = sp.coo_matrix((w1.astype(np.float64), (row, col)), shape=(r1 - r0, shape)).tocsr()      # sums duplicates
+        m = (m + sp.coo_matrix((np.ones(r1 - r0), (np.arange(r1 - r0), np.arange(r0, r1))), shape=(r1 - r0, shape))).tocsr()
+        m.sort_indices()
+        return m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32)
+
 
 def stochastic(n, deg, seed):
     import scipy.sparse as sp
@@ -71,7 +115,16 @@ def _worker(rank, world, port, q):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
+        sharded.MAX_MESSAGE_BYTES = 4096            # every collective of this test takes several rounds
         eng = OracleEngine()
+        # ragged all-to-all(v) / all-gather(v) against plain arithmetic, including empty pieces
+        send = torch.arange(3000 + 500 * rank, dtype=torch.int64) + 100000 * rank
+        counts = [1200, len(send) - 1200] if rank == 0 else [0, len(send)]
+        got, rc = sharded._all_to_all_var(send, counts, dist, torch)
+        exp = torch.cat([torch.arange(0, 1200), torch.arange(0, 0) + 100000]) if rank == 0 else torch.cat([torch.arange(1200, 3000), torch.arange(0, 3500) + 100000])
+        assert torch.equal(got, exp) and rc == ([1200, 0] if rank == 0 else [1800, 3500])
+        parts = sharded._all_gather_var(send, dist, torch)
+        assert torch.equal(parts[0], torch.arange(3000)) and torch.equal(parts[1], torch.arange(3500) + 100000)
         # ---- MCL row-block shard
         T = stochastic(400, 6, 5)
         res, n_iter, conv, stats = sharded.mcl_sharded_engine(eng, T, 2, 2.0, 100, 1e-4, dist)
@@ -100,8 +153,16 @@ def _worker(rank, world, port, q):
         np.minimum.at(first, inv, go)
         order = np.argsort(first, kind='stable')
         merged = (len(uniq), (uniq[order] >> 29).astype(np.int32), (uniq[order] & ((1 << 29) - 1)).astype(np.int32), cnt[order])
+        # ---- the row-owner build of the link matrix from the same two chunks (all-reduce(min) + all-to-all(v))
+        in_set = np.ones(n, np.uint8)
+        in_set[::11] = 0                                               # a filtered fragment set
+        src = {'i': loc['flank_i'], 'j': loc['flank_j'], 'cnt': loc['flank_cnt'], 'ord': ordk}
+        block, fi, n_linked, shape = sharded.build_link_matrix_sharded(eng, src, in_set, dist)
+        norm = eng.normalize_l1(block)
+        res2, n_iter2, conv2, _st2 = sharded.mcl_sharded_engine(eng, None, 2, 2.0, 100, 1e-4, dist, local_block=norm, n=shape)
+        built = (block, fi, n_linked, shape, res2, n_iter2, conv2)
         sweep = sharded.inflation_sweep(lambda infl: (round(infl * 10), rank), [1.2, 1.4, 1.6, 1.8, 2.0], dist)
-        q.put((rank, res, n_iter, conv, stats, merged, sweep))
+        q.put((rank, res, n_iter, conv, stats, merged, sweep, built))
     finally:
         dist.destroy_process_group()
 
@@ -131,7 +192,7 @@ def test_sharded_mcl_and_merge_world2():
     T = stochastic(400, 6, 5)
     pre = orc.spgemm(T, T, mode=1, fx_shift=52)
     o = orc.mcl(pre, 2, 2.0, 100, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True)
-    for rank, res, n_iter, conv, stats, merged, sweep in outs:
+    for rank, res, n_iter, conv, stats, merged, sweep, _built in outs:
         assert sweep == [(12, 0), (14, 1), (16, 0), (18, 1), (20, 0)]      # inflations dealt round-robin, results in order
         assert (n_iter, conv) == (o[3], o[4])
         assert all(np.array_equal(x, y) for x, y in zip(res, o[:3])), 'sharded MCL is not bit-identical to 1 process'
@@ -145,9 +206,30 @@ def test_sharded_mcl_and_merge_world2():
     id1, p1, id2, p2 = [a.numpy() for a in synth.sample_pairs(gen, 40_000, seed=3)]
     keep = id1 != id2
     whole = orc.ingest(t, id1[keep], p1[keep].astype(np.int64), id2[keep], p2[keep].astype(np.int64), 3000)
-    for rank, _res, _n, _c, _st, (k, mi, mj, mc), _sw in outs:
+    for rank, _res, _n, _c, _st, (k, mi, mj, mc), _sw, _built in outs:
         assert k == len(whole['flank_i'])
         assert np.array_equal(mi, whole['flank_i']) and np.array_equal(mj, whole['flank_j']) and np.array_equal(mc, whole['flank_cnt'])
+
+
+    # row-owner build: the two row blocks stacked == dict_to_matrix of the whole stream; MCL from the blocks == 1 process
+    in_set = np.ones(n, np.uint8)
+    in_set[::11] = 0
+    ok = in_set[whole['flank_i']].astype(bool) & in_set[whole['flank_j']].astype(bool)
+    linked = np.zeros(n, bool)
+    linked[whole['flank_i'][ok]] = True
+    linked[whole['flank_j'][ok]] = True
+    n_rest = int(in_set.sum() - linked.sum())
+    rp, rj, rx, ridx, rl = orc.dict_to_matrix(whole['flank_i'], whole['flank_j'], whole['flank_cnt'].astype(np.float64), n, in_set, n_rest)
+    blocks = [o[7][0] for o in outs]
+    assert np.array_equal(np.concatenate([blocks[0][0][:-1], blocks[1][0] + blocks[0][0][-1]]), rp)
+    assert np.array_equal(np.concatenate([b[1] for b in blocks]), rj) and np.array_equal(np.concatenate([b[2] for b in blocks]), rx)
+    T2 = (rp, rj, orc.normalize_l1(rp, rx))
+    o2 = orc.mcl(orc.spgemm(T2, T2, mode=1, fx_shift=52), 2, 2.0, 100, 1e-4, spgemm_mode=1, fx_shift=52)
+    for o in outs:
+        _b, fi, n_linked, shape, res2, n_iter2, conv2 = o[7]
+        assert (n_linked, shape) == (rl, len(rp) - 1) and np.array_equal(fi[ridx >= 0][fi[ridx >= 0] < rl], ridx[ridx >= 0][ridx[ridx >= 0] < rl])
+        assert np.array_equal(fi >= 0, in_set.astype(bool))
+        assert (n_iter2, conv2) == (o2[3], o2[4]) and all(np.array_equal(x, y) for x, y in zip(res2, o2[:3]))
 
 
 def test_row_ranges():

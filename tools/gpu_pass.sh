@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (through gpurun): bash tools/gpu_pass.sh [tests] [c2] [c3] [prof_c2] [prof_c3]
 mkdir -p gpurun_out
+ulimit -c 0                        # a GPU memory fault must not spend minutes writing a core file
 export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-.}
 C3="--contigs 100000 --pairs 500000000 --nchrs 24 --mean-len 30000"
