@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--force-sharded', action='store_true', help='take the multi-GPU code path on one rank (1-rank nccl group)')
     ap.add_argument('--cpu-sample-pairs', type=int, default=20_000_000)
     ap.add_argument('--text-lines', type=int, default=1_000_000, help='a1 leg: lines of .pairs text formatted on the host (0 = skip)')
+    ap.add_argument('--text-file-tile', type=int, default=8, help='a1 leg: copies of that text written to the .pairs file of the end-to-end figure')
     ap.add_argument('--text-tile', type=int, default=16, help='a1 leg: copies of that text concatenated in HBM')
     return ap.parse_args()
 
@@ -102,7 +103,8 @@ def main():
         if sharded_path:
             # all-reduce(min) of the first positions + all-to-all(v) of the matrix entries by row owner: every rank ends
             # up with ITS row block of the link matrix (no rank ever holds another rank's table)
-            m, _fi, n_linked, shape = sharded.build_link_matrix_sharded(sharded.HipEngine(dev), ing, in_set, dist)
+            state['shard_ms'] = {}
+            m, _fi, n_linked, shape = sharded.build_link_matrix_sharded(sharded.HipEngine(dev), ing, in_set, dist, timings=state['shard_ms'])
         else:
             # dict_to_matrix fused onto the device-resident table; link-less contigs get trailing indices
             m, fidx, n_linked = ing.link_matrix(in_set)
@@ -222,6 +224,8 @@ def main():
                'mcl_iters_per_s': mcl['iters_per_s'], 'ingest': ingest, 'mcl': mcl, 'roofline': roofline}
         if world == 1 and args.text_lines:
             out['ingest']['text'] = text_leg(args, gen, id1, p1, id2, p2, dev)
+        if sharded_path:
+            out['ingest']['sharded_build_ms_last_step'] = state.get('shard_ms')
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state)
         print(json.dumps(out))
@@ -266,6 +270,34 @@ def text_leg(args, gen, id1, p1, id2, p2, dev):
     res['roofline'] = {'kernel': 'k_parse_lines', 'bound': 'hbm', 'achieved': (n_bytes + 16 * n_lines) / (res['kernel_ms']['text_parse'] * 1e-3) / 1e9,
                        'peak': 8000.0, 'unit': 'GB/s'}
     res['roofline']['frac'] = res['roofline']['achieved'] / 8000.0
+    # end to end from a FILE: .pairs text on disk (page cache) -> mmap -> device tokeniser -> group-by -> link matrix
+    import tempfile
+    from haphic_amd import cluster
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'bench.pairs')
+        with open(path, 'wb') as f:
+            for _ in range(args.text_file_tile):
+                f.write(raw)
+        n_file = k * args.text_file_tile
+        tb = cluster.FragTable.for_contigs(gen.lexical_rank(), gen.length, np.ones(gen.n, np.uint8), names=names)
+        for tag, bed_path in (('file_to_link_matrix', None), ('file_to_link_matrix_with_bed', os.path.join(td, 'alignments.bed'))):
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                aln = cluster.pairs_generator_inter_ctgs(path, 'pairs')
+                aln.bed_path = bed_path
+                ing = _lib.Ingest(tb, 500_000, bins=False, skip_intra=True)
+                for parser, kk in aln.batches(names):
+                    ing.push_device(kk, *parser.device_arrays()[:4])
+                ing.finalize()
+                mm, _fidx, _nl = ing.link_matrix(np.ones(gen.n, np.uint8))
+                _lib.check(_lib.load().hhx_synchronize())
+                dt = time.perf_counter() - t0
+                mm.free()
+                ing.destroy()
+                best = dt if best is None else min(best, dt)
+            res[tag] = {'lines': n_file, 'file_bytes': len(raw) * args.text_file_tile, 'ms': best * 1e3, 'pairs_per_s': n_file / best,
+                        'text_GBs': len(raw) * args.text_file_tile / best / 1e9}
     out = ps.fetch()                                 # every tile must reproduce the sample it was formatted from
     for c in range(4):
         assert np.array_equal(out[c].reshape(args.text_tile, k), np.broadcast_to(h[c], (args.text_tile, k))), 'text leg mismatch'

@@ -312,7 +312,7 @@ def merge_flank_and_build(ing, table, flank, bins, in_set, dist, device, full_ta
     return m, n_linked, merged
 
 
-def build_link_matrix_sharded(engine, src, in_set, dist):
+def build_link_matrix_sharded(engine, src, in_set, dist, timings=None):
     """dict_to_matrix (:310-373, add_self_loops) over a pair stream that is split across the ranks: `src` is this rank's
     finalized ingest of its chunk (global ordinals, hhx_ingest_set_ordinal_base).  One all-reduce(min) of the first
     positions (8 B per fragment) fixes every fragment's matrix index on all ranks; one all-to-all(v) moves each matrix
@@ -322,18 +322,34 @@ def build_link_matrix_sharded(engine, src, in_set, dist):
     shape)."""
     torch = engine.torch
     world, rank = dist.get_world_size(), dist.get_rank()
+    import time
     in_set = np.ascontiguousarray(in_set, np.uint8)
+    marks = [('start', time.perf_counter())]
+
+    def mark(name):                      # stage wall times for bench.py (a sync per stage: only when asked for)
+        if timings is not None:
+            engine.sync()
+            marks.append((name, time.perf_counter()))
     st = engine.shard_open(src, in_set)
     try:
         first = engine.shard_first(st).clone()
+        mark('partition_by_row')
         dist.all_reduce(first, op=dist.ReduceOp.MIN)                       # exchange 1: first positions
         fidx, n_linked = engine.rank_first(first)
+        mark('allreduce_rank')
         shape = int(in_set.sum())                                          # every member of frag_set gets a row (linked ones first)
         bounds = row_ranges(shape, world)
         w0, w1, counts = engine.shard_emit(st, fidx, bounds)
+        mark('emit')
         e0, _recv = _all_to_all_var(w0, counts, dist, torch)                # exchange 2: the entries, to their row owners
         e1, _recv = _all_to_all_var(w1, counts, dist, torch)
+        mark('all_to_all')
         block = engine.rows_from_entries(e0, e1, bounds[rank], bounds[rank + 1], shape)
+        mark('rows')
+        if timings is not None:
+            for (_, t0), (name, t1) in zip(marks[:-1], marks[1:]):
+                timings[name + '_ms'] = timings.get(name + '_ms', 0.0) + (t1 - t0) * 1e3
+            timings['entries_sent'] = int(sum(counts))
     finally:
         engine.shard_close(st)
     fi = fidx.cpu().numpy().astype(np.int32)
