@@ -149,6 +149,13 @@ struct HbmText {
 };
 
 struct Tok { i64 s; i32 len; };
+// tok[n] = (s, len) with n known only at run time: statically indexed selects keep the five tokens in registers
+// (a dynamically indexed private array lands in scratch memory)
+__device__ __forceinline__ void tok_set(Tok tok[5], int n, i64 s, i32 len) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        if (q == n) { tok[q].s = s; tok[q].len = len; }
+}
 
 // the first five tokens of [a, e); returns how many were found
 template <class RD>
@@ -160,8 +167,7 @@ __device__ __forceinline__ int first_tokens(const RD &rd, i64 a, i64 e, Tok tok[
         if (p >= e) break;
         const i64 s = p;
         while (p < e && !is_ws(rd(p))) ++p;
-        tok[n].s = s;
-        tok[n].len = (i32)(p - s);
+        tok_set(tok, n, s, (i32)(p - s));
         ++n;
     }
     return n;
@@ -195,11 +201,11 @@ __device__ __forceinline__ int first_tokens(const LdsText &rd, i64 a, i64 e, Tok
             const int k = __ffs(ev) - 1;
             ev &= ev - 1;
             if ((starts >> k) & 1) ts = (wi << 3) + k;
-            else { tok[n].s = rd.bias + ts; tok[n].len = (i32)((wi << 3) + k - ts); ++n; }
+            else { tok_set(tok, n, rd.bias + ts, (i32)((wi << 3) + k - ts)); ++n; }
         }
         in_tok = (tokb >> 7) & 1;
     }
-    if (n < 5 && in_tok) { tok[n].s = rd.bias + ts; tok[n].len = (i32)(eo - ts); ++n; }
+    if (n < 5 && in_tok) { tok_set(tok, n, rd.bias + ts, (i32)(eo - ts)); ++n; }
     return n;
 }
 
@@ -213,23 +219,29 @@ struct NameTable {
 };
 
 template <class RD>
+__device__ __forceinline__ u64 tok_word(const RD &rd, const Tok &k, int q) {
+    return rd.word(k.s + 8 * (i64)q, k.len - 8 * q < 8 ? k.len - 8 * q : 8);
+}
+template <class RD>
 __device__ __forceinline__ i32 lookup(const NameTable &T, const RD &rd, const Tok &k) {
-    constexpr int MAXW = 8;                                      // names up to 64 bytes stay in registers
+    constexpr int MAXW = 8;                                      // the words of names up to 64 bytes stay in registers
     const int nw = (k.len + 7) >> 3;
     u64 w[MAXW];
     u64 h = HASH_SEED;
-    for (int q = 0; q < nw; ++q) {
-        const u64 v = rd.word(k.s + 8 * (i64)q, k.len - 8 * q < 8 ? k.len - 8 * q : 8);
-        if (q < MAXW) w[q] = v;
-        h = hash_step(h, v);
-    }
+#pragma unroll
+    for (int q = 0; q < MAXW; ++q)
+        if (q < nw) { w[q] = tok_word(rd, k, q); h = hash_step(h, w[q]); }
+    for (int q = MAXW; q < nw; ++q) h = hash_step(h, tok_word(rd, k, q));
     for (u32 s = (u32)h & T.mask;; s = (s + 1) & T.mask) {
         const i32 id = T.slot_id[s];
         if (id < 0) return -1;
         if (T.slot_hash[s] != h || T.name_len[id] != k.len) continue;
         const u64 *nm = T.names + T.name_off[id];
         u64 diff = 0;
-        for (int q = 0; q < nw; ++q) diff |= nm[q] ^ (q < MAXW ? w[q] : rd.word(k.s + 8 * (i64)q, k.len - 8 * q < 8 ? k.len - 8 * q : 8));
+#pragma unroll
+        for (int q = 0; q < MAXW; ++q)
+            if (q < nw) diff |= nm[q] ^ w[q];
+        for (int q = MAXW; q < nw; ++q) diff |= nm[q] ^ tok_word(rd, k, q);
         if (!diff) return id;
     }
 }
