@@ -61,11 +61,16 @@ __device__ __forceinline__ bool is_flank(i64 coord, i64 length, i64 flank) {   /
 //           split, because fragment == contig then);  stream 1 (bins only): the fragment-pair flank table.
 // COMBINED (no split contigs, parse_alignments_for_ctgs :1596-1655) is a compile-time variant: two
 // 16-byte gathers and no divisions per pair.
-template <bool COMBINED>
-__device__ __forceinline__ bool map_pair(const DevTables &t, int stream, i32 r, i32 m, i32 p1, i32 p2, u64 &rec, u64 *xy = nullptr) {
+// the part of the map that comes before the table look-ups
+__device__ __forceinline__ bool pair_admitted(const DevTables &t, i32 r, i32 m) {
     if (t.skip_intra && r == m) return false;                                    // pairs_generator_inter_ctgs :1582
-    if ((u32)r >= (u32)t.n_ctg || (u32)m >= (u32)t.n_ctg) return false;         // :1625 / :1702 (name not in fa_dict)
-    UnitInfo a = t.ctg[r], b = t.ctg[m];
+    return (u32)r < (u32)t.n_ctg && (u32)m < (u32)t.n_ctg;                       // :1625 / :1702 (name not in fa_dict)
+}
+// ... and the part after them: a = t.ctg[r], b = t.ctg[m] are handed in, so that a caller can issue the gathers of
+// several pairs before any of them is consumed (k_map_records)
+template <bool COMBINED>
+__device__ __forceinline__ bool map_pair_with(const DevTables &t, int stream, i32 r, i32 m, i32 p1, i32 p2, UnitInfo a, UnitInfo b, u64 &rec,
+                                              u64 *xy = nullptr) {
     if (!COMBINED && t.bins && r == m && !(a.lenf & SPLIT_BIT)) return false;    // :1699
     i32 ci = r, cj = m;
     i64 xi = (i64)p1 + 1, xj = (i64)p2 + 1;                                      // 1-based, :1629
@@ -112,6 +117,11 @@ __device__ __forceinline__ bool map_pair(const DevTables &t, int stream, i32 r, 
         return false;                                                            // :1726
     rec = ((u64)(u32)fi << ID_BITS) | (u64)(u32)fj | FLANK_BIT;
     return true;
+}
+template <bool COMBINED>
+__device__ __forceinline__ bool map_pair(const DevTables &t, int stream, i32 r, i32 m, i32 p1, i32 p2, u64 &rec, u64 *xy = nullptr) {
+    if (!pair_admitted(t, r, m)) return false;
+    return map_pair_with<COMBINED>(t, stream, r, m, p1, p2, t.ctg[r], t.ctg[m], rec, xy);
 }
 
 #endif

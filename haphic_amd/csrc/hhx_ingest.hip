@@ -52,12 +52,48 @@ struct SrcPairs {
 // The map is evaluated ONCE per pair (k_map_records: 16 B read, 8 B written); the count and scatter passes of the
 // first radix level then stream the 8-byte records instead of re-running the predicate chain on the 16-byte pairs
 // (measured: count 6.8 -> 0.8 ms, scatter 8.1 -> 3 ms per 500 M pairs, for 4 GB of scratch).
-template <bool COMBINED>
-__global__ __launch_bounds__(256) void k_map_records(SrcPairs<COMBINED> src, i64 n, u64 *__restrict__ rec) {
-    for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (i64)gridDim.x * blockDim.x) {
-        u64 w0; u32 w1;
-        rec[idx] = src.get(idx, w0, w1) ? w0 : EMPTY_KEY;
+// Four consecutive pairs per lane: the four streams arrive as 16-byte loads, the eight table gathers (clamped ids,
+// unconditional) are all issued before the first is consumed, and the records leave as two 16-byte stores — the
+// kernel is bound by the latency of its dependent loads, not by bytes.  VEC = false: any alignment, any tail.
+template <bool COMBINED, bool VEC>
+__global__ __launch_bounds__(256) void k_map_records(SrcPairs<COMBINED> src, i64 i0, i64 n, u64 *__restrict__ rec) {
+    if (!VEC) {
+        for (i64 idx = i0 + (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (i64)gridDim.x * blockDim.x) {
+            u64 w0; u32 w1;
+            rec[idx] = src.get(idx, w0, w1) ? w0 : EMPTY_KEY;
+        }
+        return;
     }
+    const i64 groups = n >> 2;
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (i64)gridDim.x * blockDim.x) {
+        const int4 q1 = reinterpret_cast<const int4 *>(src.id1)[g], q2 = reinterpret_cast<const int4 *>(src.id2)[g];
+        const int4 x1 = reinterpret_cast<const int4 *>(src.pos1)[g], x2 = reinterpret_cast<const int4 *>(src.pos2)[g];
+        const i32 r[4] = {q1.x, q1.y, q1.z, q1.w}, m[4] = {q2.x, q2.y, q2.z, q2.w};
+        const i32 p1[4] = {x1.x, x1.y, x1.z, x1.w}, p2[4] = {x2.x, x2.y, x2.z, x2.w};
+        bool ok[4];
+        UnitInfo a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ok[k] = pair_admitted(src.t, r[k], m[k]);
+            a[k] = src.t.ctg[ok[k] ? r[k] : 0];
+            b[k] = src.t.ctg[ok[k] ? m[k] : 0];
+        }
+        u64 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            u64 v;
+            w[k] = (ok[k] && map_pair_with<COMBINED>(src.t, src.stream, r[k], m[k], p1[k], p2[k], a[k], b[k], v)) ? v : EMPTY_KEY;
+        }
+        reinterpret_cast<ulonglong2 *>(rec)[2 * g] = make_ulonglong2(w[0], w[1]);
+        reinterpret_cast<ulonglong2 *>(rec)[2 * g + 1] = make_ulonglong2(w[2], w[3]);
+    }
+}
+template <bool COMBINED>
+void launch_map(const SrcPairs<COMBINED> &src, i64 n, u64 *rec) {
+    const bool aligned = ((((uintptr_t)src.id1) | ((uintptr_t)src.id2) | ((uintptr_t)src.pos1) | ((uintptr_t)src.pos2) | ((uintptr_t)rec)) & 15) == 0;
+    const i64 bulk = aligned && src.t.n_ctg > 0 ? (n & ~(i64)3) : 0;
+    if (bulk) k_map_records<COMBINED, true><<<(unsigned)std::max<i64>(1, std::min<i64>((bulk / 4 + 255) / 256, 256 * 16)), 256, 0, g_stream>>>(src, 0, bulk, rec);
+    if (bulk < n) k_map_records<COMBINED, false><<<(unsigned)std::max<i64>(1, std::min<i64>((n - bulk + 255) / 256, 256 * 16)), 256, 0, g_stream>>>(src, bulk, n, rec);
 }
 struct SrcMapped {
     typedef u32 w1_t;
@@ -572,13 +608,12 @@ extern "C" int hhx_ingest_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const
     { KTimer kt("ingest");
     DevBuf<u64> mapped;
     if (mapped.alloc((size_t)n_pairs)) return 1;
-    const unsigned mgrid = (unsigned)std::max<i64>(1, std::min<i64>((n_pairs + 255) / 256, 256 * 32));
     for (int stream = 0; stream < 3; ++stream) {
         if (stream == 1 && h->combined) continue;
         if (stream == 2 && !h->keep_frag_pairs) continue;
         { KTimer kt2("map");
-        if (h->combined && stream == 0) k_map_records<true><<<mgrid, 256, 0, g_stream>>>(SrcPairs<true>{src[0], src[1], src[2], src[3], h->t, 0}, n_pairs, mapped.p);
-        else k_map_records<false><<<mgrid, 256, 0, g_stream>>>(SrcPairs<false>{src[0], src[1], src[2], src[3], h->t, stream}, n_pairs, mapped.p); }
+        if (h->combined && stream == 0) launch_map(SrcPairs<true>{src[0], src[1], src[2], src[3], h->t, 0}, n_pairs, mapped.p);
+        else launch_map(SrcPairs<false>{src[0], src[1], src[2], src[3], h->t, stream}, n_pairs, mapped.p); }
         HHX_LAUNCH_CHECK();
         LinkRun *run = nullptr;
         HHX_TRY((build_run<SrcMapped, 0>(SrcMapped{mapped.p}, n_pairs, Payload(), ord0, &run)));

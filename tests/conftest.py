@@ -15,8 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+class Golden(dict):
+    """a fixture file read ONCE into memory (an NpzFile inflates the member again on every `g[key]`: a per-entry loop
+    over a large fixture took minutes)"""
+    @property
+    def files(self):
+        return list(self)
+
+
 def load_golden(name):
-    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+        return Golden({k: z[k] for k in z.files})
 
 
 @pytest.fixture(scope='session')
