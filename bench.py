@@ -356,12 +356,21 @@ def cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state):
     t1 = time.perf_counter()
     res = orc.mcl(pre, 2, args.inflation, 200, 1e-4)
     dm = time.perf_counter() - t1
+    # a1 beside it: the reference's tokeniser loop (pairs_generator :1539-1559, restated in oracle.parse_pairs_text) on
+    # 300 k lines of this workload's .pairs text
+    names = list(gen.names)
+    nt = min(300_000, S)
+    text = ''.join('r%d\t%s\t%d\t%s\t%d\t+\t-\n' % (i, names[u], x + 1, names[v], y + 1)
+                   for i, (u, x, v, y) in enumerate(zip(h[0][:nt].tolist(), h[1][:nt].tolist(), h[2][:nt].tolist(), h[3][:nt].tolist()))).encode()
+    t2 = time.perf_counter()
+    orc.parse_pairs_text(text, names)
+    dtok = time.perf_counter() - t2
     return {'value': S / dt, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
             'sample': 'ingest: first %d pairs of the rank-0 shard through the C oracle (hash-map port of '
                       'parse_alignments_for_ctgs); mcl: oracle mcl() on the %d-contig sub-assembly (first quarter '
                       'of the chromosomes) built from those pairs' % (S, nq),
             'ingest_seconds': dt, 'mcl_iters_per_s': res[3] / dm, 'mcl_n': int(nq), 'mcl_iterations': int(res[3]),
-            'host_cpus': os.cpu_count()}
+            'text_tokeniser_pairs_per_s': nt / dtok, 'text_tokeniser_lines': nt, 'host_cpus': os.cpu_count()}
 
 
 if __name__ == '__main__':
