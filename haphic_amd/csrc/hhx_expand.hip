@@ -205,7 +205,10 @@ __device__ __forceinline__ void acc_add(double *slot, double p) {
 // consecutive entries and keeps two tiles in flight: the loads of tile t+1 are issued before the LDS
 // atomics of tile t, so a wave never sits out a full memory round trip per segment (segments are short
 // when the row is cut into many column windows).  All cursor state is wave-uniform.
-constexpr int TILE_U = 8;
+constexpr int TILE_U = 8;           // entries per lane and tile for long segments; short segments (later iterations, many
+                                    // windows) take the U = 2 instantiation: a tile costs its 2 * U loads whether filled or not
+                                    // (iteration 1 at n = 100k, segments of 67: 98 -> 78 ms; a ring of eight 2-entry tiles in
+                                    // flight per wave spilled registers and was slower, 94 ms)
 struct SegCursor {
     i32 e, q, qe; double da, s, r; bool valid;
 };
@@ -217,8 +220,9 @@ __device__ __forceinline__ void seg_open(const ExLds &l, SegCursor &c, i32 len) 
         if (CODED) { c.s = l.st_s[c.e]; c.r = 1.0 / c.s; }
     }
 }
+template <int U>
 struct Tile {
-    u32 j[TILE_U], v[TILE_U];      // window-local column (0xffffffff = none); float bits or link count
+    u32 j[U], v[U];      // window-local column (0xffffffff = none); float bits or link count
     double da, s, r; bool valid;
 };
 // value of a count-coded entry: float(count / s) exactly as sklearn's normalisation forms it
@@ -237,13 +241,13 @@ __device__ __forceinline__ float coded_value(u32 cnt, double s, double r) {
 // around them the compiler's s_waitcnt pass can count, so consuming tile t waits with vmcnt(16) for the
 // older tile only while the loads of tile t+1 stay in flight (with predicated loads it emitted vmcnt(0)
 // before every LDS atomic and the prefetch was worthless).
-template <bool CODED>
-__device__ __forceinline__ void tile_fetch(const ExParams &P, const ExLds &l, SegCursor &c, i32 len, Tile &t) {
+template <bool CODED, int U>
+__device__ __forceinline__ void tile_fetch(const ExParams &P, const ExLds &l, SegCursor &c, i32 len, Tile<U> &t) {
     t.valid = c.valid;
     t.da = c.da; t.s = c.s; t.r = c.r;
     const i32 q0 = c.q + lane_id(), qe = c.valid ? c.qe : 0;
 #pragma unroll
-    for (int u = 0; u < TILE_U; ++u) {
+    for (int u = 0; u < U; ++u) {
         const i32 qq = q0 + u * HHX_WAVE;
         const bool in = qq < qe;
         const i32 qs = in ? qq : 0;
@@ -253,16 +257,16 @@ __device__ __forceinline__ void tile_fetch(const ExParams &P, const ExLds &l, Se
         t.v[u] = val;
     }
     if (c.valid) {
-        c.q += TILE_U * HHX_WAVE;
+        c.q += U * HHX_WAVE;
         if (c.q >= c.qe) { c.e += EX_WAVES; seg_open<CODED>(l, c, len); }
     }
 }
 // PROBE (HHX_PROBE, measurement only — results are garbage): 1 = no LDS operation per product (register sink),
 // 2 = a plain ds_write_b64 instead of the atomic add
-template <bool CODED, int PROBE = 0>
-__device__ __forceinline__ void tile_consume(const ExLds &l, const Tile &t, double &sink) {
+template <bool CODED, int PROBE, int U>
+__device__ __forceinline__ void tile_consume(const ExLds &l, const Tile<U> &t, double &sink) {
 #pragma unroll
-    for (int u = 0; u < TILE_U; ++u)
+    for (int u = 0; u < U; ++u)
         if (t.j[u] != 0xffffffffu) {
             const float b = CODED ? coded_value(t.v[u], t.s, t.r) : __uint_as_float(t.v[u]);
             if (PROBE == 1) sink += (t.da * (double)b + 1.0) - 1.0;
@@ -270,21 +274,21 @@ __device__ __forceinline__ void tile_consume(const ExLds &l, const Tile &t, doub
             else acc_add(&l.acc[t.j[u]], t.da * (double)b);
         }
 }
-template <bool CODED, int PROBE = 0>
+template <bool CODED, int PROBE, int U>
 __device__ __forceinline__ void accumulate_window(const ExParams &P, const ExLds &l, i32 len) {
     SegCursor c;
     c.e = threadIdx.x / HHX_WAVE;
     c.q = c.qe = 0; c.da = 0.0; c.s = 1.0; c.r = 1.0;
     seg_open<CODED>(l, c, len);
-    Tile ta, tb;
-    tile_fetch<CODED>(P, l, c, len, ta);
+    Tile<U> ta, tb;
+    tile_fetch<CODED, U>(P, l, c, len, ta);
     double sink = 0.0;
     for (;;) {
-        tile_fetch<CODED>(P, l, c, len, tb);
-        tile_consume<CODED, PROBE>(l, ta, sink);
+        tile_fetch<CODED, U>(P, l, c, len, tb);
+        tile_consume<CODED, PROBE, U>(l, ta, sink);
         if (!tb.valid) break;
-        tile_fetch<CODED>(P, l, c, len, ta);
-        tile_consume<CODED, PROBE>(l, tb, sink);
+        tile_fetch<CODED, U>(P, l, c, len, ta);
+        tile_consume<CODED, PROBE, U>(l, tb, sink);
         if (!ta.valid) break;
     }
     if (PROBE == 1 && sink == 123.456) l.acc[0] = sink;
@@ -524,7 +528,7 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
 // B[:, w] (nnz_B / n_win entries), which raises the Infinity Cache / L2 hit rate of the B-row stream
 // compared with a row-outer nest (measured at n = 100k, 6 windows: 1.59 s vs 1.76 s before tile
 // pipelining), and the per-row epilogue (finalize) becomes its own uniform launch.
-template <bool CODED, int PROBE = 0>
+template <bool CODED, int PROBE = 0, int U = TILE_U>
 __global__ __launch_bounds__(EX_T_WIN) void k_expand_window_pass(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap,
                                                                  i32 wv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(EX_T_WIN) void k_expand_window_pass(ExParams P, con
             if (n_win > 1) stage_chunk<true, CODED>(P, l, a0, len, wv);
             else stage_chunk<false, CODED>(P, l, a0, len, wv);
             __syncthreads();
-            accumulate_window<CODED, PROBE>(P, l, len);
+            accumulate_window<CODED, PROBE, U>(P, l, len);
             __syncthreads();
         }
         i32 nz;
@@ -831,6 +835,8 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_expand_compact, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -877,8 +883,14 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, list_w.p, list_c.p, list_t.p, counts.p, cursors.p);
         HHX_LAUNCH_CHECK();
         unsigned int hc[4];
+        unsigned long long hw[2];                            // products / A entries of the window class
         HHX_HIP(hipMemcpyAsync(hc, counts.p, sizeof hc, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipMemcpyAsync(hw, cursors.p + 5, sizeof hw, hipMemcpyDeviceToHost, g_stream));
         HHX_HIP(hipStreamSynchronize(g_stream));
+        // mean length of a B-row segment inside one column window: tiles of 2 / 4 / 8 entries per lane
+        static const int tile_env = getenv("HHX_TILE_U") ? atoi(getenv("HHX_TILE_U")) : 0;
+        const double seg_len = hw[1] ? (double)hw[0] / (double)hw[1] / (double)n_win : 0.0;
+        const int tile_u = tile_env ? tile_env : (seg_len >= 192.0 ? 8 : (seg_len >= 96.0 ? 4 : 2));
         ExParams P;
         P.Ap = a->indptr.p; P.Aj = a->indices.p; P.Ax = a->data.p;
         P.Bp = b->indptr.p; P.Bj = b->indices.p; P.Bx = b->data.p;
@@ -908,6 +920,8 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 if (is_coded) k_expand_window_pass<true><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
                 else if (probe == 1) k_expand_window_pass<false, 1><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
                 else if (probe == 2) k_expand_window_pass<false, 2><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
+                else if (tile_u == 2) k_expand_window_pass<false, 0, 2><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
+                else if (tile_u == 4) k_expand_window_pass<false, 0, 4><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
                 else k_expand_window_pass<false><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
             } }
             KTimer kt("expand_finalize");
@@ -930,8 +944,8 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         HHX_HIP(hipStreamSynchronize(g_stream));
         if (debug)
             fprintf(stderr, "[hhx expand] %d x %d, nnzA %lld nnzB %lld: window rows %u (n_win %d x %d cols, lds %zu), compact rows %u; "
-                    "candidates %llu / %lld, survivors %llu / %lld, %.1f ms since entry%s\n", n_rows, n_cols, (long long)a->nnz, (long long)b->nnz, hc[0], n_win,
-                    cap_win, lds_win, hc[1], cur[0], (long long)cand_cap, cur[1], (long long)pool_cap,
+                    "candidates %llu / %lld, survivors %llu / %lld, tile %d (segments of %.0f), %.1f ms since entry%s\n", n_rows, n_cols, (long long)a->nnz, (long long)b->nnz, hc[0], n_win,
+                    cap_win, lds_win, hc[1], cur[0], (long long)cand_cap, cur[1], (long long)pool_cap, tile_u, seg_len,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count(), cur[2] ? "  OVERFLOW -> retry" : "");
         if (cur[2]) {                                  // a pool overflowed: grow and redo the launches
             if ((i64)cur[0] > cand_cap) cand_cap = std::max<i64>(cand_cap * 2, (i64)cur[0] + (i64)n_rows);

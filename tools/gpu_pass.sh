@@ -10,7 +10,7 @@ for what in "$@"; do
     tests) timeout 900 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; grep -A8 "slowest" gpurun_out/pytest_gpu.log | head -9; tail -2 gpurun_out/pytest_gpu.log;;
     c2) timeout 600 python bench.py --contigs 10000 --pairs 50000000 --nchrs 16 --mean-len 50000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_c2.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c2.log; python tools/bench_brief.py gpurun_out/bench_c2.log;;
     c3) timeout 900 python bench.py $C3 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/bench_c3.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3.log; grep "hhx expand" gpurun_out/bench_c3.log | head -3; python tools/bench_brief.py gpurun_out/bench_c3.log;;
-    c3w) HHX_DEBUG=1 timeout 900 python bench.py $C3 --steps 1 --warmup 1 --no-cpu-baseline --text-lines 0 > gpurun_out/bench_c3w.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3w.log; grep "hhx expand" gpurun_out/bench_c3w.log | cut -c150-420 | awk 'NR>1 && /2645152512|1322576256/ {print}' | tail -2; python tools/bench_brief.py gpurun_out/bench_c3w.log | head -2;;
+    c3w) HHX_DEBUG=1 timeout 900 python bench.py $C3 --steps 1 --warmup 1 --no-cpu-baseline --text-lines 0 > gpurun_out/bench_c3w.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3w.log; grep "hhx expand" gpurun_out/bench_c3w.log | cut -c150-420 | tail -26 | head -4; python tools/bench_brief.py gpurun_out/bench_c3w.log | head -2;;
     sharded1) timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --force-sharded > gpurun_out/bench_sh.log 2>&1; echo "rc=$?" >> gpurun_out/bench_sh.log; python tools/bench_brief.py gpurun_out/bench_sh.log; tail -3 gpurun_out/bench_sh.log | cut -c1-300;;
     pushes4) timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --pushes 4 > gpurun_out/bench_p4.log 2>&1; echo "rc=$?" >> gpurun_out/bench_p4.log; python tools/bench_brief.py gpurun_out/bench_p4.log | head -4;;
     text) timeout 600 python -m pytest tests -m gpu -x -q -k "pairs_text" 2>&1 | tail -3; timeout 600 python bench.py --contigs 10000 --pairs 20000000 --nchrs 16 --mean-len 50000 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/bench_text.log 2>&1; echo "rc=$?"; python -c "
