@@ -76,6 +76,10 @@ SIGNATURES = {
     'hhx_ingest_flank_count_device': (C.c_int, [C.c_void_p, c_vpp]),
     'hhx_ingest_destroy': (C.c_int, [C.c_void_p]),
     'hhx_ingest_keep_pairs': (C.c_int, [C.c_void_p, C.c_int]),
+    'hhx_csr_vstack': (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), c_vpp]),
+    'hhx_mem_info': (C.c_int, [c_i64p, c_i64p]),
+    'hhx_inflate_prune_keep': (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_vpp]),
+    'hhx_mcl_resume': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, c_vpp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
     'hhx_shard_create': (C.c_int, [C.c_void_p, C.c_void_p, c_vpp]),
     'hhx_shard_first': (C.c_int, [C.c_void_p, c_vpp]),
     'hhx_rank_first': (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, c_i32p]),
@@ -265,6 +269,34 @@ def inflate_prune(c, inflation, pruning):
     out = C.c_void_p()
     check(load().hhx_inflate_prune(c.h, float(inflation), float(pruning), C.byref(out)))
     return DeviceCSR(out)
+
+
+def inflate_prune_keep(c, inflation, pruning):
+    out = C.c_void_p()
+    check(load().hhx_inflate_prune_keep(c.h, float(inflation), float(pruning), C.byref(out)))
+    return DeviceCSR(out)
+
+
+def vstack(blocks):
+    arr = (C.c_void_p * len(blocks))(*[b.h.value for b in blocks])
+    out = C.c_void_p()
+    check(load().hhx_csr_vstack(len(blocks), arr, C.byref(out)))
+    return DeviceCSR(out)
+
+
+def mem_info():
+    f, t = C.c_int64(0), C.c_int64(0)
+    check(load().hhx_mem_info(C.byref(f), C.byref(t)))
+    return f.value, t.value
+
+
+def mcl_resume(m, done, expansion, inflation, max_iter, pruning):
+    out = C.c_void_p()
+    n_iter, conv = C.c_int(0), C.c_int(0)
+    stats = np.zeros((max(int(max_iter), 1), 4), np.int64)
+    check(load().hhx_mcl_resume(m.h, int(done), int(expansion), float(inflation), int(max_iter), float(pruning),
+                                C.byref(out), C.byref(n_iter), C.byref(conv), ptr(stats)))
+    return DeviceCSR(out), n_iter.value, bool(conv.value)
 
 
 def spgemm(a, b, fx_shift=-1, want_products=False):

@@ -382,6 +382,11 @@ def mcl_device(pre_expanded, expansion, inflation, iters, pruning, links=False):
     """mcl() on a device-resident pre-expanded matrix (links=True: on the raw link matrix, normalisation and
     pre-expansion fused into iteration 0); logs like the reference (:2047 :2058)."""
     res, n_iter, converged = _lib.mcl(pre_expanded, expansion, inflation, iters, pruning, links=links)
+    _log_mcl(n_iter, converged, expansion, inflation, iters, pruning)
+    return res
+
+
+def _log_mcl(n_iter, converged, expansion, inflation, iters, pruning):
     if converged:
         logger.info('The matrix has converged after {} rounds of iterations '
                     '(expansion: {}, inflation: {}, maximum iterations: {}, pruning threshold: {})'.format(
@@ -390,6 +395,26 @@ def mcl_device(pre_expanded, expansion, inflation, iters, pruning, links=False):
         logger.info('The matrix does not converge after {} rounds of iterations '
                     '(expansion: {}, inflation: {}, maximum iterations: {}, pruning threshold: {})'.format(
                         n_iter, expansion, inflation, iters, pruning))
+
+
+def mcl_device_blocked(blocks, expansion, inflation, iters, pruning):
+    """mcl() on a pre-expanded matrix that is held as row blocks (more than 2^31 entries in total): iteration 0
+    (:2030-2042 without the expansion) is row-local — inflate + prune per block, the blocks are left untouched for
+    the next inflation — and the pruned blocks stacked are an ordinary matrix from which the loop resumes."""
+    parts = [_lib.inflate_prune_keep(b, inflation, pruning) for b in blocks]
+    try:
+        first = _lib.vstack(parts)
+    finally:
+        for p in parts:
+            p.free()
+    if iters <= 1:
+        _log_mcl(min(iters, 1), False, expansion, inflation, iters, pruning)
+        return first
+    try:
+        res, n_iter, converged = _lib.mcl_resume(first, 1, expansion, inflation, iters, pruning)
+    finally:
+        first.free()
+    _log_mcl(n_iter, converged, expansion, inflation, iters, pruning)
     return res
 
 
@@ -794,7 +819,7 @@ def recommend_inflation(result_stat, nchrs, len_ratio):
 
 def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, expansion, min_inflation,
                        max_inflation, inflation_step, max_iter, pruning, fa_dict, nchrs, dense_matrix=False,
-                       outdir_root='.', dist=None):
+                       outdir_root='.', dist=None, _block_rows=None):
     """run_mcl_clustering() :2132-2242.  link_matrix: scipy CSC or a DeviceCSR.  The normalised,
     pre-expanded matrix is built once and stays in HBM for the whole inflation sweep.  With a torch.distributed
     group (`dist`, one process per GPU, every rank holding the link matrix) the inflations are dealt round-robin
@@ -810,9 +835,28 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
     # nearly dense: it is materialised only while it is guaranteed to fit scipy's int32 index range
     # (n^2 < 2^31); beyond that every inflation starts from the link matrix and the pre-expansion is fused
     # into its iteration 0 (hhx_mcl_links) — same results, the n^2-entry matrix never exists.
-    materialise = expansion > 1 and n * n < 2 ** 31
+    materialise = expansion > 1 and n * n < 2 ** 31 and not _block_rows
+    inflations = _inflation_values(min_inflation, max_inflation, inflation_step)
     pre = None
-    if materialise:
+    blocks = None
+    if expansion == 2 and not materialise and len(inflations) > 1 and max_iter >= 1:
+        # Beyond the int32 range M^2 still fits HBM (n = 100k: ~10^10 entries, 80 GB of 288): keep it as row blocks of
+        # at most 2^31 / n rows, so that the expansion of the link matrix is paid once for the whole sweep.
+        rows_per = int(_block_rows) if _block_rows else max(1, (2 ** 31 - 1) // n)
+        _lib.check(_lib.load().hhx_pool_trim())
+        free_bytes, _total = _lib.mem_info()
+        if _block_rows or 8.0 * n * n + 40.0 * rows_per * n < 0.85 * free_bytes:     # the blocks + one block's work pools
+            _lib.normalize_l1(m)                                     # :2144
+            blocks = []
+            for r0 in range(0, n, rows_per):
+                a = m.row_block(r0, min(n, r0 + rows_per))
+                try:
+                    blocks.append(_lib.spgemm(a, m, fx_shift=52))    # :2146-2147, rows [r0, r1) of M^2
+                finally:
+                    a.free()
+    if blocks is not None:
+        pass
+    elif materialise:
         _lib.normalize_l1(m)                                         # :2144
         pre = m
         for _ in range(2, expansion + 1):                            # :2146-2147
@@ -825,10 +869,11 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
         pre = m
     result_clusters_list = []
     mcl_nrounds = 0
-    inflations = _inflation_values(min_inflation, max_inflation, inflation_step)
 
     def run_one(inflation):
-        if pre is not None:
+        if blocks is not None:
+            res = mcl_device_blocked(blocks, expansion, float(inflation), max_iter, pruning)
+        elif pre is not None:
             res = mcl_device(pre, expansion, float(inflation), max_iter, pruning)
         else:
             res = mcl_device(m, expansion, float(inflation), max_iter, pruning, links=True)
@@ -887,6 +932,8 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
         result_clusters_list.append((inflation, result_clusters))
     if pre is not None and pre is not m:
         pre.free()
+    for b in blocks or ():
+        b.free()
     m.free()
     max_nclusters = max([len(rc) for _, rc in result_clusters_list])
     if max_nclusters < nchrs:

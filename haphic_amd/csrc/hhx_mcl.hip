@@ -206,8 +206,17 @@ __global__ __launch_bounds__(256) void k_any_zero(i32 n, const double *__restric
     if (__any(bad) && lane_id() == 0) atomicExch(flags, 1u);
 }
 
-int inflate_prune_impl(hhx_csr *c, int mode, double inflation, double pruning, hhx_csr **out) {
+// keep != 0: c->data is left untouched (the inflated values go to a scratch copy): a row block of M^e that the
+// inflation sweep revisits for every inflation
+int inflate_prune_impl(hhx_csr *c, int mode, double inflation, double pruning, hhx_csr **out, int keep = 0) {
     const i32 n = c->n_rows;
+    DevBuf<float> scratch;
+    float *cdata = c->data.p;
+    if (keep && mode == 1) {
+        if (scratch.alloc((size_t)c->nnz + 1)) return 1;
+        if (c->nnz) HHX_HIP(hipMemcpyAsync(scratch.p, c->data.p, sizeof(float) * (size_t)c->nnz, hipMemcpyDeviceToDevice, g_stream));
+        cdata = scratch.p;
+    }
     DevBuf<i32> cnt, amax, optr;
     DevBuf<double> s2;
     if (cnt.alloc((size_t)n + 1) || amax.alloc((size_t)n + 1) || s2.alloc((size_t)n + 1) || optr.alloc((size_t)n + 1)) return 1;
@@ -216,9 +225,9 @@ int inflate_prune_impl(hhx_csr *c, int mode, double inflation, double pruning, h
     const int square = (inflation == 2.0);
     { KTimer kt("inflate_stats");
     if (mode == 0)
-        k_inflate_stats<0><<<row_grid(n), ROW_T, 0, g_stream>>>(n, c->indptr.p, c->data.p, r, square, thr, cnt.p, amax.p, s2.p);
+        k_inflate_stats<0><<<row_grid(n), ROW_T, 0, g_stream>>>(n, c->indptr.p, cdata, r, square, thr, cnt.p, amax.p, s2.p);
     else
-        k_inflate_stats<1><<<row_grid(n), ROW_T, 0, g_stream>>>(n, c->indptr.p, c->data.p, r, square, thr, cnt.p, amax.p, s2.p);
+        k_inflate_stats<1><<<row_grid(n), ROW_T, 0, g_stream>>>(n, c->indptr.p, cdata, r, square, thr, cnt.p, amax.p, s2.p);
     }
     HHX_LAUNCH_CHECK();
     i64 total = 0;
@@ -227,9 +236,10 @@ int inflate_prune_impl(hhx_csr *c, int mode, double inflation, double pruning, h
     HHX_TRY(hhx_csr_alloc_internal(n, c->n_cols, total, &p));
     HHX_HIP(hipMemcpyAsync(p->indptr.p, optr.p, sizeof(i32) * ((size_t)n + 1), hipMemcpyDeviceToDevice, g_stream));
     { KTimer kt("prune_write");
-    k_prune_write<<<row_grid(n), ROW_T, 0, g_stream>>>(n, c->indptr.p, c->indices.p, c->data.p, thr, amax.p, s2.p,
+    k_prune_write<<<row_grid(n), ROW_T, 0, g_stream>>>(n, c->indptr.p, c->indices.p, cdata, thr, amax.p, s2.p,
                                                        p->indptr.p, p->indices.p, p->data.p); }
     HHX_LAUNCH_CHECK();
+    if (scratch.p) HHX_HIP(hipStreamSynchronize(g_stream));       // the scratch copy dies with this frame
     *out = p;
     return 0;
 }
@@ -265,6 +275,12 @@ extern "C" int hhx_inflate_prune(hhx_csr *c, double inflation, double pruning, h
     return inflate_prune_impl(c, 1, inflation, pruning, out);
 }
 
+extern "C" int hhx_inflate_prune_keep(const hhx_csr *c, double inflation, double pruning, hhx_csr **out) {
+    if (!c || !out) return fail("null pointer");
+    if (!(inflation > 0)) return fail("inflation must be positive");
+    return inflate_prune_impl(const_cast<hhx_csr *>(c), 1, inflation, pruning, out, 1);
+}
+
 extern "C" int hhx_convergence_stat(const hhx_csr *m, const hhx_csr *last, float *stat) {
     if (!m || !last || !stat) return fail("null pointer");
     if (m->n_rows != last->n_rows) return fail("shape mismatch");
@@ -287,16 +303,16 @@ extern "C" int hhx_convergence_stat(const hhx_csr *m, const hhx_csr *last, float
 // fused into iteration 0.  Every expansion that feeds an inflate+prune goes through the fused kernel.
 static int mcl_impl(const hhx_csr *m, int pre_expanded, int expansion, double inflation, int max_iter, double pruning,
                     hhx_csr **out, int *n_iter, int *converged, i64 *stats, const unsigned short *n16 = nullptr,
-                    const double *row_sum = nullptr) {
+                    const double *row_sum = nullptr, int first_it = 0) {
     if (!m || !out || !n_iter || !converged) return fail("null pointer");
     if (m->n_rows != m->n_cols) return fail("mcl needs a square matrix");
     if (expansion < 1) return fail("expansion must be >= 1");
     if (!(inflation > 0)) return fail("inflation must be positive");
-    *n_iter = 0;
+    *n_iter = first_it;
     *converged = 0;
     hhx_csr *cur = nullptr;                  // matrix at the end of the previous iteration (== last_matrix)
     int rc = 0;
-    for (int it = 0; it < max_iter && !rc; ++it) {
+    for (int it = first_it; it < max_iter && !rc; ++it) {
         const hhx_csr *src = cur ? cur : m;  // operand of this iteration's expansion
         const bool expand = (it > 0 || !pre_expanded) && expansion > 1;
         i64 st_a = src->nnz, st_f = 0, st_c = 0;
@@ -352,6 +368,15 @@ static int mcl_impl(const hhx_csr *m, int pre_expanded, int expansion, double in
 extern "C" int hhx_mcl(const hhx_csr *pre, int expansion, double inflation, int max_iter, double pruning,
                        hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
     return mcl_impl(pre, 1, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats);
+}
+
+// mcl() :2026-2062 picked up after its first `done` iterations: `m` is the matrix those iterations left (for the
+// inflation sweep: iteration 0 = inflate + prune of the blocked M^e, hhx_inflate_prune_keep per row block).  done >= 1;
+// the convergence test needs two computed iterations, so it first runs at iteration max(done, 1) + 1 as in the loop.
+extern "C" int hhx_mcl_resume(const hhx_csr *m, int done, int expansion, double inflation, int max_iter, double pruning,
+                              hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
+    if (done < 1) return fail("hhx_mcl_resume: done must be >= 1");
+    return mcl_impl(m, 1, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats, nullptr, nullptr, done);
 }
 
 extern "C" int hhx_mcl_normalized(const hhx_csr *norm, int expansion, double inflation, int max_iter, double pruning,

@@ -368,6 +368,44 @@ extern "C" int hhx_csr_row_block(const hhx_csr *m, i32 r0, i32 r1, hhx_csr **out
     return 0;
 }
 
+// the row blocks stacked in order (equal column counts); the total number of entries must stay below 2^31
+extern "C" int hhx_csr_vstack(i32 n_blocks, const hhx_csr *const *blocks, hhx_csr **out) {
+    if (n_blocks < 1 || !blocks || !out) return fail("hhx_csr_vstack: bad argument");
+    i64 rows = 0, nnz = 0;
+    for (i32 k = 0; k < n_blocks; ++k) {
+        if (!blocks[k] || blocks[k]->n_cols != blocks[0]->n_cols) return fail("hhx_csr_vstack: block %d is null or has another column count", k);
+        rows += blocks[k]->n_rows;
+        nnz += blocks[k]->nnz;
+    }
+    if (rows > INT32_MAX || nnz > INT32_MAX) return fail("hhx_csr_vstack: %lld rows / %lld entries exceed int32", (long long)rows, (long long)nnz);
+    hhx_csr *m = nullptr;
+    HHX_TRY(csr_alloc((i32)rows, blocks[0]->n_cols, nnz, &m));
+    i64 r = 0, z = 0;
+    hipError_t e = hipSuccess;
+    for (i32 k = 0; k < n_blocks && e == hipSuccess; ++k) {
+        const hhx_csr *b = blocks[k];
+        // indptr of the block shifted by the entries above it; the last block also writes the closing entry
+        k_rebase_indptr<<<(b->n_rows + 1 + 255) / 256, 256, 0, g_stream>>>(b->indptr.p, m->indptr.p + r, k + 1 == n_blocks ? b->n_rows : b->n_rows - 1, (i32)-z);
+        e = hipGetLastError();
+        if (e == hipSuccess && b->nnz) e = hipMemcpyAsync(m->indices.p + z, b->indices.p, sizeof(i32) * (size_t)b->nnz, hipMemcpyDeviceToDevice, g_stream);
+        if (e == hipSuccess && b->nnz) e = hipMemcpyAsync(m->data.p + z, b->data.p, sizeof(float) * (size_t)b->nnz, hipMemcpyDeviceToDevice, g_stream);
+        r += b->n_rows;
+        z += b->nnz;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    if (e != hipSuccess) { delete m; return fail("hhx_csr_vstack: %s", hipGetErrorString(e)); }
+    *out = m;
+    return 0;
+}
+
+extern "C" int hhx_mem_info(i64 *free_bytes, i64 *total_bytes) {
+    size_t f = 0, t = 0;
+    HHX_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (i64)f;
+    if (total_bytes) *total_bytes = (i64)t;
+    return 0;
+}
+
 extern "C" int hhx_csr_free(hhx_csr *m) {
     delete m;
     return 0;

@@ -64,6 +64,10 @@ int hhx_csr_device_ptrs(const hhx_csr *m, void **dev_indptr, void **dev_indices,
 int hhx_csr_copy(const hhx_csr *m, hhx_csr **out);
 /* rows [r0, r1) as a new (r1-r0) x n_cols matrix: the row-block shard of SURVEY §8e */
 int hhx_csr_row_block(const hhx_csr *m, int32_t r0, int32_t r1, hhx_csr **out);
+/* row blocks stacked in order (same column count; fewer than 2^31 entries in total) */
+int hhx_csr_vstack(int32_t n_blocks, const hhx_csr *const *blocks, hhx_csr **out);
+/* free / total device memory in bytes (memory cached by the library's pool counts as used: hhx_pool_trim first) */
+int hhx_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 int hhx_csr_free(hhx_csr *m);
 
 /* ---------------------------------------------------------------- S3: normalize / power / prune
@@ -76,6 +80,9 @@ int hhx_inflate(hhx_csr *m, double inflation);
 int hhx_prune(const hhx_csr *m, double pruning, hhx_csr **out);
 /* :2037-2042 fused: prune(normalize(power(C, inflation))); C is consumed (its data is overwritten). */
 int hhx_inflate_prune(hhx_csr *c, double inflation, double pruning, hhx_csr **out);
+/* same result, c untouched: for a row block of the pre-expanded matrix that run_mcl_clustering's inflation sweep
+ * (:2155-2158) revisits for every inflation */
+int hhx_inflate_prune_keep(const hhx_csr *c, double inflation, double pruning, hhx_csr **out);
 
 /* ---------------------------------------------------------------- S1: expansion
  * sparse_dot_mkl.dot_product_mkl(A_csc, B_csc) :39-43, used by mkl_matrix_power :2017-2023.
@@ -107,6 +114,13 @@ int hhx_mcl(const hhx_csr *pre_expanded, int expansion, double inflation, int ma
             hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
 /* run_mcl_clustering :2144-2158 for one inflation, starting from the L1-normalised link matrix: the
  * pre-expansion (:2146-2147) is fused into iteration 0 instead of being materialised. */
+/* mcl() :2026-2062 picked up after its first `done` (>= 1) iterations, `m` being the matrix they left; n_iter and
+ * stats[] keep counting from `done`.  run_mcl_clustering at orders where M^e has more than 2^31 entries keeps M^e in
+ * HBM as row blocks (hhx_spgemm on hhx_csr_row_block), forms iteration 0 of every inflation with
+ * hhx_inflate_prune_keep per block + hhx_csr_vstack, and resumes here: the expansion of the link matrix (a second
+ * per inflation at n = 100k) is paid once for the whole sweep, as in the reference (:2146-2147). */
+int hhx_mcl_resume(const hhx_csr *m, int done, int expansion, double inflation, int max_iter, double pruning,
+                   hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
 int hhx_mcl_normalized(const hhx_csr *normalized, int expansion, double inflation, int max_iter, double pruning,
                        hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
 

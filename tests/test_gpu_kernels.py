@@ -561,6 +561,38 @@ def test_mcl_normalized_fuses_pre_expansion(golden_mcl):
         assert stats[0, 0] == len(g[tag + '_norm_j']) and stats[0, 1] == len(g[tag + '_m2_j']) and stats[0, 3] > 0
 
 
+def test_mcl_blocked_pre_expansion_resume(golden_mcl):
+    """M^2 as row blocks (hhx_spgemm on hhx_csr_row_block), iteration 0 per block without touching the blocks
+    (hhx_inflate_prune_keep), hhx_csr_vstack, hhx_mcl_resume == hhx_mcl on the whole pre-expanded matrix: same
+    matrix bit for bit, same iteration count and convergence flag, for two inflations from the same blocks"""
+    A = clustered_stochastic(6000, 100, 12, 1, 7)
+    d = _lib.DeviceCSR.from_arrays(*A)
+    pre = _lib.spgemm(d, d, fx_shift=52)
+    n = d.shape3[0]
+    blocks = []
+    for r0 in range(0, n, 1300):
+        a = d.row_block(r0, min(n, r0 + 1300))
+        blocks.append(_lib.spgemm(a, d, fx_shift=52))
+        a.free()
+    stacked = _lib.vstack(blocks)
+    assert all(np.array_equal(x, y) for x, y in zip(stacked.to_arrays(), pre.to_arrays()))
+    keep = [b.to_arrays()[2].copy() for b in blocks]
+    for infl in (2.0, 1.4):
+        want, it_w, cv_w = _lib.mcl(pre, 2, infl, 100, 1e-4)
+        parts = [_lib.inflate_prune_keep(b, infl, 1e-4) for b in blocks]
+        first = _lib.vstack(parts)
+        got, it_g, cv_g = _lib.mcl_resume(first, 1, 2, infl, 100, 1e-4)
+        assert (it_g, cv_g) == (it_w, cv_w)
+        assert all(np.array_equal(x, y) for x, y in zip(got.to_arrays(), want.to_arrays()))
+        one, it_1, cv_1 = _lib.mcl(pre, 2, infl, 1, 1e-4)             # a single iteration == the stacked iteration 0
+        assert all(np.array_equal(x, y) for x, y in zip(first.to_arrays(), one.to_arrays())) and (it_1, cv_1) == (1, False)
+        for x in parts + [first, got, want, one]:
+            x.free()
+    assert all(np.array_equal(b.to_arrays()[2], k) for b, k in zip(blocks, keep))       # the blocks were not written
+    free_b, total_b = _lib.mem_info()
+    assert 0 < free_b <= total_b
+
+
 def test_mcl_links_count_coded_iteration0():
     """hhx_mcl_links (normalisation fused, iteration 0 streaming 16-bit link counts + 16-bit window-local
     columns) must give exactly the bits of hhx_normalize_l1 + hhx_mcl_normalized, on a matrix wide enough

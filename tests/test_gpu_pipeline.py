@@ -19,7 +19,9 @@ class Args:
     nwindows = 50
 
 
-def test_cluster_files_byte_identical(golden_pipeline, tmp_path):
+@pytest.mark.parametrize('block_rows', [None, 37])
+def test_cluster_files_byte_identical(golden_pipeline, tmp_path, block_rows):
+    """block_rows: the inflation sweep on M^2 held as row blocks (the n^2 >= 2^31 regime) must write the same files"""
     from haphic_amd import cluster
     g = golden_pipeline
     names = [str(x) for x in g['names']]
@@ -39,7 +41,7 @@ def test_cluster_files_byte_identical(golden_pipeline, tmp_path):
     cluster.logger.setLevel('INFO')
     try:
         res, nrounds = cluster.run_mcl_clustering(mat, set(), frag_len_dict, fidx, 2, 1.2, 2.0, 0.4, 200, 1e-4, fa_dict,
-                                                  int(g['nchrs']), False, outdir_root=str(tmp_path))
+                                                  int(g['nchrs']), False, outdir_root=str(tmp_path), _block_rows=block_rows)
     finally:
         cluster.logger.removeHandler(handler)
     assert nrounds == 3
