@@ -868,9 +868,17 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     // candidate pool: early windows test against a partial row sum and admit more than finally survive
     i64 pool_cap = std::max<i64>(4 * a->nnz + 16 * (i64)n_rows, (i64)1 << 22);
     i64 cand_cap = n_win > 1 ? 2 * pool_cap : pool_cap;
-    if (coded.raw) {                    // the product of two sparse matrices is at most dense
+    if (coded.raw) {                    // every entry is kept: at most dense, and at most one entry per product
+        HHX_HIP(hipMemsetAsync(counts.p, 0, 4 * sizeof(unsigned int), g_stream));
+        HHX_HIP(hipMemsetAsync(cursors.p, 0, 8 * sizeof(unsigned long long), g_stream));
+        k_classify<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 63) / 64, 4096)), 256, 0, g_stream>>>(
+            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, list_w.p, list_c.p, list_t.p, counts.p, cursors.p);
+        HHX_LAUNCH_CHECK();
+        unsigned long long products = 0;
+        HHX_HIP(hipMemcpyAsync(&products, cursors.p + 4, sizeof products, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
         const i64 dense = (i64)n_rows * n_cols;
-        pool_cap = cand_cap = std::min<i64>(dense, std::max<i64>(pool_cap, 32 * a->nnz)) + n_rows;
+        pool_cap = cand_cap = std::min<i64>(dense, (i64)products) + n_rows;
     }
     for (int attempt = 0; attempt < 6; ++attempt) {
         DevBuf<i32> cand_col, out_col;
