@@ -174,12 +174,14 @@ def main():
         if win_n:
             alg = 6.0 * F_w + 16.0 * A_w
             ach = alg / (win_ms * 1e-3) / 1e9
-            roofline = {'kernel': 'k_expand_window_pass', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': ach / HBM_PEAK_GBS, 'traffic': pick(traffic, 'k_expand_window_pass'),
+            roofline = {'kernel': 'k_expand_window_pass<false, 0, 8>', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': ach / HBM_PEAK_GBS, 'traffic': pick(traffic, 'k_expand_window_pass<false, 0, 8>'),
                         'alg_bytes_per_launch': alg / win_n, 'avg_launch_ms': win_ms / win_n, 'launches_per_step': win_n / K,
                         'products_per_step': F_w / K, 'bytes_per_product': 6,
                         'achieved_survey_8B_model': (8.0 * F_w + 16.0 * A_w) / (win_ms * 1e-3) / 1e9,
-                        'note': 'traffic = fabric bytes per launch from rocprofv3 PMC (profiles/), null if no profile matches this workload'}
+                        'note': 'the long-segment instantiation (8 entries per lane and tile: iteration 0, where the link matrix is the operand); '
+                                'the short-segment launches of later iterations are in mcl.kernel_ms_per_step.expand_window_short; '
+                                'traffic = fabric bytes per launch from rocprofv3 PMC (profiles/), null if no profile matches this workload'}
         # ---- ingest: the kernel that bounds `value` is the level-1 scatter of the group-by
         sc_ms, sc_n = pg('map')
         ing_roofline = None
@@ -203,7 +205,7 @@ def main():
                'pre_expansion': 'fused into iteration 0', 'clusters': state.get('clusters'),
                'alg_bytes_per_mcl_survey': b_iter, 'alg_GBs_survey': b_iter * K / t_mcl / 1e9 if t_mcl else None,
                'stats_nnzA_nnzC_nnzP_F': stats.tolist(),
-               'kernel_ms_per_step': {'expand_window': win_ms / K, 'expand_finalize': fin_ms / K, 'expand_compact': cmp_ms / K,
+               'kernel_ms_per_step': {'expand_window': win_ms / K, 'expand_window_short': pg('expand_window_short')[0] / K, 'expand_finalize': fin_ms / K, 'expand_compact': cmp_ms / K,
                                       'expand_tiny': tiny_ms / K,
                                       'convergence': cvg_ms / K}}
         ingest = {'pairs_per_s': value, 'ms_per_step': t_ing / K * 1e3, 'alg_bytes_survey': b_ingest,

@@ -923,7 +923,9 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             P.Bc16 = c16.p;
             const unsigned per_cu = lds_win > 80 * 1024 ? 1 : 2;
             const unsigned grid = std::min<unsigned>(hc[0], 256 * per_cu);
-            { KTimer kt("expand_window", n_win);            // one timer scope, n_win launches of k_expand_window_pass
+            // one timer scope, n_win launches of k_expand_window_pass; the long-segment instantiation (U = 8: iteration 0)
+            // and the short-segment ones are timed apart, as rocprof lists them apart
+            { KTimer kt(tile_u == TILE_U || is_coded ? "expand_window" : "expand_window_short", n_win);
             for (i32 wv = 0; wv < n_win; ++wv) {
                 if (is_coded) k_expand_window_pass<true><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
                 else if (probe == 1) k_expand_window_pass<false, 1><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
@@ -961,8 +963,9 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             continue;
         }
         if (prof_enabled() && hc[0]) {
-            prof_count("expand_window_products", (i64)cur[5]);
-            prof_count("expand_window_a_reads", (i64)cur[6] * n_win);
+            const bool longseg = tile_u == TILE_U || is_coded;
+            prof_count(longseg ? "expand_window_products" : "expand_window_short_products", (i64)cur[5]);
+            prof_count(longseg ? "expand_window_a_reads" : "expand_window_short_a_reads", (i64)cur[6] * n_win);
         }
         if (n_products) *n_products = (i64)cur[4];
         if (nnz_expanded) *nnz_expanded = (i64)cur[3];

@@ -23,7 +23,7 @@ for l in open('gpurun_out/bench_text.log'):
     prof) rm -rf gpurun_out/prof; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof.log 2>&1; echo "rc=$?" >> gpurun_out/prof.log; ls -R gpurun_out/prof | head; tail -2 gpurun_out/prof.log | cut -c1-400;;
     pmc:*) # pmc:NAME:COUNTER1,COUNTER2  -> one rocprofv3 --pmc pass of the default bench (1 step, no warmup)
         spec="${what#pmc:}"; name="${spec%%:*}"; ctrs="${spec#*:}"; rm -rf gpurun_out/pmc_$name
-        timeout 900 rocprofv3 --kernel-trace --pmc ${ctrs//,/ } --output-format csv -d gpurun_out/pmc_$name -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline $PMC_ARGS > gpurun_out/pmc_$name.log 2>&1; echo "pmc $name rc=$?"; ls gpurun_out/pmc_$name | head -5;;
+        timeout 900 rocprofv3 --kernel-trace --pmc ${ctrs//,/ } --output-format csv -d gpurun_out/pmc_$name -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --text-lines 0 $PMC_ARGS > gpurun_out/pmc_$name.log 2>&1; echo "pmc $name rc=$?"; ls gpurun_out/pmc_$name | head -5;;
     listpmc) rocprofv3 -L > gpurun_out/pmc_list.txt 2>&1; grep -c . gpurun_out/pmc_list.txt;;
     env:*) export "${what#env:}"; echo "set ${what#env:}";;
     *) echo "unknown $what";;
