@@ -526,7 +526,9 @@ class PairsText:
             size = os.path.getsize(self.path)
             if size == 0:
                 return
-            with open(self.path, 'rb') as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+            f = open(self.path, 'rb')
+            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+            try:
                 at = 0
                 while at < size:
                     end = min(at + self.chunk_bytes, size)
@@ -536,8 +538,14 @@ class PairsText:
                         cut = end if end == size else mm.rfind(b'\n', at, end) + 1
                     view = np.frombuffer(mm, np.uint8, cut - at, at)
                     yield view
-                    del view                                     # the map cannot close while a view is alive
+                    del view
                     at = cut
+            finally:
+                try:
+                    mm.close()
+                except BufferError:                              # a consumer still holds a view of a chunk: the map goes
+                    pass                                         # when that view does
+                f.close()
             return
         import gzip
         with gzip.open(self.path, 'rb') as f:
