@@ -481,7 +481,7 @@ extern "C" int hhx_pairs_parse(hhx_pairs_parser *p, const uint8_t *text, i64 n_b
     { KTimer kt("text_starts");
     k_write_starts<<<grid_for(n_blocks, 1), 256, 0, g_stream>>>(t, n_bytes, n_blocks, pre.p, p->starts.p); }
     HHX_LAUNCH_CHECK();
-    if (p->id1.n < (size_t)nl)
+    if (std::min(std::min(p->id1.n, p->pos1.n), std::min(p->id2.n, p->pos2.n)) < (size_t)nl)
         if (p->id1.alloc((size_t)nl) || p->pos1.alloc((size_t)nl) || p->id2.alloc((size_t)nl) || p->pos2.alloc((size_t)nl)) return 1;
     DevBuf<i64> bed_len;
     if (want_bed && bed_len.alloc((size_t)nl)) return 1;
