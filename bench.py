@@ -228,7 +228,7 @@ def main():
             out['ingest']['text'] = text_leg(args, gen, id1, p1, id2, p2, dev)
         if sharded_path:
             out['ingest']['sharded_build_ms_last_step'] = state.get('shard_ms')
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # a reported baseline of the N = 1 line only
             out['cpu_baseline'] = cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state)
         print(json.dumps(out))
     if sharded_path:
