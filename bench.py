@@ -84,8 +84,14 @@ def main():
     flank = 500_000                                   # --flank 500 (kb), HapHiC_cluster.py default
     # this rank's shard of the read-pair stream, generated straight into HBM
     local_pairs = args.pairs // world
-    id1, p1, id2, p2 = synth.sample_pairs(gen, local_pairs, seed=12345 + rank, device=dev)
+    # generated in slices of 500 M (the sampler's temporaries are ~80 B per pair) and torch's cache handed back, so
+    # that the library's own allocator sees the whole HBM
+    parts = [synth.sample_pairs(gen, min(500_000_000, local_pairs - lo), seed=12345 + rank + 1000 * k, device=dev)
+             for k, lo in enumerate(range(0, local_pairs, 500_000_000))]
+    id1, p1, id2, p2 = [torch.cat([q[c] for q in parts]) if len(parts) > 1 else parts[0][c] for c in range(4)]
+    del parts
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     in_set = np.ones(n, np.uint8)
 
     if sharded_path:

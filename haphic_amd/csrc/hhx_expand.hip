@@ -111,7 +111,7 @@ __device__ __forceinline__ float ex_inflate(float x, double r, int square) {
 
 __device__ __forceinline__ i32 lower_bound_i32(const i32 *__restrict__ a, i32 b, i32 e, i32 v) {
     while (b < e) {
-        const i32 m = (b + e) >> 1;
+        const i32 m = b + ((e - b) >> 1);              // b + e overflows int32 beyond 2^30 entries
         if (a[m] < v) b = m + 1; else e = m;
     }
     return b;

@@ -19,7 +19,7 @@ constexpr int RK_MAX_TOP = 64;
 
 __device__ __forceinline__ i32 lb_cols(const i32 *__restrict__ cols, i32 b, i32 e, i32 x) {
     while (b < e) {
-        const i32 m = (b + e) >> 1;
+        const i32 m = b + ((e - b) >> 1);
         if (cols[m] < x) b = m + 1; else e = m;
     }
     return b;

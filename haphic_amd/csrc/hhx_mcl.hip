@@ -149,7 +149,7 @@ __global__ __launch_bounds__(ROW_T) void k_prune_write(i32 n_rows, const i32 *__
 // ---- convergence statistic -------------------------------------------------------------------
 __device__ __forceinline__ i32 find_col(const i32 *__restrict__ idx, i32 b, i32 e, i32 c) {
     while (b < e) {
-        i32 m = (b + e) >> 1;
+        i32 m = b + ((e - b) >> 1);                     // b + e overflows int32 beyond 2^30 entries
         i32 v = idx[m];
         if (v < c) b = m + 1;
         else e = m;

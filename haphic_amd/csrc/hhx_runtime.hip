@@ -41,9 +41,11 @@ void *pool_alloc(size_t bytes) {
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, c);
     if (e != hipSuccess) {
+        (void)hipGetLastError();                 // the failed attempt must not surface at the next launch check
         pool_trim();
         e = hipMalloc(&p, c);
         if (e != hipSuccess) {
+            (void)hipGetLastError();
             fail("hipMalloc(%zu bytes) failed: %s", c, hipGetErrorString(e));
             return nullptr;
         }
