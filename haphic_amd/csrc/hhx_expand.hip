@@ -799,6 +799,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     if (!a || !b || !out) return fail("null pointer");
     if (a->n_cols != b->n_rows) return fail("expand shape mismatch");
     if (!(inflation > 0)) return fail("inflation must be positive");
+    if (b->nnz > (i64)INT32_MAX - 4096) return fail("expand: right operand has %lld entries; the tile cursors need 4096 below 2^31", (long long)b->nnz);
     if (fx_shift < 0 || fx_shift > 52) fx_shift = 52;        // the exact-double accumulation holds 52 fractional bits
     const auto t_enter = std::chrono::steady_clock::now();
     const i32 n_rows = a->n_rows, n_cols = b->n_cols;
