@@ -353,22 +353,30 @@ __device__ __forceinline__ bool stage_lines(const unsigned char *__restrict__ t,
     return true;
 }
 
+// STAGED = true: the blocks of 128 lines whose text fits the LDS window; the others (lines of kilobytes, or an
+// unaligned device buffer) only raise O.err[1] and are taken by a second launch with STAGED = false, which reads HBM
+// directly — so that the common kernel carries one reader, not two (registers, instruction cache).
+template <bool STAGED>
 __global__ __launch_bounds__(LN_BLOCK) void k_parse_lines(const unsigned char *__restrict__ t, i64 n, const i64 *__restrict__ starts, i64 n_lines,
                                                           NameTable T, LineOut O) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_in[IN_CAP + 16];
+    __shared__ __attribute__((aligned(16))) unsigned char s_in[STAGED ? IN_CAP + 16 : 16];
+    const bool aligned = ((uintptr_t)t & 15) == 0;
     for (i64 k0 = (i64)blockIdx.x * LN_BLOCK; k0 < n_lines; k0 += (i64)gridDim.x * LN_BLOCK) {
         const i64 k1 = k0 + LN_BLOCK < n_lines ? k0 + LN_BLOCK : n_lines;
         const i64 a0 = starts[k0], e0 = k1 < n_lines ? starts[k1] : n;
-        i64 bias;
-        const bool staged = stage_lines(t, n, a0, e0, s_in, &bias);
-        __syncthreads();
+        const bool fits = aligned && e0 - (a0 & ~(i64)15) <= IN_CAP;
         const i64 k = k0 + threadIdx.x;
-        if (k < k1) {
-            const i64 a = starts[k], e = k + 1 < n_lines ? starts[k + 1] : n;
-            if (staged) parse_one(LdsText{s_in, bias}, k, a, e, T, O);
-            else parse_one(HbmText{t}, k, a, e, T, O);
+        if (STAGED) {
+            if (!fits) { if (threadIdx.x == 0) atomicOr(&O.err[1], 1ull); continue; }
+            i64 bias;
+            (void)stage_lines(t, n, a0, e0, s_in, &bias);
+            __syncthreads();
+            if (k < k1) parse_one(LdsText{s_in, bias}, k, starts[k], k + 1 < n_lines ? starts[k + 1] : n, T, O);
+            __syncthreads();
+        } else {
+            if (fits) continue;
+            if (k < k1) parse_one(HbmText{t}, k, starts[k], k + 1 < n_lines ? starts[k + 1] : n, T, O);
         }
-        __syncthreads();
     }
 }
 
@@ -434,7 +442,7 @@ extern "C" int hhx_pairs_parser_create(i32 n_names, const uint8_t *names, const 
         sh[s] = h;
     }
     if (p->names.alloc(words.size()) || p->name_off.alloc(off.size()) || p->name_len.alloc(len.size()) || p->slot_hash.alloc(cap) ||
-        p->slot_id.alloc(cap) || p->err.alloc(1)) { delete p; return 1; }
+        p->slot_id.alloc(cap) || p->err.alloc(2)) { delete p; return 1; }
     hipError_t e = hipMemcpyAsync(p->names.p, words.data(), sizeof(u64) * words.size(), hipMemcpyHostToDevice, g_stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->name_off.p, off.data(), sizeof(i64) * off.size(), hipMemcpyHostToDevice, g_stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->name_len.p, len.data(), sizeof(i32) * len.size(), hipMemcpyHostToDevice, g_stream);
@@ -485,15 +493,23 @@ extern "C" int hhx_pairs_parse(hhx_pairs_parser *p, const uint8_t *text, i64 n_b
         if (p->id1.alloc((size_t)nl) || p->pos1.alloc((size_t)nl) || p->id2.alloc((size_t)nl) || p->pos2.alloc((size_t)nl)) return 1;
     DevBuf<i64> bed_len;
     if (want_bed && bed_len.alloc((size_t)nl)) return 1;
-    HHX_HIP(hipMemsetAsync(p->err.p, 0xff, sizeof(unsigned long long), g_stream));
+    HHX_HIP(hipMemsetAsync(p->err.p, 0xff, sizeof(unsigned long long), g_stream));      // [0] first error (min), [1] unstaged blocks seen
+    HHX_HIP(hipMemsetAsync(p->err.p + 1, 0, sizeof(unsigned long long), g_stream));
     const NameTable T{p->names.p, p->name_off.p, p->name_len.p, p->slot_hash.p, p->slot_id.p, p->mask};
+    const LineOut O{p->id1.p, p->pos1.p, p->id2.p, p->pos2.p, want_bed ? bed_len.p : nullptr, p->err.p};
     { KTimer kt("text_parse");
-    k_parse_lines<<<grid_for(nl, LN_BLOCK), LN_BLOCK, 0, g_stream>>>(
-        t, n_bytes, p->starts.p, nl, T, LineOut{p->id1.p, p->pos1.p, p->id2.p, p->pos2.p, want_bed ? bed_len.p : nullptr, p->err.p}); }
+    k_parse_lines<true><<<grid_for(nl, LN_BLOCK), LN_BLOCK, 0, g_stream>>>(t, n_bytes, p->starts.p, nl, T, O); }
     HHX_LAUNCH_CHECK();
-    unsigned long long err = 0;
-    HHX_HIP(hipMemcpyAsync(&err, p->err.p, sizeof err, hipMemcpyDeviceToHost, g_stream));
+    unsigned long long errw[2] = {0, 0};
+    HHX_HIP(hipMemcpyAsync(errw, p->err.p, sizeof errw, hipMemcpyDeviceToHost, g_stream));
     HHX_HIP(hipStreamSynchronize(g_stream));
+    if (errw[1]) {                                           // some block of lines did not fit LDS
+        k_parse_lines<false><<<grid_for(nl, LN_BLOCK), LN_BLOCK, 0, g_stream>>>(t, n_bytes, p->starts.p, nl, T, O);
+        HHX_LAUNCH_CHECK();
+        HHX_HIP(hipMemcpyAsync(errw, p->err.p, sizeof errw, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+    }
+    const unsigned long long err = errw[0];
     if (err != ~0ull) {
         const long long line = (long long)(p->lines_before + (i64)(err >> 8) + 1);
         switch ((int)(err & 0xff)) {

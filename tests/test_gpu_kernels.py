@@ -326,6 +326,12 @@ def test_pairs_text_tokeniser_golden():
     assert ps.parse(b'') == 0
     assert ps.parse(b'r1 ctg1 5 ctg2 9') == 1
     assert [a.tolist() for a in ps.fetch()[:4]] == [[1], [4], [2], [8]]
+    # a line far longer than the LDS window (40 kB read name) among ordinary ones: the HBM reader takes its block
+    long_text = b'r0\tctg2\t11\tctg3\t12\n' + b'R' * 40000 + b'\tctg5\t100\tctg7\t200\textra\n' + b'r2\tctg1\t5\tctg4\t6\n'
+    assert ps.parse(long_text, want_bed=True) == 3
+    got = ps.fetch(want_bed=True)
+    want_long = orc.parse_pairs_text(long_text, names)
+    assert all(np.array_equal(x, y) for x, y in zip(got[:4], want_long[:4])) and got[4] == want_long[4]
     # malformed lines raise what the reference raises
     with pytest.raises(IndexError):
         ps.parse(b'r1\tctg1\t5\tctg2\n')
