@@ -428,6 +428,13 @@ class PairsParser:
         check(load().hhx_pairs_parser_fetch(self.h, *[ptr(a) for a in out], ptr(bed) if bed.size else None))
         return out + [bed.tobytes()]
 
+    def fetch_bed(self):
+        """the alignments.bed bytes of the last parse (uint8 array)"""
+        bed = np.empty(self.bed_bytes, np.uint8)
+        if self.bed_bytes:
+            check(load().hhx_pairs_parser_fetch(self.h, None, None, None, None, ptr(bed)))
+        return bed
+
     def destroy(self):
         if self.h is not None and self.h.value:
             load().hhx_pairs_parser_destroy(self.h)

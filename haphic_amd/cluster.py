@@ -591,9 +591,7 @@ class PairsText:
                 n = parser.parse(chunk, want_bed=fbed is not None)
                 del chunk
                 if fbed is not None and parser.bed_bytes:
-                    bed = np.empty(parser.bed_bytes, np.uint8)
-                    _lib.check(_lib.load().hhx_pairs_parser_fetch(parser.h, None, None, None, None, _lib.ptr(bed)))
-                    todo.put(bed)
+                    todo.put(parser.fetch_bed())
                 if failed:
                     raise failed[0]
                 yield parser, n
