@@ -39,3 +39,18 @@ def test_seven_containers(host_only, monkeypatch):
 
 def test_pairs_file_front_end(host_only, tmp_path, monkeypatch):
     tk.test_pairs_text_through_ingest(tmp_path, monkeypatch)
+
+
+@pytest.fixture
+def host_only_everywhere(monkeypatch, host_only):
+    import haphic_amd
+    monkeypatch.setattr(haphic_amd, '_lib', oracle_lib)        # `from haphic_amd import _lib` inside the test bodies
+    return host_only
+
+
+def test_stat_fragments_mirror(host_only_everywhere):
+    tp.test_re_sites_and_stat_fragments()
+
+
+def test_filter_fragments_mirror(host_only_everywhere):
+    tp.test_filter_fragments_and_rank_sums()
