@@ -118,13 +118,13 @@ def _worker(rank, world, port, q):
         sharded.MAX_MESSAGE_BYTES = 4096            # every collective of this test takes several rounds
         eng = OracleEngine()
         # ragged all-to-all(v) / all-gather(v) against plain arithmetic, including empty pieces
-        send = torch.arange(3000 + 500 * rank, dtype=torch.int64) + 100000 * rank
-        counts = [1200, len(send) - 1200] if rank == 0 else [0, len(send)]
-        got, rc = sharded._all_to_all_var(send, counts, dist, torch)
-        exp = torch.cat([torch.arange(0, 1200), torch.arange(0, 0) + 100000]) if rank == 0 else torch.cat([torch.arange(1200, 3000), torch.arange(0, 3500) + 100000])
-        assert torch.equal(got, exp) and rc == ([1200, 0] if rank == 0 else [1800, 3500])
+        def piece(src, dst):                          # what rank src sends to rank dst: empty on the diagonal + 1
+            return torch.arange(0 if dst == (src + 1) % world else 700 * src + 300 * dst + 5, dtype=torch.int64) + 100000 * src + 1000 * dst
+        send = torch.cat([piece(rank, d) for d in range(world)])
+        got, rc = sharded._all_to_all_var(send, [piece(rank, d).numel() for d in range(world)], dist, torch)
+        assert torch.equal(got, torch.cat([piece(s_, rank) for s_ in range(world)])) and rc == [piece(s_, rank).numel() for s_ in range(world)]
         parts = sharded._all_gather_var(send, dist, torch)
-        assert torch.equal(parts[0], torch.arange(3000)) and torch.equal(parts[1], torch.arange(3500) + 100000)
+        assert all(torch.equal(parts[r], torch.cat([piece(r, d) for d in range(world)])) for r in range(world))
         # ---- MCL row-block shard
         T = stochastic(400, 6, 5)
         res, n_iter, conv, stats = sharded.mcl_sharded_engine(eng, T, 2, 2.0, 100, 1e-4, dist)
@@ -137,12 +137,12 @@ def _worker(rank, world, port, q):
         id1, p1, id2, p2 = [a.numpy() for a in synth.sample_pairs(gen, 40_000, seed=3)]
         keep = id1 != id2
         a = [x[keep] for x in (id1, p1, id2, p2)]
-        half = len(a[0]) // 2 + 17
-        sl = slice(0, half) if rank == 0 else slice(half, None)
+        cuts = _chunk_cuts(len(a[0]), world)
+        sl = slice(cuts[rank], cuts[rank + 1])
         loc = orc.ingest(t, a[0][sl], a[1][sl].astype(np.int64), a[2][sl], a[3][sl].astype(np.int64), 3000)
         # this rank's aggregated table: key, first-seen ordinal (chunk base + position in the chunk's
         # insertion order: order-preserving, and earlier chunks win), count
-        base = 0 if rank == 0 else half
+        base = cuts[rank]
         key = (loc['flank_i'].astype(np.int64) << 29) | loc['flank_j'].astype(np.int64)
         ordk = base + np.arange(len(key), dtype=np.int64)
         g = sharded.gather_tables(eng, [torch.from_numpy(key), torch.from_numpy(ordk), torch.from_numpy(loc['flank_cnt'])], dist)
@@ -167,6 +167,14 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _chunk_cuts(n, world):
+    """uneven contiguous chunks of the pair stream; the last rank gets only a handful of pairs"""
+    cuts = [0] + [n * (k + 1) // world + 17 for k in range(world - 1)] + [n]
+    if world > 2:
+        cuts[-2] = n - 5
+    return cuts
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -176,8 +184,8 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_sharded_mcl_and_merge_world2():
-    world = 2
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_mcl_and_merge(world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -193,7 +201,7 @@ def test_sharded_mcl_and_merge_world2():
     pre = orc.spgemm(T, T, mode=1, fx_shift=52)
     o = orc.mcl(pre, 2, 2.0, 100, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True)
     for rank, res, n_iter, conv, stats, merged, sweep, _built in outs:
-        assert sweep == [(12, 0), (14, 1), (16, 0), (18, 1), (20, 0)]      # inflations dealt round-robin, results in order
+        assert sweep == [(12 + 2 * k, k % world) for k in range(5)]        # inflations dealt round-robin, results in order
         assert (n_iter, conv) == (o[3], o[4])
         assert all(np.array_equal(x, y) for x, y in zip(res, o[:3])), 'sharded MCL is not bit-identical to 1 process'
         # iteration 0 of the sharded driver includes the fused pre-expansion: nnz entering = nnz(T), F > 0
@@ -221,7 +229,8 @@ def test_sharded_mcl_and_merge_world2():
     n_rest = int(in_set.sum() - linked.sum())
     rp, rj, rx, ridx, rl = orc.dict_to_matrix(whole['flank_i'], whole['flank_j'], whole['flank_cnt'].astype(np.float64), n, in_set, n_rest)
     blocks = [o[7][0] for o in outs]
-    assert np.array_equal(np.concatenate([blocks[0][0][:-1], blocks[1][0] + blocks[0][0][-1]]), rp)
+    offs = np.cumsum([0] + [b[0][-1] for b in blocks])
+    assert np.array_equal(np.concatenate([b[0][:-1] + o_ for b, o_ in zip(blocks, offs)] + [offs[-1:]]), rp)
     assert np.array_equal(np.concatenate([b[1] for b in blocks]), rj) and np.array_equal(np.concatenate([b[2] for b in blocks]), rx)
     T2 = (rp, rj, orc.normalize_l1(rp, rx))
     o2 = orc.mcl(orc.spgemm(T2, T2, mode=1, fx_shift=52), 2, 2.0, 100, 1e-4, spgemm_mode=1, fx_shift=52)
