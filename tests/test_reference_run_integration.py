@@ -1,0 +1,115 @@
+"""The whole of the reference's own `haphic cluster` entry point, HapHiC_cluster.run(args), twice on the same FASTA +
+.pairs input: once untouched (sparse mode with SURVEY's scipy stand-in for MKL), once with every seam re-bound by
+haphic_amd.patch.patch_reference — and every file it writes compared (cluster and group files of every inflation, paired_links.clm,
+alignments.bed byte for byte; full_links.pkl and HT_links.pkl as unpickled dicts, order and value types included).  This is the drop-in claim end to end: the
+reference's CLI code drives the mirrors.  It needs the reference checkout, so it runs only in the dev container; there
+is no GPU there, so tests/oracle_lib.py stands in for the HIP library (what is pinned here is the seam wiring and the
+host mirrors inside run(); the kernels are pinned by the -m gpu tests against the same oracle)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+REF = '/root/reference/scripts'
+
+
+def _load_reference():
+    for name, attrs in (('pysam', {'set_verbosity': lambda *a, **k: None, 'AlignmentFile': None}),
+                        ('portion', {'closed': None, 'empty': None})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+    sys.path.insert(0, REF)
+    try:
+        import HapHiC_cluster as H
+    finally:
+        sys.path.remove(REF)
+    return H
+
+
+def _write_inputs(d, split):
+    from haphic_amd import synth
+    rng = np.random.default_rng(17)
+    gen = synth.make_genome(3, 1_200_000, 30_000 if not split else 150_000, cv=0.4, min_len=6000, seed=23)
+    with open(os.path.join(d, 'asm.fa'), 'w') as f:
+        for nm, ln in zip(gen.names, gen.length.tolist()):
+            seq = ''.join(rng.choice(list('ACGT'), ln))
+            f.write('>%s\n' % nm)
+            for k in range(0, ln, 80):
+                f.write(seq[k:k + 80] + '\n')
+    id1, p1, id2, p2 = [t.numpy() for t in synth.sample_pairs(gen, 60_000, seed=29, cis=0.9)]
+    with open(os.path.join(d, 'hic.pairs'), 'w') as f:
+        f.write('## pairs format v1.0\n#columns: readID chr1 pos1 chr2 pos2 strand1 strand2\n')
+        for k, (a, x, b, y) in enumerate(zip(id1.tolist(), p1.tolist(), id2.tolist(), p2.tolist())):
+            f.write('r%d\t%s\t%d\t%s\t%d\t+\t-\n' % (k, gen.names[a], x + 1, gen.names[b], y + 1))
+    return gen
+
+
+def _run(H, d, extra):
+    argv = sys.argv
+    cwd = os.getcwd()
+    os.makedirs(d, exist_ok=True)
+    os.chdir(d)
+    try:
+        sys.argv = ['haphic', '../asm.fa', '../hic.pairs', '3', '--min_inflation', '1.2', '--max_inflation', '2.4', '--inflation_step', '0.4',
+                    '--Nx', '100', '--flank', '20'] + extra
+        args = H.parse_arguments()
+        H.run(args)
+    finally:
+        sys.argv = argv
+        os.chdir(cwd)
+
+
+def _tree(d):
+    out = {}
+    for root, _dirs, files in os.walk(d):
+        for f in files:
+            if f.endswith(('.log', '.pdf', '.png')):          # logs carry times, matplotlib stamps a creation date
+                continue
+            with open(os.path.join(root, f), 'rb') as fh:
+                out[os.path.relpath(os.path.join(root, f), d)] = fh.read()
+    return out
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
+@pytest.mark.parametrize('split,extra', [(False, []), (True, ['--bin_size', '40']), (False, ['--remove_allelic_links', '2', '--max_read_pairs', '60'])])
+def test_reference_run_with_and_without_the_seams(tmp_path, monkeypatch, split, extra):
+    import haphic_amd
+    from haphic_amd import cluster, patch
+    from tests import oracle_lib
+    H = _load_reference()
+    _write_inputs(str(tmp_path), split)
+    # ---- the reference as it is (sparse mode: dot_product_mkl = scipy's float32 product)
+    monkeypatch.setattr(H, 'dot_product_mkl', lambda a, b, **k: (a @ b).tocsc(), raising=False)
+    monkeypatch.setattr(H, 'INTEL_MKL', True, raising=False)
+    _run(H, str(tmp_path / 'ref'), extra)
+    # ---- the same entry point with the seams re-bound
+    monkeypatch.setattr(haphic_amd, '_lib', oracle_lib)
+    monkeypatch.setattr(cluster, '_lib', oracle_lib)
+    monkeypatch.setattr(patch, '_lib', oracle_lib, raising=False)
+    saved = patch.patch_reference(H)
+    try:
+        _run(H, str(tmp_path / 'ours'), extra)
+    finally:
+        patch.unpatch_reference(H, saved)
+    want, got = _tree(str(tmp_path / 'ref')), _tree(str(tmp_path / 'ours'))
+    assert sorted(want) == sorted(got), (sorted(want), sorted(got))
+    assert any(k.endswith('.clusters.txt') for k in want) and 'full_links.pkl' in want and 'paired_links.clm' in want
+    import pickle
+    for k in want:
+        if k.endswith('.pkl'):
+            # same dict, same insertion order, same value types; the BYTES differ only through pickle's memo (the reference
+            # keys hold a fresh str object per parsed line, the mirror re-uses one object per contig name)
+            a, b = pickle.loads(want[k]), pickle.loads(got[k])
+            if k == 'HT_links.pkl':
+                # same keys and counts; the insertion order is NOT reproduced (the device keeps one first-seen ordinal
+                # per contig pair, not per head/tail quadrant) — its only consumer, HapHiC_sort.py:117-131, does key lookups
+                assert type(a) is type(b) and a == b and sorted(a) == sorted(b), 'pickle differs: ' + k
+                continue
+            assert type(a) is type(b) and list(a.items()) == list(b.items()), 'pickle differs: ' + k
+            assert [type(v) for v in a.values()] == [type(v) for v in b.values()], 'value types differ: ' + k
+        else:
+            assert want[k] == got[k], 'file differs: ' + k
