@@ -742,7 +742,9 @@ def _pair_dicts(out, table, fa_dict, args, pos_int_type, dist_int_type):
                     shorter_len = min(fa_dict[pair[0]][1], fa_dict[pair[1]][1])
                     ctg_coord_dict[pair] = [cal_concordance_ratio(c, shorter_len, args.nwindows), 1]
                 if args.remove_concentrated_links:
-                    adj_ratio = cal_concentration_adj_ratio(c)
+                    # as the reference (:466): evaluated on the dict entry AFTER the replacement above, i.e. on the
+                    # two-element [ratio, 1] when both options are on (which always gives 1.0)
+                    adj_ratio = cal_concentration_adj_ratio(ctg_coord_dict[pair])
                     if args.remove_allelic_links:
                         ctg_coord_dict[pair][1] = adj_ratio
                     else:

@@ -48,13 +48,13 @@ def _write_inputs(d, split):
     return gen
 
 
-def _run(H, d, extra):
+def _run(H, d, extra, pairs='../hic.pairs'):
     argv = sys.argv
     cwd = os.getcwd()
     os.makedirs(d, exist_ok=True)
     os.chdir(d)
     try:
-        sys.argv = ['haphic', '../asm.fa', '../hic.pairs', '3', '--min_inflation', '1.2', '--max_inflation', '2.4', '--inflation_step', '0.4',
+        sys.argv = ['haphic', '../asm.fa', pairs, '3', '--min_inflation', '1.2', '--max_inflation', '2.4', '--inflation_step', '0.4',
                     '--Nx', '100', '--flank', '20'] + extra
         args = H.parse_arguments()
         H.run(args)
@@ -75,24 +75,36 @@ def _tree(d):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
-@pytest.mark.parametrize('split,extra', [(False, []), (True, ['--bin_size', '40']), (False, ['--remove_allelic_links', '2', '--max_read_pairs', '60'])])
+@pytest.mark.parametrize('split,extra', [(False, []), (True, ['--bin_size', '40']), (False, ['--remove_allelic_links', '2', '--max_read_pairs', '60']),
+                                         (False, ['--normalize_by_nlinks']),
+                                         (True, ['--bin_size', '40', '--remove_allelic_links', '2', '--remove_concentrated_links', '--max_read_pairs', '40']),
+                                         (False, ['--remove_concentrated_links', '--max_read_pairs', '40']),
+                                         (False, ['--RE', 'GATC,GANTC', '--gz']),
+                                         (True, ['--bin_size', '40', '--density_lower', '0.3X', '--rank_sum_hard_cutoff', '500', '--gz'])])
 def test_reference_run_with_and_without_the_seams(tmp_path, monkeypatch, split, extra):
     import haphic_amd
     from haphic_amd import cluster, patch
     from tests import oracle_lib
     H = _load_reference()
     _write_inputs(str(tmp_path), split)
+    pairs = '../hic.pairs'
+    if '--gz' in extra:                                      # bgzipped_pairs input (:1544)
+        import gzip
+        extra = [e for e in extra if e != '--gz']
+        with open(tmp_path / 'hic.pairs', 'rb') as fi, gzip.open(tmp_path / 'hic.pairs.gz', 'wb') as fo:
+            fo.write(fi.read())
+        pairs = '../hic.pairs.gz'
     # ---- the reference as it is (sparse mode: dot_product_mkl = scipy's float32 product)
     monkeypatch.setattr(H, 'dot_product_mkl', lambda a, b, **k: (a @ b).tocsc(), raising=False)
     monkeypatch.setattr(H, 'INTEL_MKL', True, raising=False)
-    _run(H, str(tmp_path / 'ref'), extra)
+    _run(H, str(tmp_path / 'ref'), extra, pairs)
     # ---- the same entry point with the seams re-bound
     monkeypatch.setattr(haphic_amd, '_lib', oracle_lib)
     monkeypatch.setattr(cluster, '_lib', oracle_lib)
     monkeypatch.setattr(patch, '_lib', oracle_lib, raising=False)
     saved = patch.patch_reference(H)
     try:
-        _run(H, str(tmp_path / 'ours'), extra)
+        _run(H, str(tmp_path / 'ours'), extra, pairs)
     finally:
         patch.unpatch_reference(H, saved)
     want, got = _tree(str(tmp_path / 'ref')), _tree(str(tmp_path / 'ours'))
