@@ -33,6 +33,23 @@ OPTIONAL = {
 }
 
 
+# position of `dense_matrix` in the reference signatures: --dense_matrix (:2723) is the reference's own numpy mode, which
+# stays the reference's code — a seam called with dense_matrix=True is handed back to the original function
+DENSE_ARG = {'mcl': 5, 'prune': 2, 'interpret_result': 1, 'run_mcl_clustering': 12}
+
+
+def _dense_dispatch(ours, original, idx):
+    def seam(*args, **kwargs):
+        dense = kwargs.get('dense_matrix', args[idx] if len(args) > idx else False)
+        if dense and original is not None:
+            return original(*args, **kwargs)
+        return ours(*args, **kwargs)
+    seam.__wrapped__ = ours
+    seam.__name__ = getattr(ours, '__name__', 'seam')
+    seam.__doc__ = ours.__doc__
+    return seam
+
+
 def patch_reference(H, ingest=True, matrix_build=True):
     """H: the imported reference module (HapHiC_cluster).  Returns {name: original} so the caller can undo."""
     from . import _lib
@@ -48,7 +65,7 @@ def patch_reference(H, ingest=True, matrix_build=True):
         seams['pairs_generator_inter_ctgs'] = OPTIONAL['pairs_generator_inter_ctgs']
     for name, (_cite, fn) in seams.items():
         saved[name] = getattr(H, name, None)
-        setattr(H, name, fn)
+        setattr(H, name, _dense_dispatch(fn, saved[name], DENSE_ARG[name]) if name in DENSE_ARG else fn)
     saved['INTEL_MKL'] = getattr(H, 'INTEL_MKL', None)
     H.INTEL_MKL = True                   # :2764-2768 would otherwise force the dense (numpy) mode
     return saved

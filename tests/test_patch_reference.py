@@ -32,9 +32,9 @@ def test_patch_binds_every_seam():
         assert our_params[:len(ref_params)] == ref_params, (name, ref_params, our_params)
     saved = patch.patch_reference(H, ingest=True, matrix_build=True)
     try:
-        assert H.mcl is cluster.mcl and H.run_mcl_clustering is cluster.run_mcl_clustering
+        assert H.mcl.__wrapped__ is cluster.mcl and H.run_mcl_clustering.__wrapped__ is cluster.run_mcl_clustering
         assert H.dot_product_mkl is cluster.dot_product_mkl and H.INTEL_MKL is True
         assert H.parse_alignments_for_ctgs is cluster.parse_alignments_for_ctgs
     finally:
         patch.unpatch_reference(H, saved)
-    assert H.mcl is not cluster.mcl
+    assert H.mcl is not cluster.mcl and not hasattr(H.mcl, '__wrapped__')

@@ -80,6 +80,7 @@ def _tree(d):
                                          (True, ['--bin_size', '40', '--remove_allelic_links', '2', '--remove_concentrated_links', '--max_read_pairs', '40']),
                                          (False, ['--remove_concentrated_links', '--max_read_pairs', '40']),
                                          (False, ['--RE', 'GATC,GANTC', '--gz']),
+                                         (False, ['--dense_matrix']),
                                          (True, ['--bin_size', '40', '--density_lower', '0.3X', '--rank_sum_hard_cutoff', '500', '--gz'])])
 def test_reference_run_with_and_without_the_seams(tmp_path, monkeypatch, split, extra):
     import haphic_amd
