@@ -167,6 +167,62 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _sweep_worker(rank, world, port, outdir, q):
+    """run_mcl_clustering(dist=...) : the inflations dealt to the ranks, rank 0 writes the files"""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from haphic_amd import cluster
+        from tests import oracle_lib
+        from tests.conftest import load_golden
+        cluster._lib = oracle_lib
+        g = load_golden('pipeline_toy.npz')
+        names = [str(x) for x in g['names']]
+        fa_dict = {n_: [None, int(l), int(r)] for n_, l, r in zip(names, g['length'], g['re_sites'])}
+        aln = ((names[a], names[b], int(x), int(y)) for a, x, b, y in zip(g['id1'], g['pos1'], g['id2'], g['pos2']))
+
+        class A:
+            flank = 500
+            remove_allelic_links = 0
+            remove_concentrated_links = False
+            max_read_pairs = 200
+            nwindows = 50
+        frag_len_dict = {n_: fa_dict[n_][1] for n_ in names}
+        full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(aln, fa_dict, A(), frag_len_dict, set(names), 'int32', 'int32')
+        mat, fidx = cluster.dict_to_matrix(flank, set(names), dense_matrix=False, add_self_loops=True, _device=True)
+        res, nrounds = cluster.run_mcl_clustering(mat, set(), frag_len_dict, fidx, 2, 1.2, 2.0, 0.4, 200, 1e-4, fa_dict, int(g['nchrs']), False,
+                                                  outdir_root=outdir, dist=dist)
+        q.put((rank, nrounds, [(str(i), [(list(c), l) for c, l in r]) for i, r in res]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_inflation_sweep_across_ranks_writes_the_reference_files(tmp_path):
+    from tests.conftest import load_golden
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda o: o[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert outs[0][1:] == outs[1][1:] and outs[0][1] == 3            # every rank returns the whole sweep
+    g = load_golden('pipeline_toy.npz')
+    for infl in g['inflations']:
+        infl = str(infl)
+        d = tmp_path / ('inflation_' + infl)
+        assert (d / 'mcl_inflation_{}.clusters.txt'.format(infl)).read_text() == str(g['clusters_txt_' + infl])
+        groups = sorted(f for f in os.listdir(d) if f.startswith('group'))
+        assert groups == [str(x) for x in g['group_files_' + infl]]
+        assert (d / groups[0]).read_text() == str(g['group0_txt_' + infl])
+
+
 def _chunk_cuts(n, world):
     """uneven contiguous chunks of the pair stream; the last rank gets only a handful of pairs"""
     cuts = [0] + [n * (k + 1) // world + 17 for k in range(world - 1)] + [n]
