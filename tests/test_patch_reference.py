@@ -26,7 +26,8 @@ def test_patch_binds_every_seam():
     import inspect
     # the mirror keeps the reference's signatures (same names, same positional order)
     for name in ('mcl', 'prune', 'interpret_result', 'dict_to_matrix', 'parse_alignments_for_ctgs', 'parse_alignments',
-                 'run_mcl_clustering', 'mkl_matrix_power'):
+                 'run_mcl_clustering', 'mkl_matrix_power', 'parse_fasta', 'stat_fragments', 'count_RE_sites', 'filter_fragments',
+                 'pairs_generator', 'pairs_generator_inter_ctgs'):
         ref_params = list(inspect.signature(getattr(H, name)).parameters)
         our_params = [p for p in inspect.signature(getattr(cluster, name)).parameters if not p.startswith('_') and p != 'outdir_root']
         assert our_params[:len(ref_params)] == ref_params, (name, ref_params, our_params)
