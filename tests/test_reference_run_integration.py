@@ -133,3 +133,30 @@ def test_reference_run_with_and_without_the_seams(tmp_path, monkeypatch, split, 
             assert [type(v) for v in a.values()] == [type(v) for v in b.values()], 'value types differ: ' + k
         else:
             assert want[k] == got[k], 'file differs: ' + k
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
+def test_dict_to_matrix_as_reassign_calls_it(monkeypatch):
+    """HapHiC_reassign.py:538 — group names as keys, float link densities as values, dense result, a group without links"""
+    from haphic_amd import cluster
+    from tests import oracle_lib
+    H = _load_reference()
+    monkeypatch.setattr(cluster, '_lib', oracle_lib)
+    rng = np.random.default_rng(4)
+    groups = ['group%d' % k for k in range(1, 13)]
+    d = {}
+    for a in range(11):
+        for b in range(a + 1, 11):
+            if rng.random() < 0.6:
+                d[(groups[a], groups[b])] = float(rng.random() * 3.7)
+    for dense, loops in ((True, False), (False, True), (False, False)):
+        want, widx = H.dict_to_matrix(dict(d), set(groups), dense_matrix=dense, add_self_loops=loops)
+        got, gidx = cluster.dict_to_matrix(dict(d), set(groups), dense_matrix=dense, add_self_loops=loops)
+        assert widx == gidx and list(widx) == list(gidx)
+        if dense:
+            assert got.dtype == want.dtype and np.array_equal(got, want)
+        else:
+            want.sort_indices()
+            got.sort_indices()
+            assert got.dtype == want.dtype and np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices) \
+                and np.array_equal(got.data, want.data)
