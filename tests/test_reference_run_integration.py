@@ -30,16 +30,25 @@ def _load_reference():
     return H
 
 
-def _write_inputs(d, split):
+def _write_inputs(d, split, messy=False):
     from haphic_amd import synth
     rng = np.random.default_rng(17)
     gen = synth.make_genome(3, 1_200_000, 30_000 if not split else 150_000, cv=0.4, min_len=6000, seed=23)
     with open(os.path.join(d, 'asm.fa'), 'w') as f:
         for nm, ln in zip(gen.names, gen.length.tolist()):
             seq = ''.join(rng.choice(list('ACGT'), ln))
-            f.write('>%s\n' % nm)
-            for k in range(0, ln, 80):
-                f.write(seq[k:k + 80] + '\n')
+            width = 80
+            if messy:                                  # soft-masked runs, N gaps, GATC straddling line ends, header text
+                a, b = sorted(rng.integers(0, ln, 2).tolist())
+                seq = seq[:a] + seq[a:b].lower() + seq[b:]
+                g0 = int(rng.integers(0, max(1, ln - 500)))
+                seq = seq[:g0] + 'N' * 300 + seq[g0 + 300:]
+                width = int(rng.choice([60, 61, 70, 80, 100]))
+            f.write('>%s%s\n' % (nm, ' len=%d some description' % ln if messy else ''))
+            for k in range(0, ln, width):
+                f.write(seq[k:k + width] + '\n')
+            if messy and rng.random() < 0.3:
+                f.write('\n')
     id1, p1, id2, p2 = [t.numpy() for t in synth.sample_pairs(gen, 60_000, seed=29, cis=0.9)]
     with open(os.path.join(d, 'hic.pairs'), 'w') as f:
         f.write('## pairs format v1.0\n#columns: readID chr1 pos1 chr2 pos2 strand1 strand2\n')
@@ -82,6 +91,8 @@ def _tree(d):
                                          (False, ['--RE', 'GATC,GANTC', '--gz']),
                                          (False, ['--dense_matrix']),
                                          (False, ['--expansion', '3']),
+                                         (False, ['--messy']),
+                                         (True, ['--messy', '--bin_size', '40', '--RE', 'GATC,GANTC']),
                                          (False, ['--max_iter', '3']),
                                          (True, ['--bin_size', '40', '--Nx', '60', '--flank', '0']),
                                          (False, ['--quick_view']),
@@ -92,7 +103,8 @@ def test_reference_run_with_and_without_the_seams(tmp_path, monkeypatch, split, 
     from haphic_amd import cluster, patch
     from tests import oracle_lib
     H = _load_reference()
-    _write_inputs(str(tmp_path), split)
+    _write_inputs(str(tmp_path), split, messy='--messy' in extra)
+    extra = [e for e in extra if e != '--messy']
     pairs = '../hic.pairs'
     if '--gz' in extra:                                      # bgzipped_pairs input (:1544)
         import gzip
