@@ -91,6 +91,7 @@ SIGNATURES = {
     'hhx_pairs_parser_arrays': (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5),
     'hhx_pairs_parser_fetch': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     'hhx_pairs_parser_destroy': (C.c_int, [C.c_void_p]),
+    'hhx_ingest_fetch_ht_order': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hhx_ingest_keep_frag_pairs': (C.c_int, [C.c_void_p, C.c_int]),
     'hhx_ingest_fetch_frag_pairs': (C.c_int, [C.c_void_p, c_i64p, C.c_void_p, C.c_void_p]),
     'hhx_ingest_fetch_pairs': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -520,6 +521,12 @@ class Ingest:
         crd = np.zeros(max(2 * capped, 1), np.int64)
         check(load().hhx_ingest_fetch_pairs(self.h, int(max_read_pairs), ptr(clm_ptr), ptr(clm), ptr(crd_ptr), ptr(crd)))
         return clm_ptr, clm[:4 * total], crd_ptr, crd[:2 * capped]
+
+    def fetch_ht_order(self):
+        """[n_full, 4] stream positions of the first pair per head/tail quadrant (INT64_MAX: none): HT_link_dict's order"""
+        first = np.full((max(self.n_full, 1), 4), np.iinfo(np.int64).max, np.int64)
+        check(load().hhx_ingest_fetch_ht_order(self.h, ptr(first)))
+        return first[:self.n_full]
 
     def keep_frag_pairs(self, on=True):
         check(load().hhx_ingest_keep_frag_pairs(self.h, int(on)))

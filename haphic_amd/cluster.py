@@ -663,6 +663,7 @@ def ingest_links(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False
         out = ing.fetch()
         if want_pairs:
             out['clm_ptr'], out['clm'], out['crd_ptr'], out['crd'] = ing.fetch_pairs(max_read_pairs, out['full_cnt'])
+            out['ht_first'] = ing.fetch_ht_order()
         if want_frag_pairs:
             out['fp_i'], out['fp_j'] = ing.fetch_frag_pairs()
         return out
@@ -703,11 +704,21 @@ def _link_dicts(out, table):
     flank = defaultdict(int)
     frag_link = defaultdict(int)
     suffix = ('_H', '_T')
-    for i, j, c, ht in zip(out['full_i'].tolist(), out['full_j'].tolist(), out['full_cnt'].tolist(), out['ht_cnt'].tolist()):
+    fi, fj, ht_cnt = out['full_i'].tolist(), out['full_j'].tolist(), out['ht_cnt']
+    for i, j, c in zip(fi, fj, out['full_cnt'].tolist()):
         full[(cn[i], cn[j])] = c
-        for q, v in enumerate(ht):
-            if v:
-                HT[(cn[i] + suffix[q >> 1], cn[j] + suffix[q & 1])] = v
+    if 'ht_first' in out:
+        # HT_link_dict in the reference's insertion order: the (pair, quadrant) entries by the stream position of their
+        # first read pair (:404-416)
+        k, q = np.nonzero(ht_cnt)
+        order = np.argsort(out['ht_first'][k, q], kind='stable')
+        for kk, qq in zip(k[order].tolist(), q[order].tolist()):
+            HT[(cn[fi[kk]] + suffix[qq >> 1], cn[fj[kk]] + suffix[qq & 1])] = int(ht_cnt[kk, qq])
+    else:
+        for i, j, ht in zip(fi, fj, ht_cnt.tolist()):
+            for q, v in enumerate(ht):
+                if v:
+                    HT[(cn[i] + suffix[q >> 1], cn[j] + suffix[q & 1])] = v
     for i, j, c in zip(out['flank_i'].tolist(), out['flank_j'].tolist(), out['flank_cnt'].tolist()):
         flank[(fn[i], fn[j])] = c
     for f, c in enumerate(out['frag_links'].tolist()):

@@ -129,6 +129,36 @@ inline unsigned grid_for(u64 n) {
     return (unsigned)b;
 }
 
+__global__ __launch_bounds__(256) void k_iota_u64(i64 n, u64 *__restrict__ v) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) v[i] = (u64)i;
+}
+// one wavefront per contig pair: stream position (index among the kept pairs) of the first pair that fell into each
+// head/tail quadrant — HT_link_dict's keys enter the dict in that order (update_HT_link_dict :404-416)
+__global__ __launch_bounds__(256) void k_ht_first(i64 n_groups, const u64 *__restrict__ stk, const i64 *__restrict__ gstart, const u64 *__restrict__ srank,
+                                                  const u64 *__restrict__ sidx, const u64 *__restrict__ xy, const UnitInfo *__restrict__ ctg,
+                                                  i64 *__restrict__ first) {
+    const int lane = lane_id();
+    for (i64 g = (i64)blockIdx.x * 4 + threadIdx.x / HHX_WAVE; g < n_groups; g += (i64)gridDim.x * 4) {
+        const i64 b = gstart[g], e = gstart[g + 1], r = (i64)srank[g];
+        const u64 key = stk[g];
+        const i64 li = ctg[key >> ID_BITS].lenf & LEN_MASK, lj = ctg[key & ID_MASK].lenf & LEN_MASK;
+        long long m0 = INT64_MAX, m1 = INT64_MAX, m2 = INT64_MAX, m3 = INT64_MAX;
+        for (i64 p = b + lane; p < e; p += HHX_WAVE) {
+            const long long i = (long long)sidx[p];
+            const u64 v = xy[i];
+            const i64 xi = (i64)(v >> 32), xj = (i64)(v & 0xffffffffu);
+            const int q = (xi * 2 > li ? 2 : 0) + (xj * 2 > lj ? 1 : 0);          // :408 coord * 2 > ctg_len -> '_T'
+            if (q == 0) m0 = min(m0, i); else if (q == 1) m1 = min(m1, i); else if (q == 2) m2 = min(m2, i); else m3 = min(m3, i);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m0 = min(m0, __shfl_down(m0, o, HHX_WAVE)); m1 = min(m1, __shfl_down(m1, o, HHX_WAVE));
+            m2 = min(m2, __shfl_down(m2, o, HHX_WAVE)); m3 = min(m3, __shfl_down(m3, o, HHX_WAVE));
+        }
+        if (lane == 0) { first[4 * r] = m0; first[4 * r + 1] = m1; first[4 * r + 2] = m2; first[4 * r + 3] = m3; }
+    }
+}
+
 int sort_pairs_u64(const u64 *kin, u64 *kout, const u64 *vin, u64 *vout, i64 n) {
     size_t tmp_bytes = 0;
     HHX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0, 2 * ID_BITS, g_stream));
@@ -222,6 +252,53 @@ extern "C" int hhx_ingest_fetch_pairs(hhx_ingest *h, i64 max_read_pairs, i64 *cl
     if (crd_ptr) HHX_HIP(hipMemcpyAsync(crd_ptr, crd_off.p, sizeof(i64) * ((size_t)K + 1), hipMemcpyDeviceToHost, g_stream));
     if (clm && N) HHX_HIP(hipMemcpyAsync(clm, d_clm.p, sizeof(i64) * (size_t)N * 4, hipMemcpyDeviceToHost, g_stream));
     if (crd && crd_total) HHX_HIP(hipMemcpyAsync(crd, d_crd.p, sizeof(i64) * (size_t)crd_total * 2, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+// HT_link_dict's insertion order (update_HT_link_dict :404-416 inside the loops :1646 / :1746): for every contig pair of
+// full_link_dict, in dict order, the stream position of the first read pair of each quadrant [HH, HT, TH, TT]
+// (INT64_MAX: that quadrant never occurred).  Positions count the pairs that entered full_link_dict, in stream order, so
+// sorting the non-empty (pair, quadrant) entries by them gives the dict order.  Same grouping as hhx_ingest_fetch_pairs
+// (stable sort of the kept pairs by key), with the stream position carried as the sorted value.
+extern "C" int hhx_ingest_fetch_ht_order(hhx_ingest *h, i64 *first) {
+    if (!h || !h->finalized) return fail("ingest handle not finalized");
+    if (!h->keep_pairs) return fail("hhx_ingest_fetch_ht_order: the handle was not created with hhx_ingest_keep_pairs");
+    const i32 *fi = nullptr, *fj = nullptr;
+    HHX_TRY(hhx_ingest_ordered_full_device(h, &fi, &fj));
+    const i64 K = h->n_full, N = h->n_side;
+    if (K == 0) return 0;
+    if (!first) return fail("hhx_ingest_fetch_ht_order: null output");
+    DevBuf<u64> key, xy, skey, idx, sidx, tkey, trnk, stk, srank;
+    if (key.alloc((size_t)N) || xy.alloc((size_t)N) || skey.alloc((size_t)N) || idx.alloc((size_t)N) || sidx.alloc((size_t)N) || tkey.alloc((size_t)K) ||
+        trnk.alloc((size_t)K) || stk.alloc((size_t)K) || srank.alloc((size_t)K)) return 1;
+    i64 o = 0;
+    for (size_t b = 0; b < h->side_key.size(); ++b) {
+        const i64 nb = (i64)h->side_key[b].n;
+        if (nb) {
+            HHX_HIP(hipMemcpyAsync(key.p + o, h->side_key[b].p, 8 * (size_t)nb, hipMemcpyDeviceToDevice, g_stream));
+            HHX_HIP(hipMemcpyAsync(xy.p + o, h->side_xy[b].p, 8 * (size_t)nb, hipMemcpyDeviceToDevice, g_stream));
+        }
+        o += nb;
+    }
+    k_iota_u64<<<grid_for((u64)N), 256, 0, g_stream>>>(N, idx.p);
+    HHX_LAUNCH_CHECK();
+    HHX_TRY(sort_pairs_u64(key.p, skey.p, idx.p, sidx.p, N));
+    k_table_keys<<<grid_for((u64)K), 256, 0, g_stream>>>(K, fi, fj, tkey.p, trnk.p);
+    HHX_LAUNCH_CHECK();
+    HHX_TRY(sort_pairs_u64(tkey.p, stk.p, trnk.p, srank.p, K));
+    DevBuf<i64> flag, gidx, gstart, d_first;
+    if (flag.alloc((size_t)N + 1) || gidx.alloc((size_t)N + 2) || gstart.alloc((size_t)K + 2) || d_first.alloc((size_t)K * 4)) return 1;
+    k_boundary_flags<<<grid_for((u64)N), 256, 0, g_stream>>>(N, skey.p, flag.p);
+    HHX_LAUNCH_CHECK();
+    i64 n_groups = 0;
+    HHX_TRY(exclusive_scan_i64(flag.p, gidx.p, N, &n_groups));
+    if (n_groups != K) return fail("hhx_ingest_fetch_ht_order: %lld contig pairs in the records, %lld in the table", (long long)n_groups, (long long)K);
+    k_group_starts<<<grid_for((u64)N), 256, 0, g_stream>>>(N, skey.p, gidx.p, gstart.p);
+    HHX_HIP(hipMemcpyAsync(gstart.p + K, &N, sizeof(i64), hipMemcpyHostToDevice, g_stream));
+    k_ht_first<<<grid_for((u64)K * 64), 256, 0, g_stream>>>(K, stk.p, gstart.p, srank.p, sidx.p, xy.p, h->t.ctg, d_first.p);
+    HHX_LAUNCH_CHECK();
+    HHX_HIP(hipMemcpyAsync(first, d_first.p, sizeof(i64) * (size_t)K * 4, hipMemcpyDeviceToHost, g_stream));
     HHX_HIP(hipStreamSynchronize(g_stream));
     return 0;
 }

@@ -259,6 +259,10 @@ int hhx_pairs_parser_arrays(hhx_pairs_parser *p, void **id1, void **pos1, void *
 int hhx_pairs_parser_fetch(hhx_pairs_parser *p, int32_t *id1, int32_t *pos1, int32_t *id2, int32_t *pos2, uint8_t *bed);
 int hhx_pairs_parser_destroy(hhx_pairs_parser *p);
 
+/* HT_link_dict's insertion order (update_HT_link_dict :404-416): first[4 * k + q] = stream position (among the pairs that
+ * entered full_link_dict) of the first read pair of contig pair k (dict order of hhx_ingest_fetch) in quadrant
+ * q = [HH, HT, TH, TT], INT64_MAX if the quadrant is empty.  Needs hhx_ingest_keep_pairs. */
+int hhx_ingest_fetch_ht_order(hhx_ingest *h, int64_t *first);
 /* ctg_pair_to_frag :1731-1733 (split contigs + --remove_allelic_links): every distinct oriented fragment pair the
  * stream produced, whatever its flank / Nx status.  Request before the first push; fetch after finalize (call with
  * NULL arrays for the size). */

@@ -228,6 +228,26 @@ def parse_pairs_text(text, names):
     return a[:, 0].astype(np.int32), a[:, 1].astype(np.int32), a[:, 2].astype(np.int32), a[:, 3].astype(np.int32), ''.join(bed).encode()
 
 
+def ht_first(table, id1, pos1, id2, pos2, full_i, full_j):
+    """HT_link_dict's insertion order (update_HT_link_dict scripts/HapHiC_cluster.py:404-416, called at :1646 / :1746 for
+    every pair that enters full_link_dict): [K, 4] position, among those pairs in stream order, of the first pair of
+    contig pair k = (full_i[k], full_j[k]) in quadrant [HH, HT, TH, TT]; INT64_MAX where the quadrant is empty."""
+    id1, pos1, id2, pos2 = (np.asarray(a, np.int64) for a in (id1, pos1, id2, pos2))
+    ok = (id1 >= 0) & (id2 >= 0) & (id1 != id2)
+    id1, pos1, id2, pos2 = id1[ok], pos1[ok], id2[ok], pos2[ok]
+    sw = table.ctg_rank[id1] > table.ctg_rank[id2]                                 # :1629 / :1706 sorted by contig name
+    ci, cj = np.where(sw, id2, id1), np.where(sw, id1, id2)
+    xi, xj = np.where(sw, pos2, pos1) + 1, np.where(sw, pos1, pos2) + 1
+    q = (xi * 2 > table.ctg_len[ci]).astype(np.int64) * 2 + (xj * 2 > table.ctg_len[cj])    # :408
+    row = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(full_i, full_j))}
+    first = np.full((len(row), 4), np.iinfo(np.int64).max, np.int64)
+    for n, (a, b, qq) in enumerate(zip(ci.tolist(), cj.tolist(), q.tolist())):
+        k = row[(a, b)]
+        if first[k, qq] > n:
+            first[k, qq] = n
+    return first
+
+
 def frag_pairs(table, id1, pos1, id2, pos2):
     """ctg_pair_to_frag (scripts/HapHiC_cluster.py:1696-1733): the distinct oriented fragment pairs of a stream on
     split contigs, whatever their flank / Nx status.  numpy restatement; returns sorted (frag_i, frag_j) rows."""

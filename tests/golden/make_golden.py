@@ -184,6 +184,8 @@ def ingest_case(nchrs, chr_len, mean_len, npairs, flank_kb, Nx, bin_size_kb, see
         k = kidx[(a[:-2], b[:-2])]
         ht[k, (a[-1] == 'T') * 2 + (b[-1] == 'T')] = c
     out['ht_cnt'] = ht
+    # insertion order of HT_link_dict: (row of full_link_dict, quadrant) per key
+    out['ht_order'] = np.array([(kidx[(a[:-2], b[:-2])], (a[-1] == 'T') * 2 + (b[-1] == 'T')) for a, b in HT], np.int32).reshape(-1, 2)
     clm_ptr, clm_all = [0], []
     for k in full:
         clm_all += list(clm[k])

@@ -216,6 +216,11 @@ class Ingest:
         crd_ptr = o['crd_ptr'] // 2 if 'crd_ptr' in o else np.zeros(len(full_cnt) + 1, np.int64)
         return o['clm_ptr'] // 4, o['clm'], crd_ptr, o.get('crd', np.zeros(0, np.int64))
 
+    def fetch_ht_order(self):
+        a = self._stream()
+        o = self.out if self.out is not None else self.fetch()
+        return orc.ht_first(self.t, a[0], a[1], a[2], a[3], o['full_i'], o['full_j'])
+
     def fetch_frag_pairs(self):
         a = self._stream()
         return orc.frag_pairs(self.t, a[0], a[1], a[2], a[3])

@@ -232,6 +232,12 @@ def test_ingest_pairs_side_products_golden(golden_ingest, chunk):
     clm_ptr, clm, crd_ptr, crd = ing.fetch_pairs(int(g['max_read_pairs']), out['full_cnt'])
     assert np.array_equal(4 * clm_ptr, g['clm_ptr']) and np.array_equal(clm, g['clm'])
     assert np.array_equal(2 * crd_ptr, g['crd_ptr']) and np.array_equal(crd, g['crd'])
+    # HT_link_dict's insertion order (:404-416) from the first stream position of every (contig pair, quadrant)
+    first = ing.fetch_ht_order()
+    k, q = np.nonzero(out['ht_cnt'])
+    order = np.argsort(first[k, q], kind='stable')
+    assert np.array_equal(np.stack([k[order], q[order]], 1), g['ht_order'])
+    assert (first[out['ht_cnt'] == 0] == np.iinfo(np.int64).max).all()
 
 
 def _random_bins_case(npairs, seed):

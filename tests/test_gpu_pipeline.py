@@ -265,6 +265,8 @@ def test_parse_alignments_seven_containers_allelic(monkeypatch):
         ht = g['ht_cnt'][k]
         for q, (a, b) in enumerate((('H', 'H'), ('H', 'T'), ('T', 'H'), ('T', 'T'))):
             assert HT.get((pair[0] + '_' + a, pair[1] + '_' + b), 0) == ht[q]
+    quad = (('_H', '_H'), ('_H', '_T'), ('_T', '_H'), ('_T', '_T'))
+    assert list(HT) == [(names[g['full_i'][k]] + quad[q][0], names[g['full_j'][k]] + quad[q][1]) for k, q in g['ht_order'].tolist()]
     want = {}
     for ci, cj, fi, fj in g['c2f'].tolist():
         want.setdefault((names[ci], names[cj]), set()).add((frag_names[fi], frag_names[fj]))

@@ -121,6 +121,17 @@ def test_frag_pairs_restatement_pinned():
     assert np.array_equal(np.stack([fi, fj], 1), want)
 
 
+def test_ht_order_restatement_pinned(golden_ingest):
+    """HT_link_dict's insertion order (:404-416), frozen from the reference: sorting the non-empty (contig pair,
+    quadrant) entries by the first stream position the restatement finds reproduces it"""
+    g = golden_ingest
+    first = orc.ht_first(table_of(g), g['id1'], g['pos1'], g['id2'], g['pos2'], g['full_i'], g['full_j'])
+    k, q = np.nonzero(g['ht_cnt'])
+    assert (first[k, q] != np.iinfo(np.int64).max).all() and (first[g['ht_cnt'] == 0] == np.iinfo(np.int64).max).all()
+    order = np.argsort(first[k, q], kind='stable')
+    assert np.array_equal(np.stack([k[order], q[order]], 1), g['ht_order'])
+
+
 def test_dict_to_matrix(golden_ingest):
     g = golden_ingest
     in_set = g['d2m_in_set']

@@ -136,11 +136,6 @@ def test_reference_run_with_and_without_the_seams(tmp_path, monkeypatch, split, 
             # same dict, same insertion order, same value types; the BYTES differ only through pickle's memo (the reference
             # keys hold a fresh str object per parsed line, the mirror re-uses one object per contig name)
             a, b = pickle.loads(want[k]), pickle.loads(got[k])
-            if k == 'HT_links.pkl':
-                # same keys and counts; the insertion order is NOT reproduced (the device keeps one first-seen ordinal
-                # per contig pair, not per head/tail quadrant) — its only consumer, HapHiC_sort.py:117-131, does key lookups
-                assert type(a) is type(b) and a == b and sorted(a) == sorted(b), 'pickle differs: ' + k
-                continue
             assert type(a) is type(b) and list(a.items()) == list(b.items()), 'pickle differs: ' + k
             assert [type(v) for v in a.values()] == [type(v) for v in b.values()], 'value types differ: ' + k
         else:
