@@ -30,10 +30,14 @@ def _load_reference():
     return H
 
 
-def _write_inputs(d, split, messy=False):
+def _write_inputs(d, split, messy=False, poly=False):
     from haphic_amd import synth
     rng = np.random.default_rng(17)
     gen = synth.make_genome(3, 1_200_000, 30_000 if not split else 150_000, cv=0.4, min_len=6000, seed=23)
+    base_n = gen.n
+    if poly:                                           # autotetraploid: four collinear haplotypes, 8 % allelic contacts
+        gen = synth.make_polyploid(synth.make_genome(1, 900_000, 45_000, cv=0.3, min_len=8000, seed=23), 4)
+        base_n = gen.n // 4
     with open(os.path.join(d, 'asm.fa'), 'w') as f:
         for nm, ln in zip(gen.names, gen.length.tolist()):
             seq = ''.join(rng.choice(list('ACGT'), ln))
@@ -50,6 +54,8 @@ def _write_inputs(d, split, messy=False):
             if messy and rng.random() < 0.3:
                 f.write('\n')
     id1, p1, id2, p2 = [t.numpy() for t in synth.sample_pairs(gen, 60_000, seed=29, cis=0.9)]
+    if poly:
+        id1, p1, id2, p2 = synth.add_allelic_pairs(gen, base_n, 4, id1, p1, id2, p2, 0.08, 31)
     with open(os.path.join(d, 'hic.pairs'), 'w') as f:
         f.write('## pairs format v1.0\n#columns: readID chr1 pos1 chr2 pos2 strand1 strand2\n')
         for k, (a, x, b, y) in enumerate(zip(id1.tolist(), p1.tolist(), id2.tolist(), p2.tolist())):
@@ -57,13 +63,13 @@ def _write_inputs(d, split, messy=False):
     return gen
 
 
-def _run(H, d, extra, pairs='../hic.pairs'):
+def _run(H, d, extra, pairs='../hic.pairs', nchrs=3):
     argv = sys.argv
     cwd = os.getcwd()
     os.makedirs(d, exist_ok=True)
     os.chdir(d)
     try:
-        sys.argv = ['haphic', '../asm.fa', pairs, '3', '--min_inflation', '1.2', '--max_inflation', '2.4', '--inflation_step', '0.4',
+        sys.argv = ['haphic', '../asm.fa', pairs, str(nchrs), '--min_inflation', '1.2', '--max_inflation', '2.4', '--inflation_step', '0.4',
                     '--Nx', '100', '--flank', '20'] + extra
         args = H.parse_arguments()
         H.run(args)
@@ -92,6 +98,8 @@ def _tree(d):
                                          (False, ['--dense_matrix']),
                                          (False, ['--expansion', '3']),
                                          (False, ['--messy']),
+                                         (False, ['--poly', '--remove_allelic_links', '4', '--max_read_pairs', '40']),
+                                         (False, ['--poly', '--remove_allelic_links', '4', '--remove_concentrated_links', '--normalize_by_nlinks']),
                                          (True, ['--messy', '--bin_size', '40', '--RE', 'GATC,GANTC']),
                                          (False, ['--max_iter', '3']),
                                          (True, ['--bin_size', '40', '--Nx', '60', '--flank', '0']),
@@ -103,8 +111,9 @@ def test_reference_run_with_and_without_the_seams(tmp_path, monkeypatch, split, 
     from haphic_amd import cluster, patch
     from tests import oracle_lib
     H = _load_reference()
-    _write_inputs(str(tmp_path), split, messy='--messy' in extra)
-    extra = [e for e in extra if e != '--messy']
+    poly_case = '--poly' in extra
+    _write_inputs(str(tmp_path), split, messy='--messy' in extra, poly=poly_case)
+    extra = [e for e in extra if e not in ('--messy', '--poly')]
     pairs = '../hic.pairs'
     if '--gz' in extra:                                      # bgzipped_pairs input (:1544)
         import gzip
@@ -115,14 +124,15 @@ def test_reference_run_with_and_without_the_seams(tmp_path, monkeypatch, split, 
     # ---- the reference as it is (sparse mode: dot_product_mkl = scipy's float32 product)
     monkeypatch.setattr(H, 'dot_product_mkl', lambda a, b, **k: (a @ b).tocsc(), raising=False)
     monkeypatch.setattr(H, 'INTEL_MKL', True, raising=False)
-    _run(H, str(tmp_path / 'ref'), extra, pairs)
+    nchrs = 4 if poly_case else 3
+    _run(H, str(tmp_path / 'ref'), extra, pairs, nchrs)
     # ---- the same entry point with the seams re-bound
     monkeypatch.setattr(haphic_amd, '_lib', oracle_lib)
     monkeypatch.setattr(cluster, '_lib', oracle_lib)
     monkeypatch.setattr(patch, '_lib', oracle_lib, raising=False)
     saved = patch.patch_reference(H)
     try:
-        _run(H, str(tmp_path / 'ours'), extra, pairs)
+        _run(H, str(tmp_path / 'ours'), extra, pairs, nchrs)
     finally:
         patch.unpatch_reference(H, saved)
     want, got = _tree(str(tmp_path / 'ref')), _tree(str(tmp_path / 'ours'))
