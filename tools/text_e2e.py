@@ -1,6 +1,6 @@
 """End-to-end a1 + a2 from a .pairs TEXT FILE: file -> chunks -> hhx_pairs_parse -> hhx_ingest_push(device) ->
-hhx_ingest_link_matrix, beside the reference's way of doing the first half (a Python loop over the lines, restated in
-oracle.parse_pairs_text) on a bounded sample.  usage: python tools/text_e2e.py [lines] [contigs]"""
+hhx_ingest_link_matrix (the CPU baseline of the tokeniser is in bench.py's cpu_baseline).
+usage: python tools/text_e2e.py [lines] [contigs]"""
 import os
 import sys
 import time
@@ -13,7 +13,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     import torch
     from haphic_amd import _lib, cluster, synth
-    from oracle import oracle as orc
     lines = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
     contigs = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
     gen = synth.make_genome(16, contigs // 16 * 50_000, 50_000, seed=12345)
@@ -49,14 +48,6 @@ def main():
             m.free()
             ing.destroy()
         print('device path, bed=%s: %.3f s  %.1f M pairs/s  %.2f GB/s of text  (link matrix nnz %d)' % (want_bed, dt, lines / dt / 1e6, size / dt / 1e9, nnz))
-    # the reference's tokeniser (Python loop per line), bounded sample
-    with open(path, 'rb') as f:
-        sample = f.read(64 << 20)
-    sample = sample[:sample.rfind(b'\n') + 1]
-    t0 = time.perf_counter()
-    out = orc.parse_pairs_text(sample, names)
-    dt = time.perf_counter() - t0
-    print('python restatement of pairs_generator (+BED string): %.1f s for %d lines -> %.2f M pairs/s, 1 core' % (dt, len(out[0]), len(out[0]) / dt / 1e6))
 
 
 if __name__ == '__main__':
