@@ -59,7 +59,19 @@ def _write_inputs(d, split, messy=False, poly=False):
     with open(os.path.join(d, 'hic.pairs'), 'w') as f:
         f.write('## pairs format v1.0\n#columns: readID chr1 pos1 chr2 pos2 strand1 strand2\n')
         for k, (a, x, b, y) in enumerate(zip(id1.tolist(), p1.tolist(), id2.tolist(), p2.tolist())):
-            f.write('r%d\t%s\t%d\t%s\t%d\t+\t-\n' % (k, gen.names[a], x + 1, gen.names[b], y + 1))
+            na, nb = gen.names[a], gen.names[b]
+            end = '\n'
+            if messy:                                  # names that are not in the FASTA, CRLF ends, extra columns, blank / comment lines
+                r = rng.random()
+                if r < 0.01:
+                    na = 'unplaced_scaffold_%d' % (k % 7)
+                elif r < 0.02:
+                    nb = 'chrUn'
+                elif r < 0.05:
+                    end = '\r\n'
+                elif r < 0.06:
+                    f.write('\n' if k % 2 else '#note\n')
+            f.write('r%d\t%s\t%d\t%s\t%d\t+\t-%s%s' % (k, na, x + 1, nb, y + 1, '\tmapq=60' if messy and k % 11 == 0 else '', end))
     return gen
 
 
