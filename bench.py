@@ -340,6 +340,7 @@ def cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state):
     sample of the same workload: the first S pairs for ingest, and mcl() on the link matrix those
     pairs produce at 1/4 of the contigs (so that the CPU leg stays within ~30 s)."""
     from oracle import oracle as orc
+    orc.set_threads(1)                                   # the scalar port: "cores": 1 below
     S = min(args.cpu_sample_pairs, id1.numel())
     h = [a[:S].cpu().numpy() for a in (id1, p1, id2, p2)]
     keep = h[0] != h[2]

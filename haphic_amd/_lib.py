@@ -37,6 +37,7 @@ SIGNATURES = {
     'hhx_set_stream': (C.c_int, [C.c_void_p]),
     'hhx_synchronize': (C.c_int, []),
     'hhx_pool_trim': (C.c_int, []),
+    'hhx_tune': (C.c_int, [C.c_char_p, C.c_int64]),
     'hhx_profile_enable': (C.c_int, [C.c_int]),
     'hhx_profile_reset': (C.c_int, []),
     'hhx_profile_get': (C.c_int, [C.c_char_p, c_f64p, c_i64p]),
@@ -137,6 +138,11 @@ def device_count():
     n = C.c_int(0)
     check(load().hhx_device_count(C.byref(n)))
     return n.value
+
+
+def tune(name, value):
+    """measurement / experiment switch of the kernels (hhx_tune)"""
+    check(load().hhx_tune(name.encode(), int(value)))
 
 
 def profile_enable(on=True):

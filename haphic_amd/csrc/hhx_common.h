@@ -97,6 +97,10 @@ struct KTimer {
 void prof_count(const char *name, i64 v);
 bool prof_enabled();
 
+// ------------------------------------------------------------------ tuning knobs (hhx_tune): measurement / experiment
+// switches read at call time; unset -> the environment variable HHX_<NAME> (upper case) -> the default
+i64 tune_get(const char *name, i64 dflt);
+
 // ------------------------------------------------------------------ scans / reductions (hhx_scan.hip)
 // exclusive scan of n int32 counts into int32 offsets out[0..n] (out[n] = total); total returned
 // through *total_host after a stream sync.  in and out may alias only if out == in is NOT used.

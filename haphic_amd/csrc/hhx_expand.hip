@@ -3,15 +3,14 @@
 // prune) and run_mcl_clustering :2144-2147 (the un-pruned pre-expansion, which at n = 100k would be a
 // 10^10-entry matrix — it is consumed row by row here instead).
 //
-// One 256-thread workgroup owns one output row.  The row of A is staged in LDS (column k, a * 2^shift
-// as a double, and the [begin,end) of row k of B) so the inner loop has no dependent global loads; each
-// wave then walks one row of B at a time, lanes striding its entries (256 contiguous bytes of indices
-// and of values per wave instruction), four loads in flight per lane.
-// Accumulators are 64-bit fixed point in LDS (ds_add_u64; integer adds commute -> order-free, bit
-// reproducible for any GPU count).  Two row classes, chosen from the row's product count F_i:
+// One workgroup owns one output row.  Accumulators are 64-bit FIXED POINT in LDS (ds_add_u64: integer adds
+// commute -> order-free, bit reproducible for any lane / wave / GPU count).  Measured on MI355X
+// (tools/lds_atomic_bench.hip): a wave-wide ds_add_u64 on random slots costs 12.8 clk, ds_add_f64 25.4 clk, so the
+// integer form it is; the float64 -> fixed conversion is one v_add_f64 and one 32-bit integer add (fx_bits below).
+// Two row classes, chosen from the row's product count F_i:
 //   WINDOW : F_i >> n_cols.  Dense accumulators indexed by (column - window start); several windows if
 //            the row is wider than LDS, each window reading only its sub-range of every B row (rows
-//            are sorted -> two binary searches per staged entry), so the products are traversed once.
+//            are sorted -> split points precomputed), so the products are traversed once.
 //   COMPACT: light rows.  An n_cols-bit LDS bitmap + popcount prefix maps a column to its rank in the
 //            sorted output row; accumulators are indexed by rank.
 // Epilogue per window: x = float(acc), p = x^r, deterministic block sum S.  Entries that can still
@@ -29,69 +28,66 @@ int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
 
 namespace {
 
-constexpr int EX_T_WIN = 1024;      // window kernel: 16 waves, one workgroup per CU (it owns all of LDS) — the B-row
-                                    // stream is latency-bound, so as many loads in flight as the CU can hold
+constexpr int EX_T_WIN = 1024;      // window kernel: 16 waves, one workgroup per CU (it owns all of LDS)
 constexpr int EX_T_CMP = 256;       // compact kernel: light rows, several workgroups per CU
 constexpr int EX_T_MAX = 1024;
 constexpr int EX_WAVES_MAX = EX_T_MAX / HHX_WAVE;
 #define EX_T ((int)blockDim.x)      // device code below is written for either width
 #define EX_WAVES ((int)blockDim.x / HHX_WAVE)
-constexpr int STAGE = 1024;         // staged A entries per chunk
+constexpr int STAGE = 1024;         // compact kernel: staged A entries per chunk
 constexpr int MAX_WIN = 512;
+constexpr int N_DUMMY = HHX_WAVE;   // window kernel: one scratch accumulator per lane behind the window (masked entries)
 
 struct ExParams {
     const i32 *Ap, *Aj; const float *Ax;
     const i32 *Bp, *Bj; const float *Bx;
-    // window kernel operand stream: 16-bit column offsets inside the column window (the windows are at most
-    // 17k columns wide) and either the float32 value (6 B per product; measured HBM-bound: 1.15e12 products in
-    // 1.08 s = 6.4 TB/s at n = 100k) or, when B = D^-1 * L with integer link counts L (iteration 0 of
-    // run_mcl_clustering: the normalised raw link matrix), the 16-bit COUNT (4 B per product) from which the
-    // value float(count / rowsum) is rebuilt bit-exactly on the fly.  The 4-byte stream turned out f64-ALU
-    // bound (1.42 s) on MI355X, so it is opt-in (HHX_CODED=1) and the 6-byte stream is the default.
-    const unsigned short *Bc16, *Bn16;
-    const double *Bs;               // [n_rows(B)] L1 row sums of L (coded operand only)
+    // window kernel operand stream.  Every (B row, column window) segment is described by one 16-byte record
+    // {b0, b1, b2, float bits of v}: entries [b0, b1) of the stream all hold the SAME value v and are streamed as
+    // 16-bit window-local columns alone (2 B per product: their product with a_ik is formed once per segment);
+    // entries [b1, b2) are (16-bit column, float32 value) pairs (6 B per product).  For a general operand b1 == b0.
+    // When B = D^-1 * L with integer link counts L (iteration 0 of run_mcl_clustering: the normalised raw link
+    // matrix) the layout pass moves the count-1 entries of every segment (75 % of a Hi-C link matrix) to the front:
+    // v = float(1 / rowsum).  Sc16 / Sx are the (regrouped) columns / values, rec the records.
+    const unsigned short *Sc16; const float *Sx; const int4 *rec;
     i32 n_rows, n_cols;
-    double scale, inv_scale;        // 2^(shift-52), 2^(52-shift): products are rounded on the 2^-52 grid of [1,2)
+    double scale, inv_scale;        // 2^(shift-52), 2^(52-shift): products are rounded on the 2^-52 grid of [0, 1]
     double r; int square; float thr;
-    int fake_decode;                // probe only (HHX_CODED_FAKE): skip the count decode, results are garbage
     int raw;                        // 1: plain product C = A * B (hhx_spgemm): every non-zero entry is written, nothing else
     // candidate + survivor pools (col, value) and the per-row table
     i32 *cand_col; float *cand_val; i64 cand_cap;
     i32 *out_col; float *out_val; i64 out_cap;
-    unsigned long long *cursors;    // [0] cand cursor [1] out cursor [2] overflow flag [3] nnz_C [4] products
+    unsigned long long *cursors;    // [0] cand cursor [1] out cursor [2] overflow flag [3] nnz_C [4] products [5..6] window class [7] uniform products
     i64 *row_off; i32 *row_cnt;
-    const i32 *win_ptr; i32 n_win;  // [n_rows(B)][n_win + 1] split points of every B row at the column windows
+    i32 n_win;
     // window class, one launch per column window: per-row state carried between the launches
     double *s_run;                  // [n_rows] running sum of p over the windows done so far
     i64 *g_win_off; i32 *g_win_cnt; // [n_rows][n_win] candidate segment of every (row, window)
 };
 
 struct ExLds {
-    double *acc;         // [cap] exact sums of grid-rounded products (see acc_add)
-    double *st_da;       // [STAGE]
-    double *st_s;        // [STAGE] row sum of the staged B row (coded operand only)
+    u64 *acc;            // [cap (+ N_DUMMY)] exact fixed-point sums (see fx_bits); the epilogue reuses the slots for float p
+    double *st_da;       // [STAGE]   (compact kernel)
     i64 *bcast;          // [1] block broadcast slot
-    i32 *st_qb, *st_qe;  // [STAGE]
+    i32 *st_qb, *st_qe;  // [STAGE]   (compact kernel)
     double *red_d;       // [EX_WAVES_MAX]
     i32 *red_i;          // [EX_WAVES_MAX]
     float *red_f;        // [EX_WAVES_MAX]
-    i64 *win_off;        // [MAX_WIN]
+    i64 *win_off;        // [MAX_WIN] (compact kernel)
     i32 *win_cnt;        // [MAX_WIN]
     u32 *bitmap, *prefix;  // [W] each (compact mode only)
+    i32 *ctr;            // [2] window kernel: batch cursor of the row
 };
 
-// nslots: entries of the LDS (offset, count) segment table (compact kernel: MAX_WIN; the window passes keep it in HBM)
-__host__ __device__ inline size_t ex_fixed_bytes(i32 W, int nslots, bool coded) {
-    return (size_t)STAGE * (8 + 4 + 4 + (coded ? 8 : 0)) + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + (size_t)nslots * (8 + 4) +
+// compact kernel.  nslots: entries of the LDS (offset, count) segment table
+__host__ __device__ inline size_t ex_fixed_bytes(i32 W, int nslots) {
+    return (size_t)STAGE * (8 + 4 + 4) + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + (size_t)nslots * (8 + 4) +
            (size_t)W * 8;
 }
-
-__device__ __forceinline__ ExLds ex_carve(unsigned char *smem, i32 cap, i32 W, int nslots, bool coded) {
+__device__ __forceinline__ ExLds ex_carve(unsigned char *smem, i32 cap, i32 W, int nslots) {
     ExLds l;
     unsigned char *p = smem;
-    l.acc = (double *)p; p += (size_t)cap * 8;
+    l.acc = (u64 *)p; p += (size_t)cap * 8;
     l.st_da = (double *)p; p += STAGE * 8;
-    l.st_s = (double *)p; p += coded ? STAGE * 8 : 0;
     l.red_d = (double *)p; p += EX_WAVES_MAX * 8;
     l.bcast = (i64 *)p; p += 8;
     l.win_off = (i64 *)p; p += (size_t)nslots * 8;
@@ -102,6 +98,24 @@ __device__ __forceinline__ ExLds ex_carve(unsigned char *smem, i32 cap, i32 W, i
     l.win_cnt = (i32 *)p; p += (size_t)nslots * 4;
     l.bitmap = (u32 *)p; p += (size_t)W * 4;
     l.prefix = (u32 *)p;
+    l.ctr = nullptr;
+    return l;
+}
+// window kernel: the accumulators, one scratch slot per lane, the reduction scratch — no staging arrays (every wave
+// fetches its own batches of A entries), so a window is (160 KiB - 1 KiB) / 8 = 20k columns wide
+__host__ __device__ inline size_t win_fixed_bytes() {
+    return (size_t)N_DUMMY * 8 + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + 8;
+}
+__device__ __forceinline__ ExLds win_carve(unsigned char *smem, i32 cap) {
+    ExLds l;
+    unsigned char *p = smem;
+    l.acc = (u64 *)p; p += ((size_t)cap + N_DUMMY) * 8;
+    l.red_d = (double *)p; p += EX_WAVES_MAX * 8;
+    l.bcast = (i64 *)p; p += 8;
+    l.red_i = (i32 *)p; p += EX_WAVES_MAX * 4;
+    l.red_f = (float *)p; p += EX_WAVES_MAX * 4;
+    l.ctr = (i32 *)p;
+    l.st_da = nullptr; l.st_qb = l.st_qe = nullptr; l.win_off = nullptr; l.win_cnt = nullptr; l.bitmap = l.prefix = nullptr;
     return l;
 }
 
@@ -170,129 +184,181 @@ __device__ __forceinline__ void block_argmax(float &q, i32 &c, float *redf, i32 
         if (redf[k] > q || (redf[k] == q && redi[k] < c)) { q = redf[k]; c = redi[k]; }
 }
 
-// ---- stage one chunk of the A row: (a * scale, begin, end) of every referenced B row, optionally
-// narrowed to the column window [c0, c1)
-template <bool NARROW, bool CODED = false>
-__device__ __forceinline__ void stage_chunk(const ExParams &P, const ExLds &l, i32 a0, i32 len, i32 wv) {
+// ---- stage one chunk of the A row (compact kernel): (a * scale, begin, end) of every referenced B row
+__device__ __forceinline__ void stage_chunk(const ExParams &P, const ExLds &l, i32 a0, i32 len) {
     for (i32 t = threadIdx.x; t < len; t += EX_T) {
         const i32 k = P.Aj[a0 + t];
-        i32 qb, qe;
-        if (NARROW) {       // B row k restricted to column window wv: precomputed split points (k_window_ptrs)
-            const i32 *wp = P.win_ptr + (size_t)k * (P.n_win + 1) + wv;
-            qb = wp[0]; qe = wp[1];
-        } else { qb = P.Bp[k]; qe = P.Bp[k + 1]; }
         l.st_da[t] = (double)P.Ax[a0 + t] * P.scale;
-        if (CODED) l.st_s[t] = P.fake_decode ? -1.0 : P.Bs[k];
-        l.st_qb[t] = qb;
-        l.st_qe[t] = qe;
+        l.st_qb[t] = P.Bp[k];
+        l.st_qe[t] = P.Bp[k + 1];
     }
 }
 
-// ---- inner loops -------------------------------------------------------------------------------
-// Fixed-point accumulation without integers.  The operands are stochastic (0 <= a, b <= 1, row sums 1), so a
-// scaled product p = a * b * 2^(shift-52) lies in [0, 1]: (p + 1.0) - 1.0 rounds it (to nearest, ties to even)
-// to a multiple of 2^-52, and any sum of such multiples below 2 is exactly representable in a double —
-// every ds_add_f64 is therefore EXACT, the additions commute, and the row is bit-reproducible for any order
-// of lanes, waves or GPUs, exactly like 64-bit integer adds but at 4 instead of ~9 f64 VALU ops per product
-// (the f64 -> i64 conversion was the kernel's bottleneck).  Specification: oracle mode 1,
+// ---- fixed point -----------------------------------------------------------------------------------
+// The operands are stochastic (0 <= a, b <= 1, row sums <= 1), so a scaled product p = a * b * 2^(shift-52) lies in
+// [0, 1]: p + 1.0 rounds it (to nearest, ties to even) to a multiple of 2^-52 inside [1, 2], where consecutive
+// doubles are consecutive integers — the bit pattern of (p + 1.0) minus the bit pattern of 1.0 IS rint(p * 2^52).
+// One v_add_f64 and one 32-bit integer add on the high word instead of a float64 -> int64 conversion (~9 VALU).
+// Sums of at most 2^12 such values stay below 2^64 and add exactly in any order.  Specification: oracle mode 1,
 // sum of rint(a * b * 2^shift), one rounding to float32 at the end.
-__device__ __forceinline__ void acc_add(double *slot, double p) {
-    atomicAdd(slot, (p + 1.0) - 1.0);
+__device__ __forceinline__ u64 fx_bits(double p) {
+    return (u64)__double_as_longlong(p + 1.0) - 0x3ff0000000000000ull;
+}
+__device__ __forceinline__ void acc_add(u64 *slot, double p) {
+    atomicAdd((unsigned long long *)slot, (unsigned long long)fx_bits(p));
 }
 
-// window mode: acc[c - c0] += fixed(a * b)
-// A wave walks its staged B-row segments (wave, wave + nw, ...) as a sequence of TILES of up to U * 64
-// consecutive entries and keeps two tiles in flight: the loads of tile t+1 are issued before the LDS
-// atomics of tile t, so a wave never sits out a full memory round trip per segment (segments are short
-// when the row is cut into many column windows).  All cursor state is wave-uniform.
-constexpr int TILE_U = 8;           // entries per lane and tile for long segments; short segments (later iterations, many
-                                    // windows) take the U = 2 instantiation: a tile costs its 2 * U loads whether filled or not
-                                    // (iteration 1 at n = 100k, segments of 67: 98 -> 78 ms; a ring of eight 2-entry tiles in
-                                    // flight per wave spilled registers and was slower, 94 ms)
-struct SegCursor {
-    i32 e, q, qe; double da, s, r; bool valid;
+// ---- window mode: acc[c - c0] += fixed(a * b) -----------------------------------------------------------------
+// Every WAVE works on its own: it draws batches of WB consecutive A entries of the row from an LDS cursor (dynamic
+// balance, no workgroup barrier inside a row), one entry per lane: the lane loads (k, a_ik) and the 16-byte record of
+// (B row k, this window) and forms the segment's uniform product once.  The wave then walks the batch twice with
+// wave-uniform cursors (v_readlane): first the value-uniform sub-segments as WIDE tiles — a lane loads 8 consecutive
+// 16-bit columns with one 16-byte load, two such loads per tile = up to 1024 entries, 16 LDS atomics per lane — then
+// the (column, value) sub-segments as tiles of UX entries per lane.  Both walks issue the loads of a GROUP of tiles
+// back to back and consume the tiles in order while the later ones are still in flight.  Everything between a tile's
+// loads and its atomics is branch-free per lane (masked entries go to a per-lane scratch slot behind the window),
+// so that the compiler's s_waitcnt pass counts the loads exactly instead of falling back to vmcnt(0):
+// tools/stream_bench.hip is the prototype of this loop.
+constexpr int WB = 32;              // A entries per wave batch
+constexpr int WIDE_UNIT = 512;      // entries per 16-byte lane load of a wave
+
+struct BatchRegs {                  // one A entry per lane (lanes >= cnt: empty segments)
+    i32 b0, b1, b2;                 // record boundaries: [b0, b1) uniform value, [b1, b2) explicit values
+    u32 g_lo, g_hi;                 // fx_bits(a_ik * scale * v): the uniform sub-segment's fixed-point product
+    u32 da_lo, da_hi;               // a_ik * scale (double bits)
 };
-template <bool CODED>
-__device__ __forceinline__ void seg_open(const ExLds &l, SegCursor &c, i32 len) {
-    c.valid = c.e < len;
-    if (c.valid) {
-        c.da = l.st_da[c.e]; c.q = l.st_qb[c.e]; c.qe = l.st_qe[c.e];
-        if (CODED) { c.s = l.st_s[c.e]; c.r = 1.0 / c.s; }
+__device__ __forceinline__ void batch_load(const ExParams &P, i32 a_b, i32 a_e, i32 batch, i32 wv, BatchRegs &r) {
+    const i32 e = a_b + batch * WB + lane_id();
+    const bool ok = lane_id() < WB && e < a_e;
+    const i32 ec = ok ? e : a_b;                      // unconditional loads (a_b < a_e whenever a batch exists)
+    const i32 k = P.Aj[ec];
+    const double da = (double)P.Ax[ec] * P.scale;
+    const int4 rc = P.rec[(size_t)k * P.n_win + wv];
+    r.b0 = ok ? rc.x : 0; r.b1 = ok ? rc.y : 0; r.b2 = ok ? rc.z : 0;
+    const u64 g = fx_bits(da * (double)__int_as_float(rc.w));
+    r.g_lo = (u32)g; r.g_hi = (u32)(g >> 32);
+    const u64 d = (u64)__double_as_longlong(da);
+    r.da_lo = (u32)d; r.da_hi = (u32)(d >> 32);
+}
+
+// wide tiles -------------------------------------------------------------------------------------------------
+struct WTile { uint4 x0, x1; i32 lo, hi; u32 g_lo, g_hi; bool valid; };   // valid positions lo <= lane * 8 + j (+ 512) < hi
+struct WCursor { i32 l, q, qb, qe; u32 g_lo, g_hi; };                     // all wave-uniform
+__device__ __forceinline__ void wtile_fetch(const ExParams &P, const BatchRegs &r, i32 cnt, WCursor &c, WTile &t) {
+    while (c.q >= c.qe && c.l + 1 < cnt) {            // next A entry of the batch with a uniform sub-segment
+        ++c.l;
+        c.qb = __builtin_amdgcn_readlane(r.b0, c.l);
+        c.qe = __builtin_amdgcn_readlane(r.b1, c.l);
+        c.g_lo = __builtin_amdgcn_readlane(r.g_lo, c.l);
+        c.g_hi = __builtin_amdgcn_readlane(r.g_hi, c.l);
+        c.q = c.qb & ~7;
     }
+    t.valid = c.q < c.qe;
+    t.lo = t.valid ? c.qb - c.q : 0;                  // negative on the follow-up tiles of a long segment: no masking
+    t.hi = t.valid ? c.qe - c.q : 0;
+    t.g_lo = c.g_lo; t.g_hi = c.g_hi;
+    const i32 base = t.valid ? c.q : 0;
+    const i32 e0 = base + lane_id() * 8, e1 = e0 + WIDE_UNIT;
+    t.x0 = *reinterpret_cast<const uint4 *>(P.Sc16 + (lane_id() * 8 < t.hi ? e0 : 0));
+    t.x1 = *reinterpret_cast<const uint4 *>(P.Sc16 + (lane_id() * 8 + WIDE_UNIT < t.hi ? e1 : 0));
+    c.q += 2 * WIDE_UNIT;
 }
-template <int U>
-struct Tile {
-    u32 j[U], v[U];      // window-local column (0xffffffff = none); float bits or link count
-    double da, s, r; bool valid;
-};
-// value of a count-coded entry: float(count / s) exactly as sklearn's normalisation forms it
-// (x = float(double(x) / sum)).  Fast path: count * (1/s) is within 2 ulp(double) of the correctly rounded
-// quotient, so both round to the same float unless a float rounding boundary (a double whose low 29 mantissa
-// bits are 1000...0) lies that close — then, about once per 10^8 entries, the exact division is done.
-__device__ __forceinline__ float coded_value(u32 cnt, double s, double r) {
-    if (s < 0.0) return (float)cnt * 1e-6f;
-    const double q = (double)cnt * r;
-    const u32 low = (u32)__double_as_longlong(q) & 0x1fffffffu;
-    if (__builtin_expect(low - 0x0ffffffcu <= 8u, 0)) return (float)((double)cnt / s);
-    return (float)q;
-}
-// Issues the loads of the next tile.  The loads are UNCONDITIONAL (out-of-range lanes and an exhausted
-// cursor read entry 0 and are masked afterwards) and always TILE_U * 2 in number: with no per-lane branches
-// around them the compiler's s_waitcnt pass can count, so consuming tile t waits with vmcnt(16) for the
-// older tile only while the loads of tile t+1 stay in flight (with predicated loads it emitted vmcnt(0)
-// before every LDS atomic and the prefetch was worthless).
-template <bool CODED, int U>
-__device__ __forceinline__ void tile_fetch(const ExParams &P, const ExLds &l, SegCursor &c, i32 len, Tile<U> &t) {
-    t.valid = c.valid;
-    t.da = c.da; t.s = c.s; t.r = c.r;
-    const i32 q0 = c.q + lane_id(), qe = c.valid ? c.qe : 0;
+template <int PROBE>
+__device__ __forceinline__ void wunit_consume(const ExLds &l, const uint4 &x, i32 pos0, i32 lo, i32 hi, u64 g, i32 dummy, u64 &sink) {
+    const u32 w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const i32 qq = q0 + u * HHX_WAVE;
-        const bool in = qq < qe;
-        const i32 qs = in ? qq : 0;
-        const u32 col = (u32)P.Bc16[qs];
-        const u32 val = CODED ? (u32)P.Bn16[qs] : __float_as_uint(P.Bx[qs]);
-        t.j[u] = in ? col : 0xffffffffu;
-        t.v[u] = val;
-    }
-    if (c.valid) {
-        c.q += U * HHX_WAVE;
-        if (c.q >= c.qe) { c.e += EX_WAVES; seg_open<CODED>(l, c, len); }
+    for (int j = 0; j < 8; ++j) {
+        const u32 col = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu);
+        const bool ok = pos0 + j >= lo && pos0 + j < hi;
+        if (PROBE == 1) sink += ok ? g + col : 0;
+        else atomicAdd((unsigned long long *)&l.acc[ok ? (i32)col : dummy], (unsigned long long)g);
     }
 }
-// PROBE (HHX_PROBE, measurement only — results are garbage): 1 = no LDS operation per product (register sink),
-// 2 = a plain ds_write_b64 instead of the atomic add
-template <bool CODED, int PROBE, int U>
-__device__ __forceinline__ void tile_consume(const ExLds &l, const Tile<U> &t, double &sink) {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        if (t.j[u] != 0xffffffffu) {
-            const float b = CODED ? coded_value(t.v[u], t.s, t.r) : __uint_as_float(t.v[u]);
-            if (PROBE == 1) sink += (t.da * (double)b + 1.0) - 1.0;
-            else if (PROBE == 2) l.acc[t.j[u]] = (t.da * (double)b + 1.0) - 1.0;
-            else acc_add(&l.acc[t.j[u]], t.da * (double)b);
-        }
+template <int PROBE>
+__device__ __forceinline__ void wtile_consume(const ExLds &l, const WTile &t, i32 dummy, u64 &sink) {
+    const u64 g = ((u64)t.g_hi << 32) | t.g_lo;
+    wunit_consume<PROBE>(l, t.x0, lane_id() * 8, t.lo, t.hi, g, dummy, sink);
+    if (t.hi > WIDE_UNIT) wunit_consume<PROBE>(l, t.x1, lane_id() * 8 + WIDE_UNIT, t.lo, t.hi, g, dummy, sink);   // wave-uniform
 }
-template <bool CODED, int PROBE, int U>
-__device__ __forceinline__ void accumulate_window(const ExParams &P, const ExLds &l, i32 len) {
-    SegCursor c;
-    c.e = threadIdx.x / HHX_WAVE;
-    c.q = c.qe = 0; c.da = 0.0; c.s = 1.0; c.r = 1.0;
-    seg_open<CODED>(l, c, len);
-    Tile<U> ta, tb;
-    tile_fetch<CODED, U>(P, l, c, len, ta);
-    double sink = 0.0;
+// G tiles per group: the loads of the whole group are issued back to back, then the tiles are consumed in order while
+// the later ones are still in flight (s_waitcnt vmcnt(2 (G - 1)), vmcnt(2 (G - 2)), ...).  Nothing that was loaded is
+// carried across the loop's back edge: when a ring of tiles was kept in flight ACROSS iterations the register
+// allocator copied loaded registers at the back edge, and every such copy is an s_waitcnt vmcnt(0).  The other waves
+// of the CU cover the refill of a wave's group.
+template <int K, int G, class Tile, class Fetch>
+__device__ __forceinline__ void group_fetch(Tile (&t)[G], Fetch &fetch) {
+    if constexpr (K < G) { fetch(t[K]); group_fetch<K + 1, G>(t, fetch); }
+}
+template <int K, int G, class Tile, class Consume>
+__device__ __forceinline__ bool group_consume(const Tile (&t)[G], Consume &consume) {
+    if constexpr (K == G) return true;
+    else {
+        if (!t[K].valid) return false;                // tiles are issued in order: the first invalid one ends the pass
+        consume(t[K]);
+        return group_consume<K + 1, G>(t, consume);
+    }
+}
+template <int PROBE, int G>
+__device__ __forceinline__ void pass_wide(const ExParams &P, const ExLds &l, const BatchRegs &r, i32 cnt, i32 dummy, u64 &sink) {
+    WCursor c = {-1, 0, 0, 0, 0u, 0u};
+    auto fetch = [&](WTile &t) { wtile_fetch(P, r, cnt, c, t); };
+    auto consume = [&](const WTile &t) { wtile_consume<PROBE>(l, t, dummy, sink); };
     for (;;) {
-        tile_fetch<CODED, U>(P, l, c, len, tb);
-        tile_consume<CODED, PROBE, U>(l, ta, sink);
-        if (!tb.valid) break;
-        tile_fetch<CODED, U>(P, l, c, len, ta);
-        tile_consume<CODED, PROBE, U>(l, tb, sink);
-        if (!ta.valid) break;
+        WTile t[G];
+        group_fetch<0, G>(t, fetch);
+        if (!group_consume<0, G>(t, consume)) return;
     }
-    if (PROBE == 1 && sink == 123.456) l.acc[0] = sink;
 }
+
+// explicit tiles -----------------------------------------------------------------------------------------------
+template <int UX>
+struct XTile { u32 j[UX], v[UX]; i32 n; u32 da_lo, da_hi; bool valid; };      // entry u of the lane: position lane + 64 u < n
+struct XCursor { i32 l, q, qe; u32 da_lo, da_hi; };
+template <int UX>
+__device__ __forceinline__ void xtile_fetch(const ExParams &P, const BatchRegs &r, i32 cnt, XCursor &c, XTile<UX> &t) {
+    while (c.q >= c.qe && c.l + 1 < cnt) {
+        ++c.l;
+        c.q = __builtin_amdgcn_readlane(r.b1, c.l);
+        c.qe = __builtin_amdgcn_readlane(r.b2, c.l);
+        c.da_lo = __builtin_amdgcn_readlane(r.da_lo, c.l);
+        c.da_hi = __builtin_amdgcn_readlane(r.da_hi, c.l);
+    }
+    t.valid = c.q < c.qe;
+    t.n = t.valid ? c.qe - c.q : 0;
+    t.da_lo = c.da_lo; t.da_hi = c.da_hi;
+    const i32 base = t.valid ? c.q : 0;
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+        const i32 pos = lane_id() + u * HHX_WAVE;
+        const i32 qs = pos < t.n ? base + pos : 0;
+        t.j[u] = (u32)P.Sc16[qs];
+        t.v[u] = __float_as_uint(P.Sx[qs]);
+    }
+    c.q += UX * HHX_WAVE;
+}
+template <int PROBE, int UX>
+__device__ __forceinline__ void xtile_consume(const ExLds &l, const XTile<UX> &t, i32 dummy, u64 &sink) {
+    const double da = __longlong_as_double((long long)(((u64)t.da_hi << 32) | t.da_lo));
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+        const bool ok = lane_id() + u * HHX_WAVE < t.n;
+        const u64 g = fx_bits(da * (double)__uint_as_float(t.v[u]));
+        if (PROBE == 1) sink += ok ? g + t.j[u] : 0;
+        else atomicAdd((unsigned long long *)&l.acc[ok ? (i32)t.j[u] : dummy], (unsigned long long)g);
+    }
+}
+template <int PROBE, int UX, int G>
+__device__ __forceinline__ void pass_explicit(const ExParams &P, const ExLds &l, const BatchRegs &r, i32 cnt, i32 dummy, u64 &sink) {
+    XCursor c = {-1, 0, 0, 0u, 0u};
+    auto fetch = [&](XTile<UX> &t) { xtile_fetch<UX>(P, r, cnt, c, t); };
+    auto consume = [&](const XTile<UX> &t) { xtile_consume<PROBE, UX>(l, t, dummy, sink); };
+    for (;;) {
+        XTile<UX> t[G];
+        group_fetch<0, G>(t, fetch);
+        if (!group_consume<0, G>(t, consume)) return;
+    }
+}
+
 // compact mode: mark, then acc[rank(c)] += fixed(a * b)
 __device__ __forceinline__ void mark_compact(const ExParams &P, const ExLds &l, i32 len) {
     const int lane = lane_id(), wave = threadIdx.x / HHX_WAVE;
@@ -361,10 +427,10 @@ __device__ __forceinline__ double window_power_sum(const ExParams &P, const ExLd
     double s = 0.0;
     i32 nz = 0;
     for (i32 t = s0; t < s1; ++t) {
-        const double a = l.acc[t];
+        const u64 ai = l.acc[t];                          // exact: the sum is below 2^53
         float p = -1.0f;
-        if (COMPACT || a != 0.0) {
-            const float x = (float)(a * P.inv_scale);
+        if (COMPACT || ai != 0) {
+            const float x = (float)((double)(long long)ai * 0x1p-52 * P.inv_scale);
             p = P.raw ? x : ex_inflate(x, P.r, P.square);
             s += (double)p;
             ++nz;
@@ -522,34 +588,48 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
     }
 }
 
-// ---- the two kernels ----------------------------------------------------------------------------
+// ---- the kernels ----------------------------------------------------------------------------------
 // Window class.  The loop nest is WINDOW-OUTER: one launch per column window, every launch sweeping all
 // the rows.  While window w is being processed the only part of B that is read is its column slice
-// B[:, w] (nnz_B / n_win entries), which raises the Infinity Cache / L2 hit rate of the B-row stream
-// compared with a row-outer nest (measured at n = 100k, 6 windows: 1.59 s vs 1.76 s before tile
-// pipelining), and the per-row epilogue (finalize) becomes its own uniform launch.
-template <bool CODED, int PROBE = 0, int U = TILE_U>
-__global__ __launch_bounds__(EX_T_WIN) void k_expand_window_pass(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap,
-                                                                 i32 wv) {
+// B[:, w] (nnz_B / n_win entries: at n = 100k the class stream of one slice fits the 256 MiB Infinity Cache),
+// and the per-row epilogue (finalize) becomes its own uniform launch.
+// UX / RX: entries per lane of an explicit tile and explicit tiles per group; RW: wide tiles per group.
+template <int PROBE, int UX, int RX, int RW>
+__global__ __launch_bounds__(EX_T_WIN) void k_expand_window(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 wv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ExLds l = ex_carve(smem, cap, 0, 0, CODED);
+    const ExLds l = win_carve(smem, cap);
     const int tid = threadIdx.x;
-    i64 nnzc = 0;
+    i64 nnzc = 0, n_uni = 0;                    // n_uni: products streamed as 16-bit columns only (cursors[7])
+    u64 sink = 0;
     const i32 n_win = P.n_win;
     const i32 c0 = wv * cap, c1 = min(P.n_cols, c0 + cap), wlen = c1 - c0;
+    const i32 dummy = cap + lane_id();
     for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
         const i32 row = rows[li];
         const i32 a_b = P.Ap[row], a_e = P.Ap[row + 1];
-        for (i32 t = tid; t < wlen; t += EX_T) l.acc[t] = 0.0;
+        const i32 n_batches = (a_e - a_b + WB - 1) / WB;
+        if (tid == 0) l.ctr[0] = 0;
+        for (i32 t = tid; t < wlen; t += EX_T) l.acc[t] = 0;
         __syncthreads();
-        for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
-            const i32 len = min(STAGE, a_e - a0);
-            if (n_win > 1) stage_chunk<true, CODED>(P, l, a0, len, wv);
-            else stage_chunk<false, CODED>(P, l, a0, len, wv);
-            __syncthreads();
-            accumulate_window<CODED, PROBE, U>(P, l, len);
-            __syncthreads();
+        // every wave: draw a batch, prefetch the next one, walk the current one
+        i32 batch = 0;
+        if (lane_id() == 0) batch = atomicAdd(&l.ctr[0], 1);
+        batch = __builtin_amdgcn_readfirstlane(batch);
+        BatchRegs nxt;
+        if (batch < n_batches) batch_load(P, a_b, a_e, batch, wv, nxt);
+        while (batch < n_batches) {
+            const BatchRegs cur = nxt;
+            const i32 cnt = min(WB, a_e - (a_b + batch * WB));
+            i32 nb = 0;
+            if (lane_id() == 0) nb = atomicAdd(&l.ctr[0], 1);
+            nb = __builtin_amdgcn_readfirstlane(nb);
+            if (nb < n_batches) batch_load(P, a_b, a_e, nb, wv, nxt);
+            n_uni += cur.b1 - cur.b0;
+            pass_wide<PROBE, RW>(P, l, cur, cnt, dummy, sink);
+            pass_explicit<PROBE, UX, RX>(P, l, cur, cnt, dummy, sink);
+            batch = nb;
         }
+        __syncthreads();
         i32 nz;
         const double sw = window_power_sum<false>(P, l, wlen, &nz);
         nnzc += nz;
@@ -561,11 +641,70 @@ __global__ __launch_bounds__(EX_T_WIN) void k_expand_window_pass(ExParams P, con
     }
     nnzc = wave_sum_i64(nnzc);          // products are counted by the classification pass (cursors[4])
     if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
+    n_uni = wave_sum_i64(n_uni);
+    if (lane_id() == 0 && n_uni) atomicAdd(&P.cursors[7], (unsigned long long)n_uni);
+    if (PROBE == 1 && sink == 0x123456789abcdefull) l.acc[0] = sink;
+}
+
+// Records of a general operand: the whole (B row, window) segment is explicit.  One thread per (row, window).
+__global__ __launch_bounds__(256) void k_window_recs(i32 n_rows, const i32 *__restrict__ Bp, const i32 *__restrict__ Bj, i32 cap, i32 n_win,
+                                                     int4 *__restrict__ rec) {
+    const i64 total = (i64)n_rows * n_win;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+        const i32 k = (i32)(t / n_win), w = (i32)(t % n_win);
+        const i32 qb = Bp[k], qe = Bp[k + 1];
+        const i32 lo = w == 0 ? qb : lower_bound_i32(Bj, qb, qe, w * cap);
+        const i32 hi = w == n_win - 1 ? qe : lower_bound_i32(Bj, qb, qe, (w + 1) * cap);
+        rec[t] = make_int4(lo, lo, hi, 0);
+    }
+}
+
+// Layout pass of the class stream: one wave per (B row, column window) segment moves the entries whose link count is 1
+// to the front (stable: columns stay ascending inside both parts) and writes the record.  n16 = link count per entry,
+// row_sum = the L1 row sums the normalisation divided by (k_normalize_l1): float(1.0 / row_sum) is bit for bit the
+// value the normalised matrix holds for a count-1 entry.
+__global__ __launch_bounds__(256) void k_class_layout(i32 n_rows, i32 n_win, i32 cap, const i32 *__restrict__ Bp,
+                                                      const i32 *__restrict__ Bj, const float *__restrict__ Bx,
+                                                      const unsigned short *__restrict__ n16, const double *__restrict__ row_sum,
+                                                      unsigned short *__restrict__ oc, float *__restrict__ ox, int4 *__restrict__ rec,
+                                                      unsigned long long *__restrict__ n_uniform) {
+    const int lane = lane_id();
+    const u64 lt = (1ull << lane) - 1ull;
+    const i64 total = (i64)n_rows * n_win;
+    i64 uni = 0;
+    for (i64 sg = (i64)blockIdx.x * 4 + threadIdx.x / HHX_WAVE; sg < total; sg += (i64)gridDim.x * 4) {
+        const i32 k = (i32)(sg / n_win), w = (i32)(sg % n_win);
+        const i32 rb = Bp[k], re = Bp[k + 1];
+        const i32 qb = w == 0 ? rb : lower_bound_i32(Bj, rb, re, w * cap);
+        const i32 qe = w == n_win - 1 ? re : lower_bound_i32(Bj, rb, re, (w + 1) * cap);
+        i32 n1 = 0;
+        for (i32 q0 = qb; q0 < qe; q0 += HHX_WAVE) {
+            const i32 q = q0 + lane;
+            n1 += __popcll(__ballot(q < qe && n16[q] == 1));
+        }
+        if (lane == 0) rec[sg] = make_int4(qb, qb + n1, qe, __float_as_int((float)(1.0 / row_sum[k])));
+        uni += n1;
+        i32 o1 = qb, ox_ = qb + n1;
+        for (i32 q0 = qb; q0 < qe; q0 += HHX_WAVE) {
+            const i32 q = q0 + lane;
+            const bool in = q < qe;
+            const bool one = in && n16[q] == 1;
+            const u64 m1 = __ballot(one), mx = __ballot(in && !one);
+            if (in) {
+                const i32 o = one ? o1 + __popcll(m1 & lt) : ox_ + __popcll(mx & lt);
+                oc[o] = (unsigned short)(Bj[q] - w * cap);
+                ox[o] = Bx[q];
+            }
+            o1 += __popcll(m1);
+            ox_ += __popcll(mx);
+        }
+    }
+    if (lane == 0 && uni) atomicAdd(n_uniform, (unsigned long long)uni);
 }
 
 __global__ __launch_bounds__(EX_T_CMP) void k_expand_window_finalize(ExParams P, const i32 *__restrict__ rows, i32 n_list) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ExLds l = ex_carve(smem, 0, 0, 0, false);
+    const ExLds l = ex_carve(smem, 0, 0, 0);
     for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
         const i32 row = rows[li];
         finalize_row(P, l, row, P.n_win, P.s_run[row], &P.g_win_off[(size_t)row * P.n_win], &P.g_win_cnt[(size_t)row * P.n_win]);
@@ -575,7 +714,7 @@ __global__ __launch_bounds__(EX_T_CMP) void k_expand_window_finalize(ExParams P,
 
 __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ExLds l = ex_carve(smem, cap, W, MAX_WIN, false);
+    const ExLds l = ex_carve(smem, cap, W, MAX_WIN);
     const int tid = threadIdx.x;
     i64 nnzc = 0;
     for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
@@ -585,7 +724,7 @@ __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i
         __syncthreads();
         for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
             const i32 len = min(STAGE, a_e - a0);
-            stage_chunk<false>(P, l, a0, len, 0);
+            stage_chunk(P, l, a0, len);
             __syncthreads();
             mark_compact(P, l, len);
             __syncthreads();
@@ -596,11 +735,11 @@ __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i
         i32 n_win = 0;
         for (i32 r0 = 0; r0 < nnz_row; r0 += cap, ++n_win) {      // rank windows (one for almost every row)
             const i32 rlen = min(cap, nnz_row - r0);
-            for (i32 t = tid; t < rlen; t += EX_T) l.acc[t] = 0.0;
+            for (i32 t = tid; t < rlen; t += EX_T) l.acc[t] = 0;
             __syncthreads();
             for (i32 a0 = a_b; a0 < a_e; a0 += STAGE) {
                 const i32 len = min(STAGE, a_e - a0);
-                stage_chunk<false>(P, l, a0, len, 0);
+                stage_chunk(P, l, a0, len);
                 __syncthreads();
                 accumulate_compact(P, l, len, r0, rlen);
                 __syncthreads();
@@ -753,17 +892,6 @@ __global__ __launch_bounds__(256) void k_expand_tiny(ExParams P, const i32 *__re
     if (lane == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
 }
 
-// ---- split points of every B row at the column-window boundaries (window kernel, n_win > 1) -------------
-__global__ __launch_bounds__(256) void k_window_ptrs(i32 n_rows, const i32 *__restrict__ Bp, const i32 *__restrict__ Bj,
-                                                     i32 cap, i32 n_win, i32 *__restrict__ out) {
-    const i64 total = (i64)n_rows * (n_win + 1);
-    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
-        const i32 k = (i32)(t / (n_win + 1)), w = (i32)(t % (n_win + 1));
-        const i32 qb = Bp[k], qe = Bp[k + 1];
-        out[t] = w == 0 ? qb : (w == n_win ? qe : lower_bound_i32(Bj, qb, qe, w * cap));
-    }
-}
-
 // ---- window-local 16-bit column offsets of B (the window kernel's operand stream) -------------------------
 __global__ __launch_bounds__(256) void k_local_cols(i64 nnz, const i32 *__restrict__ Bj, i32 cap, unsigned short *__restrict__ out) {
     for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (i64)gridDim.x * blockDim.x) {
@@ -786,13 +914,25 @@ __global__ __launch_bounds__(256) void k_pack_rows(i32 n_rows, const i64 *__rest
 
 }  // namespace
 
-// coded: B's entries as 16-bit link counts (same positions as b's) + the L1 row sums of the link matrix;
-// b itself still holds the float32 values (used by the light-row kernel and by the shape/size logic)
+// Optional description of the right operand.  n16 / row_sum: b is the L1-normalised link matrix, entry p of row k
+// equals float(n16[p] / row_sum[k]) (checked by the caller): the window class then streams b regrouped by link
+// count (the class stream above).  b itself still holds the float32 values (used by the light-row kernels).
 struct CodedOperand {
     const unsigned short *n16 = nullptr;
     const double *row_sum = nullptr;
     int raw = 0;                        // plain product (no inflation / pruning): hhx_spgemm's fast path
 };
+
+template <int PROBE, int UX, int RX, int RW>
+static int launch_window(const ExParams &P, const i32 *rows, i32 n_list, i32 cap, size_t lds, unsigned grid) {
+    static bool attr = false;
+    if (!attr) {
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window<PROBE, UX, RX, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    for (i32 wv = 0; wv < P.n_win; ++wv) k_expand_window<PROBE, UX, RX, RW><<<grid, EX_T_WIN, lds, g_stream>>>(P, rows, n_list, cap, wv);
+    return 0;
+}
 
 int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &coded, int fx_shift, double inflation, double pruning,
                     hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
@@ -805,17 +945,14 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     const i32 n_rows = a->n_rows, n_cols = b->n_cols;
     const i32 W = (n_cols + 31) / 32;
     // ---- plans
-    const bool is_coded = coded.n16 != nullptr;
-    const size_t fixed_win = ex_fixed_bytes(0, 0, is_coded), fixed_cmp = ex_fixed_bytes(W, MAX_WIN, false);
+    const bool use_cls = coded.n16 != nullptr && !coded.raw && tune_get("cls", 1) != 0;
+    const size_t fixed_win = win_fixed_bytes(), fixed_cmp = ex_fixed_bytes(W, MAX_WIN);
     // window class: the column window must fit LDS (8 B per column).  Measured on MI355X (n = 100k, 330M
     // entries): the fewest, widest windows win — 6 windows 1.41 s, 13 windows 1.54 s, 27 windows 2.24 s —
     // because the per-segment cost grows faster than the Infinity Cache hit rate of a narrower column slice
-    // B[:, w].  HHX_CACHE_SLICE_MB (MB of B per slice) forces more windows for experiments.
-    static const i64 slice_bytes = []() {
-        const char *e = getenv("HHX_CACHE_SLICE_MB");
-        const i64 mb = e ? atoll(e) : 0;
-        return mb > 0 ? mb << 20 : (i64)1 << 60;
-    }();
+    // B[:, w].  tune "cache_slice_mb" (MB of B per slice) forces more windows for experiments.
+    const i64 slice_mb = tune_get("cache_slice_mb", 0);
+    const i64 slice_bytes = slice_mb > 0 ? slice_mb << 20 : (i64)1 << 60;
     const i32 cap_max = (i32)((160 * 1024 - fixed_win) / 8) & ~63;
     i64 n_win64 = ((i64)n_cols + cap_max - 1) / cap_max;
     const i64 by_cache = (b->nnz * 8 + slice_bytes - 1) / slice_bytes;
@@ -832,17 +969,11 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     const size_t lds_win = (size_t)cap_win * 8 + fixed_win, lds_cmp = (size_t)cap_cmp * 8 + fixed_cmp;
     static bool attr_set = false;
     if (!attr_set) {
-        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window_pass<false, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_expand_compact, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     static const bool debug = getenv("HHX_DEBUG") != nullptr;
-    static const int probe = getenv("HHX_PROBE") ? atoi(getenv("HHX_PROBE")) : 0;
+    const int probe = (int)tune_get("probe", 0);
     // rows whose product count is well above the number of accumulator slots a dense sweep touches
     static const double wfac = getenv("HHX_WINDOW_FACTOR") ? atof(getenv("HHX_WINDOW_FACTOR")) : 0.5;
     const i64 window_min = std::max<i64>(4096, (i64)((double)n_cols * wfac));
@@ -856,16 +987,11 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || counts.alloc(4) || cursors.alloc(8) ||
         s_run.alloc((size_t)n_rows + 1) || g_win_off.alloc((size_t)n_rows * n_win + 1) || g_win_cnt.alloc((size_t)n_rows * n_win + 1))
         return 1;
-    DevBuf<i32> win_ptr;
+    DevBuf<int4> rec;                   // window kernel: records + stream of the right operand, built once per call
     DevBuf<unsigned short> c16;
+    DevBuf<float> cls_x;
+    double explicit_frac = 1.0;         // share of B's entries outside the value-uniform sub-segments
     if (cap_win > 65536) return fail("expand: column window wider than 16 bits");
-    if (n_win > 1) {
-        if (win_ptr.alloc((size_t)b->n_rows * (n_win + 1))) return 1;
-        const i64 total = (i64)b->n_rows * (n_win + 1);
-        k_window_ptrs<<<(unsigned)std::min<i64>((total + 255) / 256, 65536), 256, 0, g_stream>>>(b->n_rows, b->indptr.p, b->indices.p,
-                                                                                             cap_win, n_win, win_ptr.p);
-        HHX_LAUNCH_CHECK();
-    }
     // candidate pool: early windows test against a partial row sum and admit more than finally survive
     i64 pool_cap = std::max<i64>(4 * a->nnz + 16 * (i64)n_rows, (i64)1 << 22);
     i64 cand_cap = n_win > 1 ? 2 * pool_cap : pool_cap;
@@ -897,9 +1023,10 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         HHX_HIP(hipMemcpyAsync(hw, cursors.p + 5, sizeof hw, hipMemcpyDeviceToHost, g_stream));
         HHX_HIP(hipStreamSynchronize(g_stream));
         // mean length of a B-row segment inside one column window: tiles of 2 / 4 / 8 entries per lane
-        static const int tile_env = getenv("HHX_TILE_U") ? atoi(getenv("HHX_TILE_U")) : 0;
+        const int tile_env = (int)tune_get("tile_u", 0);
         const double seg_len = hw[1] ? (double)hw[0] / (double)hw[1] / (double)n_win : 0.0;
-        const int tile_u = tile_env ? tile_env : (seg_len >= 192.0 ? 8 : (seg_len >= 96.0 ? 4 : 2));
+        int tile_u = 0;
+        const bool long_segments = seg_len >= 192.0;          // iteration 0 (the link matrix is the operand) vs the pruned iterations: timed apart
         ExParams P;
         P.Ap = a->indptr.p; P.Aj = a->indices.p; P.Ax = a->data.p;
         P.Bp = b->indptr.p; P.Bj = b->indices.p; P.Bx = b->data.p;
@@ -910,33 +1037,53 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         P.cand_col = cand_col.p; P.cand_val = cand_val.p; P.cand_cap = cand_cap;
         P.out_col = out_col.p; P.out_val = out_val.p; P.out_cap = pool_cap;
         P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
-        P.win_ptr = win_ptr.p; P.n_win = n_win;
+        P.n_win = n_win;
         P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
-        P.Bc16 = nullptr; P.Bn16 = coded.n16; P.Bs = coded.row_sum;
-        P.fake_decode = getenv("HHX_CODED_FAKE") != nullptr;
+        P.Sc16 = nullptr; P.Sx = nullptr; P.rec = nullptr;
         if (hc[0]) {
-            if (!c16.p) {                                 // 16-bit window-local columns of B, built once per call
-                if (c16.alloc((size_t)b->nnz)) return 1;
-                k_local_cols<<<(unsigned)std::max<i64>(1, std::min<i64>((b->nnz + 255) / 256, 65536)), 256, 0, g_stream>>>(
-                    b->nnz, b->indices.p, cap_win, c16.p);
+            const unsigned grid = std::min<unsigned>(hc[0], 256);
+            if (!rec.p) {
+                // slack: a wide tile reads up to 8 entries past a segment end, an exhausted cursor entry 0
+                if (rec.alloc((size_t)b->n_rows * n_win + 1) || c16.alloc((size_t)b->nnz + 64)) return 1;
+                const i64 segs = (i64)b->n_rows * n_win;
+                if (use_cls) {
+                    DevBuf<unsigned long long> n_uni;
+                    if (cls_x.alloc((size_t)b->nnz + 64) || n_uni.alloc(1)) return 1;
+                    HHX_HIP(hipMemsetAsync(n_uni.p, 0, sizeof(unsigned long long), g_stream));
+                    { KTimer kt("class_layout");
+                    k_class_layout<<<(unsigned)std::max<i64>(1, std::min<i64>((segs + 3) / 4, 65536)), 256, 0, g_stream>>>(
+                        b->n_rows, n_win, cap_win, b->indptr.p, b->indices.p, b->data.p, coded.n16, coded.row_sum, c16.p, cls_x.p, rec.p, n_uni.p); }
+                    unsigned long long h = 0;
+                    HHX_HIP(hipMemcpyAsync(&h, n_uni.p, sizeof h, hipMemcpyDeviceToHost, g_stream));
+                    HHX_HIP(hipStreamSynchronize(g_stream));
+                    explicit_frac = b->nnz ? 1.0 - (double)h / (double)b->nnz : 1.0;
+                } else {
+                    k_window_recs<<<(unsigned)std::max<i64>(1, std::min<i64>((segs + 255) / 256, 65536)), 256, 0, g_stream>>>(
+                        b->n_rows, b->indptr.p, b->indices.p, cap_win, n_win, rec.p);
+                    k_local_cols<<<(unsigned)std::max<i64>(1, std::min<i64>((b->nnz + 255) / 256, 65536)), 256, 0, g_stream>>>(
+                        b->nnz, b->indices.p, cap_win, c16.p);
+                }
                 HHX_LAUNCH_CHECK();
             }
-            P.Bc16 = c16.p;
-            const unsigned per_cu = lds_win > 80 * 1024 ? 1 : 2;
-            const unsigned grid = std::min<unsigned>(hc[0], 256 * per_cu);
-            // one timer scope, n_win launches of k_expand_window_pass; the long-segment instantiation (U = 8: iteration 0)
-            // and the short-segment ones are timed apart, as rocprof lists them apart
-            { KTimer kt(tile_u == TILE_U || is_coded ? "expand_window" : "expand_window_short", n_win);
-            for (i32 wv = 0; wv < n_win; ++wv) {
-                if (is_coded) k_expand_window_pass<true><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
-                else if (probe == 1) k_expand_window_pass<false, 1><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
-                else if (probe == 2) k_expand_window_pass<false, 2><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
-                else if (tile_u == 2) k_expand_window_pass<false, 0, 2><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
-                else if (tile_u == 4) k_expand_window_pass<false, 0, 4><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
-                else k_expand_window_pass<false><<<grid, EX_T_WIN, lds_win, g_stream>>>(P, list_w.p, (i32)hc[0], cap_win, wv);
-            } }
+            P.Sc16 = c16.p; P.Sx = use_cls ? cls_x.p : b->data.p; P.rec = rec.p;
+            // explicit tiles: UX x 64 entries, sized to the mean explicit sub-segment (a tile costs its 2 UX loads and UX
+            // LDS atomics per lane whether filled or not); tune "tile_u" overrides
+            const double xlen = seg_len * explicit_frac;
+            const int ux = tile_env ? tile_env : (xlen > 288.0 ? 8 : (xlen > 200.0 ? 4 : (xlen > 136.0 ? 3 : (xlen > 68.0 ? 2 : 1))));
+            tile_u = ux;
+            {
+                KTimer kt(long_segments ? "expand_window" : "expand_window_short", n_win);
+                if (probe == 1 && ux >= 4) HHX_TRY((launch_window<1, 8, 3, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
+                else if (probe == 1) HHX_TRY((launch_window<1, 3, 5, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
+                else if (ux >= 8) HHX_TRY((launch_window<0, 8, 3, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
+                else if (ux == 4) HHX_TRY((launch_window<0, 4, 4, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
+                else if (ux == 3) HHX_TRY((launch_window<0, 3, 5, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
+                else if (ux == 2) HHX_TRY((launch_window<0, 2, 6, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
+                else HHX_TRY((launch_window<0, 1, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
+            }
+            HHX_LAUNCH_CHECK();
             KTimer kt("expand_finalize");
-            k_expand_window_finalize<<<std::min<unsigned>(hc[0], 256 * 8), EX_T_CMP, ex_fixed_bytes(0, 0, false), g_stream>>>(P, list_w.p, (i32)hc[0]);
+            k_expand_window_finalize<<<std::min<unsigned>(hc[0], 256 * 8), EX_T_CMP, ex_fixed_bytes(0, 0), g_stream>>>(P, list_w.p, (i32)hc[0]);
         }
         HHX_LAUNCH_CHECK();
         if (hc[2]) {
@@ -964,9 +1111,10 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             continue;
         }
         if (prof_enabled() && hc[0]) {
-            const bool longseg = tile_u == TILE_U || is_coded;
+            const bool longseg = long_segments;
             prof_count(longseg ? "expand_window_products" : "expand_window_short_products", (i64)cur[5]);
             prof_count(longseg ? "expand_window_a_reads" : "expand_window_short_a_reads", (i64)cur[6] * n_win);
+            if (use_cls) prof_count("expand_window_uniform_products", (i64)cur[7]);
         }
         if (n_products) *n_products = (i64)cur[4];
         if (nnz_expanded) *nnz_expanded = (i64)cur[3];
@@ -992,7 +1140,7 @@ extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int 
 }
 
 // b is the L1-normalised link matrix whose entry p equals float(n16[p] / row_sum[row]) (checked by the caller)
-int hhx_expand_coded(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
+int hhx_expand_links(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
                      double inflation, double pruning, hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
     CodedOperand c;
     c.n16 = n16; c.row_sum = row_sum;

@@ -10,7 +10,7 @@
 using namespace hhx;
 
 int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
-int hhx_expand_coded(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
+int hhx_expand_links(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
                      double inflation, double pruning, hhx_csr **out, i64 *n_products, i64 *nnz_expanded);
 
 namespace {
@@ -336,7 +336,7 @@ static int mcl_impl(const hhx_csr *m, int pre_expanded, int expansion, double in
             if (!rc) {
                 i64 f = 0;
                 if (it == 0 && n16)   // iteration 0 right operand = the normalised link matrix itself: 4-byte count-coded stream
-                    rc = hhx_expand_coded(run, src, n16, row_sum, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);
+                    rc = hhx_expand_links(run, src, n16, row_sum, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);
                 else
                     rc = hhx_expand_inflate_prune(run, src, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);   // :2030-2042
                 st_f += f;
@@ -413,7 +413,6 @@ extern "C" int hhx_mcl_links(const hhx_csr *links, int expansion, double inflati
         if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
         if (e != hipSuccess) rc = fail("hhx_mcl_links: %s", hipGetErrorString(e));
     }
-    if (!getenv("HHX_CODED")) bad = 1;      // opt-in: the 4-byte stream is ALU-bound on MI355X (hhx_expand.hip)
     if (!rc) rc = mcl_impl(norm, 0, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats, bad ? nullptr : n16.p,
                            bad ? nullptr : row_sum.p);
     hhx_csr_free(norm);

@@ -77,6 +77,23 @@ void pool_trim() {
     for (void *p : blocks) (void)hipFree(p);
 }
 
+// ------------------------------------------------------------------ tuning knobs
+namespace {
+std::mutex g_tune_mu;
+std::map<std::string, i64> g_tune;
+}  // namespace
+i64 tune_get(const char *name, i64 dflt) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tune.find(name);
+    if (it != g_tune.end()) return it->second;
+    std::string env = "HHX_";
+    for (const char *c = name; *c; ++c) env += (char)toupper((unsigned char)*c);
+    const char *e = getenv(env.c_str());
+    const i64 v = e ? atoll(e) : dflt;
+    if (e) g_tune[name] = v;
+    return v;
+}
+
 // ------------------------------------------------------------------ kernel timing
 namespace {
 bool g_prof_on = false;
@@ -243,6 +260,12 @@ extern "C" int hhx_synchronize(void) {
 }
 extern "C" int hhx_pool_trim(void) {
     pool_trim();
+    return 0;
+}
+extern "C" int hhx_tune(const char *name, int64_t value) {
+    if (!name) return fail("null name");
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tune[name] = value;
     return 0;
 }
 extern "C" int hhx_profile_enable(int on) {

@@ -42,7 +42,11 @@ int hhx_pool_trim(void);                       /* release cached device memory *
 /* per-kernel device timing with HIP events on the launch stream (bench.py's roofline leg):
  * names: "ingest" (map + partition + aggregate of one push), "aggregate", "ingest_merge", "link_matrix",
  * "spgemm_symbolic", "spgemm_numeric", "expand_window", "expand_compact", "inflate_stats", "prune_write",
- * "convergence" */
+ * "convergence", "class_layout" */
+/* measurement / experiment switches of the kernels (tools/ and bench.py only; no reference counterpart): e.g.
+ * "cls" 0 = stream iteration 0 as (column, value) pairs instead of the class stream, "probe" 1 = no LDS atomics (garbage
+ * results).  Unset knobs fall back to the environment variable HHX_<NAME>. */
+int hhx_tune(const char *name, int64_t value);
 int hhx_profile_enable(int on);
 int hhx_profile_reset(void);
 int hhx_profile_get(const char *kernel, double *total_ms, int64_t *launches);

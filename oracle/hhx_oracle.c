@@ -15,6 +15,7 @@
  * Each function cites the reference lines (HapHiC_cluster.py unless said otherwise) it restates.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -69,46 +70,66 @@ static int cmp_i32(const void *a, const void *b) {
     return (x > y) - (x < y);
 }
 
+/* Rows are independent, so the sweep is spread over host threads (OpenMP, static per-thread scratch); the
+ * arithmetic inside a row — and therefore every result bit, mode 0's sequential float32 sums included — is
+ * what the serial loop produces.  orc_set_threads(1) (bench.py's cpu_baseline leg) gives the scalar port. */
+static int g_threads = 0;                        /* 0: OpenMP default (all cores) */
+void orc_set_threads(int n) { g_threads = n; }
+int orc_get_threads(void) { return g_threads > 0 ? g_threads : omp_get_max_threads(); }
+
 i64 orc_spgemm(i32 n_rows, i32 n_cols, const i32 *Ap, const i32 *Aj, const float *Ax, const i32 *Bp,
                const i32 *Bj, const float *Bx, i32 *Cp, i32 *Cj, float *Cx, int mode, int fx_shift) {
-    i32 *mark = (i32 *)malloc(sizeof(i32) * (size_t)n_cols);
-    float *accf = (float *)calloc((size_t)n_cols, sizeof(float));
-    i64 *acci = (i64 *)calloc((size_t)n_cols, sizeof(i64));
-    i32 *cols = (i32 *)malloc(sizeof(i32) * (size_t)n_cols);
-    for (i32 c = 0; c < n_cols; ++c) mark[c] = -1;
     const double scale = ldexp(1.0, fx_shift), inv_scale = ldexp(1.0, -fx_shift);
-    i64 nnz = 0;
-    Cp[0] = 0;
-    for (i32 i = 0; i < n_rows; ++i) {
-        i32 cnt = 0;
-        for (i32 p = Ap[i]; p < Ap[i + 1]; ++p) {
-            i32 k = Aj[p];
-            float a = Ax[p];
-            for (i32 q = Bp[k]; q < Bp[k + 1]; ++q) {
-                i32 j = Bj[q];
-                if (mark[j] != i) {
-                    mark[j] = i;
-                    cols[cnt++] = j;
-                    accf[j] = 0.0f;
-                    acci[j] = 0;
+    const int nt = orc_get_threads();
+    i64 *row_nnz = (i64 *)calloc((size_t)n_rows + 1, sizeof(i64));
+    for (int pass = 0; pass < (Cj ? 2 : 1); ++pass) {
+#pragma omp parallel num_threads(nt)
+        {
+            i32 *mark = (i32 *)malloc(sizeof(i32) * (size_t)n_cols);
+            float *accf = (float *)calloc((size_t)n_cols, sizeof(float));
+            i64 *acci = (i64 *)calloc((size_t)n_cols, sizeof(i64));
+            i32 *cols = (i32 *)malloc(sizeof(i32) * (size_t)n_cols);
+            for (i32 c = 0; c < n_cols; ++c) mark[c] = -1;
+#pragma omp for schedule(dynamic, 16)
+            for (i32 i = 0; i < n_rows; ++i) {
+                i32 cnt = 0;
+                for (i32 p = Ap[i]; p < Ap[i + 1]; ++p) {
+                    i32 k = Aj[p];
+                    float a = Ax[p];
+                    for (i32 q = Bp[k]; q < Bp[k + 1]; ++q) {
+                        i32 j = Bj[q];
+                        if (mark[j] != i) {
+                            mark[j] = i;
+                            cols[cnt++] = j;
+                            accf[j] = 0.0f;
+                            acci[j] = 0;
+                        }
+                        if (pass == 1) {
+                            if (mode == 0) accf[j] += a * Bx[q];
+                            else acci[j] += (i64)llrint((double)a * (double)Bx[q] * scale);
+                        }
+                    }
                 }
-                if (Cj) {
-                    if (mode == 0) accf[j] += a * Bx[q];
-                    else acci[j] += (i64)llrint((double)a * (double)Bx[q] * scale);
+                if (pass == 0) row_nnz[i + 1] = cnt;
+                else {
+                    const i64 base = row_nnz[i];
+                    qsort(cols, (size_t)cnt, sizeof(i32), cmp_i32);
+                    for (i32 c = 0; c < cnt; ++c) {
+                        Cj[base + c] = cols[c];
+                        Cx[base + c] = mode == 0 ? accf[cols[c]] : (float)((double)acci[cols[c]] * inv_scale);
+                    }
                 }
+                for (i32 c = 0; c < cnt; ++c) mark[cols[c]] = -1;       /* the row id is reused by the second pass */
             }
+            free(mark); free(accf); free(acci); free(cols);
         }
-        if (Cj) {
-            qsort(cols, (size_t)cnt, sizeof(i32), cmp_i32);
-            for (i32 c = 0; c < cnt; ++c) {
-                Cj[nnz + c] = cols[c];
-                Cx[nnz + c] = mode == 0 ? accf[cols[c]] : (float)((double)acci[cols[c]] * inv_scale);
-            }
+        if (pass == 0) {
+            for (i32 i = 0; i < n_rows; ++i) row_nnz[i + 1] += row_nnz[i];
+            for (i32 i = 0; i <= n_rows; ++i) Cp[i] = (i32)row_nnz[i];
         }
-        nnz += cnt;
-        Cp[i + 1] = (i32)nnz;
     }
-    free(mark); free(accf); free(acci); free(cols);
+    const i64 nnz = row_nnz[n_rows];
+    free(row_nnz);
     return nnz;
 }
 

@@ -42,6 +42,10 @@ def lib():
         L.orc_spgemm.argtypes = [C.c_int32, C.c_int32, _i32p, _i32p, _f32p, _i32p, _i32p, _f32p, _i32p,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_spgemm.restype = C.c_int64
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads.restype = None
+        L.orc_get_threads.argtypes = []
+        L.orc_get_threads.restype = C.c_int
         L.orc_prune.argtypes = [C.c_int32, _i32p, _i32p, _f32p, C.c_double, _i32p, _i32p, _f32p]
         L.orc_prune.restype = C.c_int64
         L.orc_convergence_stat.argtypes = [C.c_int32, _i32p, _i32p, _f32p, _i32p, _i32p, _f32p]
@@ -73,6 +77,15 @@ def lib():
         L.orc_count_re_sites.restype = None
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    """host threads of the row-parallel SpGEMM (0 = all cores); results do not depend on it"""
+    lib().orc_set_threads(int(n))
+
+
+def get_threads():
+    return int(lib().orc_get_threads())
 
 
 def _csr(indptr, indices, data):

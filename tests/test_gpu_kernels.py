@@ -605,10 +605,11 @@ def test_mcl_blocked_pre_expansion_resume(golden_mcl):
     assert 0 < free_b <= total_b
 
 
-def test_mcl_links_count_coded_iteration0():
-    """hhx_mcl_links (normalisation fused, iteration 0 streaming 16-bit link counts + 16-bit window-local
-    columns) must give exactly the bits of hhx_normalize_l1 + hhx_mcl_normalized, on a matrix wide enough
-    for several column windows; non-integer values must fall back to the generic stream."""
+def test_mcl_links_class_stream_iteration0():
+    """hhx_mcl_links (normalisation fused, iteration 0 streaming the link matrix with the count-1 entries of every
+    segment moved to the front: 16-bit window-local columns only for those, column + value for the rest) must give
+    exactly the bits of hhx_normalize_l1 + hhx_mcl_normalized, on a matrix wide enough for several column windows,
+    for every tile shape of the kernel; non-integer values must fall back to the generic stream."""
     import torch
     from haphic_amd import synth
     gen = synth.make_genome(8, 60_000_000, 20_000, seed=8)          # ~24k contigs -> 2 column windows
@@ -622,19 +623,25 @@ def test_mcl_links_count_coded_iteration0():
     torch.cuda.synchronize()
     links, fidx, n_linked = ing.link_matrix(np.ones(n, np.uint8))
     assert links.shape3[0] > 17_500
-    import os
-    os.environ['HHX_CODED'] = '1'                                # opt-in 4-byte stream (read at call time)
+    r1, n1, c1, st1 = _lib.mcl(links, 2, 2.0, 200, 1e-4, want_stats=True, links=True)      # default class stream
     try:
-        r1, n1, c1, st1 = _lib.mcl(links, 2, 2.0, 200, 1e-4, want_stats=True, links=True)
+        _lib.tune('cls', 0)                                          # generic (column, value) stream
+        r0, n0, c0 = _lib.mcl(links, 2, 2.0, 200, 1e-4, links=True)
+        assert (n0, c0) == (n1, c1) and all(np.array_equal(x, y) for x, y in zip(r0.to_arrays(), r1.to_arrays()))
+        one0 = _lib.mcl(links, 2, 2.0, 1, 1e-4, links=True)[0].to_arrays()
+        for cls, tile_u in ((1, 0), (1, 1), (1, 2), (1, 3), (1, 4), (1, 8), (0, 1), (0, 2), (0, 3), (0, 4)):
+            _lib.tune('cls', cls)
+            _lib.tune('tile_u', tile_u)
+            one = _lib.mcl(links, 2, 2.0, 1, 1e-4, links=True)[0].to_arrays()
+            assert all(np.array_equal(x, y) for x, y in zip(one, one0)), 'stream layout changed bits: %r' % ((cls, tile_u),)
     finally:
-        del os.environ['HHX_CODED']
-    r0, n0, c0 = _lib.mcl(links, 2, 2.0, 200, 1e-4, links=True)     # default 6-byte stream
-    assert all(np.array_equal(x, y) for x, y in zip(r0.to_arrays(), r1.to_arrays()))
+        _lib.tune('cls', 1)
+        _lib.tune('tile_u', 0)
     norm = links.copy()
     _lib.normalize_l1(norm)
     r2, n2, c2, st2 = _lib.mcl(norm, 2, 2.0, 200, 1e-4, want_stats=True, normalized=True)
     assert (n1, c1) == (n2, c2) and np.array_equal(st1, st2)
-    assert all(np.array_equal(x, y) for x, y in zip(r1.to_arrays(), r2.to_arrays())), 'count-coded iteration 0 changed bits'
+    assert all(np.array_equal(x, y) for x, y in zip(r1.to_arrays(), r2.to_arrays())), 'class-stream iteration 0 changed bits'
     # one fused iteration against the oracle on a slice of rows (the oracle is too slow for all of them)
     A = norm.to_arrays()
     blk = norm.row_block(100, 140)

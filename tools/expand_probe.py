@@ -1,0 +1,91 @@
+"""Iteration 0 of the MCL (run_mcl_clustering :2144-2147 fused with mcl :2030-2042) on the BASELINE configs[2] link
+matrix under the layout variants of the class stream (hhx_tune knobs) — measurement tool, one JSON line per variant.
+Every variant must reproduce the bits of the generic (column, value) stream; the probes (no LDS atomics / plain
+stores) produce garbage by construction and are only timed."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--contigs', type=int, default=100000)
+    ap.add_argument('--pairs', type=int, default=500_000_000)
+    ap.add_argument('--nchrs', type=int, default=24)
+    ap.add_argument('--mean-len', type=int, default=30000)
+    ap.add_argument('--quick', action='store_true')
+    args = ap.parse_args()
+    import torch
+    from haphic_amd import _lib, synth
+    from haphic_amd.cluster import FragTable
+    dev = 'cuda:0'
+    gen = synth.make_genome(args.nchrs, max(1, args.contigs // args.nchrs) * args.mean_len, args.mean_len, seed=12345)
+    n = gen.n
+    table = FragTable.for_contigs(gen.lexical_rank(), gen.length, np.ones(n, np.uint8))
+    id1, p1, id2, p2 = synth.sample_pairs(gen, args.pairs, seed=12345, device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    ing = _lib.Ingest(table, 500_000, bins=False, skip_intra=True)
+    ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+    ing.finalize()
+    m, _fidx, _nl = ing.link_matrix(np.ones(n, np.uint8))
+    ing.destroy()
+    del id1, p1, id2, p2
+    torch.cuda.empty_cache()
+    print(json.dumps({'n': n, 'nnz': m.nnz}), flush=True)
+    knobs = ('cls', 'tile_u', 'probe')
+    variants = [('generic 6B stream', (0, 0, 0)),
+                ('class stream (auto tile)', (1, 0, 0)),
+                ('class stream, explicit tiles x1', (1, 1, 0)),
+                ('class stream, explicit tiles x2', (1, 2, 0)),
+                ('class stream, explicit tiles x3', (1, 3, 0)),
+                ('class stream, explicit tiles x4', (1, 4, 0)),
+                ('generic, tiles x4', (0, 4, 0)),
+                ('generic, probe 1 (no LDS op)', (0, 0, 1)),
+                ('class stream, probe 1 (no LDS op)', (1, 0, 1))]
+    if args.quick:
+        variants = variants[:2]
+    ref = None
+    for name, vals in variants:
+        for k, v in zip(knobs, vals):
+            _lib.tune(k, v)
+        best = None
+        for rep in range(2):
+            _lib.profile_reset()
+            _lib.profile_enable(True)
+            _lib.check(_lib.load().hhx_synchronize())
+            t0 = time.perf_counter()
+            res, n_iter, conv, stats = _lib.mcl(m, 2, 2.0, 1, 1e-4, want_stats=True, links=True)
+            _lib.check(_lib.load().hhx_synchronize())
+            dt = time.perf_counter() - t0
+            _lib.profile_enable(False)
+            win_ms, win_n = _lib.profile_get('expand_window')
+            lay_ms, _ = _lib.profile_get('class_layout')
+            fin_ms, _ = _lib.profile_get('expand_finalize')
+            rec = {'variant': name, 'wall_ms': dt * 1e3, 'expand_window_ms': win_ms, 'launches': win_n, 'class_layout_ms': lay_ms,
+                   'finalize_ms': fin_ms, 'products': int(stats[0, 3]), 'uniform_products': _lib.profile_counter('expand_window_uniform_products'),
+                   'nnz_out': res.nnz}
+            if best is None or rec['expand_window_ms'] < best['expand_window_ms']:
+                best = rec
+            if vals[2] == 0 and rep == 0:
+                got = res.to_arrays()
+                if ref is None:
+                    ref = got
+                else:
+                    best_ok = all(np.array_equal(x, y) for x, y in zip(got, ref))
+                    rec['bit_identical_to_generic'] = bool(best_ok)
+                    best['bit_identical_to_generic'] = bool(best_ok)
+            res.free()
+        print(json.dumps(best), flush=True)
+    for k, v in zip(knobs, (1, 0, 0)):
+        _lib.tune(k, v)
+
+
+if __name__ == '__main__':
+    main()

@@ -24,6 +24,17 @@ for l in open('gpurun_out/bench_text.log'):
     pmc:*) # pmc:NAME:COUNTER1,COUNTER2  -> one rocprofv3 --pmc pass of the default bench (1 step, no warmup)
         spec="${what#pmc:}"; name="${spec%%:*}"; ctrs="${spec#*:}"; rm -rf gpurun_out/pmc_$name
         timeout 900 rocprofv3 --kernel-trace --pmc ${ctrs//,/ } --output-format csv -d gpurun_out/pmc_$name -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --text-lines 0 $PMC_ARGS > gpurun_out/pmc_$name.log 2>&1; echo "pmc $name rc=$?"; ls gpurun_out/pmc_$name | head -5;;
+    probe) timeout 1200 python tools/expand_probe.py $PROBE_ARGS > gpurun_out/expand_probe.log 2>&1; echo "probe rc=$?"; cut -c1-330 gpurun_out/expand_probe.log | tail -20;;
+    ktests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q > gpurun_out/pytest_k.log 2>&1; echo "ktests rc=$?"; tail -5 gpurun_out/pytest_k.log;;
+    calib) # known-byte microkernels under the PMC counters (tools/pmc_calib.hip), one pass per counter group
+        ./tools/pmc_calib > gpurun_out/calib_plain.log 2>&1; cat gpurun_out/calib_plain.log
+        for spec in "a:FETCH_SIZE TCC_MISS_sum" "b:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "c:WRITE_SIZE TCC_EA0_WRREQ_sum" "d:TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum TCC_READ_sum TCC_WRITE_sum"; do
+            name="${spec%%:*}"; ctrs="${spec#*:}"; rm -rf gpurun_out/calib_$name
+            timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/calib_$name -o p -- ./tools/pmc_calib > gpurun_out/calib_$name.log 2>&1; echo "calib $name rc=$?"
+        done
+        python tools/pmc_calib_summary.py gpurun_out | tee gpurun_out/calib_summary.txt;;
+    sbench) timeout 600 ./tools/stream_bench > gpurun_out/stream_bench.log 2>&1; echo "sbench rc=$?"; cat gpurun_out/stream_bench.log;;
+    ldsbench) timeout 600 ./tools/lds_atomic_bench > gpurun_out/lds_atomic_bench.log 2>&1; echo "ldsbench rc=$?"; cat gpurun_out/lds_atomic_bench.log;;
     listpmc) rocprofv3 -L > gpurun_out/pmc_list.txt 2>&1; grep -c . gpurun_out/pmc_list.txt;;
     env:*) export "${what#env:}"; echo "set ${what#env:}";;
     *) echo "unknown $what";;
