@@ -121,8 +121,8 @@ def main():
         # ---- run_mcl_clustering :2144-2158 at one inflation
         t2 = time.perf_counter()
         if sharded_path:
-            _lib.normalize_l1(m)                                                # :2144, row-local
-            res, n_iter, conv, stats = sharded.mcl_sharded(None, 2, args.inflation, 200, 1e-4, dist, dev, local_block=m, n=shape)
+            # the raw row blocks are all-gathered once; normalisation (:2144) is row-local, iteration 0 = class stream
+            res, n_iter, conv, stats = sharded.mcl_sharded(None, 2, args.inflation, 200, 1e-4, dist, dev, local_links=m, n=shape)
         else:
             # normalisation (:2144) and pre-expansion (:2146-2147) fused into iteration 0: the 10^8..10^10-entry
             # M^2 never exists, and iteration 0 streams the link matrix as 16-bit counts
@@ -167,27 +167,36 @@ def main():
         value = pairs_total / t_ing
         stats = np.asarray(state['stats'])
         pg = _lib.profile_get
-        # ---- dominant kernel of the step: k_expand_window_pass (the B-row stream of the fused expansion).
-        # Algorithmic bytes: SURVEY §8d's B_iter gather term with this kernel's stream format — 6 B per product
-        # (16-bit window-local column + float32 value; SURVEY counts 8 B for an int32 + float32 entry) + 16 B per
-        # staged A entry and window (column, value, two split pointers); survivors are written by the finalize
-        # kernel.  Time: HIP events on the launch stream around the n_win launches of every call.
+        # ---- dominant kernel of the step: k_expand_window (the B-row stream of the fused expansion), iteration 0.
+        # Algorithmic bytes = what the kernel's stream format moves per launch: 2 B per product of a value-uniform
+        # sub-segment (16-bit window-local column; the count-1 entries of the link matrix), 6 B per other product
+        # (column + float32 value; SURVEY §8d counts 8 B for an int32 + float32 entry: `achieved_survey_8B_model`)
+        # + 24 B per staged A entry and window (column, value, 16-byte segment record); survivors are written by the
+        # finalize kernel.  Time: HIP events on the launch stream around the n_win launches of every call.
         win_ms, win_n = pg('expand_window')
         F_w = _lib.profile_counter('expand_window_products')
+        F_u = _lib.profile_counter('expand_window_uniform_products')
         A_w = _lib.profile_counter('expand_window_a_reads')
         traffic = pmc_traffic(n, local_pairs)
         roofline = None
         if win_n:
-            alg = 6.0 * F_w + 16.0 * A_w
+            alg = 2.0 * F_u + 6.0 * (F_w - F_u) + 24.0 * A_w
             ach = alg / (win_ms * 1e-3) / 1e9
-            roofline = {'kernel': 'k_expand_window_pass<false, 0, 8>', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': ach / HBM_PEAK_GBS, 'traffic': pick(traffic, 'k_expand_window_pass<false, 0, 8>'),
+            roofline = {'kernel': 'k_expand_window', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': ach / HBM_PEAK_GBS, 'traffic': pick(traffic, 'k_expand_window<0'),
                         'alg_bytes_per_launch': alg / win_n, 'avg_launch_ms': win_ms / win_n, 'launches_per_step': win_n / K,
-                        'products_per_step': F_w / K, 'bytes_per_product': 6,
+                        'products_per_step': F_w / K, 'uniform_products_per_step': F_u / K, 'bytes_per_product': alg / F_w if F_w else None,
+                        'products_per_s': F_w / (win_ms * 1e-3),
                         'achieved_survey_8B_model': (8.0 * F_w + 16.0 * A_w) / (win_ms * 1e-3) / 1e9,
-                        'note': 'the long-segment instantiation (8 entries per lane and tile: iteration 0, where the link matrix is the operand); '
-                                'the short-segment launches of later iterations are in mcl.kernel_ms_per_step.expand_window_short; '
-                                'traffic = fabric bytes per launch from rocprofv3 PMC (profiles/), null if no profile matches this workload'}
+                        'measured_stream_ceiling_GBs': 6290.0, 'frac_of_measured_ceiling': ach / 6290.0,
+                        'lds_atomic_ceiling_products_per_s': 256 * 2.4e9 * 64 / 12.77,
+                        'note': 'iteration 0 (the link matrix is the operand; long segments); the launches of later iterations are in '
+                                'mcl.kernel_ms_per_step.expand_window_short.  The stream is served by the fabric behind L2 (HBM + the 256 MB '
+                                'Infinity Cache: one column-window slice of the class stream is ~200 MB), so the HBM peak is the contract '
+                                'denominator and the float4-copy ceiling of MI355X_MICROARCH.md (6.29 TB/s) the practical one; the second '
+                                'ceiling is the LDS atomic rate (ds_add_u64 on random slots: 12.8 clk per wave instruction, '
+                                'profiles/r02_lds_atomic_bench.jsonl).  traffic = fabric bytes per launch from rocprofv3 PMC (profiles/), '
+                                'null if no profile matches this workload'}
         # ---- ingest: the kernel that bounds `value` is the level-1 scatter of the group-by
         sc_ms, sc_n = pg('map')
         ing_roofline = None
@@ -223,7 +232,7 @@ def main():
         out = {'metric': 'Hi-C pairs/s ingested (link-matrix build) + MCL iters/s', 'value': value, 'unit': 'pairs/s',
                'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': elapsed / K * 1e3,
                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-               'dtype': 'u64 keys + u32 counts (ingest); f32 values, exact f64 accumulation (MCL)',
+               'dtype': 'u64 keys + u32 counts (ingest); f32 values, exact u64 fixed-point accumulation (MCL)',
                'data': 'synthetic',
                'config': {'workload': '%d contigs / %d pairs (whole job, %d per GPU), %d chr, mean contig %d bp, inflation %.1f, dense-block off'
                                       % (n, local_pairs * world, local_pairs, args.nchrs, args.mean_len, args.inflation),

@@ -57,6 +57,8 @@ SIGNATURES = {
     'hhx_spgemm': (C.c_int, [C.c_void_p, C.c_void_p, c_vpp]),
     'hhx_spgemm_ex': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_vpp, c_i64p]),
     'hhx_expand_inflate_prune': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, c_vpp, c_i64p, c_i64p]),
+    'hhx_row_products': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'hhx_expand_links': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, c_vpp, c_i64p, c_i64p]),
     'hhx_convergence_stat': (C.c_int, [C.c_void_p, C.c_void_p, c_f32p]),
     'hhx_mcl': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, c_vpp, C.POINTER(C.c_int),
                           C.POINTER(C.c_int), C.c_void_p]),
@@ -325,6 +327,21 @@ def expand_inflate_prune(a, b, inflation, pruning, fx_shift=52):
     f, z = C.c_int64(0), C.c_int64(0)
     check(load().hhx_expand_inflate_prune(a.h, b.h, int(fx_shift), float(inflation), float(pruning), C.byref(out),
                                           C.byref(f), C.byref(z)))
+    return DeviceCSR(out), f.value, z.value
+
+
+def row_products(a, b):
+    """products per row of a * b (int64 numpy)"""
+    out = np.zeros(max(a.shape3[0], 1), np.int64)
+    check(load().hhx_row_products(a.h, b.h, ptr(out)))
+    return out[:a.shape3[0]]
+
+
+def expand_links(a, links, inflation, pruning, fx_shift=52):
+    """iteration 0 for a row block: a = rows of the normalised link matrix, links = the whole RAW link matrix"""
+    out = C.c_void_p()
+    f, z = C.c_int64(0), C.c_int64(0)
+    check(load().hhx_expand_links(a.h, links.h, int(fx_shift), float(inflation), float(pruning), C.byref(out), C.byref(f), C.byref(z)))
     return DeviceCSR(out), f.value, z.value
 
 

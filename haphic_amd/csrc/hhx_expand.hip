@@ -811,6 +811,18 @@ __global__ __launch_bounds__(256) void k_classify(i32 n_rows, const i32 *__restr
     }
 }
 
+// products per row of a * b (the cost of a row of the expansion): one wave per row
+__global__ __launch_bounds__(256) void k_row_products(i32 n_rows, const i32 *__restrict__ Ap, const i32 *__restrict__ Aj,
+                                                      const i32 *__restrict__ Bp, i64 *__restrict__ out) {
+    const int lane = lane_id();
+    for (i32 row = blockIdx.x * 4 + threadIdx.x / HHX_WAVE; row < n_rows; row += gridDim.x * 4) {
+        i64 f = 0;
+        for (i32 p = Ap[row] + lane; p < Ap[row + 1]; p += HHX_WAVE) { const i32 k = Aj[p]; f += Bp[k + 1] - Bp[k]; }
+        f = wave_sum_i64(f);
+        if (lane == 0) out[row] = f;
+    }
+}
+
 // ---- tiny rows (<= TINY_MAX products): one THREAD per row ------------------------------------------------
 // After a few iterations almost every row of T has one to three entries; a workgroup per row then spends
 // its time clearing an n-bit bitmap.  Here a thread merges the row's products into a sorted local list
@@ -1134,13 +1146,26 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     return fail("expand: survivor pool kept overflowing");
 }
 
+extern "C" int hhx_row_products(const hhx_csr *a, const hhx_csr *b, i64 *products_host) {
+    if (!a || !b || !products_host) return fail("null pointer");
+    if (a->n_cols != b->n_rows) return fail("row_products shape mismatch");
+    DevBuf<i64> f;
+    if (f.alloc((size_t)a->n_rows + 1)) return 1;
+    k_row_products<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)a->n_rows + 3) / 4, 8192)), 256, 0, g_stream>>>(a->n_rows, a->indptr.p,
+                                                                                                                   a->indices.p, b->indptr.p, f.p);
+    HHX_LAUNCH_CHECK();
+    HHX_HIP(hipMemcpyAsync(products_host, f.p, sizeof(i64) * (size_t)a->n_rows, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
 extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int fx_shift, double inflation, double pruning,
                                         hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
     return hhx_expand_impl(a, b, CodedOperand(), fx_shift, inflation, pruning, out, n_products, nnz_expanded);
 }
 
 // b is the L1-normalised link matrix whose entry p equals float(n16[p] / row_sum[row]) (checked by the caller)
-int hhx_expand_links(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
+int hhx_expand_class_stream(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
                      double inflation, double pruning, hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
     CodedOperand c;
     c.n16 = n16; c.row_sum = row_sum;

@@ -10,7 +10,7 @@
 using namespace hhx;
 
 int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
-int hhx_expand_links(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
+int hhx_expand_class_stream(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
                      double inflation, double pruning, hhx_csr **out, i64 *n_products, i64 *nnz_expanded);
 
 namespace {
@@ -336,7 +336,7 @@ static int mcl_impl(const hhx_csr *m, int pre_expanded, int expansion, double in
             if (!rc) {
                 i64 f = 0;
                 if (it == 0 && n16)   // iteration 0 right operand = the normalised link matrix itself: 4-byte count-coded stream
-                    rc = hhx_expand_links(run, src, n16, row_sum, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);
+                    rc = hhx_expand_class_stream(run, src, n16, row_sum, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);
                 else
                     rc = hhx_expand_inflate_prune(run, src, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);   // :2030-2042
                 st_f += f;
@@ -384,39 +384,56 @@ extern "C" int hhx_mcl_normalized(const hhx_csr *norm, int expansion, double inf
     return mcl_impl(norm, 0, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats);
 }
 
+// The raw link matrix normalised (:2144) together with what the class stream needs: the L1 row sums the
+// normalisation divided by and the 16-bit link counts.  *usable = 0 if some value is not an integer in [0, 65535] or
+// some row sum is zero (then only the normalised matrix is meaningful).
+struct NormalisedLinks {
+    hhx_csr *norm = nullptr;
+    DevBuf<double> row_sum;
+    DevBuf<unsigned short> n16;
+    bool usable = false;
+    ~NormalisedLinks() { if (norm) hhx_csr_free(norm); }
+};
+static int normalise_links(const hhx_csr *links, NormalisedLinks *o) {
+    HHX_TRY(hhx_csr_copy(links, &o->norm));
+    DevBuf<unsigned int> flags;
+    if (o->row_sum.alloc((size_t)links->n_rows + 1) || o->n16.alloc((size_t)links->nnz + 1) || flags.alloc(1)) return 1;
+    unsigned int bad = 1;
+    HHX_HIP(hipMemsetAsync(flags.p, 0, sizeof(unsigned int), g_stream));
+    k_normalize_l1<<<row_grid(links->n_rows), ROW_T, 0, g_stream>>>(links->n_rows, o->norm->indptr.p, o->norm->data.p, o->row_sum.p);
+    if (links->nnz)
+        k_link_counts<<<(unsigned)std::max<i64>(1, std::min<i64>((links->nnz + 255) / 256, 65536)), 256, 0, g_stream>>>(
+            links->nnz, links->data.p, o->n16.p, flags.p);
+    if (links->n_rows)
+        k_any_zero<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)links->n_rows + 255) / 256, 4096)), 256, 0, g_stream>>>(
+            links->n_rows, o->row_sum.p, flags.p);
+    HHX_LAUNCH_CHECK();
+    HHX_HIP(hipMemcpyAsync(&bad, flags.p, sizeof bad, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    o->usable = !bad;
+    return 0;
+}
+
 // run_mcl_clustering :2144-2158 for one inflation straight from the RAW link matrix of dict_to_matrix
 // (:362-368): L1 normalisation (:2144), pre-expansion (:2146-2147) fused into iteration 0, mcl().  When the
 // matrix holds integer link counts <= 65535 (always, unless --normalize_by_nlinks / GFA weights were applied)
-// iteration 0 streams its right operand as 16-bit counts.  `normalized_out` (optional) receives the
-// normalised matrix so that an inflation sweep can reuse it.
+// iteration 0 streams its right operand as the class stream (hhx_expand.hip).
 extern "C" int hhx_mcl_links(const hhx_csr *links, int expansion, double inflation, int max_iter, double pruning,
                              hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
     if (!links || !out) return fail("null pointer");
-    hhx_csr *norm = nullptr;
-    HHX_TRY(hhx_csr_copy(links, &norm));
-    DevBuf<double> row_sum;
-    DevBuf<unsigned short> n16;
-    DevBuf<unsigned int> flags;
-    int rc = (row_sum.alloc((size_t)links->n_rows + 1) || n16.alloc((size_t)links->nnz) || flags.alloc(1)) ? 1 : 0;
-    unsigned int bad = 1;
-    if (!rc) {
-        hipError_t e = hipMemsetAsync(flags.p, 0, sizeof(unsigned int), g_stream);
-        k_normalize_l1<<<row_grid(norm->n_rows), ROW_T, 0, g_stream>>>(norm->n_rows, norm->indptr.p, norm->data.p, row_sum.p);
-        if (links->nnz)
-            k_link_counts<<<(unsigned)std::max<i64>(1, std::min<i64>((links->nnz + 255) / 256, 65536)), 256, 0, g_stream>>>(
-                links->nnz, links->data.p, n16.p, flags.p);
-        if (links->n_rows)
-            k_any_zero<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)links->n_rows + 255) / 256, 4096)), 256, 0, g_stream>>>(
-                links->n_rows, row_sum.p, flags.p);
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(&bad, flags.p, sizeof bad, hipMemcpyDeviceToHost, g_stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
-        if (e != hipSuccess) rc = fail("hhx_mcl_links: %s", hipGetErrorString(e));
-    }
-    if (!rc) rc = mcl_impl(norm, 0, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats, bad ? nullptr : n16.p,
-                           bad ? nullptr : row_sum.p);
-    hhx_csr_free(norm);
-    return rc;
+    NormalisedLinks nl;
+    HHX_TRY(normalise_links(links, &nl));
+    return mcl_impl(nl.norm, 0, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats, nl.usable ? nl.n16.p : nullptr,
+                    nl.usable ? nl.row_sum.p : nullptr);
+}
+
+extern "C" int hhx_expand_links(const hhx_csr *a, const hhx_csr *links, int fx_shift, double inflation, double pruning,
+                                hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
+    if (!a || !links || !out) return fail("null pointer");
+    NormalisedLinks nl;
+    HHX_TRY(normalise_links(links, &nl));
+    if (!nl.usable) return hhx_expand_inflate_prune(a, nl.norm, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
+    return hhx_expand_class_stream(a, nl.norm, nl.n16.p, nl.row_sum.p, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
 }
 
 // interpret_result(), array half.  The final matrix holds ~n entries, so this is a host pass over a

@@ -65,6 +65,13 @@ class HipEngine:
     def expand_inflate_prune(self, a, b, inflation, pruning):
         return _lib.expand_inflate_prune(a, b, inflation, pruning, fx_shift=52)
 
+    def expand_links(self, a, links, inflation, pruning):
+        """iteration 0: a = this rank's rows of the normalised link matrix, links = the whole RAW link matrix"""
+        return _lib.expand_links(a, links, inflation, pruning, fx_shift=52)
+
+    def row_products(self, a, b):
+        return _lib.row_products(a, b)
+
     def convergence_stat(self, m, last):
         return _lib.convergence_stat(m, last)
 
@@ -125,6 +132,46 @@ class HipEngine:
         key, of, ok, ht, fl = ptrs
         return [self.view(key, n, '<i8', t.int64), self.view(of, n, '<i8', t.int64), self.view(ok, n, '<i8', t.int64),
                 self.view(ht, 4 * n, '<i4', t.int32), self.view(fl, n, '<i4', t.int32)]
+
+
+# ------------------------------------------------------------------ transport without RCCL
+class HostStagedCollectives:
+    """The slice of the torch.distributed API this module uses, on a process group whose backend cannot move device
+    memory (gloo): every collective stages its tensors through host memory.  The data path — kernels, layouts, the
+    order and content of every exchange — is the RCCL one; only the wire differs.  Used to run the HIP engine under
+    several ranks that share ONE GPU (tests; a box without xGMI), where RCCL refuses duplicate devices."""
+
+    def __init__(self, dist, group=None):
+        self._d, self._g = dist, group
+        self.ReduceOp = dist.ReduceOp
+
+    def get_world_size(self):
+        return self._d.get_world_size(self._g)
+
+    def get_rank(self):
+        return self._d.get_rank(self._g)
+
+    def barrier(self):
+        self._d.barrier(self._g)
+
+    def all_gather_object(self, out, obj):
+        self._d.all_gather_object(out, obj, group=self._g)
+
+    def all_reduce(self, t, op=None):
+        h = t.cpu()
+        self._d.all_reduce(h, op=op if op is not None else self.ReduceOp.SUM, group=self._g)
+        t.copy_(h)
+
+    def all_gather_into_tensor(self, out, inp):
+        h = out.new_empty(out.shape, device='cpu')
+        self._d.all_gather_into_tensor(h, inp.cpu().contiguous(), group=self._g)
+        out.copy_(h)
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None):
+        h = out.new_empty(out.shape, device='cpu')
+        self._d.all_to_all_single(h, inp.cpu().contiguous(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes,
+                                  group=self._g)
+        out.copy_(h)
 
 
 # ------------------------------------------------------------------ collectives on variable-size blocks
@@ -194,6 +241,20 @@ def row_ranges(n, world):
     return bounds
 
 
+def balanced_ranges(cost, world):
+    """contiguous row blocks of (nearly) equal total cost: block k ends at the first row where the running cost reaches
+    (k + 1) / world of the total.  cost: int64 per row (products of the expansion, hhx_row_products)."""
+    c = np.cumsum(np.asarray(cost, np.int64))
+    total = int(c[-1]) if len(c) else 0
+    n = len(c)
+    bounds = [0]
+    for k in range(1, world):
+        cut = int(np.searchsorted(c, total * k / world, side='left')) + 1 if total else n * k // world
+        bounds.append(max(bounds[-1], min(n, cut)))
+    bounds.append(n)
+    return bounds
+
+
 def allgather_rows(engine, local, n_cols, dist):
     """all-gather(v) of row blocks -> the full matrix on every rank (rows in rank order)"""
     torch = engine.torch
@@ -209,23 +270,37 @@ def allgather_rows(engine, local, n_cols, dist):
     return engine.from_tensors(n_rows, n_cols, indptr, torch.cat(ix_all).contiguous(), torch.cat(dx_all).contiguous())
 
 
-def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, dist, local_block=None, n=None):
+def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, dist, local_block=None, n=None, local_links=None):
     """run_mcl_clustering's pre-expansion (:2146-2147) + mcl() (:2026-2062) with T sharded by row block.
-    full_norm: the L1-normalised link matrix, replicated — or None with local_block = this rank's rows
-    [row_ranges(n)[rank], ...) of it (build_link_matrix_sharded + normalize_l1): the right operand of iteration 0 is
-    then all-gathered once.  The pre-expansion is fused into iteration 0 (the expanded rows are consumed in LDS,
-    never materialised).  Returns (full result, n_iter, converged, stats)."""
+    Three ways in:  full_norm = the L1-normalised link matrix, replicated;  local_block = this rank's rows
+    [row_ranges(n)[rank], ...) of it (the right operand of iteration 0 is then all-gathered once);  local_links = this
+    rank's rows of the RAW link matrix as build_link_matrix_sharded leaves them: the raw blocks are all-gathered and
+    iteration 0 goes through the class stream (hhx_expand_links), the normalisation (:2144) being row-local.
+    The pre-expansion is fused into iteration 0 (the expanded rows are consumed in LDS, never materialised).
+    Returns (full result, n_iter, converged, stats)."""
     torch = engine.torch
     world, rank = dist.get_world_size(), dist.get_rank()
     own_full = False
-    if full_norm is None:
+    links_full = None
+    if local_links is not None:
+        links_full = allgather_rows(engine, local_links, n, dist)       # exchange: the raw link matrix, once
+        full_norm = links_full                                           # shape / nnz bookkeeping of iteration 0
+    elif full_norm is None:
         full_norm = allgather_rows(engine, local_block, n, dist)         # n: order of the matrix
         own_full = True
     n = engine.shape(full_norm)[0]
-    b = row_ranges(n, world)
-    r0, r1 = b[rank], b[rank + 1]
     stats = []
-    cur_local = engine.row_block(full_norm, r0, r1) if local_block is None else engine.copy(local_block)
+    if local_links is not None:
+        # Every rank holds the whole raw matrix now, so the MCL row blocks need not be the build's: they are cut at
+        # equal PRODUCT counts of iteration 0 (SURVEY §8e).  Equal row counts are not balanced: a contig's matrix
+        # index is its first-seen rank in the pair stream, and heavily linked contigs are seen first.
+        b = balanced_ranges(engine.row_products(links_full, links_full), world)
+        r0, r1 = b[rank], b[rank + 1]
+        cur_local = engine.normalize_l1(engine.row_block(links_full, r0, r1))
+    else:
+        b = row_ranges(n, world)
+        r0, r1 = b[rank], b[rank + 1]
+        cur_local = engine.row_block(full_norm, r0, r1) if local_block is None else engine.copy(local_block)
     cur_full = full_norm                              # all rows: right operand of the expansion
     converged = False
     n_iter = 0
@@ -234,13 +309,18 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
         st_f = 0
         run = cur_local
         for _ in range(2, expansion):                 # T^(e-1) rows, :2017-2023
+            if links_full is not None:
+                raise NotImplementedError('expansion > 2 from raw link blocks: normalise and pass local_block')
             nxt, f = engine.spgemm(run, cur_full)
             st_f += f
             if run is not cur_local:
                 engine.free(run)
             run = nxt
         if expansion > 1:
-            p, f, st_c = engine.expand_inflate_prune(run, cur_full, inflation, pruning)   # :2030-2042 fused
+            if links_full is not None:
+                p, f, st_c = engine.expand_links(run, links_full, inflation, pruning)          # iteration 0, class stream
+            else:
+                p, f, st_c = engine.expand_inflate_prune(run, cur_full, inflation, pruning)   # :2030-2042 fused
             st_f += f
         else:
             c = engine.copy(run)
@@ -260,22 +340,28 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
         full = allgather_rows(engine, p, n, dist)            # the per-iteration all-gather(v)
         stats.append([st_a, int(red[1].item()), int(red[2].item()), int(red[3].item())])
         engine.free(cur_local)
-        if own_full:
+        if links_full is not None:
+            engine.free(links_full)
+            links_full = None
+        elif own_full:
             engine.free(cur_full)
         cur_local, cur_full, own_full = p, full, True
         if it > 1 and np.float32(mx.item()) <= np.float32(1e-8):
             converged = True
             break
     engine.free(cur_local)
-    if not own_full:
+    if links_full is not None:                         # iters == 0
+        engine.free(links_full)
+        cur_full = engine.normalize_l1(allgather_rows(engine, local_links, n, dist))
+    elif not own_full:
         cur_full = engine.copy(cur_full)
     return cur_full, n_iter, converged, np.asarray(stats, np.int64)
 
 
 # ------------------------------------------------------------------ product entry points (HIP engine)
-def mcl_sharded(full_norm, expansion, inflation, iters, pruning, dist, device, local_block=None, n=None):
+def mcl_sharded(full_norm, expansion, inflation, iters, pruning, dist, device, local_block=None, n=None, local_links=None):
     eng = HipEngine(device)
-    return mcl_sharded_engine(eng, full_norm, expansion, inflation, iters, pruning, dist, local_block=local_block, n=n)
+    return mcl_sharded_engine(eng, full_norm, expansion, inflation, iters, pruning, dist, local_block=local_block, n=n, local_links=local_links)
 
 
 def gather_tables(engine, tensors, dist):

@@ -131,10 +131,20 @@ int hhx_mcl_normalized(const hhx_csr *normalized, int expansion, double inflatio
 /* run_mcl_clustering :2144-2158 for one inflation straight from the RAW link matrix that dict_to_matrix
  * returns (:362-368): the L1 normalisation (:2144), the pre-expansion (:2146-2147, fused into iteration 0) and
  * mcl().  Same results as hhx_normalize_l1 + hhx_mcl_normalized; when the matrix holds integer link counts
- * <= 65535 and HHX_CODED=1 is set, iteration 0 streams its right operand as 16-bit counts (4 B per product,
- * bit-identical; off by default because it is ALU-bound on MI355X while the 6-byte stream is HBM-bound). */
+ * <= 65535 (always, unless --normalize_by_nlinks / GFA weights were applied) iteration 0 streams its right operand
+ * as the CLASS STREAM: the count-1 entries of every (row, column window) segment — 75 % of a Hi-C link matrix —
+ * share the value float(1 / rowsum) and go as 16-bit columns alone, 2 B per product instead of 6; bit-identical. */
 int hhx_mcl_links(const hhx_csr *links, int expansion, double inflation, int max_iter, double pruning,
                   hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
+/* Iteration 0 of the above for ONE ROW BLOCK (multi-GPU shard): a = rows [r0, r1) of the L1-normalised
+ * link matrix (hhx_normalize_l1 on the rank's block of the raw matrix: row-local), links = the WHOLE raw link matrix
+ * (all-gathered).  out = prune(normalize(power(a * normalize(links), inflation))) — hhx_expand_inflate_prune(a,
+ * normalize(links)) bit for bit, through the class stream when the counts allow it. */
+/* products_host[i] = sum over the entries (i, k) of a of nnz(row k of b): the cost of row i of a * b.  The multi-GPU driver
+ * cuts the row blocks of the expansion at equal product counts with it (SURVEY §8e "row-block ... by balanced nnz"). */
+int hhx_row_products(const hhx_csr *a, const hhx_csr *b, int64_t *products_host);
+int hhx_expand_links(const hhx_csr *a, const hhx_csr *links, int fx_shift, double inflation, double pruning,
+                     hhx_csr **out, int64_t *n_products, int64_t *nnz_expanded);
 
 /* ---------------------------------------------------------------- a12: interpret_result :2065-2095
  * Array half: attractors (ascending) = rows with a non-zero diagonal; members of attractor a =

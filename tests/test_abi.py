@@ -39,3 +39,16 @@ def test_no_oracle_in_product():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 src = open(os.path.join(dirpath, f), errors='replace').read()
                 assert not re.search(r'^\s*(from|import)\s+oracle|hhx_oracle|\borc_', src, flags=re.M), (dirpath, f)
+
+
+def test_new_bindings_marshal_and_reject_null_handles():
+    """argument marshalling of the round-2 entry points (a ctypes ArgumentError only shows at call time); a null
+    handle must come back as an error code, not a crash"""
+    import numpy as np
+    from haphic_amd import _lib
+    L = _lib.load()
+    out = np.zeros(4, np.int64)
+    assert L.hhx_row_products(None, None, _lib.ptr(out)) != 0 and b'null' in L.hhx_last_error()
+    o, f, z = _lib.C.c_void_p(), _lib.C.c_int64(0), _lib.C.c_int64(0)
+    assert L.hhx_expand_links(None, None, 52, 2.0, 1e-4, _lib.C.byref(o), _lib.C.byref(f), _lib.C.byref(z)) != 0
+    assert L.hhx_tune(b'cls', 1) == 0

@@ -44,6 +44,12 @@ class OracleEngine:
         c, f = self.spgemm(a, b)
         return self.inflate_prune(c, inflation, pruning), f, int(c[0][-1])
 
+    def row_products(self, a, b):
+        return np.add.reduceat(np.concatenate([np.diff(b[0])[a[1]].astype(np.int64), [0]]), np.minimum(a[0][:-1], len(a[1]))) * (np.diff(a[0]) > 0)
+
+    def expand_links(self, a, links, inflation, pruning):
+        return self.expand_inflate_prune(a, self.normalize_l1(links), inflation, pruning)
+
     def convergence_stat(self, m, last):
         return orc.convergence_stat(m, last)
 
@@ -160,6 +166,9 @@ def _worker(rank, world, port, q):
         block, fi, n_linked, shape = sharded.build_link_matrix_sharded(eng, src, in_set, dist)
         norm = eng.normalize_l1(block)
         res2, n_iter2, conv2, _st2 = sharded.mcl_sharded_engine(eng, None, 2, 2.0, 100, 1e-4, dist, local_block=norm, n=shape)
+        # the same from the RAW row blocks (all-gathered once, iteration 0 through expand_links): identical results
+        res3, n_iter3, conv3, _st3 = sharded.mcl_sharded_engine(eng, None, 2, 2.0, 100, 1e-4, dist, local_links=block, n=shape)
+        assert (n_iter3, conv3) == (n_iter2, conv2) and all(np.array_equal(x, y) for x, y in zip(res3, res2))
         built = (block, fi, n_linked, shape, res2, n_iter2, conv2)
         sweep = sharded.inflation_sweep(lambda infl: (round(infl * 10), rank), [1.2, 1.4, 1.6, 1.8, 2.0], dist)
         q.put((rank, res, n_iter, conv, stats, merged, sweep, built))
@@ -300,3 +309,11 @@ def test_sharded_mcl_and_merge(world):
 def test_row_ranges():
     assert sharded.row_ranges(10, 3) == [0, 4, 7, 10]
     assert sharded.row_ranges(2, 4) == [0, 1, 2, 2, 2]
+    assert sharded.balanced_ranges([5, 1, 1, 1, 1, 1], 2) == [0, 1, 6]
+    assert sharded.balanced_ranges([1, 1, 1, 1, 1, 5], 2) == [0, 5, 6]
+    assert sharded.balanced_ranges([0, 0, 0], 2) == [0, 1, 3] and sharded.balanced_ranges([], 3) == [0, 0, 0, 0]
+    b = sharded.balanced_ranges(np.arange(1000), 4)
+    c = np.cumsum(np.arange(1000))
+    assert b[0] == 0 and b[-1] == 1000 and all(x <= y for x, y in zip(b, b[1:]))
+    per = [int(np.arange(1000)[b[k]:b[k + 1]].sum()) for k in range(4)]
+    assert max(per) - min(per) <= 2 * 999

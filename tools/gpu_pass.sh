@@ -35,6 +35,9 @@ for l in open('gpurun_out/bench_text.log'):
         python tools/pmc_calib_summary.py gpurun_out | tee gpurun_out/calib_summary.txt;;
     sbench) timeout 600 ./tools/stream_bench > gpurun_out/stream_bench.log 2>&1; echo "sbench rc=$?"; cat gpurun_out/stream_bench.log;;
     ldsbench) timeout 600 ./tools/lds_atomic_bench > gpurun_out/lds_atomic_bench.log 2>&1; echo "ldsbench rc=$?"; cat gpurun_out/lds_atomic_bench.log;;
+    scale) timeout 1500 python -m pytest tests/test_gpu_scale.py -m gpu -x -q --durations=5 > gpurun_out/pytest_scale.log 2>&1; echo "scale rc=$?"; tail -12 gpurun_out/pytest_scale.log;;
+    flips) timeout 1200 python tools/flip_count.py > gpurun_out/flip_count_c2.json 2> gpurun_out/flip_count.err; echo "flips rc=$?"; cut -c1-1500 gpurun_out/flip_count_c2.json; tail -3 gpurun_out/flip_count.err;;
+    multirank) timeout 1500 python -m pytest tests/test_gpu_multirank.py -m gpu -x -q --durations=3 > gpurun_out/pytest_multirank.log 2>&1; echo "multirank rc=$?"; tail -15 gpurun_out/pytest_multirank.log;;
     listpmc) rocprofv3 -L > gpurun_out/pmc_list.txt 2>&1; grep -c . gpurun_out/pmc_list.txt;;
     env:*) export "${what#env:}"; echo "set ${what#env:}";;
     *) echo "unknown $what";;
