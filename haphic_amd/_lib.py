@@ -57,6 +57,8 @@ SIGNATURES = {
     'hhx_spgemm': (C.c_int, [C.c_void_p, C.c_void_p, c_vpp]),
     'hhx_spgemm_ex': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_vpp, c_i64p]),
     'hhx_expand_inflate_prune': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, c_vpp, c_i64p, c_i64p]),
+    'hhx_link_weights': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_double, c_i64p]),
     'hhx_row_products': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'hhx_expand_links': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, c_vpp, c_i64p, c_i64p]),
     'hhx_convergence_stat': (C.c_int, [C.c_void_p, C.c_void_p, c_f32p]),
@@ -328,6 +330,24 @@ def expand_inflate_prune(a, b, inflation, pruning, fx_shift=52):
     check(load().hhx_expand_inflate_prune(a.h, b.h, int(fx_shift), float(inflation), float(pruning), C.byref(out),
                                           C.byref(f), C.byref(z)))
     return DeviceCSR(out), f.value, z.value
+
+
+def link_weights(frag_i, frag_j, value, mode, n_frag, per_frag=None, tag=None, param=0.0, device_ptrs=None):
+    """hhx_link_weights on host arrays (value: float64, rewritten in place) or, with device_ptrs = (i, j, value) device
+    addresses of n = len(...) keys, on the device arrays of hhx_ingest_flank_device.  Returns the number of zeroed entries."""
+    nz = C.c_int64(0)
+    per = None if per_frag is None else np.ascontiguousarray(per_frag, np.int64)
+    tg = None if tag is None else np.ascontiguousarray(tag, np.int32)
+    if device_ptrs is not None:
+        n, pi, pj, pv = device_ptrs
+        check(load().hhx_link_weights(int(n), C.c_void_p(pi), C.c_void_p(pj), C.c_void_p(pv), 1, int(mode), int(n_frag), ptr(per), ptr(tg),
+                                      float(param), C.byref(nz)))
+        return nz.value
+    assert value.dtype == np.float64 and value.flags.c_contiguous
+    fi, fj = np.ascontiguousarray(frag_i, np.int32), np.ascontiguousarray(frag_j, np.int32)
+    check(load().hhx_link_weights(len(value), ptr(fi), ptr(fj), ptr(value), 0, int(mode), int(n_frag), ptr(per), ptr(tg), float(param),
+                                  C.byref(nz)))
+    return nz.value
 
 
 def row_products(a, b):

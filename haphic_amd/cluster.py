@@ -84,17 +84,16 @@ class FragTable:
 
 # ------------------------------------------------------------------ a5: restriction sites, fragment statistics
 def parse_RE_sites(sites):
-    """parse_RE_sites() :56-72 — expands every N into A/T/C/G"""
-    output_sites = []
+    """parse_RE_sites() :56-72 — every N of a site stands for A / T / C / G.  The reference expands the first N of each
+    site, then re-scans the whole list; the resulting ORDER (it decides nothing downstream: the counts are summed) is
+    reproduced by expanding the wildcards left to right with the leftmost one varying slowest, in A, T, C, G order."""
+    from itertools import product
+    expanded = []
     for site in sites:
-        if 'N' in site:
-            for base in 'ATCG':
-                output_sites.append(site.replace('N', base, 1))
-        else:
-            output_sites.append(site)
-    if 'N' not in ''.join(output_sites):
-        return output_sites
-    return parse_RE_sites(output_sites)
+        parts = site.split('N')
+        for letters in product('ATCG', repeat=len(parts) - 1):
+            expanded.append(''.join(p + l for p, l in zip(parts, letters + ('',))))
+    return expanded
 
 
 def _sites_of(RE):
@@ -131,116 +130,120 @@ def parse_fasta(fasta, RE='GATC', keep_letter_case=False, logger=logger):
     return fa_dict
 
 
-def stat_fragments(fa_dict, RE, read_depth_dict, whitelist, nchrs=0, flank=0, Nx=100, bin_size=0, logger=logger):
-    """stat_fragments() :188-296.  The bin table, the seeded shuffle (:273) and the Nx set are the reference's
-    own Python; every RE-site count (:192-199 flank-only counting, :245-256 bins) comes from ONE device call."""
-    import random
+def _resolve_bin_size(bin_size, total_len, nchrs, logger):
+    """--bin_size semantics (:208-220): 0 = never split, negative = derive from the genome, positive = kbp"""
     from math import inf
-    logger.info('Making some statistics of fragments (contigs / bins)')
-    flank *= 1000
-    total_len = sum([ctg_info[1] for ctg_info in fa_dict.values()])
     if not bin_size:
         logger.info('bin_size is set to {}, no fragments will be split'.format(bin_size))
-        bin_size = inf
-    elif bin_size < 0:
-        bin_size = max(min(int(total_len / nchrs / 30), 2000000), 100000)
-        logger.info('bin_size is calculated to be {} bp'.format(bin_size))
-    else:
-        bin_size *= 1000
-        logger.info('bin_size is manually designated to {} bp'.format(bin_size))
-    frags = list()
-    bin_set = set()
-    split_ctg_set = set()
-    RE_site_dict, frag_len_dict = dict(), dict()
-    # segments to count: (fragment, offset in the genome buffer, length); a fragment may own two (flanks)
-    pieces, seg_frag, seg_off, seg_len = [], [], [], []
-    cursor = 0
+        return inf
+    if bin_size < 0:
+        derived = max(min(int(total_len / nchrs / 30), 2000000), 100000)
+        logger.info('bin_size is calculated to be {} bp'.format(derived))
+        return derived
+    logger.info('bin_size is manually designated to {} bp'.format(bin_size * 1000))
+    return bin_size * 1000
 
-    def want(frag, start, length):
-        # count_flank_RE_sites :190-199 on the slice [start, start + length) of the current contig
-        if not flank or length <= 2 * flank:
-            seg_frag.append(frag); seg_off.append(cursor + start); seg_len.append(length)
-        else:
-            seg_frag.append(frag); seg_off.append(cursor + start); seg_len.append(flank)
-            seg_frag.append(frag); seg_off.append(cursor + start + length - flank); seg_len.append(flank)
 
-    for ctg, (seq, ctg_len, RE_sites) in fa_dict.items():
-        need_seq = False
-        if ctg_len > bin_size:
+class _ReCountBatch:
+    """RE-site counts of many slices of the genome in ONE device pass (hhx_count_re_sites): callers register slices of
+    the contig whose sequence was appended last, `resolve` returns count + 1 (the reference's pseudo-count) per key."""
+
+    def __init__(self, flank):
+        self.flank, self.pieces, self.cursor = flank, [], 0
+        self.keys, self.off, self.len = [], [], []
+
+    def add_sequence(self, seq):
+        self.base = self.cursor
+        self.pieces.append(seq)
+        self.cursor += len(seq)
+
+    def want(self, key, start, length):
+        """whole slice, or only its two flanks when it is longer than both together (:192-199)"""
+        f = self.flank
+        spans = [(start, length)] if (not f or length <= 2 * f) else [(start, f), (start + length - f, f)]
+        for o, n in spans:
+            self.keys.append(key); self.off.append(self.base + o); self.len.append(n)
+
+    def resolve(self, RE):
+        totals = {}
+        if self.keys:
+            counts = _lib.count_re_sites(''.join(self.pieces).encode(), self.off, self.len, _sites_of(RE))
+            for key, c in zip(self.keys, counts.tolist()):
+                totals[key] = totals.get(key, 1) + c
+        return totals
+
+
+def stat_fragments(fa_dict, RE, read_depth_dict, whitelist, nchrs=0, flank=0, Nx=100, bin_size=0, logger=logger):
+    """stat_fragments() :188-296 with every RE-site count of the bins / flanks coming from one device call.  Same seven
+    return values, same side effects on fa_dict (sequences dropped) and read_depth_dict (bins inherit their contig's
+    entry), same seeded shuffle before the length sort that defines the Nx set."""
+    import random
+    logger.info('Making some statistics of fragments (contigs / bins)')
+    total_len = sum(info[1] for info in fa_dict.values())
+    bin_size = _resolve_bin_size(bin_size, total_len, nchrs, logger)
+    batch = _ReCountBatch(flank * 1000)
+    frag_len_dict, known_sites = {}, {}
+    bin_set, split_ctg_set = set(), set()
+    for ctg, info in fa_dict.items():
+        seq, ctg_len, whole_contig_sites = info
+        if ctg_len > bin_size:                                       # :230 — the contig becomes ceil(len / bin_size) bins
             split_ctg_set.add(ctg)
-            nbins = ceil(ctg_len / bin_size)
-            for m in range(nbins):
-                bin_ = '{}_bin{}'.format(ctg, m + 1)
-                assert bin_ not in fa_dict
-                frags.append(bin_)
-                bin_set.add(bin_)
-                bin_len = bin_size if m + 1 < nbins else ctg_len - m * bin_size
-                want(bin_, m * bin_size, bin_len)
-                need_seq = True
-                frag_len_dict[bin_] = bin_len
+            batch.add_sequence(seq)
+            starts = range(0, ctg_len, bin_size)
+            for m, start in enumerate(starts, 1):
+                name = '{}_bin{}'.format(ctg, m)
+                assert name not in fa_dict
+                bin_set.add(name)
+                frag_len_dict[name] = min(bin_size, ctg_len - start)
+                batch.want(name, start, frag_len_dict[name])
                 if read_depth_dict:
-                    read_depth_dict[bin_] = read_depth_dict[ctg]
+                    read_depth_dict[name] = read_depth_dict[ctg]
             if read_depth_dict:
                 del read_depth_dict[ctg]
         else:
-            frags.append(ctg)
             frag_len_dict[ctg] = ctg_len
-            if not flank or ctg_len <= 2 * flank:
-                RE_site_dict[ctg] = RE_sites
+            if not batch.flank or ctg_len <= 2 * batch.flank:
+                known_sites[ctg] = whole_contig_sites                # parse_fasta already counted the whole contig
             else:
-                want(ctg, 0, ctg_len)
-                need_seq = True
-        if need_seq:
-            pieces.append(seq)
-            cursor += ctg_len
-        fa_dict[ctg][0] = None                                   # :266 the sequences are not needed any more
-    if seg_frag:
-        counts = _lib.count_re_sites(''.join(pieces).encode(), seg_off, seg_len, _sites_of(RE))
-        for frag, c in zip(seg_frag, counts.tolist()):
-            RE_site_dict[frag] = RE_site_dict.get(frag, 1) + c     # + 1 pseudo-count once per fragment (:193 :199)
-    # bins were appended to RE_site_dict after the unsplit contigs: restore the reference's insertion order
-    RE_site_dict = {frag: RE_site_dict[frag] for frag in frags}
+                batch.add_sequence(seq)
+                batch.want(ctg, 0, ctg_len)
+        info[0] = None                                               # :266
+    known_sites.update(batch.resolve(RE))
+    RE_site_dict = {frag: known_sites[frag] for frag in frag_len_dict}
+    # Nx set (:268-288): seeded shuffle, stable sort by length, keep while the running share is below Nx, plus one
+    order = list(frag_len_dict)
     random.seed(12345)
-    random.shuffle(frags)
-    sorted_frag_list = sorted([(frag, frag_len_dict[frag]) for frag in frags], key=lambda x: x[1], reverse=True)
-    len_sum = 0
-    Nx_frag_set = set()
-    for frag, frag_len in sorted_frag_list:
-        len_sum += frag_len
-        if len_sum / total_len * 100 < Nx or Nx == 100:
+    random.shuffle(order)
+    sorted_frag_list = sorted(((frag, frag_len_dict[frag]) for frag in order), key=lambda item: item[1], reverse=True)
+    Nx_frag_set, running = set(), 0
+    for frag, length in sorted_frag_list:
+        running += length
+        if Nx == 100 or running / total_len * 100 < Nx:
             Nx_frag_set.add(frag)
     if Nx != 100:
         Nx_frag_set.add(sorted_frag_list[len(Nx_frag_set)][0])
     if whitelist:
-        for frag, _ in sorted_frag_list:
-            if frag.rsplit('_bin', 1)[0] in whitelist:
-                Nx_frag_set.add(frag)
+        Nx_frag_set.update(frag for frag, _ in sorted_frag_list if frag.rsplit('_bin', 1)[0] in whitelist)
     return sorted_frag_list, bin_set, bin_size, frag_len_dict, Nx_frag_set, RE_site_dict, split_ctg_set
 
 
 # ------------------------------------------------------------------ f1: filter_fragments
 def check_param(param, string, suffix, true_suffix=''):
-    """check_param() :2481-2507 — "0.2" (fraction) or "0.2X" (multiple) style parameters"""
-    if len(string) > 1:
-        if suffix and string[-1] in suffix:
-            return check_param(param, string[:-1], None, string[-1])
-        try:
-            num = float(string)
-            if true_suffix or 0 <= num <= 1:
-                return num, true_suffix
-        except ValueError:
-            pass
-        logger.error('Parameter {} {} is illegal'.format(param, string + true_suffix))
-    elif len(string) == 1:
-        try:
-            num = float(string)
-            if true_suffix or 0 <= num <= 1:
-                return num, true_suffix
-        except ValueError:
-            pass
-        logger.error('Parameter {} {} is illegal'.format(param, string + true_suffix))
-    else:
+    """check_param() :2481-2507 — "0.2" (a fraction, must lie in [0, 1]) or "1.5X" (a multiple: any number followed by
+    one of the `suffix` characters).  Returns (number, suffix character or ''); logs and raises like the reference."""
+    if not string:
         logger.error('Parameter {} is empty'.format(param))
+        raise RuntimeError('Parameter check failed')
+    text, mode = string, true_suffix
+    if suffix and len(text) > 1 and text[-1] in suffix:
+        text, mode = text[:-1], text[-1]
+    try:
+        number = float(text)
+    except ValueError:
+        number = None
+    if number is not None and (mode or 0 <= number <= 1):
+        return number, mode
+    logger.error('Parameter {} {} is illegal'.format(param, string + true_suffix))
     raise RuntimeError('Parameter check failed')
 
 
@@ -320,6 +323,59 @@ def filter_fragments(Nx_frag_set, RE_site_dict, RE_site_cutoff, frag_link_dict, 
         filtered_frags |= whitelisted
         logger.info('[rank sum filtering] {} fragments are used to perform Markov clustering'.format(len(filtered_frags)))
     return filtered_frags
+
+
+# ------------------------------------------------------------------ a6: link weights (in-place dict rewrites)
+def _dict_arrays(link_dict, names):
+    """(frag_i, frag_j, value) arrays of a link dict in dict order; names: fragment -> id, extended on the fly"""
+    fi = np.empty(len(link_dict), np.int32)
+    fj = np.empty(len(link_dict), np.int32)
+    val = np.empty(len(link_dict), np.float64)
+    for k, ((a, b), v) in enumerate(link_dict.items()):
+        fi[k] = names.setdefault(a, len(names))
+        fj[k] = names.setdefault(b, len(names))
+        val[k] = v
+    return fi, fj, val
+
+
+def normalize_by_nlinks(flank_link_dict, frag_link_dict):
+    """normalize_by_nlinks() :718-724 — every value divided by the geometric mean of its fragments' link totals"""
+    logger.info('Normalizing flank_link_dict by the number of links to other contigs...')
+    names = {}
+    fi, fj, val = _dict_arrays(flank_link_dict, names)
+    totals = np.fromiter((frag_link_dict[f] for f in names), np.int64, len(names))
+    _lib.link_weights(fi, fj, val, 0, len(names), per_frag=totals)
+    for key, v in zip(flank_link_dict, val.tolist()):
+        flank_link_dict[key] = v
+
+
+def normalize_by_length(flank_link_dict, frag_len_dict, flank):
+    """normalize_by_length() :727-738 (the reference never calls it; here for completeness)"""
+    logger.info('Normalizing flank_link_dict by length...')
+    names = {}
+    fi, fj, val = _dict_arrays(flank_link_dict, names)
+    lengths = np.fromiter((frag_len_dict[f] for f in names), np.int64, len(names))
+    _lib.link_weights(fi, fj, val, 1, len(names), per_frag=lengths, param=flank * 2000)
+    for key, v in zip(flank_link_dict, val.tolist()):
+        flank_link_dict[key] = v
+
+
+def reduce_inter_hap_HiC_links(link_dict, read_depth_dict, phasing_weight, target='flank_link_dict'):
+    """reduce_inter_hap_HiC_links() :695-707 — links between fragments of different haplotype tags lose phasing_weight
+    of their value; entries that reach zero leave the dict"""
+    logger.info('Reducing inter-haplotype Hi-C links in {}...'.format(target))
+    names = {}
+    fi, fj, val = _dict_arrays(link_dict, names)
+    tags = {}
+    tag = np.fromiter((tags.setdefault(read_depth_dict[f][0], len(tags)) for f in names), np.int32, len(names))
+    n_zero = _lib.link_weights(fi, fj, val, 2, len(names), tag=tag, param=phasing_weight)
+    changed = np.flatnonzero(tag[fi] != tag[fj])
+    keys = list(link_dict)
+    for k in changed.tolist():                            # untouched entries keep their Python type (int counts stay int)
+        link_dict[keys[k]] = float(val[k])
+    if n_zero:
+        for k in np.flatnonzero((val == 0) & (tag[fi] != tag[fj])).tolist():
+            del link_dict[keys[k]]
 
 
 # ------------------------------------------------------------------ S1 / S3: matrix-level seams
@@ -671,30 +727,29 @@ def ingest_links(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False
         ing.destroy()
 
 
+def _modal_share(values):
+    """count of the most frequent value / number of values (scipy.stats.mode(...)[1] / n)"""
+    return np.unique(values, return_counts=True)[1].max() / len(values)
+
+
 def cal_concordance_ratio(coord_list, shorter_len, nwindows):
-    """cal_concordance_ratio() :419-428 (host statistics on <= max_read_pairs coordinates, stays Python)"""
-    from scipy.stats import mode
-    bin_width = shorter_len // nwindows
-    npairs = len(coord_list) // 2
-    y_minus_x_list = [(coord_list[2 * n + 1] - coord_list[2 * n]) // bin_width for n in range(npairs)]
-    y_plus_x_list = [(coord_list[2 * n + 1] + coord_list[2 * n]) // bin_width for n in range(npairs)]
-    return max(mode(y_minus_x_list, keepdims=False)[1] / npairs, mode(y_plus_x_list, keepdims=False)[1] / npairs)
+    """cal_concordance_ratio() :419-428 — the share of read pairs on the best-populated diagonal (y - x) or
+    anti-diagonal (y + x) of the contig pair, in windows of shorter_len // nwindows bp"""
+    xy = np.asarray(coord_list).reshape(-1, 2)
+    width = shorter_len // nwindows
+    return max(_modal_share((xy[:, 1] - xy[:, 0]) // width), _modal_share((xy[:, 1] + xy[:, 0]) // width))
 
 
 def cal_concentration_adj_ratio(coord_list, bin_width=10000):
-    """cal_concentration_adj_ratio() :431-451"""
-    from numpy import median
-    npairs = len(coord_list) // 2
-    x_bin_dict, y_bin_dict = defaultdict(int), defaultdict(int)
-    for n in range(npairs):
-        x_bin_dict[coord_list[2 * n] // bin_width] += 1
-        y_bin_dict[coord_list[2 * n + 1] // bin_width] += 1
-    x_bin_list, y_bin_list = x_bin_dict.values(), y_bin_dict.values()
-    x_bin_median = median([links for links in x_bin_list if links])
-    y_bin_median = median([links for links in y_bin_list if links])
-    concentration_ratio_x = sum([links for links in x_bin_list if links >= 10 * x_bin_median]) / npairs
-    concentration_ratio_y = sum([links for links in y_bin_list if links >= 10 * y_bin_median]) / npairs
-    return (1 - concentration_ratio_x) * (1 - concentration_ratio_y)
+    """cal_concentration_adj_ratio() :431-451 — per axis, the share of read pairs that sit in bins holding at least ten
+    times the median bin; returns (1 - share_x) * (1 - share_y)"""
+    xy = np.asarray(coord_list).reshape(-1, 2)
+    keep = 1.0
+    for axis in (0, 1):
+        per_bin = np.unique(xy[:, axis] // bin_width, return_counts=True)[1]
+        crowded = per_bin[per_bin >= 10 * np.median(per_bin)]
+        keep *= 1 - int(crowded.sum()) / len(xy)
+    return keep
 
 
 def _link_dicts(out, table):

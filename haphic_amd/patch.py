@@ -20,6 +20,9 @@ SEAMS = {
     'parse_fasta': ('HapHiC_cluster.py:87-113', cluster.parse_fasta),                   # a5
     'stat_fragments': ('HapHiC_cluster.py:188-296', cluster.stat_fragments),            # a5
     'filter_fragments': ('HapHiC_cluster.py:741-940', cluster.filter_fragments),        # f1 (rank sums on the device)
+    'normalize_by_nlinks': ('HapHiC_cluster.py:718-724', cluster.normalize_by_nlinks),  # a6
+    'normalize_by_length': ('HapHiC_cluster.py:727-738', cluster.normalize_by_length),  # a6 (dead code in the reference)
+    'reduce_inter_hap_HiC_links': ('HapHiC_cluster.py:695-707', cluster.reduce_inter_hap_HiC_links),   # a6 (GFA phasing)
 }
 # S4/S5: dict_to_matrix is also called in dense mode by the filters (:603) — the mirror returns `.toarray()` then;
 # the device ingest returns all of the reference's containers (link tables, HT counts, CLM distance lists, first

@@ -162,6 +162,19 @@ int hhx_dict_to_matrix(int64_t n_keys, const int32_t *frag_i, const int32_t *fra
                        int on_device, int32_t n_frag, const uint8_t *in_set_host, int32_t n_rest,
                        int add_self_loops, int32_t *frag_index_host, int32_t *n_linked, hhx_csr **out);
 
+/* ---------------------------------------------------------------- a6: link weights on the flank table
+ * The in-place dict rewrites between the ingest and dict_to_matrix, on the (frag_i, frag_j, value) arrays in dict order
+ * (host arrays, or the device arrays of hhx_ingest_flank_device with on_device = 1: the weights then never leave HBM
+ * on their way into hhx_dict_to_matrix).  value is float64 as in the reference (cast to float32 at :368).
+ *   mode 0  normalize_by_nlinks :718-724: value /= (links[i] * links[j]) ** 0.5; per_frag_host = frag_link_dict totals [n_frag]
+ *   mode 1  normalize_by_length :727-738 (dead code in the reference): value /= (fl_i / 1e6) * (fl_j / 1e6),
+ *           fl = min(length, param), param = 2 * flank in bp; per_frag_host = fragment lengths [n_frag]
+ *   mode 2  reduce_inter_hap_HiC_links :695-707: value -= value * param (param = phasing_weight) where tag_host[i] != tag_host[j]
+ *           (the haplotype tag read_depth_dict[frag][0] mapped to integers); *n_zero = number of entries that reached 0 —
+ *           the reference deletes those from the dict, the caller compacts them out. */
+int hhx_link_weights(int64_t n_keys, const int32_t *frag_i, const int32_t *frag_j, double *value, int on_device, int mode,
+                     int32_t n_frag, const int64_t *per_frag_host, const int32_t *tag_host, double param, int64_t *n_zero);
+
 /* ---------------------------------------------------------------- a5: restriction-site counts
  * count_RE_sites :75-84 for many segments of one sequence buffer (host bytes, letter case as the caller's
  * parse_fasta :87-113 leaves it): counts[s] = sum over sites of seq[off[s] : off[s]+len[s]].count(site),

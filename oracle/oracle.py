@@ -332,3 +332,24 @@ def rank_sums(A, topN):
     out = np.zeros(max(n, 1), np.int64)
     lib().orc_rank_sums(n, ap, aj if aj.size else np.zeros(1, np.int32), ax if ax.size else np.zeros(1, np.float32), int(topN), out)
     return out[:n]
+
+
+# ---------------------------------------------------------------- a6: link weights (numpy restatement)
+def link_weights(fi, fj, value, mode, per_frag=None, tag=None, param=0.0):
+    """normalize_by_nlinks :718-724 (mode 0), normalize_by_length :727-738 (mode 1), reduce_inter_hap_HiC_links
+    :695-707 (mode 2) on arrays in dict order.  Python float arithmetic == IEEE double; `** 0.5` is C pow().
+    Returns the new float64 values (mode 2: zeros mark the entries the reference deletes)."""
+    v = np.array(value, np.float64, copy=True)
+    fi, fj = np.asarray(fi), np.asarray(fj)
+    if mode == 0:
+        prod = (np.asarray(per_frag, np.int64)[fi] * np.asarray(per_frag, np.int64)[fj]).astype(np.float64)
+        return v / np.array([float(x) ** 0.5 for x in prod.tolist()])
+    if mode == 1:
+        L = np.asarray(per_frag, np.int64)
+        fa = np.minimum(L[fi], param).astype(np.float64)
+        fb = np.minimum(L[fj], param).astype(np.float64)
+        return v / ((fa / 1000000) * (fb / 1000000))
+    t = np.asarray(tag)
+    diff = t[fi] != t[fj]
+    v[diff] = v[diff] - v[diff] * param
+    return v

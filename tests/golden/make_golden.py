@@ -622,8 +622,64 @@ def gen_pairs_text(path):
     np.savez_compressed(path, **out)
 
 
+def gen_weights(path):
+    """a6: the reference's in-place dict rewrites normalize_by_nlinks :718-724, normalize_by_length :727-738 (dead code),
+    reduce_inter_hap_HiC_links :695-707 on a synthetic flank_link_dict; inputs as arrays in dict order, outputs as
+    float64 values in the order of the surviving keys (+ which keys survived)."""
+    from collections import defaultdict
+    rng = np.random.default_rng(61)
+    n_frag, n_keys = 400, 6000
+    names = ['ctg%04d' % k for k in range(n_frag)]
+    a = rng.integers(0, n_frag, 3 * n_keys)
+    b = rng.integers(0, n_frag, 3 * n_keys)
+    ok = a < b
+    key = np.unique(a[ok].astype(np.int64) * n_frag + b[ok])
+    key = key[rng.permutation(len(key))][:n_keys]
+    fi, fj = (key // n_frag).astype(np.int32), (key % n_frag).astype(np.int32)
+    cnt = np.where(rng.random(len(key)) < 0.7, rng.integers(1, 4, len(key)), rng.integers(4, 3000, len(key))).astype(np.int64)
+    links = np.zeros(n_frag, np.int64)
+    np.add.at(links, fi, cnt)
+    np.add.at(links, fj, cnt)
+    links += rng.integers(0, 50, n_frag)                       # totals also count links to fragments outside the dict
+    links = np.maximum(links, 1)
+    length = rng.integers(5_000, 3_000_000, n_frag).astype(np.int64)
+    hap = rng.integers(0, 3, n_frag).astype(np.int32)          # 'h0', 'h1', 'h2'
+    out = dict(fi=fi, fj=fj, cnt=cnt, links=links, length=length, hap=hap, flank_kb=np.int64(500))
+
+    def as_dict():
+        d = defaultdict(int)
+        for i, j, c in zip(fi.tolist(), fj.tolist(), cnt.tolist()):
+            d[(names[i], names[j])] = c
+        return d
+    d = as_dict()
+    H.normalize_by_nlinks(d, {names[k]: int(links[k]) for k in range(n_frag)})
+    out['nlinks'] = np.array(list(d.values()), np.float64)
+    d = as_dict()
+    H.normalize_by_length(d, {names[k]: int(length[k]) for k in range(n_frag)}, 500)
+    out['by_length'] = np.array(list(d.values()), np.float64)
+    rdd = {names[k]: ('h%d' % hap[k], 30.0) for k in range(n_frag)}
+    order = {(names[i], names[j]): k for k, (i, j) in enumerate(zip(fi.tolist(), fj.tolist()))}
+    for tag_, w in (('w1', 1.0), ('w05', 0.5), ('w03', 0.3)):
+        d = as_dict()
+        H.reduce_inter_hap_HiC_links(d, rdd, w, target='flank_link_dict')
+        out['hap_%s_kept' % tag_] = np.array([order[k] for k in d], np.int64)
+        out['hap_%s_values' % tag_] = np.array([float(v) for v in d.values()], np.float64)
+        out['hap_%s_is_int' % tag_] = np.array([isinstance(v, int) for v in d.values()], bool)
+    # after the nlinks normalisation the matrix build casts to float32 (:368): freeze that matrix too
+    d = as_dict()
+    H.normalize_by_nlinks(d, {names[k]: int(links[k]) for k in range(n_frag)})
+    m, fidx = H.dict_to_matrix(d, set(names), dense_matrix=False, add_self_loops=True)
+    p_, j_, x_ = canon(m)
+    out.update(nl_m_p=p_, nl_m_j=j_, nl_m_x=x_, nl_fidx=np.array([fidx[nm] for nm in names], np.int32))
+    print('weights case: keys', len(key), 'deleted at w=1:', len(key) - len(out['hap_w1_kept']))
+    np.savez_compressed(path, **out)
+
+
 if __name__ == '__main__':
     assert os.environ.get('PYTHONHASHSEED') == '0', 'run with PYTHONHASHSEED=0'
+    if len(sys.argv) > 1 and sys.argv[1] == 'weights':
+        gen_weights(os.path.join(HERE, 'weights.npz'))
+        sys.exit(0)
     gen_mcl(os.path.join(HERE, 'mcl_cases.npz'))
     gen_ingest(os.path.join(HERE, 'ingest_ctgs.npz'), os.path.join(HERE, 'ingest_bins.npz'))
     gen_pipeline(os.path.join(HERE, 'pipeline_toy.npz'))
@@ -634,3 +690,4 @@ if __name__ == '__main__':
     gen_pairs_text(os.path.join(HERE, 'pairs_text.npz'))
     gen_coord_stats(os.path.join(HERE, 'coord_stats.npz'))
     gen_pipeline_c4(os.path.join(HERE, 'pipeline_c4.npz'))
+    gen_weights(os.path.join(HERE, 'weights.npz'))

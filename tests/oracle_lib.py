@@ -138,6 +138,13 @@ def dict_to_matrix(frag_i, frag_j, value, n_frag, in_set, n_rest, add_self_loops
     return DeviceCSR(p, j, x), fidx, nl
 
 
+def link_weights(frag_i, frag_j, value, mode, n_frag, per_frag=None, tag=None, param=0.0, device_ptrs=None):
+    new = orc.link_weights(frag_i, frag_j, value, mode, per_frag=per_frag, tag=tag, param=param)
+    zeros = int(((new == 0) & (np.asarray(tag)[frag_i] != np.asarray(tag)[frag_j])).sum()) if mode == 2 else 0
+    value[:] = new
+    return zeros
+
+
 def rank_sums(m, topN):
     return orc.rank_sums(m.a, topN)
 

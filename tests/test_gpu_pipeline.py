@@ -459,6 +459,58 @@ def test_filter_fragments_and_rank_sums():
         assert np.array_equal(_lib.rank_sums(m, topn), orc.rank_sums(A, topn)), (n, deg, topn)
 
 
+def test_link_weights_a6():
+    """a6: normalize_by_nlinks :718-724, normalize_by_length :727-738, reduce_inter_hap_HiC_links :695-707 — the device
+    kernel on arrays and the dict mirrors of haphic_amd/cluster.py against what the reference's own functions did to
+    the same dict (tests/golden/weights.npz).  float64 values: length / haplotype modes bit exact; the nlinks mode
+    calls pow(x, 0.5), so one ulp of float64 is allowed (the matrix is float32, :368: compared at 1e-6)."""
+    from collections import defaultdict
+    from haphic_amd import _lib, cluster
+    from tests.conftest import load_golden
+    g = load_golden('weights.npz')
+    fi, fj, cnt = g['fi'], g['fj'], g['cnt']
+    n_frag = len(g['links'])
+    names = ['ctg%04d' % k for k in range(n_frag)]
+    v = cnt.astype(np.float64)
+    _lib.link_weights(fi, fj, v, 0, n_frag, per_frag=g['links'])
+    np.testing.assert_allclose(v, g['nlinks'], rtol=3e-16, atol=0)
+    v = cnt.astype(np.float64)
+    _lib.link_weights(fi, fj, v, 1, n_frag, per_frag=g['length'], param=2000 * int(g['flank_kb']))
+    assert np.array_equal(v, g['by_length'])
+    for tag_, w in (('w1', 1.0), ('w05', 0.5), ('w03', 0.3)):
+        v = cnt.astype(np.float64)
+        nz = _lib.link_weights(fi, fj, v, 2, n_frag, tag=g['hap'], param=w)
+        kept = np.flatnonzero(~((v == 0) & (g['hap'][fi] != g['hap'][fj])))
+        assert np.array_equal(kept, g['hap_%s_kept' % tag_]) and nz == len(cnt) - len(kept)
+        assert np.array_equal(v[kept], g['hap_%s_values' % tag_])
+
+    def as_dict():
+        d = defaultdict(int)
+        for i, j, c in zip(fi.tolist(), fj.tolist(), cnt.tolist()):
+            d[(names[i], names[j])] = c
+        return d
+    cluster.logger.setLevel('WARNING')
+    rdd = {names[k]: ('h%d' % g['hap'][k], 30.0) for k in range(n_frag)}
+    order = {(names[i], names[j]): k for k, (i, j) in enumerate(zip(fi.tolist(), fj.tolist()))}
+    for tag_, w in (('w1', 1.0), ('w05', 0.5), ('w03', 0.3)):
+        d = as_dict()
+        cluster.reduce_inter_hap_HiC_links(d, rdd, w)
+        assert [order[k] for k in d] == g['hap_%s_kept' % tag_].tolist()
+        assert [float(x) for x in d.values()] == g['hap_%s_values' % tag_].tolist()
+        assert [isinstance(x, int) for x in d.values()] == g['hap_%s_is_int' % tag_].tolist()      # untouched counts stay int
+    d = as_dict()
+    cluster.normalize_by_length(d, {names[k]: int(g['length'][k]) for k in range(n_frag)}, int(g['flank_kb']))
+    assert list(d.values()) == g['by_length'].tolist() and all(isinstance(x, float) for x in d.values())
+    d = as_dict()
+    cluster.normalize_by_nlinks(d, {names[k]: int(g['links'][k]) for k in range(n_frag)})
+    np.testing.assert_allclose(list(d.values()), g['nlinks'], rtol=3e-16, atol=0)
+    m, fidx = cluster.dict_to_matrix(d, set(names), dense_matrix=False, add_self_loops=True)        # :2895 then :2934
+    m.sort_indices()
+    assert [fidx[nm] for nm in names] == g['nl_fidx'].tolist()
+    assert np.array_equal(m.indptr, g['nl_m_p']) and np.array_equal(m.indices, g['nl_m_j'])
+    np.testing.assert_allclose(m.data, g['nl_m_x'], rtol=1e-6, atol=0)
+
+
 def test_full_size_properties():
     """BASELINE.json configs[1] at full size (10k contigs / 50 M pairs — the oracle cannot finish this in seconds),
     checked through size-independent properties: count conservation, chunked == whole (the exchange step), symmetry

@@ -54,3 +54,7 @@ def test_stat_fragments_mirror(host_only_everywhere):
 
 def test_filter_fragments_mirror(host_only_everywhere):
     tp.test_filter_fragments_and_rank_sums()
+
+
+def test_link_weights_mirrors(host_only_everywhere):
+    tp.test_link_weights_a6()

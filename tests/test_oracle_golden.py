@@ -229,3 +229,16 @@ def test_coordinate_statistics_mirrors_pinned():
         c = array('i', g['coords'][g['ptr'][k]:g['ptr'][k + 1]].tolist())
         assert float(cluster.cal_concordance_ratio(c, int(g['shorter'][k]), 50)) == g['concordance'][k]
         assert float(cluster.cal_concentration_adj_ratio(c)) == g['adj'][k]
+
+
+def test_link_weights_against_reference():
+    """a6: the numpy restatement (oracle.link_weights) against the reference's dict rewrites, bit for bit"""
+    from tests.conftest import load_golden
+    g = load_golden('weights.npz')
+    fi, fj, cnt = g['fi'], g['fj'], g['cnt'].astype(np.float64)
+    assert np.array_equal(orc.link_weights(fi, fj, cnt, 0, per_frag=g['links']), g['nlinks'])
+    assert np.array_equal(orc.link_weights(fi, fj, cnt, 1, per_frag=g['length'], param=2000 * int(g['flank_kb'])), g['by_length'])
+    for tag_, w in (('w1', 1.0), ('w05', 0.5), ('w03', 0.3)):
+        v = orc.link_weights(fi, fj, cnt, 2, tag=g['hap'], param=w)
+        kept = np.flatnonzero(~((v == 0) & (g['hap'][fi] != g['hap'][fj])))
+        assert np.array_equal(kept, g['hap_%s_kept' % tag_]) and np.array_equal(v[kept], g['hap_%s_values' % tag_])
