@@ -96,6 +96,11 @@ SIGNATURES = {
     'hhx_pairs_parser_arrays': (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5),
     'hhx_pairs_parser_fetch': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     'hhx_pairs_parser_destroy': (C.c_int, [C.c_void_p]),
+    'hhx_bam_open': (C.c_int, [C.c_char_p, C.c_int, c_vpp]),
+    'hhx_bam_header': (C.c_int, [C.c_void_p, c_i32p, C.POINTER(C.c_char_p), c_i64p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    'hhx_bam_next': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_int64, c_i64p, c_vpp, c_vpp, c_vpp, c_vpp]),
+    'hhx_bam_fetch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'hhx_bam_close': (C.c_int, [C.c_void_p]),
     'hhx_ingest_fetch_ht_order': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hhx_ingest_keep_frag_pairs': (C.c_int, [C.c_void_p, C.c_int]),
     'hhx_ingest_fetch_frag_pairs': (C.c_int, [C.c_void_p, c_i64p, C.c_void_p, C.c_void_p]),
@@ -428,6 +433,48 @@ def count_re_sites(seq, seg_off, seg_len, sites):
     check(load().hhx_count_re_sites(ptr(buf) if buf.size else None, buf.size, off.size, ptr(off), ptr(ln), len(sites), ptr(pats),
                                     ptr(plen), ptr(out)))
     return out[:off.size]
+
+
+class BamReader:
+    """hhx_bam: BGZF / BAM container -> batches of device id / position arrays (f4)."""
+
+    def __init__(self, path, threads=0):
+        self.h = C.c_void_p()
+        check(load().hhx_bam_open(os.fsencode(path), int(threads), C.byref(self.h)))
+        n_ref, text, tlen = C.c_int32(0), C.c_char_p(), C.c_int64(0)
+        names, offs = C.c_void_p(), C.c_void_p()
+        check(load().hhx_bam_header(self.h, C.byref(n_ref), C.byref(text), C.byref(tlen), C.byref(names), C.byref(offs)))
+        self.header_text = C.string_at(text, tlen.value).decode('utf-8', 'replace') if tlen.value else ''
+        off = np.ctypeslib.as_array(C.cast(offs, C.POINTER(C.c_int64)), (n_ref.value + 1,)).copy() if n_ref.value else np.zeros(1, np.int64)
+        blob = C.string_at(names, int(off[-1])) if n_ref.value and off[-1] else b''
+        self.ref_names = [blob[off[k]:off[k + 1]].decode() for k in range(n_ref.value)]
+        self._map = None
+
+    def set_contigs(self, ctg_ids):
+        """ctg_ids: name -> contig id of the FASTA; BAM references outside it map to -1 (`ref not in fa_dict`)"""
+        self._map = np.fromiter((ctg_ids.get(n, -1) for n in self.ref_names), np.int32, len(self.ref_names))
+        if not len(self._map):
+            self._map = np.zeros(0, np.int32)
+
+    def next_batch(self, need_flags, drop_same_ref, max_inflated_bytes=256 << 20):
+        """-> (n_records, [id1, pos1, id2, pos2] device pointers); n_records == 0 at the end of the file"""
+        n = C.c_int64(0)
+        p = [C.c_void_p() for _ in range(4)]
+        check(load().hhx_bam_next(self.h, int(need_flags), int(drop_same_ref), len(self.ref_names), ptr(self._map) if len(self._map) else None,
+                                  int(max_inflated_bytes), C.byref(n), *[C.byref(x) for x in p]))
+        self.last_n = n.value
+        return n.value, [x.value for x in p]
+
+    def fetch(self):
+        """host copies (id1, pos1, id2, pos2) of the last batch"""
+        out = [np.empty(self.last_n, np.int32) for _ in range(4)]
+        check(load().hhx_bam_fetch(self.h, *[ptr(a) for a in out]))
+        return out
+
+    def close(self):
+        if self.h:
+            load().hhx_bam_close(self.h)
+            self.h = None
 
 
 class PairsParser:

@@ -26,7 +26,7 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
-    cmd = [HIPCC] + FLAGS + sources() + ['-o', SO]
+    cmd = [HIPCC] + FLAGS + sources() + ['-lz', '-lpthread', '-o', SO]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

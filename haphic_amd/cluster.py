@@ -677,6 +677,83 @@ def pairs_generator_inter_ctgs(pairs, aln_format):
     return PairsText(pairs, aln_format, inter_only=True)
 
 
+# ------------------------------------------------------------------ f4: BAM
+def check_sorting_order(header_text):
+    """check_sorting_order() :1347-1359 on the SAM header text: coordinate-sorted input is an error"""
+    order = None
+    for line in header_text.splitlines():
+        if line.startswith('@HD'):
+            for field in line.split('\t')[1:]:
+                if field.startswith('SO:'):
+                    order = field[3:]
+    if order in ('unsorted', 'queryname'):
+        logger.info('The sorting order of the BAM file is {}'.format(order))
+        return
+    if order == 'coordinate':
+        logger.error('The sorting order of the BAM file is {}. It should be unsorted or name-sorted'.format(order))
+        raise RuntimeError('The sorting order of the BAM file is {}. It should be unsorted or name-sorted'.format(order))
+    logger.warning('The sorting order of the BAM file is unknown, but the program will continue')
+
+
+class BamRecords:
+    """What bam_generator (:1586-1593) returns here: the BAM file, inflated by host threads and decoded on the device one
+    batch of records at a time (hhx_bam_next).  parse_alignments* push the device arrays straight into the ingest;
+    iterating it yields the reference's (ref, mref, pos, mpos) tuples for any other consumer.  Only the two htslib
+    filter expressions the reference uses are understood: 'flag.read1' and 'flag.read1 && refid != mrefid'."""
+
+    def __init__(self, bam, threads, format_options, batch_bytes=256 << 20):
+        self.path, self.threads, self.batch_bytes = bam, threads, batch_bytes
+        self.need_flags, self.drop_same_ref = 0, False
+        for opt in format_options or ():
+            text = opt.decode() if isinstance(opt, bytes) else str(opt)
+            if not text.startswith('filter='):
+                raise NotImplementedError('BAM format option {!r} is not on the MI355X path'.format(text))
+            for term in (t.strip() for t in text[len('filter='):].split('&&')):
+                if term == 'flag.read1':
+                    self.need_flags |= 0x40
+                elif term.replace(' ', '') == 'refid!=mrefid':
+                    self.drop_same_ref = True
+                else:
+                    raise NotImplementedError('BAM filter term {!r} is not on the MI355X path'.format(term))
+        self.inter_only = self.drop_same_ref
+
+    def batches(self, names):
+        """per batch: (reader, n_records, [id1, pos1, id2, pos2] device pointers)"""
+        reader = _lib.BamReader(self.path, self.threads)
+        try:
+            check_sorting_order(reader.header_text)
+            reader.set_contigs({n: i for i, n in enumerate(names)})
+            while True:
+                n, ptrs = reader.next_batch(self.need_flags, self.drop_same_ref, self.batch_bytes)
+                if n == 0:
+                    break
+                yield reader, n, ptrs
+        finally:
+            reader.close()
+
+    def __iter__(self):
+        reader = _lib.BamReader(self.path, self.threads)
+        try:
+            check_sorting_order(reader.header_text)
+            names = reader.ref_names
+            reader.set_contigs({n: i for i, n in enumerate(names)})        # identity: ids are BAM reference ids
+            while True:
+                n, _ptrs = reader.next_batch(self.need_flags, self.drop_same_ref, self.batch_bytes)
+                if n == 0:
+                    break
+                id1, p1, id2, p2 = reader.fetch()
+                for a, x, b, y in zip(id1.tolist(), p1.tolist(), id2.tolist(), p2.tolist()):
+                    if a != -2:                                  # -2: the record failed the filter, htslib never yields it
+                        yield (names[a] if a >= 0 else None, names[b] if b >= 0 else None, x, y)
+        finally:
+            reader.close()
+
+
+def bam_generator(bam, threads, format_options):
+    """bam_generator() :1586-1593"""
+    return BamRecords(bam, threads, format_options)
+
+
 # ------------------------------------------------------------------ S5: ingest
 def _ids_from_alignments(alignments, cid, chunk):
     """(ref, mref, pos, mpos) iterator -> int32 arrays, `chunk` pairs at a time"""
@@ -701,7 +778,8 @@ def ingest_links(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False
     through the device ingest; returns the insertion-ordered tables as numpy arrays (+ the CLM distances and
     the first coordinates of every contig pair when want_pairs)."""
     text = isinstance(alignments, PairsText)
-    ing = _lib.Ingest(table, flank, bins=bins, skip_intra=text and alignments.inter_only)      # :1582
+    bam = isinstance(alignments, BamRecords)
+    ing = _lib.Ingest(table, flank, bins=bins, skip_intra=(text or bam) and alignments.inter_only)      # :1582 / refid != mrefid
     try:
         if want_pairs:
             ing.keep_pairs()
@@ -711,6 +789,9 @@ def ingest_links(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False
             for parser, k in alignments.batches(table.ctg_names):
                 if k:
                     ing.push_device(k, *parser.device_arrays()[:4])
+        elif bam:                            # f4: BGZF inflate on host threads, record decode on the device
+            for _reader, k, ptrs in alignments.batches(table.ctg_names):
+                ing.push_device(k, *ptrs)
         else:
             cid = {n: i for i, n in enumerate(table.ctg_names)}
             for b1, p1, b2, p2, k in _ids_from_alignments(alignments, cid, chunk):

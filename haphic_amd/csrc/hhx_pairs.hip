@@ -3,13 +3,13 @@
 //   ctg_coord_dict record_coord_pairs :454-471 — the first max_read_pairs (coord_i, coord_j) per contig pair
 // Both are "group the pairs by contig pair, keep stream order inside a group".  The pairs counted in
 // full_link_dict are compacted (stably, so they stay in stream order) into (key, xi << 32 | xj) records at push
-// time; at fetch time one STABLE radix sort by key (rocPRIM's device radix sort — a plain library primitive, used
-// here the way hipBLASLt is meant for a plain GEMM) groups them, the insertion-ordered key table is sorted the same
-// way to pair every group with its dict position, and one wavefront per contig pair writes its distances.
+// time; at fetch time one STABLE radix sort by key (hhx_sort.h: hand-written LSD passes, ballot-ranked so that equal
+// keys keep their stream order) groups them, the insertion-ordered key table is sorted the same way to pair every
+// group with its dict position, and one wavefront per contig pair writes its distances.
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "hhx_ingest.h"
+#include "hhx_sort.h"
 
 using namespace hhx;
 
@@ -160,13 +160,7 @@ __global__ __launch_bounds__(256) void k_ht_first(i64 n_groups, const u64 *__res
 }
 
 int sort_pairs_u64(const u64 *kin, u64 *kout, const u64 *vin, u64 *vout, i64 n) {
-    size_t tmp_bytes = 0;
-    HHX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0, 2 * ID_BITS, g_stream));
-    DevBuf<unsigned char> tmp;
-    if (tmp.alloc(tmp_bytes + 16)) return 1;
-    HHX_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0, 2 * ID_BITS, g_stream));
-    HHX_HIP(hipStreamSynchronize(g_stream));
-    return 0;
+    return stable_sort_pairs_u64(kin, kout, vin, vout, n, 2 * ID_BITS);      // hhx_sort.h: hand-written stable LSD radix sort
 }
 
 }  // namespace

@@ -33,6 +33,7 @@ OPTIONAL = {
     'parse_alignments': ('HapHiC_cluster.py:1658-1752', cluster.parse_alignments),
     'pairs_generator': ('HapHiC_cluster.py:1539-1559', cluster.pairs_generator),                      # a1
     'pairs_generator_inter_ctgs': ('HapHiC_cluster.py:1562-1583', cluster.pairs_generator_inter_ctgs),
+    'bam_generator': ('HapHiC_cluster.py:1586-1593', cluster.bam_generator),                          # f4
 }
 
 
@@ -66,6 +67,7 @@ def patch_reference(H, ingest=True, matrix_build=True):
         seams['parse_alignments'] = OPTIONAL['parse_alignments']
         seams['pairs_generator'] = OPTIONAL['pairs_generator']                # a1: only together with S5, which consumes it
         seams['pairs_generator_inter_ctgs'] = OPTIONAL['pairs_generator_inter_ctgs']
+        seams['bam_generator'] = OPTIONAL['bam_generator']                    # f4: consumed by the same S5 mirrors
     for name, (_cite, fn) in seams.items():
         saved[name] = getattr(H, name, None)
         setattr(H, name, _dense_dispatch(fn, saved[name], DENSE_ARG[name]) if name in DENSE_ARG else fn)

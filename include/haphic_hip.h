@@ -286,6 +286,25 @@ int hhx_pairs_parser_arrays(hhx_pairs_parser *p, void **id1, void **pos1, void *
 int hhx_pairs_parser_fetch(hhx_pairs_parser *p, int32_t *id1, int32_t *pos1, int32_t *id2, int32_t *pos2, uint8_t *bed);
 int hhx_pairs_parser_destroy(hhx_pairs_parser *p);
 
+/* ------------------------------------------------------------------ f4: BAM front end
+ * bam_generator :1586-1593 = pysam.AlignmentFile(bam, threads=..., format_options=[b'filter=...']) yielding
+ * (reference_name, next_reference_name, reference_start, next_reference_start) per record that passes the htslib filter
+ * ('flag.read1' :2837 :2855, 'flag.read1 && refid != mrefid' :2862).  hhx_bam_open reads the BGZF container and the BAM
+ * header (SAM text for check_sorting_order :1347-1359; reference names, concatenated, name_off[n_ref + 1]).
+ * hhx_bam_next inflates the next batch of BGZF blocks (host threads), walks the record lengths and decodes the batch on the
+ * device: record k of the batch = element k of four int32 device arrays (valid until the next call), ids mapped through
+ * ref_to_ctg_host[n_ref] (BAM reference id -> contig id of the FASTA, -1 = not in fa_dict), records that fail the filter
+ * (flag & need_flags != need_flags; or refID == next_refID when drop_same_ref) carry id -2 in both columns, unmapped ends
+ * and references outside the map id -1 — hhx_ingest_push drops every negative id, as `ref not in fa_dict` does
+ * (:1610 / :1702).  *n_records == 0: end of file. */
+typedef struct hhx_bam hhx_bam;
+int hhx_bam_open(const char *path, int threads, hhx_bam **out);
+int hhx_bam_header(hhx_bam *b, int32_t *n_ref, const char **text, int64_t *text_len, const char **names, const int64_t **name_off);
+int hhx_bam_next(hhx_bam *b, int need_flags, int drop_same_ref, int32_t n_ref, const int32_t *ref_to_ctg_host, int64_t max_inflated_bytes,
+                 int64_t *n_records, void **id1_dev, void **pos1_dev, void **id2_dev, void **pos2_dev);
+int hhx_bam_fetch(hhx_bam *b, int32_t *id1, int32_t *pos1, int32_t *id2, int32_t *pos2);   /* host copies of the last batch */
+int hhx_bam_close(hhx_bam *b);
+
 /* HT_link_dict's insertion order (update_HT_link_dict :404-416): first[4 * k + q] = stream position (among the pairs that
  * entered full_link_dict) of the first read pair of contig pair k (dict order of hhx_ingest_fetch) in quadrant
  * q = [HH, HT, TH, TT], INT64_MAX if the quadrant is empty.  Needs hhx_ingest_keep_pairs. */

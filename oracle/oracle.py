@@ -353,3 +353,41 @@ def link_weights(fi, fj, value, mode, per_frag=None, tag=None, param=0.0):
     diff = t[fi] != t[fj]
     v[diff] = v[diff] - v[diff] * param
     return v
+
+
+# ---------------------------------------------------------------- f4: BAM (pure-Python restatement, small inputs only)
+def parse_bam(data, need_flags=0x40, drop_same_ref=False):
+    """bam_generator :1586-1593 on the bytes of a BAM file, following the SAM specification §4.1-4.2: gunzip the BGZF
+    members, read the header, then one (reference_name, next_reference_name, reference_start, next_reference_start)
+    tuple per record that passes the htslib filter the reference sets (:2837 :2855 'flag.read1', :2862 additionally
+    'refid != mrefid').  A reference id of -1 gives the name None, as pysam does.
+    PARITY UNPINNED against htslib itself (pysam is not installed here): pinned by the file-format specification and by a
+    BAM written byte by byte in tests/bam_fixture.py.  Returns (header_text, reference names, tuples)."""
+    import struct
+    import zlib
+    raw, rest = bytearray(), bytes(data)
+    while rest:                                           # concatenated gzip members
+        d = zlib.decompressobj(31)
+        raw += d.decompress(rest)
+        rest = d.unused_data
+    assert raw[:4] == b'BAM\x01', 'not a BAM stream'
+    l_text = struct.unpack_from('<i', raw, 4)[0]
+    text = raw[8:8 + l_text].rstrip(b'\x00').decode()
+    at = 8 + l_text
+    n_ref = struct.unpack_from('<i', raw, at)[0]
+    at += 4
+    names = []
+    for _ in range(n_ref):
+        l_name = struct.unpack_from('<i', raw, at)[0]
+        names.append(raw[at + 4:at + 4 + l_name - 1].decode())
+        at += 4 + l_name + 4
+    out = []
+    while at < len(raw):
+        block_size, ref, pos = struct.unpack_from('<iii', raw, at)
+        flag = struct.unpack_from('<H', raw, at + 18)[0]
+        mref, mpos = struct.unpack_from('<ii', raw, at + 24)
+        at += 4 + block_size
+        if (flag & need_flags) != need_flags or (drop_same_ref and ref == mref):
+            continue
+        out.append((names[ref] if ref >= 0 else None, names[mref] if mref >= 0 else None, pos, mpos))
+    return text, names, out
