@@ -59,6 +59,7 @@ SIGNATURES = {
     'hhx_expand_inflate_prune': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, c_vpp, c_i64p, c_i64p]),
     'hhx_link_weights': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_double, c_i64p]),
+    'hhx_group_link_sums': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'hhx_row_products': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'hhx_expand_links': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, c_vpp, c_i64p, c_i64p]),
     'hhx_convergence_stat': (C.c_int, [C.c_void_p, C.c_void_p, c_f32p]),
@@ -353,6 +354,17 @@ def link_weights(frag_i, frag_j, value, mode, n_frag, per_frag=None, tag=None, p
     check(load().hhx_link_weights(len(value), ptr(fi), ptr(fj), ptr(value), 0, int(mode), int(n_frag), ptr(per), ptr(tg), float(param),
                                   C.byref(nz)))
     return nz.value
+
+
+def group_link_sums(frag_i, frag_j, links, group, n_groups):
+    """hhx_group_link_sums: (sums, first) int64 [n_ctg, n_groups]; first == -1 where a cell got no contribution"""
+    fi, fj = np.ascontiguousarray(frag_i, np.int32), np.ascontiguousarray(frag_j, np.int32)
+    lk = np.ascontiguousarray(links, np.int64)
+    grp = np.ascontiguousarray(group, np.int32)
+    sums = np.zeros((len(grp), int(n_groups)), np.int64)
+    first = np.full((len(grp), int(n_groups)), -1, np.int64)
+    check(load().hhx_group_link_sums(len(lk), ptr(fi), ptr(fj), ptr(lk), len(grp), ptr(grp), int(n_groups), ptr(sums), ptr(first)))
+    return sums, first
 
 
 def row_products(a, b):

@@ -378,6 +378,45 @@ def reduce_inter_hap_HiC_links(link_dict, read_depth_dict, phasing_weight, targe
             del link_dict[keys[k]]
 
 
+# ------------------------------------------------------------------ f3: reassign's per-group link sums
+def parse_link_dict(link_dict, ctg_group_dict, normalize_by_nlinks=False, _original=None):
+    """HapHiC_reassign.py parse_link_dict() :217-263.  Integer link counts without normalisation (the default of
+    `haphic reassign`): the per-(contig, group) sums come from the device (hhx_group_link_sums), the inner dicts are
+    rebuilt in the order their keys first received a contribution, linked_ctg_dict (sets) is built on the host.
+    Anything else — normalize_by_nlinks, float links — is float arithmetic whose summation order is the dict order:
+    handed back to the reference's own function (`_original`, bound by patch_reassign)."""
+    integral = all(isinstance(v, (int, np.integer)) for v in link_dict.values())
+    if normalize_by_nlinks or not integral:
+        if _original is None:
+            raise ValueError('parse_link_dict on float links / with normalize_by_nlinks stays the reference function')
+        return _original(link_dict, ctg_group_dict, normalize_by_nlinks)
+    names = {}
+    fi, fj, val = _dict_arrays(link_dict, names)
+    id_names = list(names)
+    groups = {}
+    grp = np.fromiter((-1 if ctg_group_dict[c] == 'ungrouped' else groups.setdefault(ctg_group_dict[c], len(groups)) for c in id_names),
+                      np.int32, len(id_names))
+    group_names = list(groups)
+    sums, first = _lib.group_link_sums(fi, fj, val.astype(np.int64), grp, len(group_names))
+    ctg_group_link_dict = defaultdict(dict)
+    linked_ctg_dict = defaultdict(set)
+    rows, cols = np.nonzero(first >= 0)
+    order = np.lexsort((first[rows, cols], rows))
+    # outer dict order = order in which contigs were first touched by add_ctg_group (smallest `first` of the row)
+    row_first = np.full(len(id_names), np.iinfo(np.int64).max, np.int64)
+    np.minimum.at(row_first, rows, first[rows, cols])
+    for r in np.argsort(row_first, kind='stable').tolist():
+        if row_first[r] == np.iinfo(np.int64).max:
+            break
+        ctg_group_link_dict[id_names[r]] = {}
+    for r, c in zip(rows[order].tolist(), cols[order].tolist()):
+        ctg_group_link_dict[id_names[r]][group_names[c]] = int(sums[r, c])
+    for a, b in zip(fi.tolist(), fj.tolist()):
+        linked_ctg_dict[id_names[a]].add(id_names[b])
+        linked_ctg_dict[id_names[b]].add(id_names[a])
+    return ctg_group_link_dict, linked_ctg_dict
+
+
 # ------------------------------------------------------------------ S1 / S3: matrix-level seams
 def _to_device(matrix):
     return _lib.DeviceCSR.from_scipy_csc(matrix)

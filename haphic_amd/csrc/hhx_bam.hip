@@ -235,8 +235,9 @@ extern "C" int hhx_bam_next(hhx_bam *b, int need_flags, int drop_same_ref, i32 n
         if (blocks.empty()) {
             if (!b->eof) return fail("BAM: a BGZF block larger than the read window");
             if (!b->comp.empty()) return fail("BAM: truncated BGZF block at the end of the file");
-            if (!b->carry.empty()) return fail("BAM: truncated record at the end of the file");
-            return 0;                                            // end of file: *n_records == 0
+            if (b->carry.empty()) return 0;                      // end of file: *n_records == 0
+            // no compressed data left, but inflated bytes are (hhx_bam_open inflates ahead while it reads the header):
+            // they are walked below like any batch
         }
         const size_t total = b->carry.size() + inflated;
         if (total + 64 > b->pin_cap) {
@@ -260,7 +261,10 @@ extern "C" int hhx_bam_next(hhx_bam *b, int need_flags, int drop_same_ref, i32 n
             at += 4 + len;
         }
         b->carry.assign(b->pin + at, b->pin + total);
-        if (off.empty()) continue;                               // one record longer than the batch so far: read on
+        if (off.empty()) {                                       // one record longer than the batch so far: read on
+            if (blocks.empty()) return fail("BAM: truncated record at the end of the file");
+            continue;
+        }
         const i64 n = (i64)off.size();
         if (b->d_bytes.n < at + 16 && b->d_bytes.alloc(at + at / 4 + 16)) return 1;
         if ((i64)b->d_off.n < n && (b->d_off.alloc((size_t)n + n / 4) || b->d_id1.alloc((size_t)n + n / 4) || b->d_pos1.alloc((size_t)n + n / 4) ||

@@ -24,8 +24,10 @@ __global__ __launch_bounds__(256) void k_link_weights(i64 n, const i32 *__restri
         const i32 a = fi[k], b = fj[k];
         double v = value[k];
         if (MODE == 0) {
-            // Python: (int * int) ** 0.5 — the product is exact (< 2^53 for any real link totals), float.__pow__ is C pow()
-            v /= pow((double)(per_frag[a] * per_frag[b]), 0.5);
+            // Python: (int * int) ** 0.5 — the product is exact (< 2^53 for any real link totals); float.__pow__ is C pow(),
+            // which glibc rounds correctly in all but a handful of cases, i.e. to the IEEE square root: sqrt() here (the
+            // device pow() is 1-2 ulp off, measured against the reference's values)
+            v /= sqrt((double)(per_frag[a] * per_frag[b]));
         } else if (MODE == 1) {
             const double two_flanks = param;
             const double la = (double)per_frag[a], lb = (double)per_frag[b];
@@ -89,5 +91,63 @@ extern "C" int hhx_link_weights(i64 n_keys, const i32 *frag_i, const i32 *frag_j
     if (!on_device) HHX_HIP(hipMemcpyAsync(value, dv.p, sizeof(double) * (size_t)n_keys, hipMemcpyDeviceToHost, g_stream));
     HHX_HIP(hipStreamSynchronize(g_stream));
     if (n_zero) *n_zero = (i64)z;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// f3: reassign's link-density input, HapHiC_reassign.py parse_link_dict :217-263 (normalize_by_nlinks = False branch):
+//     ctg_group_link_dict[ctg][group] = sum of the links between ctg and the contigs of `group` (groups != 'ungrouped')
+// for every contig pair of full_link_dict — a sparse matrix times the n_ctg x n_groups group indicator.  One thread per
+// key: two 64-bit integer atomic adds into the dense n_ctg x n_groups table (order-free, exact: the links are integer
+// counts) and two atomic mins recording the dict position of the first contribution — the inner dicts of the reference
+// are insertion ordered, and run_reassignment iterates them.
+namespace {
+__global__ __launch_bounds__(256) void k_group_link_sums(i64 n, const i32 *__restrict__ fi, const i32 *__restrict__ fj, const i64 *__restrict__ links,
+                                                         const i32 *__restrict__ group, i32 n_groups, unsigned long long *__restrict__ sums,
+                                                         unsigned long long *__restrict__ first) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) {
+        const i32 a = fi[k], b = fj[k];
+        const i32 ga = group[a], gb = group[b];
+        const unsigned long long v = (unsigned long long)links[k];
+        if (gb >= 0) {                                   // add_ctg_group(ctg_i, group_j, links) :246
+            atomicAdd(&sums[(size_t)a * n_groups + gb], v);
+            atomicMin(&first[(size_t)a * n_groups + gb], (unsigned long long)(2 * k));
+        }
+        if (ga >= 0) {                                   // add_ctg_group(ctg_j, group_i, links) :247
+            atomicAdd(&sums[(size_t)b * n_groups + ga], v);
+            atomicMin(&first[(size_t)b * n_groups + ga], (unsigned long long)(2 * k + 1));
+        }
+    }
+}
+}  // namespace
+
+extern "C" int hhx_group_link_sums(i64 n_keys, const i32 *frag_i, const i32 *frag_j, const i64 *links, i32 n_ctg, const i32 *group_host,
+                                   i32 n_groups, i64 *sums_host, i64 *first_host) {
+    if (n_keys < 0 || n_ctg < 0 || n_groups < 0) return fail("hhx_group_link_sums: bad arguments");
+    const size_t cells = (size_t)n_ctg * (size_t)n_groups;
+    if (cells == 0) return 0;
+    if (!sums_host || !first_host || !group_host || (n_keys && (!frag_i || !frag_j || !links))) return fail("null pointer");
+    DevBuf<i32> di, dj, dg;
+    DevBuf<i64> dl;
+    DevBuf<unsigned long long> ds, df;
+    if (di.alloc((size_t)n_keys + 1) || dj.alloc((size_t)n_keys + 1) || dl.alloc((size_t)n_keys + 1) || dg.alloc((size_t)n_ctg) || ds.alloc(cells) ||
+        df.alloc(cells)) return 1;
+    if (n_keys) {
+        HHX_HIP(hipMemcpyAsync(di.p, frag_i, sizeof(i32) * (size_t)n_keys, hipMemcpyHostToDevice, g_stream));
+        HHX_HIP(hipMemcpyAsync(dj.p, frag_j, sizeof(i32) * (size_t)n_keys, hipMemcpyHostToDevice, g_stream));
+        HHX_HIP(hipMemcpyAsync(dl.p, links, sizeof(i64) * (size_t)n_keys, hipMemcpyHostToDevice, g_stream));
+    }
+    HHX_HIP(hipMemcpyAsync(dg.p, group_host, sizeof(i32) * (size_t)n_ctg, hipMemcpyHostToDevice, g_stream));
+    HHX_HIP(hipMemsetAsync(ds.p, 0, sizeof(unsigned long long) * cells, g_stream));
+    HHX_HIP(hipMemsetAsync(df.p, 0xff, sizeof(unsigned long long) * cells, g_stream));
+    if (n_keys) {
+        KTimer kt("group_link_sums");
+        k_group_link_sums<<<(unsigned)std::max<i64>(1, std::min<i64>((n_keys + 255) / 256, 256 * 16)), 256, 0, g_stream>>>(
+            n_keys, di.p, dj.p, dl.p, dg.p, n_groups, ds.p, df.p);
+        HHX_LAUNCH_CHECK();
+    }
+    HHX_HIP(hipMemcpyAsync(sums_host, ds.p, sizeof(i64) * cells, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipMemcpyAsync(first_host, df.p, sizeof(i64) * cells, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
     return 0;
 }

@@ -76,6 +76,20 @@ def patch_reference(H, ingest=True, matrix_build=True):
     return saved
 
 
+def patch_reassign(R):
+    """R: the imported HapHiC_reassign module.  f3: parse_link_dict :217-263 (the per-group link sums behind reassign's
+    link densities) on the device for integer link counts; float / normalised links go to the original function."""
+    from . import _lib
+    _lib.load()
+    original = R.parse_link_dict
+
+    def parse_link_dict(link_dict, ctg_group_dict, normalize_by_nlinks=False):
+        return cluster.parse_link_dict(link_dict, ctg_group_dict, normalize_by_nlinks, _original=original)
+    parse_link_dict.__wrapped__ = cluster.parse_link_dict
+    R.parse_link_dict = parse_link_dict
+    return {'parse_link_dict': original}
+
+
 def unpatch_reference(H, saved):
     for name, fn in saved.items():
         if fn is None and hasattr(H, name):

@@ -175,6 +175,15 @@ int hhx_dict_to_matrix(int64_t n_keys, const int32_t *frag_i, const int32_t *fra
 int hhx_link_weights(int64_t n_keys, const int32_t *frag_i, const int32_t *frag_j, double *value, int on_device, int mode,
                      int32_t n_frag, const int64_t *per_frag_host, const int32_t *tag_host, double param, int64_t *n_zero);
 
+/* ---------------------------------------------------------------- f3: reassign's per-group link sums
+ * HapHiC_reassign.py parse_link_dict :217-263 (normalize_by_nlinks = False): for every contig pair (i, j) of full_link_dict,
+ * in dict order, sums[i][group[j]] += links and sums[j][group[i]] += links (group -1 = 'ungrouped': skipped).  links are
+ * integer counts (64-bit integer adds: exact, order-free).  sums_host / first_host: [n_ctg][n_groups]; first = dict
+ * position (2 * key index + side) of the first contribution to the cell, -1 (all bits set) if none — the order in which
+ * the reference's inner dicts received their keys. */
+int hhx_group_link_sums(int64_t n_keys, const int32_t *frag_i, const int32_t *frag_j, const int64_t *links, int32_t n_ctg,
+                        const int32_t *group_host, int32_t n_groups, int64_t *sums_host, int64_t *first_host);
+
 /* ---------------------------------------------------------------- a5: restriction-site counts
  * count_RE_sites :75-84 for many segments of one sequence buffer (host bytes, letter case as the caller's
  * parse_fasta :87-113 leaves it): counts[s] = sum over sites of seq[off[s] : off[s]+len[s]].count(site),

@@ -391,3 +391,20 @@ def parse_bam(data, need_flags=0x40, drop_same_ref=False):
             continue
         out.append((names[ref] if ref >= 0 else None, names[mref] if mref >= 0 else None, pos, mpos))
     return text, names, out
+
+
+# ---------------------------------------------------------------- f3: reassign's per-group link sums (numpy restatement)
+def group_link_sums(fi, fj, links, group, n_groups):
+    """HapHiC_reassign.py parse_link_dict :217-263 (no normalisation) on arrays in dict order: sums[i][group[j]] += links,
+    sums[j][group[i]] += links, and the dict position (2 k + side) of each cell's first contribution (-1: none)."""
+    fi, fj, links, group = (np.asarray(a) for a in (fi, fj, links, group))
+    sums = np.zeros((len(group), n_groups), np.int64)
+    first = np.full((len(group), n_groups), -1, np.int64)
+    for k in range(len(fi)):
+        a, b = int(fi[k]), int(fj[k])
+        for side, (row, g) in enumerate(((a, int(group[b])), (b, int(group[a])))):
+            if g >= 0:
+                sums[row, g] += int(links[k])
+                if first[row, g] < 0:
+                    first[row, g] = 2 * k + side
+    return sums, first

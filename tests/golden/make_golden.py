@@ -675,8 +675,38 @@ def gen_weights(path):
     np.savez_compressed(path, **out)
 
 
+def gen_reassign(path):
+    """f3: HapHiC_reassign.parse_link_dict :217-263 (the reference's own function) on a synthetic full_link_dict:
+    the nested per-(contig, group) sums with BOTH dict orders, and linked_ctg_dict."""
+    import HapHiC_reassign as R
+    rng = np.random.default_rng(71)
+    n_ctg, n_groups, n_keys = 300, 7, 5000
+    names = ['c%03d' % k for k in range(n_ctg)]
+    a = rng.integers(0, n_ctg, 3 * n_keys)
+    b = rng.integers(0, n_ctg, 3 * n_keys)
+    ok = a < b
+    key = np.unique(a[ok].astype(np.int64) * n_ctg + b[ok])
+    key = key[rng.permutation(len(key))][:n_keys]
+    fi, fj = (key // n_ctg).astype(np.int32), (key % n_ctg).astype(np.int32)
+    links = rng.integers(1, 500, len(key)).astype(np.int64)
+    group = rng.integers(-1, n_groups, n_ctg).astype(np.int32)            # -1: 'ungrouped'
+    link_dict = {(names[i], names[j]): int(v) for i, j, v in zip(fi.tolist(), fj.tolist(), links.tolist())}
+    ctg_group_dict = {names[k]: ('ungrouped' if group[k] < 0 else 'group%d' % group[k]) for k in range(n_ctg)}
+    cgl, linked = R.parse_link_dict(link_dict, ctg_group_dict, normalize_by_nlinks=False)
+    cid = {n: k for k, n in enumerate(names)}
+    rows = [(cid[c], int(g[5:]), int(v)) for c, inner in cgl.items() for g, v in inner.items()]
+    out = dict(fi=fi, fj=fj, links=links, group=group, n_groups=np.int64(n_groups), outer=np.array([cid[c] for c in cgl], np.int32),
+               cells=np.array(rows, np.int64), linked_ptr=np.cumsum([0] + [len(linked[n]) for n in names]).astype(np.int64),
+               linked=np.array([cid[x] for n in names for x in sorted(linked[n])], np.int32))
+    print('reassign case: keys', len(key), 'cells', len(rows))
+    np.savez_compressed(path, **out)
+
+
 if __name__ == '__main__':
     assert os.environ.get('PYTHONHASHSEED') == '0', 'run with PYTHONHASHSEED=0'
+    if len(sys.argv) > 1 and sys.argv[1] == 'reassign':
+        gen_reassign(os.path.join(HERE, 'reassign.npz'))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'weights':
         gen_weights(os.path.join(HERE, 'weights.npz'))
         sys.exit(0)
@@ -691,3 +721,4 @@ if __name__ == '__main__':
     gen_coord_stats(os.path.join(HERE, 'coord_stats.npz'))
     gen_pipeline_c4(os.path.join(HERE, 'pipeline_c4.npz'))
     gen_weights(os.path.join(HERE, 'weights.npz'))
+    gen_reassign(os.path.join(HERE, 'reassign.npz'))

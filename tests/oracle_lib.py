@@ -145,6 +145,10 @@ def link_weights(frag_i, frag_j, value, mode, n_frag, per_frag=None, tag=None, p
     return zeros
 
 
+def group_link_sums(frag_i, frag_j, links, group, n_groups):
+    return orc.group_link_sums(frag_i, frag_j, links, group, n_groups)
+
+
 def rank_sums(m, topN):
     return orc.rank_sums(m.a, topN)
 

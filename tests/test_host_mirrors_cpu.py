@@ -58,3 +58,7 @@ def test_filter_fragments_mirror(host_only_everywhere):
 
 def test_link_weights_mirrors(host_only_everywhere):
     tp.test_link_weights_a6()
+
+
+def test_reassign_group_link_sums_mirror(host_only_everywhere):
+    tp.test_reassign_group_link_sums_f3()

@@ -242,3 +242,21 @@ def test_link_weights_against_reference():
         v = orc.link_weights(fi, fj, cnt, 2, tag=g['hap'], param=w)
         kept = np.flatnonzero(~((v == 0) & (g['hap'][fi] != g['hap'][fj])))
         assert np.array_equal(kept, g['hap_%s_kept' % tag_]) and np.array_equal(v[kept], g['hap_%s_values' % tag_])
+
+
+def test_group_link_sums_against_reference():
+    """f3: oracle.group_link_sums against HapHiC_reassign.parse_link_dict's nested dicts (values and first-contribution order)"""
+    from tests.conftest import load_golden
+    g = load_golden('reassign.npz')
+    sums, first = orc.group_link_sums(g['fi'], g['fj'], g['links'], g['group'], int(g['n_groups']))
+    rows, cols = np.nonzero(first >= 0)
+    row_first = np.full(len(g['group']), np.iinfo(np.int64).max)
+    np.minimum.at(row_first, rows, first[rows, cols])
+    outer = [r for r in np.argsort(row_first, kind='stable').tolist() if row_first[r] != np.iinfo(np.int64).max]
+    assert outer == g['outer'].tolist()
+    cells = []
+    for r in outer:
+        for c in np.argsort(np.where(first[r] >= 0, first[r], np.iinfo(np.int64).max), kind='stable').tolist():
+            if first[r, c] >= 0:
+                cells.append((r, c, int(sums[r, c])))
+    assert cells == [tuple(x) for x in g['cells'].tolist()]

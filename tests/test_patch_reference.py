@@ -27,7 +27,8 @@ def test_patch_binds_every_seam():
     # the mirror keeps the reference's signatures (same names, same positional order)
     for name in ('mcl', 'prune', 'interpret_result', 'dict_to_matrix', 'parse_alignments_for_ctgs', 'parse_alignments',
                  'run_mcl_clustering', 'mkl_matrix_power', 'parse_fasta', 'stat_fragments', 'count_RE_sites', 'filter_fragments',
-                 'pairs_generator', 'pairs_generator_inter_ctgs'):
+                 'pairs_generator', 'pairs_generator_inter_ctgs', 'bam_generator', 'normalize_by_nlinks', 'normalize_by_length',
+                 'reduce_inter_hap_HiC_links', 'check_param', 'cal_concordance_ratio', 'cal_concentration_adj_ratio', 'parse_RE_sites'):
         ref_params = list(inspect.signature(getattr(H, name)).parameters)
         our_params = [p for p in inspect.signature(getattr(cluster, name)).parameters if not p.startswith('_') and p != 'outdir_root']
         assert our_params[:len(ref_params)] == ref_params, (name, ref_params, our_params)
@@ -36,6 +37,37 @@ def test_patch_binds_every_seam():
         assert H.mcl.__wrapped__ is cluster.mcl and H.run_mcl_clustering.__wrapped__ is cluster.run_mcl_clustering
         assert H.dot_product_mkl is cluster.dot_product_mkl and H.INTEL_MKL is True
         assert H.parse_alignments_for_ctgs is cluster.parse_alignments_for_ctgs
+        assert H.bam_generator is cluster.bam_generator and H.normalize_by_nlinks is cluster.normalize_by_nlinks
     finally:
         patch.unpatch_reference(H, saved)
     assert H.mcl is not cluster.mcl and not hasattr(H.mcl, '__wrapped__')
+
+
+def test_patch_reassign_binds_parse_link_dict():
+    """f3: HapHiC_reassign.parse_link_dict is re-bound; float / normalised links go back to the reference function"""
+    if not os.path.isdir(REF):
+        pytest.skip('reference checkout not present')
+    for name, attrs in (('pysam', {'set_verbosity': lambda *a, **k: None, 'AlignmentFile': None}), ('portion', {'closed': None, 'empty': None})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+    sys.path.insert(0, REF)
+    try:
+        import HapHiC_reassign as R
+    finally:
+        sys.path.remove(REF)
+    import inspect
+    from haphic_amd import cluster, patch
+    ref_params = list(inspect.signature(R.parse_link_dict).parameters)
+    assert [p for p in inspect.signature(cluster.parse_link_dict).parameters if not p.startswith('_')] == ref_params
+    saved = patch.patch_reassign(R)
+    try:
+        assert R.parse_link_dict.__wrapped__ is cluster.parse_link_dict
+        d = {('a', 'b'): 0.5, ('a', 'c'): 1.5}
+        grp = {'a': 'g1', 'b': 'g1', 'c': 'ungrouped'}
+        got = R.parse_link_dict(dict(d), grp)                      # float links: the original function, through the seam
+        want = saved['parse_link_dict'](dict(d), grp)
+        assert {k: dict(v) for k, v in got[0].items()} == {k: dict(v) for k, v in want[0].items()} and got[1] == want[1]
+    finally:
+        R.parse_link_dict = saved['parse_link_dict']
