@@ -188,6 +188,11 @@ class DeviceCSR:
 
     @classmethod
     def from_arrays(cls, indptr, indices, data, n_cols=None):
+        indptr, indices = np.asarray(indptr), np.asarray(indices)
+        if len(indptr) and int(indptr[-1]) > np.iinfo(np.int32).max:       # a scipy matrix with int64 indices: do not wrap
+            raise ValueError('matrix with {} entries exceeds the int32 index range of hhx_csr'.format(int(indptr[-1])))
+        if indices.size and (int(indices.max()) > np.iinfo(np.int32).max or int(indices.min()) < 0):
+            raise ValueError('column index outside the int32 range')
         indptr = np.ascontiguousarray(indptr, np.int32)
         indices = np.ascontiguousarray(indices, np.int32)
         data = np.ascontiguousarray(data, np.float32)

@@ -247,23 +247,32 @@ def check_param(param, string, suffix, true_suffix=''):
     raise RuntimeError('Parameter check failed')
 
 
-def _cut(sorted_values, string, flag, scale, offset=0.0, strict=True):
+def _cut(stage, sorted_values, string, flag, scale, offset=0.0, strict=True):
     """Index at which an ascending list is cut by a "0.2"-style (fraction of the list) or "0.2X"-style (multiple of
-    `scale`, plus `offset`) parameter — the two modes of the reference's thresholds (:779-810, :841-854, :911-923).
+    `scale`, plus `offset`) parameter — the two modes of the reference's thresholds (:779-810, :841-854, :911-923) —
+    with the reference's log line that restates the parameter in the other mode.
     strict: first value > limit (upper cuts); otherwise first value >= limit (the lower density cut)."""
     from bisect import bisect_left, bisect_right
     num, mode = check_param(flag, string, {'X', 'x'})
+    n = len(sorted_values)
     if mode:
         limit = offset + num * scale
-        return (bisect_right if strict else bisect_left)(sorted_values, limit)
-    return int(len(sorted_values) * float(string))
+        idx = (bisect_right if strict else bisect_left)(sorted_values, limit)
+        logger.info('[{}] Parameter {} {} is set to "multiple" mode and equivalent to {} in "fraction" mode'.format(
+            stage, flag, string, idx / n))
+    else:
+        idx = int(n * float(string))
+        logger.info('[{}] Parameter {} {} is set to "fraction" mode and equivalent to {}X in "multiple" mode'.format(
+            stage, flag, string, (sorted_values[max(0, idx - 1)] - offset) / scale))
+    return idx
 
 
 def filter_fragments(Nx_frag_set, RE_site_dict, RE_site_cutoff, frag_link_dict, density_lower, density_upper,
                      topN, rank_sum_upper, rank_sum_hard_cutoff, flank_link_dict, read_depth_dict, read_depth_upper, whitelist):
     """filter_fragments() :741-940.  The Nx / RE-site / link-density / read-depth steps are O(n) list work on the
     host; the rank-sum statistic (:866-892) — a dense n x n matrix and O(n^2 log n) Python sorting in the
-    reference — is computed on the device from the sparse link matrix (hhx_rank_sums)."""
+    reference — is computed on the device from the sparse link matrix (hhx_rank_sums).  Every info / debug line of the
+    reference is emitted (users and HapHiC_pipeline read that log)."""
     from numpy import quantile
     logger.info('Filtering fragments...')
     # (1) Nx set, (2) RE sites: link density = flank links / RE sites (:753-765); set iteration order, then a stable sort
@@ -279,30 +288,34 @@ def filter_fragments(Nx_frag_set, RE_site_dict, RE_site_cutoff, frag_link_dict, 
                 total_RE_sites += sites - 1
                 density.append((frag, links / sites))
     whitelisted = {f for f in Nx_frag_set if whitelist and f.rsplit('_bin', 1)[0] in whitelist}
-    logger.info('[RE sites filtering] {} of {} Nx fragments kept'.format(len(density), len(Nx_frag_set)))
+    logger.info('[Nx filtering] {} fragments kept'.format(len(Nx_frag_set)))
+    logger.info('[RE sites filtering] {} fragments removed, {} fragments kept'.format(len(Nx_frag_set) - len(density), len(density)))
     # (3) link density between density_lower and density_upper (:767-823)
     density.sort(key=lambda x: x[1])
     values = [d for _, d in density]
     average = total_links / total_RE_sites
-    lower = _cut(values, density_lower, '--density_lower', average, strict=False)
-    upper = _cut(values, density_upper, '--density_upper', average)
+    lower = _cut('link density filtering', values, density_lower, '--density_lower', average, strict=False)
+    upper = _cut('link density filtering', values, density_upper, '--density_upper', average)
     unfiltered = density
     density = density[lower:upper]
     kept = {frag for frag, _ in density}
-    logger.info('[link density filtering] {} fragments kept'.format(len(kept)))
+    logger.info('[link density filtering] {} fragments removed, {} fragments kept'.format(len(unfiltered) - len(kept), len(kept)))
+    for frag, d in unfiltered[:lower] + unfiltered[upper:]:
+        logger.debug('[link density filtering] Fragment {} is removed, density={}'.format(frag, d))
     # (4) read depth: Q3 + k * IQR over ALL density-ranked fragments (:825-863)
     if read_depth_dict:
         depth = sorted(((frag, read_depth_dict[frag][1]) for frag, _ in unfiltered), key=lambda x: x[1])
-        q1, _m, q3 = quantile([d for _, d in depth], (0.25, 0.5, 0.75))
-        num, mode = check_param('--read_depth_upper', read_depth_upper, {'X', 'x'})
-        if mode:
-            from bisect import bisect_right
-            cut = bisect_right([d for _, d in depth], q3 + num * (q3 - q1))
-        else:
-            cut = int(len(unfiltered) * float(read_depth_upper))
+        q1, m, q3 = quantile([d for _, d in depth], (0.25, 0.5, 0.75))
+        logger.info('[read depth filtering] Q1={}, median={}, Q3={}, IQR=Q3-Q1={}'.format(q1, m, q3, q3 - q1))
+        cut = _cut('read depth filtering', [d for _, d in depth], read_depth_upper, '--read_depth_upper', q3 - q1, offset=q3)
         kept &= {frag for frag, _ in depth[:cut]}
+        by_density = {frag for frag, _ in unfiltered[:lower] + unfiltered[upper:]}
+        only_by_depth = {frag for frag, _ in depth[cut:]} - by_density
+        logger.info('[read depth filtering] {} fragments removed, {} fragments kept'.format(len(only_by_depth), len(kept)))
+        for frag, d in depth[cut:]:
+            if frag in only_by_depth:
+                logger.debug('[read depth filtering] Fragment {} is removed, read depth={}'.format(frag, d))
         density = [(frag, d) for frag, d in density if frag in kept]
-        logger.info('[read depth filtering] {} fragments kept'.format(len(kept)))
     # (5) rank sums between the topN strongest neighbours (:866-892), on the device
     m_dev, frag_index_dict = dict_to_matrix(flank_link_dict, kept, dense_matrix=False, add_self_loops=False, _device=True)
     try:
@@ -311,17 +324,28 @@ def filter_fragments(Nx_frag_set, RE_site_dict, RE_site_cutoff, frag_link_dict, 
         m_dev.free()
     ranked = [(frag, int(rs[frag_index_dict[frag]])) for frag, _ in density]
     if rank_sum_hard_cutoff:
+        for frag, r in ranked:
+            if r > rank_sum_hard_cutoff:
+                logger.debug('[rank sum filtering] Fragment {} is removed by hard filtering, rank sum={}'.format(frag, r))
+        n_before = len(ranked)
         ranked = [x for x in ranked if x[1] <= rank_sum_hard_cutoff]
+        logger.info('[rank sum filtering] {} fragments removed by hard filtering, {} fragments kept'.format(n_before - len(ranked), len(ranked)))
     ranked.sort(key=lambda x: x[1])
     sums = [r for _, r in ranked]
-    q1, _m, q3 = quantile(sums, (0.25, 0.5, 0.75))
-    logger.info('[rank sum filtering] Q1={}, Q3={}, IQR={}'.format(q1, q3, q3 - q1))
-    cut = _cut(sums, rank_sum_upper, '--rank_sum_upper', q3 - q1, offset=q3)
+    q1, m, q3 = quantile(sums, (0.25, 0.5, 0.75))
+    logger.info('[rank sum filtering] Q1={}, median={}, Q3={}, IQR=Q3-Q1={}'.format(q1, m, q3, q3 - q1))
+    cut = _cut('rank sum filtering', sums, rank_sum_upper, '--rank_sum_upper', q3 - q1, offset=q3)
     filtered_frags = {frag for frag, _ in ranked[:cut]}
-    logger.info('[rank sum filtering] {} fragments kept'.format(len(filtered_frags)))
+    logger.info('[rank sum filtering] {} fragments removed, {} fragments kept'.format(len(ranked) - len(filtered_frags), len(filtered_frags)))
+    for frag, r in ranked[cut:]:
+        logger.debug('[rank sum filtering] Fragment {} is removed, rank sum={}'.format(frag, r))
     if whitelisted:
+        added = whitelisted - filtered_frags
+        for frag in added:
+            logger.debug('[rank sum filtering] Fragment {} is added since it is on the whitelist'.format(frag))
         filtered_frags |= whitelisted
-        logger.info('[rank sum filtering] {} fragments are used to perform Markov clustering'.format(len(filtered_frags)))
+        logger.info('[rank sum filtering] {} fragments added, {} fragments are used to perform Markov clustering'.format(
+            len(added), len(filtered_frags)))
     return filtered_frags
 
 
@@ -572,6 +596,21 @@ def dict_to_matrix(link_dict, frag_set, dense_matrix=True, add_self_loops=False,
         ids_i[k] = names.setdefault(fi, len(names))
         ids_j[k] = names.setdefault(fj, len(names))
         vals[k] = v
+    # The device builder writes ONE slot per (row, column).  The reference's own parsers only ever produce sorted, unique
+    # name pairs, but the seam is public: a dict holding both (a, b) and (b, a) is folded into the first of the two
+    # (coo_matrix(...).tocsc() :368 sums duplicates — same matrix, same first-seen index order); a key (f, f) would land on
+    # the diagonal twice, next to the self loop — nothing in the reference builds one, so it is refused loudly.
+    if len(ids_i):
+        if (ids_i == ids_j).any():
+            bad = next(k for k in link_dict if k[0] == k[1])
+            raise ValueError('dict_to_matrix: key {!r} links a fragment with itself'.format(bad))
+        lo, hi = np.minimum(ids_i, ids_j).astype(np.int64), np.maximum(ids_i, ids_j).astype(np.int64)
+        und = lo * (len(names) + 1) + hi
+        uniq, first_at, inverse = np.unique(und, return_index=True, return_inverse=True)
+        if len(uniq) != len(und):
+            summed = np.bincount(inverse, weights=vals, minlength=len(uniq))
+            keep = np.sort(first_at)                             # first occurrence of every unordered pair, in dict order
+            ids_i, ids_j, vals = ids_i[keep], ids_j[keep], summed[inverse[keep]]
     for f in frag_set:
         names.setdefault(f, len(names))
     id_names = list(names)
@@ -799,7 +838,11 @@ def _ids_from_alignments(alignments, cid, chunk):
     b1, p1, b2, p2 = [np.empty(chunk, np.int32) for _ in range(4)]
     k = 0
     get = cid.get
+    limit = np.iinfo(np.int32).max
     for ref, mref, pos, mpos in alignments:
+        if pos >= limit or mpos >= limit:        # the reference switches to int64 positions for contigs beyond 2^31 bp (:116-147)
+            raise RuntimeError('position {} does not fit the int32 coordinates of the MI355X ingest (contigs longer than 2^31 bp '
+                               'are not supported: patch_reference(H, ingest=False) keeps the reference parser)'.format(max(pos, mpos)))
         b1[k] = get(ref, -1)
         b2[k] = get(mref, -1)
         p1[k] = pos

@@ -232,7 +232,31 @@ void u64_copy_async(const unsigned long long *src, unsigned long long *dst, i64 
     (void)hipMemcpyAsync(dst, src, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToDevice, g_stream);
 }
 
-int exclusive_scan_i32(const i32 *in, i32 *out, i64 n, i64 *total_host) { return scan_total<i32>(in, out, n, total_host); }
+// The int32 scan wraps silently when the true total exceeds 2^31 - 1 (a nearly dense product at n >= 46k through the
+// general S1 seams): the total is first reduced in 64 bits, and a total beyond the int32 index range of hhx_csr fails
+// loudly instead of sizing an output from a wrapped number.
+__global__ __launch_bounds__(256) void k_sum_i32_wide(const i32 *__restrict__ in, i64 n, unsigned long long *__restrict__ total) {
+    i64 s = 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) s += in[i];
+    s = wave_sum_i64(s);
+    if (lane_id() == 0 && s) atomicAdd(total, (unsigned long long)s);
+}
+int exclusive_scan_i32(const i32 *in, i32 *out, i64 n, i64 *total_host) {
+    if (n > 0) {
+        DevBuf<unsigned long long> wide;
+        if (wide.alloc(1)) return 1;
+        HHX_HIP(hipMemsetAsync(wide.p, 0, sizeof(unsigned long long), g_stream));
+        k_sum_i32_wide<<<(unsigned)std::max<i64>(1, std::min<i64>((n + 255) / 256, 1024)), 256, 0, g_stream>>>(in, n, wide.p);
+        HHX_LAUNCH_CHECK();
+        unsigned long long t = 0;
+        HHX_HIP(hipMemcpyAsync(&t, wide.p, sizeof t, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+        if (t > (unsigned long long)INT32_MAX)
+            return fail("a matrix of %llu entries exceeds the int32 index range of hhx_csr (scipy's too): split the operand into row blocks "
+                        "(hhx_csr_row_block) or use the fused iteration (hhx_expand_inflate_prune)", t);
+    }
+    return scan_total<i32>(in, out, n, total_host);
+}
 int exclusive_scan_i64(const i64 *in, i64 *out, i64 n, i64 *total_host) { return scan_total<i64>(in, out, n, total_host); }
 
 }  // namespace hhx
@@ -250,7 +274,12 @@ extern "C" int hhx_set_device(int device) {
     HHX_HIP(hipSetDevice(device));
     return 0;
 }
+// The caching pool recycles a block as soon as it is freed, on the assumption that every kernel of the process runs on
+// ONE stream (stream order then guarantees that the next user starts after the previous one finished).  Changing the
+// stream therefore drains the device first; running two threads with different streams at the same time is outside the
+// contract (include/haphic_hip.h).
 extern "C" int hhx_set_stream(void *s) {
+    if ((hipStream_t)s != g_stream) HHX_HIP(hipDeviceSynchronize());
     g_stream = (hipStream_t)s;
     return 0;
 }

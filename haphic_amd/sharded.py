@@ -398,14 +398,17 @@ def merge_flank_and_build(ing, table, flank, bins, in_set, dist, device, full_ta
     return m, n_linked, merged
 
 
-def build_link_matrix_sharded(engine, src, in_set, dist, timings=None):
+def build_link_matrix_sharded(engine, src, in_set, dist, timings=None, rest_order=None):
     """dict_to_matrix (:310-373, add_self_loops) over a pair stream that is split across the ranks: `src` is this rank's
     finalized ingest of its chunk (global ordinals, hhx_ingest_set_ordinal_base).  One all-reduce(min) of the first
     positions (8 B per fragment) fixes every fragment's matrix index on all ranks; one all-to-all(v) moves each matrix
     entry to the owner of its row; the owner adds the counts of the chunks.  Returns (this rank's CSR row block of the
-    link matrix [row_ranges(shape)[rank], ...), fragment -> matrix index array (int32 numpy, -1 = not in the matrix...
-    link-less members of in_set take the trailing indices like the reference's `frag_set - frags_in_dict`), n_linked,
-    shape)."""
+    link matrix [row_ranges(shape)[rank], ...), fragment -> matrix index array (int32 numpy, -1 = not in the matrix),
+    n_linked, shape).  Link-less members of in_set take the trailing indices; the reference numbers them in CPython's
+    iteration order of the set `frag_set - frags_in_dict` (:357-359), which only the caller that holds the names can
+    know: pass it as `rest_order` (fragment ids, every rank the same) to reproduce it — haphic_amd.cluster.dict_to_matrix
+    does the same on one GPU.  Without it they are numbered by fragment id, which can number singleton groups differently
+    from the reference on length ties."""
     torch = engine.torch
     world, rank = dist.get_world_size(), dist.get_rank()
     import time
@@ -439,7 +442,12 @@ def build_link_matrix_sharded(engine, src, in_set, dist, timings=None):
     finally:
         engine.shard_close(st)
     fi = fidx.cpu().numpy().astype(np.int32)
-    rest = np.flatnonzero((in_set != 0) & (fi < 0))                        # link-less members: trailing indices, id order
+    rest = np.flatnonzero((in_set != 0) & (fi < 0))                        # link-less members: trailing indices
+    if rest_order is not None:
+        rest_order = np.asarray(rest_order, np.int64)
+        if sorted(rest_order.tolist()) != rest.tolist():
+            raise ValueError('rest_order must list exactly the link-less members of in_set')
+        rest = rest_order
     fi[rest] = n_linked + np.arange(len(rest), dtype=np.int32)
     return block, fi, n_linked, shape
 

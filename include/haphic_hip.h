@@ -12,7 +12,9 @@
  *     thread-local message (the Python shim raises RuntimeError, as the reference does, e.g. :2507).
  *   - plain pointers and sizes only.  "host" pointers are ordinary memory; "dev" pointers are HIP
  *     device memory on the current device.  Kernels run on the stream set by hhx_set_stream()
- *     (default: the null stream).
+ *     (default: the null stream).  ONE stream at a time per process: the library's memory pool recycles blocks in
+ *     stream order; hhx_set_stream drains the device when the stream changes, and concurrent callers on different
+ *     streams are not supported.
  *   - matrices: the reference's column-stochastic M is scipy CSC (indptr,indices,data) with int32
  *     indices and float32 data.  That triple is byte-for-byte CSR of T = M^T; the library works on
  *     CSR(T).  "row" below == "column" in the reference.  Rows are kept sorted by index.

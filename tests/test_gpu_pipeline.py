@@ -463,8 +463,8 @@ def test_link_weights_a6():
     """a6: normalize_by_nlinks :718-724, normalize_by_length :727-738, reduce_inter_hap_HiC_links :695-707 — the device
     kernel on arrays and the dict mirrors of haphic_amd/cluster.py against what the reference's own functions did to
     the same dict (tests/golden/weights.npz).  float64 values: length / haplotype modes bit exact; the nlinks mode
-    is Python's `** 0.5` (C pow) against an IEEE square root: one ulp of float64 is allowed, all but a handful of values
-    must be bit equal (the matrix is float32, :368: compared at 1e-6)."""
+    is Python's `** 0.5` (C pow) against the device square root + division: two ulp of float64 are allowed (measured: 2 of
+    6000 values differ, by one ulp each side), 99 % must be bit equal (the matrix is float32, :368: compared at 1e-6)."""
     from collections import defaultdict
     from haphic_amd import _lib, cluster
     from tests.conftest import load_golden
@@ -474,7 +474,7 @@ def test_link_weights_a6():
     names = ['ctg%04d' % k for k in range(n_frag)]
     v = cnt.astype(np.float64)
     _lib.link_weights(fi, fj, v, 0, n_frag, per_frag=g['links'])
-    np.testing.assert_allclose(v, g['nlinks'], rtol=2.3e-16, atol=0)
+    np.testing.assert_allclose(v, g['nlinks'], rtol=4.5e-16, atol=0)
     assert (v != g['nlinks']).mean() < 0.01
     v = cnt.astype(np.float64)
     _lib.link_weights(fi, fj, v, 1, n_frag, per_frag=g['length'], param=2000 * int(g['flank_kb']))
@@ -505,7 +505,7 @@ def test_link_weights_a6():
     assert list(d.values()) == g['by_length'].tolist() and all(isinstance(x, float) for x in d.values())
     d = as_dict()
     cluster.normalize_by_nlinks(d, {names[k]: int(g['links'][k]) for k in range(n_frag)})
-    np.testing.assert_allclose(list(d.values()), g['nlinks'], rtol=2.3e-16, atol=0)
+    np.testing.assert_allclose(list(d.values()), g['nlinks'], rtol=4.5e-16, atol=0)
     m, fidx = cluster.dict_to_matrix(d, set(names), dense_matrix=False, add_self_loops=True)        # :2895 then :2934
     m.sort_indices()
     assert [fidx[nm] for nm in names] == g['nl_fidx'].tolist()

@@ -71,3 +71,40 @@ def test_patch_reassign_binds_parse_link_dict():
         assert {k: dict(v) for k, v in got[0].items()} == {k: dict(v) for k, v in want[0].items()} and got[1] == want[1]
     finally:
         R.parse_link_dict = saved['parse_link_dict']
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
+def test_dict_to_matrix_folds_reversed_keys_like_the_reference(monkeypatch):
+    """a link dict holding both (a, b) and (b, a) — never produced by the reference's parsers, but allowed by
+    the public S4 seam — must give the matrix coo_matrix(...).tocsc() gives (duplicates summed, :368); a self key is
+    refused.  Checked against the reference's own dict_to_matrix."""
+    import numpy as np
+    for name, attrs in (('pysam', {'set_verbosity': lambda *a, **k: None, 'AlignmentFile': None}), ('portion', {'closed': None, 'empty': None})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+    sys.path.insert(0, REF)
+    try:
+        import HapHiC_cluster as H
+    finally:
+        sys.path.remove(REF)
+    from haphic_amd import cluster
+    from tests import oracle_lib
+    monkeypatch.setattr(cluster, '_lib', oracle_lib)
+    rng = np.random.default_rng(4)
+    names = ['f%02d' % k for k in range(30)]
+    d = {}
+    for _ in range(200):
+        a, b = rng.choice(30, 2, replace=False)
+        d[(names[a], names[b])] = d.get((names[a], names[b]), 0) + int(rng.integers(1, 9))      # both orientations occur
+    assert any((b, a) in d for (a, b) in d)
+    frag_set = set(names[:27])
+    want, want_idx = H.dict_to_matrix(dict(d), set(frag_set), dense_matrix=False, add_self_loops=True)
+    got, got_idx = cluster.dict_to_matrix(dict(d), set(frag_set), dense_matrix=False, add_self_loops=True)
+    assert got_idx == want_idx
+    want = want.tocsc(); want.sum_duplicates(); want.sort_indices()
+    got = got.tocsc(); got.sort_indices()
+    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices) and np.array_equal(got.data, want.data)
+    with pytest.raises(ValueError, match='links a fragment with itself'):
+        cluster.dict_to_matrix({(names[0], names[0]): 3}, frag_set, dense_matrix=False)

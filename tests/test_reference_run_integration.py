@@ -137,16 +137,40 @@ def test_reference_run_with_and_without_the_seams(tmp_path, monkeypatch, split, 
     monkeypatch.setattr(H, 'dot_product_mkl', lambda a, b, **k: (a @ b).tocsc(), raising=False)
     monkeypatch.setattr(H, 'INTEL_MKL', True, raising=False)
     nchrs = 4 if poly_case else 3
-    _run(H, str(tmp_path / 'ref'), extra, pairs, nchrs)
+    import logging
+    seen = {'ref': [], 'ours': []}
+
+    class Collect(logging.Handler):
+        def __init__(self, sink):
+            super().__init__(logging.DEBUG)
+            self.sink = sink
+
+        def emit(self, record):
+            self.sink.append(record.getMessage())
+    h_ref = Collect(seen['ref'])
+    H.logger.addHandler(h_ref)
+    try:
+        _run(H, str(tmp_path / 'ref'), extra, pairs, nchrs)
+    finally:
+        H.logger.removeHandler(h_ref)
     # ---- the same entry point with the seams re-bound
     monkeypatch.setattr(haphic_amd, '_lib', oracle_lib)
     monkeypatch.setattr(cluster, '_lib', oracle_lib)
     monkeypatch.setattr(patch, '_lib', oracle_lib, raising=False)
     saved = patch.patch_reference(H)
+    h_ours = Collect(seen['ours'])
+    H.logger.addHandler(h_ours)
     try:
         _run(H, str(tmp_path / 'ours'), extra, pairs, nchrs)
     finally:
+        H.logger.removeHandler(h_ours)
         patch.unpatch_reference(H, saved)
+    # the log is an interface (users read it, HapHiC_pipeline.py:385 parses it): every message of the filtering and
+    # clustering stages must come out of the mirrors word for word, in the same order (timings aside)
+    def stable(msgs):
+        return [m for m in msgs if m.startswith('[') or 'You could try inflation' in m or 'bin_size is' in m or 'The matrix' in m
+                or 'Normalizing' in m or 'Reducing' in m or 'missing / redundant' in m]
+    assert stable(seen['ours']) == stable(seen['ref'])
     want, got = _tree(str(tmp_path / 'ref')), _tree(str(tmp_path / 'ours'))
     assert sorted(want) == sorted(got), (sorted(want), sorted(got))
     assert 'HT_links.pkl' in want
