@@ -46,7 +46,8 @@ def parse():
     ap.add_argument('--force-sharded', action='store_true', help='take the multi-GPU code path on one rank (1-rank nccl group)')
     ap.add_argument('--cpu-sample-pairs', type=int, default=20_000_000)
     ap.add_argument('--text-lines', type=int, default=1_000_000, help='a1 leg: lines of .pairs text formatted on the host (0 = skip)')
-    ap.add_argument('--text-file-tile', type=int, default=8, help='a1 leg: copies of that text written to the .pairs file of the end-to-end figure')
+    ap.add_argument('--text-file-tile', type=int, default=110, help='a1 leg: copies of that text written to the .pairs file of the end-to-end figure (110 x 96 MB = a 10.6 GB file; reduced automatically when the temporary directory is short of space)')
+    ap.add_argument('--no-parity', action='store_true', help='skip the oracle check of sampled rows of iteration 0')
     ap.add_argument('--text-tile', type=int, default=16, help='a1 leg: copies of that text concatenated in HBM')
     return ap.parse_args()
 
@@ -134,7 +135,10 @@ def main():
         t3 = time.perf_counter()
         state.update(t_ingest=t1 - t0, t_pre=t_pre, n_iter=n_iter, conv=conv, stats=stats, t_total=t3 - t0)
         res.free()
-        m.free()
+        if state.get('keep_matrix'):
+            state['matrix'] = m                      # the parity leg (after the timed region) re-uses the last link matrix
+        else:
+            m.free()
 
     def barrier():
         torch.cuda.synchronize()
@@ -150,7 +154,8 @@ def main():
     t0 = time.perf_counter()
     t_ing = t_mcl = t_pre = 0.0
     iters = 0
-    for _ in range(args.steps):
+    for k_step in range(args.steps):
+        state['keep_matrix'] = (k_step == args.steps - 1) and world == 1 and not sharded_path and not args.no_parity
         step()
         t_ing += state['t_ingest']; t_mcl += state['t_mcl']; t_pre += state['t_pre']; iters += state['n_iter']
     barrier()
@@ -243,6 +248,8 @@ def main():
             out['ingest']['text'] = text_leg(args, gen, id1, p1, id2, p2, dev)
         if sharded_path:
             out['ingest']['sharded_build_ms_last_step'] = state.get('shard_ms')
+        if state.get('matrix') is not None:
+            out['parity'] = parity_leg(args, state.pop('matrix'))
         if not args.no_cpu_baseline and world == 1:          # a reported baseline of the N = 1 line only
             out['cpu_baseline'] = cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state)
         print(json.dumps(out))
@@ -288,14 +295,19 @@ def text_leg(args, gen, id1, p1, id2, p2, dev):
                        'peak': 8000.0, 'unit': 'GB/s'}
     res['roofline']['frac'] = res['roofline']['achieved'] / 8000.0
     # end to end from a FILE: .pairs text on disk (page cache) -> mmap -> device tokeniser -> group-by -> link matrix
+    import shutil
     import tempfile
     from haphic_amd import cluster
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, 'bench.pairs')
+        # the file + its alignments.bed (1.35 x the text) must fit the temporary directory with room to spare
+        room = shutil.disk_usage(td).free
+        tile = max(1, min(args.text_file_tile, int(room * 0.6 / (2.4 * len(raw)))))
         with open(path, 'wb') as f:
-            for _ in range(args.text_file_tile):
+            for _ in range(tile):
                 f.write(raw)
-        n_file = k * args.text_file_tile
+        n_file = k * tile
+        res['file_tile'] = tile
         tb = cluster.FragTable.for_contigs(gen.lexical_rank(), gen.length, np.ones(gen.n, np.uint8), names=names)
         for tag, bed_path in (('file_to_link_matrix', None), ('file_to_link_matrix_with_bed', os.path.join(td, 'alignments.bed'))):
             best = None
@@ -313,13 +325,48 @@ def text_leg(args, gen, id1, p1, id2, p2, dev):
                 mm.free()
                 ing.destroy()
                 best = dt if best is None else min(best, dt)
-            res[tag] = {'lines': n_file, 'file_bytes': len(raw) * args.text_file_tile, 'ms': best * 1e3, 'pairs_per_s': n_file / best,
-                        'text_GBs': len(raw) * args.text_file_tile / best / 1e9}
+            res[tag] = {'lines': n_file, 'file_bytes': len(raw) * tile, 'ms': best * 1e3, 'pairs_per_s': n_file / best,
+                        'text_GBs': len(raw) * tile / best / 1e9}
+            if bed_path:
+                res[tag]['bed_bytes'] = os.path.getsize(bed_path)
     out = ps.fetch()                                 # every tile must reproduce the sample it was formatted from
     for c in range(4):
         assert np.array_equal(out[c].reshape(args.text_tile, k), np.broadcast_to(h[c], (args.text_tile, k))), 'text leg mismatch'
     ps.destroy()
     return res
+
+
+def parity_leg(args, m, rows=64):
+    """Outside the timed region: iteration 0 of the MCL on the link matrix of the last step (the kernel instantiation the
+    roofline is quoted on) against the oracle — the C restatement of the reference's expand / inflate / prune in the
+    kernels' exact fixed-point specification — on `rows` sampled rows of the real operand.  Bit equality expected."""
+    from haphic_amd import _lib
+    from oracle import oracle as orc
+    orc.set_threads(0)                                   # all host cores: this is the checker, not the timed baseline
+    t0 = time.perf_counter()
+    one = _lib.mcl(m, 2, args.inflation, 1, 1e-4, links=True)[0]
+    gp, gj, gx = one.to_arrays()
+    one.free()
+    mp, mj, mx = m.to_arrays()
+    n = m.shape3[0]
+    m.free()
+    norm = orc.normalize_l1(mp, mx)
+    pick_rows = np.sort(np.random.default_rng(5).choice(n, min(rows, n), replace=False))
+    sub_p = np.zeros(len(pick_rows) + 1, np.int32)
+    sub_p[1:] = np.cumsum(mp[pick_rows + 1] - mp[pick_rows])
+    take = np.concatenate([np.arange(mp[r], mp[r + 1]) for r in pick_rows])
+    c = orc.spgemm((sub_p, mj[take], norm[take]), (mp, mj, norm), n_cols=n, mode=1, fx_shift=52)
+    x = orc.normalize_l1(c[0], orc.power(c[2], args.inflation))
+    want = orc.prune((c[0], c[1], x), 1e-4)
+    bad = 0
+    for k, r in enumerate(pick_rows):
+        lo, hi, wl, wh = gp[r], gp[r + 1], want[0][k], want[0][k + 1]
+        if not (np.array_equal(gj[lo:hi], want[1][wl:wh]) and np.array_equal(gx[lo:hi], want[2][wl:wh])):
+            bad += 1
+    return {'what': 'iteration 0 (fused pre-expansion + inflate + prune, class stream) vs oracle, sampled rows of the real operand',
+            'rows_checked': int(len(pick_rows)), 'rows_differing': int(bad), 'bit_identical': bad == 0, 'products_checked': int(c[0][-1] and np.diff(mp)[mj[take]].sum()),
+            'oracle_threads': orc.get_threads(), 'seconds': time.perf_counter() - t0,
+            'full_size_tests': 'tests/test_gpu_scale.py: C2 whole mcl() bit equal, C3 256 rows + 20 M-pair ingest prefix, C4 40k-contig containers'}
 
 
 def pmc_traffic(n_contigs, pairs):
@@ -337,11 +384,9 @@ def pmc_traffic(n_contigs, pairs):
 
 
 def pick(traffic, *needles):
-    """bytes per launch of the profiled kernel whose name contains every needle"""
-    for name, v in traffic.items():
-        if all(x in name for x in needles):
-            return v
-    return None
+    """bytes per launch of the profiled kernel whose name contains every needle (the heaviest one if several do)"""
+    hits = [v for name, v in traffic.items() if all(x in name for x in needles)]
+    return max(hits) if hits else None
 
 
 def cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state):
@@ -383,7 +428,14 @@ def cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state):
     t2 = time.perf_counter()
     orc.parse_pairs_text(text, names)
     dtok = time.perf_counter() - t2
-    return {'value': S / dt, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
+    ref_py = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r02_reference_python_baseline.json')) as f:
+            ref_py = json.load(f)
+        ref_py['measured_where'] = 'dev container (the reference checkout does not exist on the GPU box): tools/reference_cpu_baseline.py'
+    except (OSError, ValueError):
+        pass
+    return {'value': S / dt, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port', 'reference_python': ref_py,
             'sample': 'ingest: first %d pairs of the rank-0 shard through the C oracle (hash-map port of '
                       'parse_alignments_for_ctgs); mcl: oracle mcl() on the %d-contig sub-assembly (first quarter '
                       'of the chromosomes) built from those pairs' % (S, nq),

@@ -96,6 +96,7 @@ SIGNATURES = {
     'hhx_pairs_parse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, c_i64p, c_i64p]),
     'hhx_pairs_parser_arrays': (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5),
     'hhx_pairs_parser_fetch': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
+    'hhx_pairs_parser_bed_host': (C.c_int, [C.c_void_p, c_vpp, c_i64p]),
     'hhx_pairs_parser_destroy': (C.c_int, [C.c_void_p]),
     'hhx_bam_open': (C.c_int, [C.c_char_p, C.c_int, c_vpp]),
     'hhx_bam_header': (C.c_int, [C.c_void_p, c_i32p, C.POINTER(C.c_char_p), c_i64p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
@@ -535,6 +536,15 @@ class PairsParser:
         bed = np.empty(self.bed_bytes if want_bed else 0, np.uint8)
         check(load().hhx_pairs_parser_fetch(self.h, *[ptr(a) for a in out], ptr(bed) if bed.size else None))
         return out + [bed.tobytes()]
+
+    def bed_host(self):
+        """the alignments.bed bytes of the last parse as a uint8 VIEW of pinned memory owned by the parser (valid until the
+        second following call)"""
+        host, n = C.c_void_p(), C.c_int64(0)
+        check(load().hhx_pairs_parser_bed_host(self.h, C.byref(host), C.byref(n)))
+        if not n.value:
+            return np.zeros(0, np.uint8)
+        return np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_uint8)), (n.value,))
 
     def fetch_bed(self):
         """the alignments.bed bytes of the last parse (uint8 array)"""

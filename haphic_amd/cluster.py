@@ -641,16 +641,22 @@ def dict_to_matrix(link_dict, frag_set, dense_matrix=True, add_self_loops=False,
 
 
 # ------------------------------------------------------------------ a1: .pairs text
+def _pwrite_all(fd, view, offset):
+    while len(view):
+        k = os.pwrite(fd, view, offset)
+        view, offset = view[k:], offset + k
+
+
 class PairsText:
     """What pairs_generator / pairs_generator_inter_ctgs (:1539-1583) return here: the .pairs file, tokenised on the
     device one chunk of whole lines at a time (hhx_pairs_parse).  parse_alignments* take it as is and push the
     device arrays straight into the ingest; iterating it yields the reference's (ref, mref, pos, mpos) tuples for
     any other consumer.  alignments.bed is written in the working directory as the reference does (:1549)."""
 
-    def __init__(self, pairs, aln_format, inter_only, chunk_bytes=256 << 20, bed_path='alignments.bed'):
+    def __init__(self, pairs, aln_format, inter_only, chunk_bytes=256 << 20, bed_path='alignments.bed', bed_writers=8):
         assert aln_format in ('pairs', 'bgzipped_pairs')
         self.path, self.aln_format, self.inter_only = pairs, aln_format, inter_only
-        self.chunk_bytes, self.bed_path = chunk_bytes, bed_path
+        self.chunk_bytes, self.bed_path, self.bed_writers = chunk_bytes, bed_path, bed_writers
 
     def _chunks(self):
         """byte chunks holding whole lines (cut after the last '\n'; the tail of the file goes as it is).  A plain
@@ -698,46 +704,39 @@ class PairsText:
                 yield carry
 
     def batches(self, names):
-        """per chunk: (parser, n_lines) with the id / position arrays of the chunk on the device; the BED bytes of
-        the chunk go to alignments.bed through a writer thread while the next chunk is parsed"""
-        import queue
-        import threading
+        """per chunk: (parser, n_lines) with the id / position arrays of the chunk on the device.  The BED bytes of the
+        chunk come back through the parser's pinned double buffer (PCIe rate) and are written to alignments.bed by a
+        pool of threads, each with its own pwrite() at its own offset of the file, while the next chunk is parsed:
+        the reference writes alignments.bed inside its generator loop (:1549-1557), so this is part of the a1 cost."""
+        from concurrent.futures import ThreadPoolExecutor, wait
         parser = _lib.PairsParser(names)
-        fbed = open(self.bed_path, 'wb') if self.bed_path else None
-        todo = queue.Queue(maxsize=2)
-        failed = []
+        fd = os.open(self.bed_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644) if self.bed_path else None
+        pool = ThreadPoolExecutor(self.bed_writers) if fd is not None else None
+        pending = []                                             # [futures of chunk k - 1, futures of chunk k]
+        offset = 0
+        piece = 8 << 20
 
-        def writer():
-            while True:
-                buf = todo.get()
-                if buf is None:
-                    return
-                try:
-                    if not failed:
-                        fbed.write(memoryview(buf))
-                except Exception as e:                           # surfaced on the caller's thread below
-                    failed.append(e)
-        th = threading.Thread(target=writer, daemon=True) if fbed is not None else None
-        if th:
-            th.start()
+        def drain(keep):
+            while len(pending) > keep:
+                for f in wait(pending.pop(0)).done:
+                    f.result()                                   # a failed write surfaces on the caller's thread
         try:
             for chunk in self._chunks():
-                n = parser.parse(chunk, want_bed=fbed is not None)
+                n = parser.parse(chunk, want_bed=fd is not None)
                 del chunk
-                if fbed is not None and parser.bed_bytes:
-                    todo.put(parser.fetch_bed())
-                if failed:
-                    raise failed[0]
+                if fd is not None and parser.bed_bytes:
+                    drain(1)                                     # the buffer handed out two calls ago is free again
+                    buf = memoryview(parser.bed_host())
+                    pending.append([pool.submit(_pwrite_all, fd, buf[a:a + piece], offset + a) for a in range(0, len(buf), piece)])
+                    offset += len(buf)
                 yield parser, n
+            drain(0)
         finally:
-            if th:
-                todo.put(None)
-                th.join()
-            if fbed is not None:
-                fbed.close()
+            if pool is not None:
+                pool.shutdown(wait=True)
+            if fd is not None:
+                os.close(fd)
             parser.destroy()
-        if failed:
-            raise failed[0]
 
     def __iter__(self):
         # name tuples would mean tokenising on the host; patch_reference binds these generators only together with S5

@@ -37,6 +37,15 @@ struct hhx_pairs_parser {
     DevBuf<i32> id1, pos1, id2, pos2;
     DevBuf<unsigned long long> err;
     i64 n_lines = 0, bed_bytes = 0, lines_before = 0;
+    // alignments.bed leaves through two pinned host buffers used in turn (hhx_pairs_parser_bed_host): the device -> host copy
+    // runs at PCIe rate, and the caller's writer threads empty buffer k while chunk k + 1 is tokenised
+    unsigned char *pin[2] = {nullptr, nullptr};
+    size_t pin_cap[2] = {0, 0};
+    int pin_next = 0;
+    ~hhx_pairs_parser() {
+        for (int k = 0; k < 2; ++k)
+            if (pin[k]) (void)hipHostFree(pin[k]);
+    }
 };
 
 namespace {
@@ -541,6 +550,26 @@ extern "C" int hhx_pairs_parser_arrays(hhx_pairs_parser *p, void **id1, void **p
     if (id2) *id2 = p->id2.p;
     if (pos2) *pos2 = p->pos2.p;
     if (bed) *bed = p->bed.p;
+    return 0;
+}
+
+extern "C" int hhx_pairs_parser_bed_host(hhx_pairs_parser *p, void **host, i64 *n_bytes) {
+    if (!p || !host || !n_bytes) return fail("null pointer");
+    const int k = p->pin_next;
+    p->pin_next ^= 1;
+    const size_t n = (size_t)p->bed_bytes;
+    if (n > p->pin_cap[k]) {
+        if (p->pin[k]) (void)hipHostFree(p->pin[k]);
+        p->pin[k] = nullptr;
+        p->pin_cap[k] = n + n / 4 + 4096;
+        HHX_HIP(hipHostMalloc((void **)&p->pin[k], p->pin_cap[k], hipHostMallocDefault));
+    }
+    if (n) {
+        HHX_HIP(hipMemcpyAsync(p->pin[k], p->bed.p, n, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+    }
+    *host = p->pin[k];
+    *n_bytes = (i64)n;
     return 0;
 }
 

@@ -295,6 +295,9 @@ int hhx_pairs_parse(hhx_pairs_parser *p, const uint8_t *text, int64_t n_bytes, i
                     int64_t *n_lines, int64_t *bed_bytes);
 int hhx_pairs_parser_arrays(hhx_pairs_parser *p, void **id1, void **pos1, void **id2, void **pos2, void **bed);
 int hhx_pairs_parser_fetch(hhx_pairs_parser *p, int32_t *id1, int32_t *pos1, int32_t *id2, int32_t *pos2, uint8_t *bed);
+/* the alignments.bed bytes of the last parse in pinned host memory owned by the parser: two buffers used in turn, so the
+ * pointer stays valid until the SECOND following call (the caller writes buffer k to the file while chunk k + 1 is parsed) */
+int hhx_pairs_parser_bed_host(hhx_pairs_parser *p, void **host, int64_t *n_bytes);
 int hhx_pairs_parser_destroy(hhx_pairs_parser *p);
 
 /* ------------------------------------------------------------------ f4: BAM front end

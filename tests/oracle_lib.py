@@ -176,6 +176,9 @@ class PairsParser:
     def fetch_bed(self):
         return np.frombuffer(self.bed, np.uint8)
 
+    def bed_host(self):
+        return np.frombuffer(self.bed, np.uint8)
+
     def destroy(self):
         pass
 

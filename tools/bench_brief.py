@@ -20,5 +20,16 @@ for line in open(sys.argv[1]):
     r = g['roofline']
     if r:
         print('  ingest roofline %s: %.0f GB/s (frac %.3f) launch %.2f ms, traffic %s' % (r['kernel'], r['achieved'], r['frac'], r['avg_launch_ms'], r['traffic']))
+    if 'parity' in d:
+        print('  parity', d['parity'])
+    t = g.get('text')
+    if t:
+        print('  text: parse %.2e pairs/s, with bed %.2e | file->matrix %.2e pairs/s (%.1f GB file), with alignments.bed %.2e pairs/s' % (
+            t['parse']['pairs_per_s'], t['parse_bed']['pairs_per_s'], t['file_to_link_matrix']['pairs_per_s'], t['file_to_link_matrix']['file_bytes'] / 1e9,
+            t['file_to_link_matrix_with_bed']['pairs_per_s']))
     if 'cpu_baseline' in d:
-        print('  cpu_baseline', d['cpu_baseline'])
+        c = dict(d['cpu_baseline'])
+        rp = c.pop('reference_python', None)
+        print('  cpu_baseline', c)
+        if rp:
+            print('  reference python: ingest %.0f pairs/s, mcl %.2f it/s at n=%d (%s cores of %s)' % (rp['ingest']['pairs_per_s'], rp['mcl']['iters_per_s'], rp['mcl']['n'], rp['cores_used'], rp['host_cpus']))

@@ -7,7 +7,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 C3="--contigs 100000 --pairs 500000000 --nchrs 24 --mean-len 30000"
 for what in "$@"; do
   case $what in
-    tests) timeout 900 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; grep -A8 "slowest" gpurun_out/pytest_gpu.log | head -9; tail -2 gpurun_out/pytest_gpu.log;;
+    tests) timeout 700 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; grep -A8 "slowest" gpurun_out/pytest_gpu.log | head -9; tail -2 gpurun_out/pytest_gpu.log;;
     c2) timeout 600 python bench.py --contigs 10000 --pairs 50000000 --nchrs 16 --mean-len 50000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_c2.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c2.log; python tools/bench_brief.py gpurun_out/bench_c2.log;;
     c3) timeout 900 python bench.py $C3 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/bench_c3.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3.log; grep "hhx expand" gpurun_out/bench_c3.log | head -3; python tools/bench_brief.py gpurun_out/bench_c3.log;;
     c3w) HHX_DEBUG=1 timeout 900 python bench.py $C3 --steps 1 --warmup 1 --no-cpu-baseline --text-lines 0 > gpurun_out/bench_c3w.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3w.log; grep "hhx expand" gpurun_out/bench_c3w.log | cut -c150-420 | tail -26 | head -4; python tools/bench_brief.py gpurun_out/bench_c3w.log | head -2;;
@@ -19,7 +19,7 @@ for l in open('gpurun_out/bench_text.log'):
     if l.startswith('{'): print(json.dumps(json.loads(l)['ingest'].get('text')))
 ";;
     pcie) timeout 600 python tools/pcie_rate.py 100000000 2>&1 | tail -4;;
-    full) timeout 1200 python bench.py > gpurun_out/bench_full.log 2>&1; echo "rc=$?" >> gpurun_out/bench_full.log; tail -c 6000 gpurun_out/bench_full.log;;
+    full) timeout 900 python bench.py > gpurun_out/bench_full.log 2>&1; echo "rc=$?" >> gpurun_out/bench_full.log; python tools/bench_brief.py gpurun_out/bench_full.log; tail -c 600 gpurun_out/bench_full.log | grep -v "^{";;
     prof) rm -rf gpurun_out/prof; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof.log 2>&1; echo "rc=$?" >> gpurun_out/prof.log; ls -R gpurun_out/prof | head; tail -2 gpurun_out/prof.log | cut -c1-400;;
     pmc:*) # pmc:NAME:COUNTER1,COUNTER2  -> one rocprofv3 --pmc pass of the default bench (1 step, no warmup)
         spec="${what#pmc:}"; name="${spec%%:*}"; ctrs="${spec#*:}"; rm -rf gpurun_out/pmc_$name
