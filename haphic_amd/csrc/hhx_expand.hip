@@ -41,14 +41,16 @@ constexpr int N_DUMMY = HHX_WAVE;   // window kernel: one scratch accumulator pe
 struct ExParams {
     const i32 *Ap, *Aj; const float *Ax;
     const i32 *Bp, *Bj; const float *Bx;
-    // window kernel operand stream.  Every (B row, column window) segment is described by one 16-byte record
-    // {b0, b1, b2, float bits of v}: entries [b0, b1) of the stream all hold the SAME value v and are streamed as
-    // 16-bit window-local columns alone (2 B per product: their product with a_ik is formed once per segment);
-    // entries [b1, b2) are (16-bit column, float32 value) pairs (6 B per product).  For a general operand b1 == b0.
-    // When B = D^-1 * L with integer link counts L (iteration 0 of run_mcl_clustering: the normalised raw link
-    // matrix) the layout pass moves the count-1 entries of every segment (75 % of a Hi-C link matrix) to the front:
-    // v = float(1 / rowsum).  Sc16 / Sx are the (regrouped) columns / values, rec the records.
+    // window kernel operand stream.  Every (B row, column window) segment is described by one 32-byte record
+    // {b0, b1, b2, b3 | b4, v1, v2, v3 (float bits)}: the entries of sub-segment c = 1, 2, 3, [b(c-1), b(c)), all hold
+    // the SAME value v_c and are streamed as 16-bit window-local columns alone (2 B per product: their product with a_ik
+    // is formed once per sub-segment); entries [b3, b4) are (16-bit column, float32 value) pairs (6 B per product).
+    // For a general operand b0 = b1 = b2 = b3.  When B = D^-1 * L with integer link counts L (iteration 0 of
+    // run_mcl_clustering: the normalised raw link matrix) the layout pass regroups every segment by link count —
+    // [count 1][count 2][count 3][other], 75 % / 12 % / 5 % / 8 % of a Hi-C link matrix — and v_c = float(c / rowsum).
+    // Sc16 / Sx are the (regrouped) columns / values, rec the records (two int4 per segment).
     const unsigned short *Sc16; const float *Sx; const int4 *rec;
+    i32 narrow_classes;             // 1: some records have count-2 / count-3 sub-segments (the class stream)
     i32 n_rows, n_cols;
     double scale, inv_scale;        // 2^(shift-52), 2^(52-shift): products are rounded on the 2^-52 grid of [0, 1]
     double r; int square; float thr;
@@ -223,8 +225,9 @@ constexpr int WB = 32;              // A entries per wave batch
 constexpr int WIDE_UNIT = 512;      // entries per 16-byte lane load of a wave
 
 struct BatchRegs {                  // one A entry per lane (lanes >= cnt: empty segments)
-    i32 b0, b1, b2;                 // record boundaries: [b0, b1) uniform value, [b1, b2) explicit values
-    u32 g_lo, g_hi;                 // fx_bits(a_ik * scale * v): the uniform sub-segment's fixed-point product
+    i32 b0, b1, b2, b3, b4;         // record boundaries
+    u32 g_lo, g_hi;                 // fx_bits(a_ik * scale * v1): the count-1 sub-segment's fixed-point product
+    u32 v2, v3;                     // float bits of the count-2 / count-3 values (their products are formed when the pass gets there)
     u32 da_lo, da_hi;               // a_ik * scale (double bits)
 };
 __device__ __forceinline__ void batch_load(const ExParams &P, i32 a_b, i32 a_e, i32 batch, i32 wv, BatchRegs &r) {
@@ -233,10 +236,12 @@ __device__ __forceinline__ void batch_load(const ExParams &P, i32 a_b, i32 a_e, 
     const i32 ec = ok ? e : a_b;                      // unconditional loads (a_b < a_e whenever a batch exists)
     const i32 k = P.Aj[ec];
     const double da = (double)P.Ax[ec] * P.scale;
-    const int4 rc = P.rec[(size_t)k * P.n_win + wv];
-    r.b0 = ok ? rc.x : 0; r.b1 = ok ? rc.y : 0; r.b2 = ok ? rc.z : 0;
-    const u64 g = fx_bits(da * (double)__int_as_float(rc.w));
+    const int4 *rp = P.rec + ((size_t)k * P.n_win + wv) * 2;
+    const int4 r0 = rp[0], r1 = rp[1];
+    r.b0 = ok ? r0.x : 0; r.b1 = ok ? r0.y : 0; r.b2 = ok ? r0.z : 0; r.b3 = ok ? r0.w : 0; r.b4 = ok ? r1.x : 0;
+    const u64 g = fx_bits(da * (double)__int_as_float(r1.y));
     r.g_lo = (u32)g; r.g_hi = (u32)(g >> 32);
+    r.v2 = (u32)r1.z; r.v3 = (u32)r1.w;
     const u64 d = (u64)__double_as_longlong(da);
     r.da_lo = (u32)d; r.da_hi = (u32)(d >> 32);
 }
@@ -318,8 +323,8 @@ template <int UX>
 __device__ __forceinline__ void xtile_fetch(const ExParams &P, const BatchRegs &r, i32 cnt, XCursor &c, XTile<UX> &t) {
     while (c.q >= c.qe && c.l + 1 < cnt) {
         ++c.l;
-        c.q = __builtin_amdgcn_readlane(r.b1, c.l);
-        c.qe = __builtin_amdgcn_readlane(r.b2, c.l);
+        c.q = (__builtin_amdgcn_readlane(r.b3, c.l) + 63) & ~63;      // the explicit part starts on the next multiple of 64 slots
+        c.qe = __builtin_amdgcn_readlane(r.b4, c.l);
         c.da_lo = __builtin_amdgcn_readlane(r.da_lo, c.l);
         c.da_hi = __builtin_amdgcn_readlane(r.da_hi, c.l);
     }
@@ -354,6 +359,60 @@ __device__ __forceinline__ void pass_explicit(const ExParams &P, const ExLds &l,
     auto consume = [&](const XTile<UX> &t) { xtile_consume<PROBE, UX>(l, t, dummy, sink); };
     for (;;) {
         XTile<UX> t[G];
+        group_fetch<0, G>(t, fetch);
+        if (!group_consume<0, G>(t, consume)) return;
+    }
+}
+
+// narrow uniform tiles: the count-2 and count-3 sub-segments (a few dozen entries each) ------------------------------
+// 16-bit columns only, UN entries per lane; the value of the sub-segment is wave-uniform, its product is formed in the fetch
+template <int UN>
+struct NTile { u32 j[UN]; i32 n; u32 g_lo, g_hi; bool valid; };
+struct NCursor { i32 l, c, q, qe; u32 g_lo, g_hi; };                      // c: 0 = count-2 part next, 1 = count-3 part next
+template <int UN>
+__device__ __forceinline__ void ntile_fetch(const ExParams &P, const BatchRegs &r, i32 cnt, NCursor &c, NTile<UN> &t) {
+    while (c.q >= c.qe && (c.c < 2 || c.l + 1 < cnt)) {
+        if (c.c >= 2) { ++c.l; c.c = 0; }
+        const i32 lo = __builtin_amdgcn_readlane(c.c ? r.b2 : r.b1, c.l), hi = __builtin_amdgcn_readlane(c.c ? r.b3 : r.b2, c.l);
+        if (hi > lo) {
+            const double da = __longlong_as_double((long long)(((u64)(u32)__builtin_amdgcn_readlane(r.da_hi, c.l) << 32) |
+                                                                 (u32)__builtin_amdgcn_readlane(r.da_lo, c.l)));
+            const u64 g = fx_bits(da * (double)__uint_as_float((u32)__builtin_amdgcn_readlane(c.c ? r.v3 : r.v2, c.l)));
+            c.g_lo = (u32)g; c.g_hi = (u32)(g >> 32);
+        }
+        c.q = lo; c.qe = hi;
+        ++c.c;
+    }
+    t.valid = c.q < c.qe;
+    t.n = t.valid ? c.qe - c.q : 0;
+    t.g_lo = c.g_lo; t.g_hi = c.g_hi;
+    const i32 base = t.valid ? c.q : 0;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const i32 pos = lane_id() + u * HHX_WAVE;
+        t.j[u] = (u32)P.Sc16[pos < t.n ? base + pos : 0];
+    }
+    c.q += UN * HHX_WAVE;
+}
+template <int PROBE, int UN>
+__device__ __forceinline__ void ntile_consume(const ExLds &l, const NTile<UN> &t, i32 dummy, u64 &sink) {
+    const u64 g = ((u64)t.g_hi << 32) | t.g_lo;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        if (u && u * HHX_WAVE >= t.n) break;                    // wave-uniform: the rest of the tile is empty
+        const bool ok = lane_id() + u * HHX_WAVE < t.n;
+        if (PROBE == 1) sink += ok ? g + t.j[u] : 0;
+        else atomicAdd((unsigned long long *)&l.acc[ok ? (i32)t.j[u] : dummy], (unsigned long long)g);
+    }
+}
+template <int PROBE, int UN, int G>
+__device__ __forceinline__ void pass_narrow(const ExParams &P, const ExLds &l, const BatchRegs &r, i32 cnt, i32 dummy, u64 &sink) {
+    NCursor c = {0, 0, 0, 0, 0u, 0u};
+    if (cnt <= 0) return;
+    auto fetch = [&](NTile<UN> &t) { ntile_fetch<UN>(P, r, cnt, c, t); };
+    auto consume = [&](const NTile<UN> &t) { ntile_consume<PROBE, UN>(l, t, dummy, sink); };
+    for (;;) {
+        NTile<UN> t[G];
         group_fetch<0, G>(t, fetch);
         if (!group_consume<0, G>(t, consume)) return;
     }
@@ -593,9 +652,11 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
 // the rows.  While window w is being processed the only part of B that is read is its column slice
 // B[:, w] (nnz_B / n_win entries: at n = 100k the class stream of one slice fits the 256 MiB Infinity Cache),
 // and the per-row epilogue (finalize) becomes its own uniform launch.
-// UX / RX: entries per lane of an explicit tile and explicit tiles per group; RW: wide tiles per group.
-template <int PROBE, int UX, int RX, int RW>
-__global__ __launch_bounds__(EX_T_WIN) void k_expand_window(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 wv) {
+// UX / RX: entries per lane of an explicit tile and explicit tiles per group; RW: wide tiles per group.  Measured at
+// n = 100k, iteration 0 (tools/expand_probe.py): groups of 3 wide / 8 explicit tiles 590 ms, 3 / 5 597, 2 / 3 636; 512-thread
+// workgroups with twice the group sizes 806 ms — the sixteen waves per CU, not the depth of a wave's group, hide the latency.
+template <int PROBE, int UX, int RX, int RW, int T = EX_T_WIN>
+__global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 wv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ExLds l = win_carve(smem, cap);
     const int tid = threadIdx.x;
@@ -624,8 +685,9 @@ __global__ __launch_bounds__(EX_T_WIN) void k_expand_window(ExParams P, const i3
             if (lane_id() == 0) nb = atomicAdd(&l.ctr[0], 1);
             nb = __builtin_amdgcn_readfirstlane(nb);
             if (nb < n_batches) batch_load(P, a_b, a_e, nb, wv, nxt);
-            n_uni += cur.b1 - cur.b0;
+            n_uni += cur.b3 - cur.b0;
             pass_wide<PROBE, RW>(P, l, cur, cnt, dummy, sink);
+            if (P.narrow_classes) pass_narrow<PROBE, 2, 8>(P, l, cur, cnt, dummy, sink);
             pass_explicit<PROBE, UX, RX>(P, l, cur, cnt, dummy, sink);
             batch = nb;
         }
@@ -646,30 +708,25 @@ __global__ __launch_bounds__(EX_T_WIN) void k_expand_window(ExParams P, const i3
     if (PROBE == 1 && sink == 0x123456789abcdefull) l.acc[0] = sink;
 }
 
-// Records of a general operand: the whole (B row, window) segment is explicit.  One thread per (row, window).
-__global__ __launch_bounds__(256) void k_window_recs(i32 n_rows, const i32 *__restrict__ Bp, const i32 *__restrict__ Bj, i32 cap, i32 n_win,
-                                                     int4 *__restrict__ rec) {
-    const i64 total = (i64)n_rows * n_win;
-    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
-        const i32 k = (i32)(t / n_win), w = (i32)(t % n_win);
-        const i32 qb = Bp[k], qe = Bp[k + 1];
-        const i32 lo = w == 0 ? qb : lower_bound_i32(Bj, qb, qe, w * cap);
-        const i32 hi = w == n_win - 1 ? qe : lower_bound_i32(Bj, qb, qe, (w + 1) * cap);
-        rec[t] = make_int4(lo, lo, hi, 0);
-    }
+// Layout of the window kernel's operand stream, two passes with a scan between them.  One wave per (B row, column
+// window) segment.  With link counts (n16 != nullptr: the class stream) the entries are regrouped by count — [count 1]
+// [count 2][count 3][other], stable: columns stay ascending inside a class — otherwise the whole segment is "other".
+// In the stream every segment starts on a multiple of 64 slots, and so does its explicit part: the 16-bit columns of a
+// sub-segment then start on a 128-byte line and its float32 values on a 256-byte boundary, so a sub-segment touches
+// ceil(bytes / 128) lines instead of one more (measured before the alignment: 1.22 x the algorithmic bytes on the
+// fabric, profiles/r02_pmc_c3.txt).  The padding slots are never read.
+//   record (two int4): {b0, b1, b2, b3 | b4, v1, v2, v3}: count-c entries in [b(c-1), b(c)), explicit entries in
+//   [ceil64(b3), b4); v_c = float(double(c) / row_sum) is bit for bit what the normalised matrix holds for a count-c entry.
+__device__ __forceinline__ i32 ceil64(i32 x) { return (x + 63) & ~63; }
+__device__ __forceinline__ int class_of(const unsigned short *__restrict__ n16, i32 q, i32 nc) {
+    if (!n16) return 3;
+    const i32 c = n16[q];
+    return (c >= 1 && c <= nc) ? c - 1 : 3;
 }
-
-// Layout pass of the class stream: one wave per (B row, column window) segment moves the entries whose link count is 1
-// to the front (stable: columns stay ascending inside both parts) and writes the record.  n16 = link count per entry,
-// row_sum = the L1 row sums the normalisation divided by (k_normalize_l1): float(1.0 / row_sum) is bit for bit the
-// value the normalised matrix holds for a count-1 entry.
-__global__ __launch_bounds__(256) void k_class_layout(i32 n_rows, i32 n_win, i32 cap, const i32 *__restrict__ Bp,
-                                                      const i32 *__restrict__ Bj, const float *__restrict__ Bx,
-                                                      const unsigned short *__restrict__ n16, const double *__restrict__ row_sum,
-                                                      unsigned short *__restrict__ oc, float *__restrict__ ox, int4 *__restrict__ rec,
+__global__ __launch_bounds__(256) void k_layout_sizes(i32 n_rows, i32 n_win, i32 cap, i32 nc, const i32 *__restrict__ Bp, const i32 *__restrict__ Bj,
+                                                      const unsigned short *__restrict__ n16, int4 *__restrict__ cnt4, i64 *__restrict__ sizes,
                                                       unsigned long long *__restrict__ n_uniform) {
     const int lane = lane_id();
-    const u64 lt = (1ull << lane) - 1ull;
     const i64 total = (i64)n_rows * n_win;
     i64 uni = 0;
     for (i64 sg = (i64)blockIdx.x * 4 + threadIdx.x / HHX_WAVE; sg < total; sg += (i64)gridDim.x * 4) {
@@ -677,29 +734,61 @@ __global__ __launch_bounds__(256) void k_class_layout(i32 n_rows, i32 n_win, i32
         const i32 rb = Bp[k], re = Bp[k + 1];
         const i32 qb = w == 0 ? rb : lower_bound_i32(Bj, rb, re, w * cap);
         const i32 qe = w == n_win - 1 ? re : lower_bound_i32(Bj, rb, re, (w + 1) * cap);
-        i32 n1 = 0;
-        for (i32 q0 = qb; q0 < qe; q0 += HHX_WAVE) {
-            const i32 q = q0 + lane;
-            n1 += __popcll(__ballot(q < qe && n16[q] == 1));
-        }
-        if (lane == 0) rec[sg] = make_int4(qb, qb + n1, qe, __float_as_int((float)(1.0 / row_sum[k])));
-        uni += n1;
-        i32 o1 = qb, ox_ = qb + n1;
-        for (i32 q0 = qb; q0 < qe; q0 += HHX_WAVE) {
-            const i32 q = q0 + lane;
-            const bool in = q < qe;
-            const bool one = in && n16[q] == 1;
-            const u64 m1 = __ballot(one), mx = __ballot(in && !one);
-            if (in) {
-                const i32 o = one ? o1 + __popcll(m1 & lt) : ox_ + __popcll(mx & lt);
-                oc[o] = (unsigned short)(Bj[q] - w * cap);
-                ox[o] = Bx[q];
+        i32 cnt[4] = {0, 0, 0, qe - qb};
+        if (n16) {
+            cnt[3] = 0;
+            for (i32 q0 = qb; q0 < qe; q0 += HHX_WAVE) {
+                const i32 q = q0 + lane;
+                const int cls = q < qe ? class_of(n16, q, nc) : -1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cnt[c] += __popcll(__ballot(cls == c));
             }
-            o1 += __popcll(m1);
-            ox_ += __popcll(mx);
         }
+        if (lane == 0) {
+            cnt4[sg] = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);
+            sizes[sg] = (i64)ceil64(cnt[0] + cnt[1] + cnt[2]) + (i64)ceil64(cnt[3]);
+        }
+        uni += cnt[0] + cnt[1] + cnt[2];
     }
     if (lane == 0 && uni) atomicAdd(n_uniform, (unsigned long long)uni);
+}
+__global__ __launch_bounds__(256) void k_layout_write(i32 n_rows, i32 n_win, i32 cap, i32 nc, const i32 *__restrict__ Bp, const i32 *__restrict__ Bj,
+                                                      const float *__restrict__ Bx, const unsigned short *__restrict__ n16,
+                                                      const double *__restrict__ row_sum, const int4 *__restrict__ cnt4, const i64 *__restrict__ off,
+                                                      unsigned short *__restrict__ oc, float *__restrict__ ox, int4 *__restrict__ rec) {
+    const int lane = lane_id();
+    const u64 lt = (1ull << lane) - 1ull;
+    const i64 total = (i64)n_rows * n_win;
+    for (i64 sg = (i64)blockIdx.x * 4 + threadIdx.x / HHX_WAVE; sg < total; sg += (i64)gridDim.x * 4) {
+        const i32 k = (i32)(sg / n_win), w = (i32)(sg % n_win);
+        const i32 rb = Bp[k], re = Bp[k + 1];
+        const i32 qb = w == 0 ? rb : lower_bound_i32(Bj, rb, re, w * cap);
+        const i32 qe = w == n_win - 1 ? re : lower_bound_i32(Bj, rb, re, (w + 1) * cap);
+        const int4 c4 = cnt4[sg];
+        const i32 s0 = (i32)off[sg];
+        i32 base[4] = {s0, s0 + c4.x, s0 + c4.x + c4.y, s0 + ceil64(c4.x + c4.y + c4.z)};
+        if (lane == 0) {
+            const double s = row_sum ? row_sum[k] : 1.0;
+            rec[2 * sg] = make_int4(base[0], base[1], base[2], base[2] + c4.z);
+            rec[2 * sg + 1] = make_int4(base[3] + c4.w, __float_as_int((float)(1.0 / s)), __float_as_int((float)(2.0 / s)), __float_as_int((float)(3.0 / s)));
+        }
+        for (i32 q0 = qb; q0 < qe; q0 += HHX_WAVE) {
+            const i32 q = q0 + lane;
+            int cls = -1;
+            i32 col = 0; float x = 0.f;
+            if (q < qe) { cls = class_of(n16, q, nc); col = Bj[q]; x = Bx[q]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u64 m = __ballot(cls == c);
+                if (cls == c) {
+                    const i32 o = base[c] + __popcll(m & lt);
+                    oc[o] = (unsigned short)(col - w * cap);
+                    ox[o] = x;
+                }
+                base[c] += __popcll(m);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(EX_T_CMP) void k_expand_window_finalize(ExParams P, const i32 *__restrict__ rows, i32 n_list) {
@@ -904,14 +993,6 @@ __global__ __launch_bounds__(256) void k_expand_tiny(ExParams P, const i32 *__re
     if (lane == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
 }
 
-// ---- window-local 16-bit column offsets of B (the window kernel's operand stream) -------------------------
-__global__ __launch_bounds__(256) void k_local_cols(i64 nnz, const i32 *__restrict__ Bj, i32 cap, unsigned short *__restrict__ out) {
-    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (i64)gridDim.x * blockDim.x) {
-        const i32 c = Bj[p];
-        out[p] = (unsigned short)(c - (c / cap) * cap);
-    }
-}
-
 // ---- pack the bump-allocated rows into CSR order ---------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_rows(i32 n_rows, const i64 *__restrict__ row_off, const i32 *__restrict__ indptr,
                                                    const i32 *__restrict__ pool_col, const float *__restrict__ pool_val,
@@ -935,14 +1016,14 @@ struct CodedOperand {
     int raw = 0;                        // plain product (no inflation / pruning): hhx_spgemm's fast path
 };
 
-template <int PROBE, int UX, int RX, int RW>
+template <int PROBE, int UX, int RX, int RW, int T = EX_T_WIN>
 static int launch_window(const ExParams &P, const i32 *rows, i32 n_list, i32 cap, size_t lds, unsigned grid) {
     static bool attr = false;
     if (!attr) {
-        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window<PROBE, UX, RX, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window<PROBE, UX, RX, RW, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    for (i32 wv = 0; wv < P.n_win; ++wv) k_expand_window<PROBE, UX, RX, RW><<<grid, EX_T_WIN, lds, g_stream>>>(P, rows, n_list, cap, wv);
+    for (i32 wv = 0; wv < P.n_win; ++wv) k_expand_window<PROBE, UX, RX, RW, T><<<grid, T, lds, g_stream>>>(P, rows, n_list, cap, wv);
     return 0;
 }
 
@@ -958,6 +1039,10 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     const i32 W = (n_cols + 31) / 32;
     // ---- plans
     const bool use_cls = coded.n16 != nullptr && !coded.raw && tune_get("cls", 1) != 0;
+    // link counts 1..n_classes are streamed as columns only.  Measured at n = 100k (profiles/r02_expand_probe_c3.jsonl): counts 1-3
+    // move 17 % fewer bytes than count 1 alone but run 20 % longer (the count-2 / count-3 sub-segments are a few dozen entries:
+    // tiles of 128 that are mostly empty), so the default is 1
+    const i32 n_classes = (i32)std::min<i64>(3, std::max<i64>(1, tune_get("cls_nc", 1)));
     const size_t fixed_win = win_fixed_bytes(), fixed_cmp = ex_fixed_bytes(W, MAX_WIN);
     // window class: the column window must fit LDS (8 B per column).  Measured on MI355X (n = 100k, 330M
     // entries): the fewest, widest windows win — 6 windows 1.41 s, 13 windows 1.54 s, 27 windows 2.24 s —
@@ -1051,33 +1136,38 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
         P.n_win = n_win;
         P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
-        P.Sc16 = nullptr; P.Sx = nullptr; P.rec = nullptr;
+        P.Sc16 = nullptr; P.Sx = nullptr; P.rec = nullptr; P.narrow_classes = 0;
         if (hc[0]) {
             const unsigned grid = std::min<unsigned>(hc[0], 256);
-            if (!rec.p) {
-                // slack: a wide tile reads up to 8 entries past a segment end, an exhausted cursor entry 0
-                if (rec.alloc((size_t)b->n_rows * n_win + 1) || c16.alloc((size_t)b->nnz + 64)) return 1;
+            if (!rec.p) {                                 // the operand stream of b, built once per call
                 const i64 segs = (i64)b->n_rows * n_win;
-                if (use_cls) {
-                    DevBuf<unsigned long long> n_uni;
-                    if (cls_x.alloc((size_t)b->nnz + 64) || n_uni.alloc(1)) return 1;
-                    HHX_HIP(hipMemsetAsync(n_uni.p, 0, sizeof(unsigned long long), g_stream));
-                    { KTimer kt("class_layout");
-                    k_class_layout<<<(unsigned)std::max<i64>(1, std::min<i64>((segs + 3) / 4, 65536)), 256, 0, g_stream>>>(
-                        b->n_rows, n_win, cap_win, b->indptr.p, b->indices.p, b->data.p, coded.n16, coded.row_sum, c16.p, cls_x.p, rec.p, n_uni.p); }
-                    unsigned long long h = 0;
-                    HHX_HIP(hipMemcpyAsync(&h, n_uni.p, sizeof h, hipMemcpyDeviceToHost, g_stream));
-                    HHX_HIP(hipStreamSynchronize(g_stream));
-                    explicit_frac = b->nnz ? 1.0 - (double)h / (double)b->nnz : 1.0;
-                } else {
-                    k_window_recs<<<(unsigned)std::max<i64>(1, std::min<i64>((segs + 255) / 256, 65536)), 256, 0, g_stream>>>(
-                        b->n_rows, b->indptr.p, b->indices.p, cap_win, n_win, rec.p);
-                    k_local_cols<<<(unsigned)std::max<i64>(1, std::min<i64>((b->nnz + 255) / 256, 65536)), 256, 0, g_stream>>>(
-                        b->nnz, b->indices.p, cap_win, c16.p);
-                }
+                DevBuf<int4> cnt4;
+                DevBuf<i64> sizes, offs;
+                DevBuf<unsigned long long> n_uni;
+                if (rec.alloc(2 * (size_t)segs + 2) || cnt4.alloc((size_t)segs + 1) || sizes.alloc((size_t)segs + 1) || offs.alloc((size_t)segs + 2) ||
+                    n_uni.alloc(1)) return 1;
+                HHX_HIP(hipMemsetAsync(n_uni.p, 0, sizeof(unsigned long long), g_stream));
+                const unsigned lgrid = (unsigned)std::max<i64>(1, std::min<i64>((segs + 3) / 4, 65536));
+                KTimer kt("class_layout");
+                k_layout_sizes<<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win, cap_win, n_classes, b->indptr.p, b->indices.p, use_cls ? coded.n16 : nullptr,
+                                                            cnt4.p, sizes.p, n_uni.p);
                 HHX_LAUNCH_CHECK();
+                i64 slots = 0;
+                HHX_TRY(exclusive_scan_i64(sizes.p, offs.p, segs, &slots));
+                if (slots > (i64)INT32_MAX - 4096) return fail("expand: the padded operand stream needs %lld slots (int32 cursors)", (long long)slots);
+                unsigned long long h = 0;
+                HHX_HIP(hipMemcpyAsync(&h, n_uni.p, sizeof h, hipMemcpyDeviceToHost, g_stream));
+                HHX_HIP(hipStreamSynchronize(g_stream));
+                explicit_frac = b->nnz ? 1.0 - (double)h / (double)b->nnz : 1.0;
+                // slack: a wide tile reads up to 8 entries past a sub-segment end, an exhausted cursor entry 0
+                if (c16.alloc((size_t)slots + 64) || cls_x.alloc((size_t)slots + 64)) return 1;
+                k_layout_write<<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win, cap_win, n_classes, b->indptr.p, b->indices.p, b->data.p,
+                                                            use_cls ? coded.n16 : nullptr, use_cls ? coded.row_sum : nullptr, cnt4.p, offs.p, c16.p, cls_x.p, rec.p);
+                HHX_LAUNCH_CHECK();
+                HHX_HIP(hipStreamSynchronize(g_stream));         // cnt4 / sizes / offs die here
             }
-            P.Sc16 = c16.p; P.Sx = use_cls ? cls_x.p : b->data.p; P.rec = rec.p;
+            P.Sc16 = c16.p; P.Sx = cls_x.p; P.rec = rec.p;
+            P.narrow_classes = use_cls && n_classes > 1;
             // explicit tiles: UX x 64 entries, sized to the mean explicit sub-segment (a tile costs its 2 UX loads and UX
             // LDS atomics per lane whether filled or not); tune "tile_u" overrides
             const double xlen = seg_len * explicit_frac;
@@ -1086,10 +1176,10 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             {
                 KTimer kt(long_segments ? "expand_window" : "expand_window_short", n_win);
                 if (probe == 1 && ux >= 4) HHX_TRY((launch_window<1, 8, 3, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
-                else if (probe == 1) HHX_TRY((launch_window<1, 3, 5, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
+                else if (probe == 1) HHX_TRY((launch_window<1, 3, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else if (ux >= 8) HHX_TRY((launch_window<0, 8, 3, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else if (ux == 4) HHX_TRY((launch_window<0, 4, 4, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
-                else if (ux == 3) HHX_TRY((launch_window<0, 3, 5, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
+                else if (ux == 3) HHX_TRY((launch_window<0, 3, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else if (ux == 2) HHX_TRY((launch_window<0, 2, 6, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else HHX_TRY((launch_window<0, 1, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
             }

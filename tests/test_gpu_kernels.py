@@ -629,13 +629,16 @@ def test_mcl_links_class_stream_iteration0():
         r0, n0, c0 = _lib.mcl(links, 2, 2.0, 200, 1e-4, links=True)
         assert (n0, c0) == (n1, c1) and all(np.array_equal(x, y) for x, y in zip(r0.to_arrays(), r1.to_arrays()))
         one0 = _lib.mcl(links, 2, 2.0, 1, 1e-4, links=True)[0].to_arrays()
-        for cls, tile_u in ((1, 0), (1, 1), (1, 2), (1, 3), (1, 4), (1, 8), (0, 1), (0, 2), (0, 3), (0, 4)):
+        for cls, nc, tile_u in ((1, 1, 0), (1, 3, 0), (1, 2, 0), (1, 3, 1), (1, 3, 2), (1, 1, 3), (1, 3, 4), (1, 2, 8), (0, 3, 1), (0, 3, 2), (0, 3, 3),
+                                (0, 3, 4)):
             _lib.tune('cls', cls)
+            _lib.tune('cls_nc', nc)
             _lib.tune('tile_u', tile_u)
             one = _lib.mcl(links, 2, 2.0, 1, 1e-4, links=True)[0].to_arrays()
-            assert all(np.array_equal(x, y) for x, y in zip(one, one0)), 'stream layout changed bits: %r' % ((cls, tile_u),)
+            assert all(np.array_equal(x, y) for x, y in zip(one, one0)), 'stream layout changed bits: %r' % ((cls, nc, tile_u),)
     finally:
         _lib.tune('cls', 1)
+        _lib.tune('cls_nc', 1)
         _lib.tune('tile_u', 0)
     norm = links.copy()
     _lib.normalize_l1(norm)

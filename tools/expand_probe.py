@@ -39,16 +39,15 @@ def main():
     del id1, p1, id2, p2
     torch.cuda.empty_cache()
     print(json.dumps({'n': n, 'nnz': m.nnz}), flush=True)
-    knobs = ('cls', 'tile_u', 'probe')
-    variants = [('generic 6B stream', (0, 0, 0)),
-                ('class stream (auto tile)', (1, 0, 0)),
-                ('class stream, explicit tiles x1', (1, 1, 0)),
-                ('class stream, explicit tiles x2', (1, 2, 0)),
-                ('class stream, explicit tiles x3', (1, 3, 0)),
-                ('class stream, explicit tiles x4', (1, 4, 0)),
-                ('generic, tiles x4', (0, 4, 0)),
-                ('generic, probe 1 (no LDS op)', (0, 0, 1)),
-                ('class stream, probe 1 (no LDS op)', (1, 0, 1))]
+    knobs = ('cls', 'cls_nc', 'tile_u', 'probe')
+    variants = [('generic 6B stream', (0, 1, 0, 0)),
+                ('class stream, count 1 uniform (default)', (1, 1, 0, 0)),
+                ('class stream, counts 1-2 uniform', (1, 2, 0, 0)),
+                ('class stream, counts 1-3 uniform', (1, 3, 0, 0)),
+                ('class stream, explicit tiles x2', (1, 1, 2, 0)),
+                ('class stream, explicit tiles x4', (1, 1, 4, 0)),
+                ('generic, probe 1 (no LDS op)', (0, 1, 0, 1)),
+                ('class stream, probe 1 (no LDS op)', (1, 1, 0, 1))]
     if args.quick:
         variants = variants[:2]
     ref = None
@@ -73,7 +72,7 @@ def main():
                    'nnz_out': res.nnz}
             if best is None or rec['expand_window_ms'] < best['expand_window_ms']:
                 best = rec
-            if vals[2] == 0 and rep == 0:
+            if vals[3] == 0 and rep == 0:
                 got = res.to_arrays()
                 if ref is None:
                     ref = got
@@ -83,7 +82,7 @@ def main():
                     best['bit_identical_to_generic'] = bool(best_ok)
             res.free()
         print(json.dumps(best), flush=True)
-    for k, v in zip(knobs, (1, 0, 0)):
+    for k, v in zip(knobs, (1, 1, 0, 0)):
         _lib.tune(k, v)
 
 
