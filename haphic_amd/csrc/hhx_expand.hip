@@ -50,7 +50,8 @@ struct ExParams {
     // [count 1][count 2][count 3][other], 75 % / 12 % / 5 % / 8 % of a Hi-C link matrix — and v_c = float(c / rowsum).
     // Sc16 / Sx are the (regrouped) columns / values, rec the records (two int4 per segment).
     const unsigned short *Sc16; const float *Sx; const int4 *rec;
-    i32 narrow_classes;             // 1: some records have count-2 / count-3 sub-segments (the class stream)
+    i32 narrow_classes;             // 1: some records have count-2 / count-3 sub-segments (the class stream); 0: count-1 only; -1: none (general operand)
+    i32 wb;                         // A entries per wave batch
     i32 n_rows, n_cols;
     double scale, inv_scale;        // 2^(shift-52), 2^(52-shift): products are rounded on the 2^-52 grid of [0, 1]
     double r; int square; float thr;
@@ -211,7 +212,7 @@ __device__ __forceinline__ void acc_add(u64 *slot, double p) {
 }
 
 // ---- window mode: acc[c - c0] += fixed(a * b) -----------------------------------------------------------------
-// Every WAVE works on its own: it draws batches of WB consecutive A entries of the row from an LDS cursor (dynamic
+// Every WAVE works on its own: it draws batches of P.wb consecutive A entries of the row from an LDS cursor (dynamic
 // balance, no workgroup barrier inside a row), one entry per lane: the lane loads (k, a_ik) and the 16-byte record of
 // (B row k, this window) and forms the segment's uniform product once.  The wave then walks the batch twice with
 // wave-uniform cursors (v_readlane): first the value-uniform sub-segments as WIDE tiles — a lane loads 8 consecutive
@@ -221,7 +222,7 @@ __device__ __forceinline__ void acc_add(u64 *slot, double p) {
 // loads and its atomics is branch-free per lane (masked entries go to a per-lane scratch slot behind the window),
 // so that the compiler's s_waitcnt pass counts the loads exactly instead of falling back to vmcnt(0):
 // tools/stream_bench.hip is the prototype of this loop.
-constexpr int WB = 32;              // A entries per wave batch
+constexpr int WB_MAX = 32;          // A entries per wave batch: P.wb <= WB_MAX (short rows take smaller batches so that every wave gets one)
 constexpr int WIDE_UNIT = 512;      // entries per 16-byte lane load of a wave
 
 struct BatchRegs {                  // one A entry per lane (lanes >= cnt: empty segments)
@@ -231,8 +232,8 @@ struct BatchRegs {                  // one A entry per lane (lanes >= cnt: empty
     u32 da_lo, da_hi;               // a_ik * scale (double bits)
 };
 __device__ __forceinline__ void batch_load(const ExParams &P, i32 a_b, i32 a_e, i32 batch, i32 wv, BatchRegs &r) {
-    const i32 e = a_b + batch * WB + lane_id();
-    const bool ok = lane_id() < WB && e < a_e;
+    const i32 e = a_b + batch * P.wb + lane_id();
+    const bool ok = lane_id() < P.wb && e < a_e;
     const i32 ec = ok ? e : a_b;                      // unconditional loads (a_b < a_e whenever a batch exists)
     const i32 k = P.Aj[ec];
     const double da = (double)P.Ax[ec] * P.scale;
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__re
     for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
         const i32 row = rows[li];
         const i32 a_b = P.Ap[row], a_e = P.Ap[row + 1];
-        const i32 n_batches = (a_e - a_b + WB - 1) / WB;
+        const i32 n_batches = (a_e - a_b + P.wb - 1) / P.wb;
         if (tid == 0) l.ctr[0] = 0;
         for (i32 t = tid; t < wlen; t += EX_T) l.acc[t] = 0;
         __syncthreads();
@@ -680,14 +681,14 @@ __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__re
         if (batch < n_batches) batch_load(P, a_b, a_e, batch, wv, nxt);
         while (batch < n_batches) {
             const BatchRegs cur = nxt;
-            const i32 cnt = min(WB, a_e - (a_b + batch * WB));
+            const i32 cnt = min(P.wb, a_e - (a_b + batch * P.wb));
             i32 nb = 0;
             if (lane_id() == 0) nb = atomicAdd(&l.ctr[0], 1);
             nb = __builtin_amdgcn_readfirstlane(nb);
             if (nb < n_batches) batch_load(P, a_b, a_e, nb, wv, nxt);
             n_uni += cur.b3 - cur.b0;
-            pass_wide<PROBE, RW>(P, l, cur, cnt, dummy, sink);
-            if (P.narrow_classes) pass_narrow<PROBE, 2, 8>(P, l, cur, cnt, dummy, sink);
+            if (P.narrow_classes >= 0) pass_wide<PROBE, RW>(P, l, cur, cnt, dummy, sink);      // -1: a general operand, every segment is explicit
+            if (P.narrow_classes > 0) pass_narrow<PROBE, 2, 8>(P, l, cur, cnt, dummy, sink);
             pass_explicit<PROBE, UX, RX>(P, l, cur, cnt, dummy, sink);
             batch = nb;
         }
@@ -1136,7 +1137,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
         P.n_win = n_win;
         P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
-        P.Sc16 = nullptr; P.Sx = nullptr; P.rec = nullptr; P.narrow_classes = 0;
+        P.Sc16 = nullptr; P.Sx = nullptr; P.rec = nullptr; P.narrow_classes = 0; P.wb = WB_MAX;
         if (hc[0]) {
             const unsigned grid = std::min<unsigned>(hc[0], 256);
             if (!rec.p) {                                 // the operand stream of b, built once per call
@@ -1167,7 +1168,12 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 HHX_HIP(hipStreamSynchronize(g_stream));         // cnt4 / sizes / offs die here
             }
             P.Sc16 = c16.p; P.Sx = cls_x.p; P.rec = rec.p;
-            P.narrow_classes = use_cls && n_classes > 1;
+            P.narrow_classes = use_cls ? (n_classes > 1 ? 1 : 0) : -1;
+            // batches: 32 A entries per wave draw when the rows are long; for the few-hundred-entry rows of the later iterations
+            // 8, so that all sixteen waves of the workgroup get work out of one row
+            const double a_len = hc[0] ? (double)hw[1] / (double)hc[0] : 0.0;
+            P.wb = (i32)tune_get("win_batch", a_len >= 1536.0 ? 32 : (a_len >= 512.0 ? 16 : 8));
+            if (P.wb < 1 || P.wb > WB_MAX) P.wb = WB_MAX;
             // explicit tiles: UX x 64 entries, sized to the mean explicit sub-segment (a tile costs its 2 UX loads and UX
             // LDS atomics per lane whether filled or not); tune "tile_u" overrides
             const double xlen = seg_len * explicit_frac;
@@ -1180,7 +1186,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 else if (ux >= 8) HHX_TRY((launch_window<0, 8, 3, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else if (ux == 4) HHX_TRY((launch_window<0, 4, 4, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else if (ux == 3) HHX_TRY((launch_window<0, 3, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
-                else if (ux == 2) HHX_TRY((launch_window<0, 2, 6, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
+                else if (ux == 2) HHX_TRY((launch_window<0, 2, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else HHX_TRY((launch_window<0, 1, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
             }
             HHX_LAUNCH_CHECK();
