@@ -2,6 +2,8 @@
 its seams (SURVEY §8b "who calls it"): import the reference's HapHiC_cluster module, re-bind S1-S6 with
 haphic_amd.patch.patch_reference, call the reference's run(args, log_file) exactly as its main() does (:2962-2967).
 Argument parsing, logging, file formats and every stage outside the hot path are the reference's own code.
+`python -m haphic_amd plot <arguments of "haphic plot">` does the same for HapHiC_plot.py: parse_pairs / parse_bam (the read-pair
+binning into the scaffold-bin contact matrix) run on the device (haphic_amd.plot.patch_plot), main() is the reference's.
 
 The reference checkout is found through --reference DIR or $HAPHIC_REFERENCE (the repository root or its scripts/
 directory).  Extra flags of the wrapper (removed before the reference parses the command line):
@@ -42,8 +44,8 @@ def main(argv=None):
         print(__doc__)
         return 0
     command = argv.pop(0)
-    if command != 'cluster':
-        raise SystemExit('haphic_amd wraps the "cluster" step only (got {!r}); run the other steps with the reference'.format(command))
+    if command not in ('cluster', 'plot'):
+        raise SystemExit('haphic_amd wraps the "cluster" and "plot" steps only (got {!r}); run the other steps with the reference'.format(command))
     ref = _take(argv, '--reference', True) or os.environ.get('HAPHIC_REFERENCE')
     device = int(_take(argv, '--device', True) or 0)
     keep_ingest = bool(_take(argv, '--keep-reference-ingest', False))
@@ -60,6 +62,13 @@ def main(argv=None):
     from . import _lib, patch
     _lib.check(_lib.load().hhx_set_device(device))                 # fails here, loudly, without a GPU or the library
     sys.path.insert(0, scripts)
+    if command == 'plot':
+        import HapHiC_plot as P                                     # needs pysam / portion / matplotlib, as the reference does
+        from . import plot
+        plot.patch_plot(P)
+        sys.argv = ['haphic plot'] + argv
+        P.main()
+        return 0
     import HapHiC_cluster as H                                      # the unmodified reference module
     patch.patch_reference(H, ingest=not keep_ingest)
     sys.argv = ['haphic cluster'] + argv

@@ -103,6 +103,12 @@ SIGNATURES = {
     'hhx_bam_next': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_int64, c_i64p, c_vpp, c_vpp, c_vpp, c_vpp]),
     'hhx_bam_fetch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'hhx_bam_close': (C.c_int, [C.c_void_p]),
+    'hhx_contact_map_create': (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_int32, c_vpp]),
+    'hhx_contact_map_push': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int32, c_i64p]),
+    'hhx_contact_map_fetch': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'hhx_contact_map_device': (C.c_int, [C.c_void_p, c_vpp, c_i32p]),
+    'hhx_contact_map_destroy': (C.c_int, [C.c_void_p]),
     'hhx_ingest_fetch_ht_order': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hhx_ingest_keep_frag_pairs': (C.c_int, [C.c_void_p, C.c_int]),
     'hhx_ingest_fetch_frag_pairs': (C.c_int, [C.c_void_p, c_i64p, C.c_void_p, C.c_void_p]),
@@ -492,6 +498,43 @@ class BamReader:
     def close(self):
         if self.h:
             load().hhx_bam_close(self.h)
+            self.h = None
+
+
+class ContactMap:
+    """hhx_contact_map: the dense scaffold-bin contact matrix of `haphic plot` (f4).  Tables as include/haphic_hip.h lists them."""
+
+    def __init__(self, in_set, aln_ptr, list_ptr, seg_lo, seg_hi, seg_bin, bin_size, n_total_bins):
+        self.in_set = np.ascontiguousarray(in_set, np.uint8)
+        self.aln_ptr = np.ascontiguousarray(aln_ptr, np.int64)
+        self.list_ptr = np.ascontiguousarray(list_ptr, np.int32)
+        self.seg = [np.ascontiguousarray(a, np.int32) for a in (seg_lo, seg_hi, seg_bin)]
+        self.n_bins = int(n_total_bins)
+        self.h = C.c_void_p()
+        check(load().hhx_contact_map_create(len(self.in_set), ptr(self.in_set), ptr(self.aln_ptr), ptr(self.list_ptr), len(self.seg[0]),
+                                            ptr(self.seg[0]), ptr(self.seg[1]), ptr(self.seg[2]), int(bin_size), self.n_bins, C.byref(self.h)))
+
+    def _push(self, n, p, on_device, pos_offset):
+        bad = C.c_int64(-1)
+        check(load().hhx_contact_map_push(self.h, int(n), p[0], p[1], p[2], p[3], int(on_device), int(pos_offset), C.byref(bad)))
+        return bad.value
+
+    def push(self, id1, pos1, id2, pos2, pos_offset=0):
+        """host int32 arrays; -> -1, or 2 * k + side of the first pair whose position is outside the AGP"""
+        arrs = [np.ascontiguousarray(a, np.int32) for a in (id1, pos1, id2, pos2)]
+        return self._push(len(arrs[0]), [ptr(a) for a in arrs], False, pos_offset)
+
+    def push_device(self, n, id1, pos1, id2, pos2, pos_offset=0):
+        return self._push(n, [C.c_void_p(x) for x in (id1, pos1, id2, pos2)], True, pos_offset)
+
+    def fetch(self):
+        out = np.empty((self.n_bins, self.n_bins), np.int64)
+        check(load().hhx_contact_map_fetch(self.h, ptr(out)))
+        return out
+
+    def destroy(self):
+        if self.h:
+            load().hhx_contact_map_destroy(self.h)
             self.h = None
 
 

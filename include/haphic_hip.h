@@ -319,6 +319,30 @@ int hhx_bam_next(hhx_bam *b, int need_flags, int drop_same_ref, int32_t n_ref, c
 int hhx_bam_fetch(hhx_bam *b, int32_t *id1, int32_t *pos1, int32_t *id2, int32_t *pos2);   /* host copies of the last batch */
 int hhx_bam_close(hhx_bam *b);
 
+/* ------------------------------------------------------------------ f4: `haphic plot` contact map
+ * HapHiC_plot.py parse_pairs :153-202 / parse_bam :205-245: contact_matrix[bin(ref, pos), bin(mref, mpos)] += 1 per read
+ * pair whose two contigs are in ctg_set, with convert_group_bin_id :155-168 as the position -> total scaffold bin lookup.
+ * The reference's dicts, flattened (haphic_amd/plot.py does this from ctg_dict / ctg_aln_dict / group_to_total_bin_dict):
+ *   in_set[c]                       contig c is in ctg_set (:145-148)
+ *   aln_ptr[c] .. aln_ptr[c + 1]    slots of the contig's alignment bins 0, 1, ... (slot = aln_ptr[c] + (pos - 1) // bin_size)
+ *   list_ptr[slot] .. [slot + 1]    the closed ranges ctg_aln_dict[ctg][bin] lists, in list order; an empty list = no such key
+ *   seg_lo/seg_hi/seg_bin[k]        range on the raw contig (1-based, closed) and group_to_total_bin_dict[ctg_dict[ctg][range]],
+ *                                   -1 when the scaffold is not in group_list (the pair is skipped, :161-162)
+ * hhx_contact_map_push adds a batch (ids < 0 are skipped: unknown names, filtered BAM records, unmapped mates;
+ * pos_offset is added to every position: 0 for .pairs text, 1 for BAM's 0-based reference_start :232 :236).
+ * *bad = -1, or 2 * k + side of the first pair k whose position has no alignment bin — where the reference raises
+ * 'Cannot find alignment position' (:165-168); the counts of that batch are then meaningless, as in the reference.
+ * hhx_contact_map_fetch: the n_total_bins x n_total_bins int64 matrix, row major (numpy dtype=int, :144). */
+typedef struct hhx_contact_map hhx_contact_map;
+int hhx_contact_map_create(int32_t n_ctg, const uint8_t *in_set, const int64_t *aln_ptr, const int32_t *list_ptr, int64_t n_list,
+                           const int32_t *seg_lo, const int32_t *seg_hi, const int32_t *seg_bin, int32_t bin_size, int32_t n_total_bins,
+                           hhx_contact_map **out);
+int hhx_contact_map_push(hhx_contact_map *m, int64_t n_pairs, const int32_t *id1, const int32_t *pos1, const int32_t *id2, const int32_t *pos2,
+                         int on_device, int32_t pos_offset, int64_t *bad);
+int hhx_contact_map_fetch(hhx_contact_map *m, int64_t *cells_host);
+int hhx_contact_map_device(hhx_contact_map *m, void **cells_dev_i64, int32_t *n_total_bins);
+int hhx_contact_map_destroy(hhx_contact_map *m);
+
 /* HT_link_dict's insertion order (update_HT_link_dict :404-416): first[4 * k + q] = stream position (among the pairs that
  * entered full_link_dict) of the first read pair of contig pair k (dict order of hhx_ingest_fetch) in quadrant
  * q = [HH, HT, TH, TT], INT64_MAX if the quadrant is empty.  Needs hhx_ingest_keep_pairs. */

@@ -702,8 +702,49 @@ def gen_reassign(path):
     np.savez_compressed(path, **out)
 
 
+def gen_plot(path):
+    """f4: HapHiC_plot.py parse_agp :41-103, generate_contact_matrix :106-150 and parse_pairs :153-202 (the reference's own
+    functions) on the synthetic AGP / .pairs texts of tests/plot_fixture.py.  `portion` is absent here: the interval stand-in
+    is oracle/plot_oracle.Closed (closed interval: intersection, containment, .lower / .upper, hashable)."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import plot_fixture
+    from oracle.plot_oracle import Closed
+    sys.modules['portion'].closed = lambda a, b: Closed(a, b)
+    import HapHiC_plot as P
+    P.logger.setLevel('CRITICAL')
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (kw, min_len, specified) in plot_fixture.CASES.items():
+            case = plot_fixture.make_case(**kw)
+            agp, pairs = os.path.join(tmp, name + '.agp'), os.path.join(tmp, name + '.pairs')
+            open(agp, 'w').write(case['agp'])
+            open(pairs, 'w').write(case['pairs'])
+            bin_size = case['bin_size']
+            ctg_dict, ctg_aln_dict, group_size_dict, frag_set, group_frag_dict = P.parse_agp(agp, bin_size)
+            mat, to_total, group_list, ctg_set = P.generate_contact_matrix(group_size_dict, frag_set, group_frag_dict, bin_size, min_len, specified)
+            try:
+                mat = P.parse_pairs(pairs, ctg_dict, ctg_aln_dict, bin_size, mat, to_total, group_list, ctg_set)
+                error = ''
+            except Exception as e:
+                error = str(e)
+            out[name + '__agp'] = np.frombuffer(case['agp'].encode(), np.uint8)
+            out[name + '__pairs'] = np.frombuffer(case['pairs'].encode(), np.uint8)
+            out[name + '__matrix'] = np.asarray(mat, np.int64)
+            out[name + '__error'] = np.frombuffer(error.encode(), np.uint8)
+            out[name + '__groups'] = np.frombuffer(','.join(group_list).encode(), np.uint8)
+            out[name + '__ctg_set'] = np.frombuffer(','.join(sorted(ctg_set)).encode(), np.uint8)
+            out[name + '__params'] = np.array([bin_size, int(round(min_len * 1000000))], np.int64)
+            out[name + '__specified'] = np.frombuffer((specified or '').encode(), np.uint8)
+            print('plot case', name, 'bins', mat.shape[0], 'contacts', int(mat.sum()), 'error' if error else '')
+    np.savez_compressed(path, **out)
+
+
 if __name__ == '__main__':
     assert os.environ.get('PYTHONHASHSEED') == '0', 'run with PYTHONHASHSEED=0'
+    if len(sys.argv) > 1 and sys.argv[1] == 'plot':
+        gen_plot(os.path.join(HERE, 'plot.npz'))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'reassign':
         gen_reassign(os.path.join(HERE, 'reassign.npz'))
         sys.exit(0)
@@ -722,3 +763,4 @@ if __name__ == '__main__':
     gen_pipeline_c4(os.path.join(HERE, 'pipeline_c4.npz'))
     gen_weights(os.path.join(HERE, 'weights.npz'))
     gen_reassign(os.path.join(HERE, 'reassign.npz'))
+    gen_plot(os.path.join(HERE, 'plot.npz'))

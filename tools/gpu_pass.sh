@@ -38,6 +38,8 @@ for l in open('gpurun_out/bench_text.log'):
     scale) timeout 1500 python -m pytest tests/test_gpu_scale.py -m gpu -x -q --durations=5 > gpurun_out/pytest_scale.log 2>&1; echo "scale rc=$?"; tail -12 gpurun_out/pytest_scale.log;;
     flips) timeout 1200 python tools/flip_count.py > gpurun_out/flip_count_c2.json 2> gpurun_out/flip_count.err; echo "flips rc=$?"; cut -c1-1500 gpurun_out/flip_count_c2.json; tail -3 gpurun_out/flip_count.err;;
     multirank) timeout 1500 python -m pytest tests/test_gpu_multirank.py -m gpu -x -q --durations=3 > gpurun_out/pytest_multirank.log 2>&1; echo "multirank rc=$?"; tail -15 gpurun_out/pytest_multirank.log;;
+    plot) timeout 600 python -m pytest tests/test_plot.py -m gpu -x -q > gpurun_out/pytest_plot.log 2>&1; echo "plot rc=$?"; grep -E "passed|failed|Error|error" gpurun_out/pytest_plot.log | tail -8;;
+    cprobe) timeout 600 python tools/contact_probe.py > gpurun_out/contact_probe.jsonl 2> gpurun_out/contact_probe.err; echo "cprobe rc=$?"; cat gpurun_out/contact_probe.jsonl; tail -3 gpurun_out/contact_probe.err;;
     listpmc) rocprofv3 -L > gpurun_out/pmc_list.txt 2>&1; grep -c . gpurun_out/pmc_list.txt;;
     env:*) export "${what#env:}"; echo "set ${what#env:}";;
     *) echo "unknown $what";;
