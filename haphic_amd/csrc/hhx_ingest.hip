@@ -41,6 +41,7 @@ __device__ __forceinline__ u32 bucket_of(u64 key, int total_bits) {
 template <bool COMBINED>
 struct SrcPairs {
     typedef u32 w1_t;
+    static constexpr bool MARK = false;
     const i32 *id1, *pos1, *id2, *pos2;
     DevTables t;
     int stream;
@@ -97,6 +98,7 @@ void launch_map(const SrcPairs<COMBINED> &src, i64 n, u64 *rec) {
 }
 struct SrcMapped {
     typedef u32 w1_t;
+    static constexpr bool MARK = false;
     const u64 *rec;
     __device__ __forceinline__ bool get(i64 idx, u64 &w0, u32 &ord) const {
         w0 = rec[idx];
@@ -106,6 +108,7 @@ struct SrcMapped {
 };
 struct SrcRows {            // table rows to be merged: the record is the bare key, the "ordinal" the row index
     typedef u32 w1_t;
+    static constexpr bool MARK = false;
     const u64 *key;
     __device__ __forceinline__ bool get(i64 idx, u64 &rec, u32 &ord) const {
         rec = key[idx] & KEY_MASK;
@@ -160,11 +163,35 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
     const u32 b1 = min(A.n_buckets, b0 + A.buckets_per_wg);
     if (b0 >= A.n_buckets) return;
     unsigned long long &s_base = *reinterpret_cast<unsigned long long *>(s_scan + 16);   // dynamic LDS only: the 160 KB attribute needs it all
-    for (u32 b = b0; b < b1; ++b) {
-        const unsigned long long rb = A.base[b], re = A.base[b + 1];
+    // A bucket is ~1k records (two per thread): a chain of dependent round trips — bounds, records, the output
+    // reservation, the stores — so the kernel is latency bound.  The first AG_R records per thread of the NEXT bucket are
+    // loaded into registers before the current bucket's insert / scan / store phases begin.
+    constexpr int AG_R = 4;
+    u32 b = b0;
+    unsigned long long rb = A.base[b], re = A.base[b + 1];
+    u64 rec_r[AG_R];
+    u32 ord_r[AG_R];
+#pragma unroll
+    for (int u = 0; u < AG_R; ++u) {
+        const unsigned long long i = rb + tid + (unsigned long long)u * AG_T;
+        rec_r[u] = i < re ? A.rec[i] : EMPTY_KEY;
+        ord_r[u] = i < re ? A.ord[i] : 0u;
+    }
+    for (;;) {
+        const u32 bn = b + 1;
+        unsigned long long rbn = 0, ren = 0;
+        u64 rec_n[AG_R];
+        u32 ord_n[AG_R];
+        if (bn < b1) { rbn = A.base[bn]; ren = A.base[bn + 1]; }
+#pragma unroll
+        for (int u = 0; u < AG_R; ++u) {
+            const unsigned long long i = rbn + tid + (unsigned long long)u * AG_T;
+            rec_n[u] = i < ren ? A.rec[i] : EMPTY_KEY;
+            ord_n[u] = i < ren ? A.ord[i] : 0u;
+        }
         const u64 n = re - rb;
-        if (n == 0) continue;
-        // A bucket holds ~8k records (read once from HBM, L2-resident afterwards); it is aggregated in 2^sbits
+        if (n) {
+        // A bucket holds ~8k records at most (read once from HBM, L2-resident afterwards); it is aggregated in 2^sbits
         // SUB-PASSES over the same records, sub-pass s taking the keys whose next sbits hash bits equal s, so
         // that each sub-pass sees ~1k records and fits the 2048-slot table.  (One more radix level would move
         // every record through HBM again instead.)
@@ -180,12 +207,10 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
             for (int c = 0; c < 5; ++c) s_cnt[c * AG_CAP + s] = 0;
         }
         __syncthreads();
-        for (u64 i = rb + tid; i < re; i += AG_T) {
-            const u64 rec = A.rec[i];
+        auto insert = [&](const u64 rec, const u32 ord) {
             const u64 key = rec & KEY_MASK;
             const u64 h = mix64(key);
-            if (sbits && (u32)((h << A.total_bits) >> (64 - sbits)) != sub) continue;
-            const u32 ord = A.ord[i];
+            if (sbits && (u32)((h << A.total_bits) >> (64 - sbits)) != sub) return;
             u32 slot = (u32)h & (tsize - 1);
             u32 probe = 0;
             for (; probe < tsize; ++probe) {
@@ -197,7 +222,7 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
                 }
                 slot = (slot + 1) & (tsize - 1);
             }
-            if (probe == tsize) { atomicExch(A.overflow, 1u); continue; }
+            if (probe == tsize) { atomicExch(A.overflow, 1u); return; }
             if constexpr (MODE == 0) {
                 if (rec & FULL_BIT) {
                     atomicMin((u32 *)&s_of[slot], ord);
@@ -218,7 +243,11 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
                 const u32 f = A.in_fl[ord];
                 if (f) atomicAdd(&s_cnt[4 * AG_CAP + slot], f);
             }
-        }
+        };
+#pragma unroll
+        for (int u = 0; u < AG_R; ++u)
+            if (rec_r[u] != EMPTY_KEY) insert(rec_r[u], ord_r[u]);
+        for (unsigned long long i = rb + tid + (unsigned long long)AG_R * AG_T; i < re; i += AG_T) insert(A.rec[i], A.ord[i]);
         __syncthreads();
         // compaction: contiguous chunk of slots per thread, block exclusive scan of the occupied counts
         const u32 per = tsize >= AG_T ? tsize / AG_T : 1;
@@ -257,6 +286,11 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
         }
         __syncthreads();
         }   // sub-passes
+        }   // n != 0
+        if (bn >= b1) break;
+        b = bn; rb = rbn; re = ren;
+#pragma unroll
+        for (int u = 0; u < AG_R; ++u) { rec_r[u] = rec_n[u]; ord_r[u] = ord_n[u]; }
     }
 }
 

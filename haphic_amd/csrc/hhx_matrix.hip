@@ -14,6 +14,7 @@
 // bitmap rank (columns of a row are unique).
 #include "hhx_ingest.h"
 #include "hhx_partition.h"
+#include "hhx_sort.h"
 
 using namespace hhx;
 
@@ -271,6 +272,7 @@ namespace {
 
 struct SrcDirected {
     typedef u64 w1_t;
+    static constexpr bool MARK = false;
     const u64 *key, *ord_flank;
     const u32 *fl;
     const unsigned char *in_set;
@@ -292,6 +294,116 @@ struct DigRow {
     __device__ __forceinline__ u32 operator()(u64 w0) const { return (u32)(w0 >> ID_BITS); }
 };
 
+// PACKED entries: fragment ids below 2^20 and counts below 2^24 (every real link table) fit ONE 64-bit word
+//     w0 = row << 44 | column-fragment << 24 | count
+// so the two partition levels and the row emit move 8 bytes per entry instead of 16 and the scatter stages 14 entries
+// per thread.  The first positions the 16-byte entries carry in w1 are taken by the level-1 count pass as a side
+// effect of reading the table (SrcDirectedPacked::first_pos).
+constexpr int PK_ID_BITS = 20, PK_CNT_BITS = 24;
+constexpr u32 PK_ID_MASK = (1u << PK_ID_BITS) - 1, PK_CNT_MASK = (1u << PK_CNT_BITS) - 1;
+__device__ __forceinline__ u32 xcc_id() {            // the XCD this wave runs on: s_getreg_b32 HW_REG_XCC_ID (register 20, bits 3:0)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+#else
+    return 0;
+#endif
+}
+struct SrcDirectedPacked {
+    typedef NoPayload w1_t;
+    static constexpr bool MARK = true;      // k_part_count calls mark_load / mark_apply once per record (level 1 only)
+    const u64 *key, *ord_flank;
+    const u32 *fl;
+    const unsigned char *in_set;
+    unsigned long long *first_pos;          // [N_XCC][n_frag]; set in the object the level-1 count pass reads through, null otherwise
+    unsigned int *too_big;
+    i32 n_frag;
+    // extra: the entry's position in the insertion order, 2 * ordinal + side (all ones: its count does not fit PK_CNT_BITS)
+    __device__ __forceinline__ bool get_marked(i64 idx, u64 &w0, u64 &extra) const {
+        const i64 k = idx >> 1;
+        const u64 ord = ord_flank[k];
+        if (ord == NO_ORD) return false;
+        const u64 ky = key[k];
+        const u32 i = (u32)(ky >> ID_BITS), j = (u32)(ky & ID_MASK);
+        if (!in_set[i] || !in_set[j]) return false;
+        const u32 side = (u32)(idx & 1);
+        const u32 a = side ? j : i, b = side ? i : j;
+        const u32 c = fl[k];
+        w0 = ((u64)a << (PK_ID_BITS + PK_CNT_BITS)) | ((u64)b << PK_CNT_BITS) | (u64)(c & PK_CNT_MASK);
+        extra = c > PK_CNT_MASK ? ~0ull : 2 * ord + side;
+        return true;
+    }
+    __device__ __forceinline__ bool get(i64 idx, u64 &w0, NoPayload &) const {
+        u64 extra;
+        return get_marked(idx, w0, extra);
+    }
+    // First position of the row fragment: an atomic min that almost never fires, because the current minimum is read first
+    // and the table is walked in hash order (a minimum settles after ~ln(entries) updates).  For that read to see the
+    // updates it must be served by the cache the atomics pass through: the per-XCD L2s are not coherent with each other, so
+    // every XCD keeps ITS OWN copy of the table (first_pos[xcc][n_frag], merged by k_min_over_xcc afterwards) — an atomic
+    // drops the line from the issuing XCD's L2, the next L2-served (sc1: past the CU's L1) load fetches the new value.
+    // With one shared table each XCD's L2 kept the initial ~0 and every lane fired: 3 ms of fabric atomics per 330 M entries.
+    __device__ __forceinline__ unsigned long long *my_table() const {
+        return first_pos + (size_t)xcc_id() * (size_t)n_frag;
+    }
+    __device__ __forceinline__ u64 mark_load(u64 w0) const {
+        if (!first_pos) return 0;
+        return __hip_atomic_load(&my_table()[(u32)(w0 >> (PK_ID_BITS + PK_CNT_BITS)) & PK_ID_MASK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void mark_apply(u64 w0, u64 pos, u64 seen) const {
+        if (!first_pos) return;
+        if (pos == ~0ull) *too_big = 1u;                                            // 16-byte entries then (the caller starts over)
+        else if (pos < seen) atomicMin(&my_table()[(u32)(w0 >> (PK_ID_BITS + PK_CNT_BITS)) & PK_ID_MASK], (unsigned long long)pos);
+    }
+};
+constexpr int N_XCC = 8;
+__global__ __launch_bounds__(256) void k_min_over_xcc(i32 n_frag, const unsigned long long *__restrict__ per_xcc, unsigned long long *__restrict__ out) {
+    for (i32 f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frag; f += gridDim.x * blockDim.x) {
+        unsigned long long m = ~0ull;
+#pragma unroll
+        for (int x = 0; x < N_XCC; ++x) m = min(m, per_xcc[(size_t)x * n_frag + f]);
+        out[f] = m;
+    }
+}
+struct DigRowPacked {
+    __device__ __forceinline__ u32 operator()(u64 w0) const { return (u32)(w0 >> (PK_ID_BITS + PK_CNT_BITS)) & PK_ID_MASK; }
+};
+__global__ __launch_bounds__(256) void k_len_from_base(i32 n_frag, const i64 *__restrict__ base, const i32 *__restrict__ frag_index, i32 *__restrict__ cnt) {
+    for (i32 f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frag; f += gridDim.x * blockDim.x)
+        if (frag_index[f] >= 0) cnt[frag_index[f]] += (i32)(base[f + 1] - base[f]);          // one writer per index
+}
+// matrix index = rank of the first position: (position, fragment) pairs through the stable radix sort; positions are
+// distinct, fragments without entries (~0) sort behind every real one.  (k_rank_first's all-pairs count is n^2:
+// 1.5 ms at 100k fragments, 6 ms at 200k.)
+__global__ __launch_bounds__(256) void k_iota_u64(i64 n, u64 *out) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) out[k] = (u64)k;
+}
+__global__ __launch_bounds__(256) void k_index_from_sorted(i64 n, const u64 *__restrict__ pos_sorted, const u64 *__restrict__ frag_sorted,
+                                                           i32 *__restrict__ frag_index, unsigned int *n_linked) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) {
+        const bool linked = pos_sorted[k] != ~0ull;
+        frag_index[frag_sorted[k]] = linked ? (i32)k : -1;
+        if (linked && (k + 1 == n || pos_sorted[k + 1] == ~0ull)) *n_linked = (unsigned int)(k + 1);
+    }
+}
+int rank_first_positions(i32 n_frag, const unsigned long long *first_pos, u64 pos_limit, i32 *frag_index, unsigned int *n_linked_dev) {
+    if (n_frag <= 4096) {
+        k_rank_first<<<(unsigned)((n_frag + 255) / 256), 256, 0, g_stream>>>(n_frag, first_pos, frag_index, n_linked_dev);
+        HHX_LAUNCH_CHECK();
+        return 0;
+    }
+    int bits = 1;
+    while (bits < 64 && (pos_limit + 1) >> bits) ++bits;              // every real position < 2^bits - 1: ~0 keeps the top slot
+    DevBuf<u64> iota, ks, vs;
+    if (iota.alloc((size_t)n_frag) || ks.alloc((size_t)n_frag) || vs.alloc((size_t)n_frag)) return 1;
+    k_iota_u64<<<(unsigned)((n_frag + 255) / 256), 256, 0, g_stream>>>(n_frag, iota.p);
+    HHX_LAUNCH_CHECK();
+    HHX_TRY(stable_sort_pairs_u64((const u64 *)first_pos, ks.p, iota.p, vs.p, n_frag, bits));
+    k_index_from_sorted<<<(unsigned)((n_frag + 255) / 256), 256, 0, g_stream>>>(n_frag, ks.p, vs.p, frag_index, n_linked_dev);
+    HHX_LAUNCH_CHECK();
+    HHX_HIP(hipStreamSynchronize(g_stream));                           // ks / vs die here
+    return 0;
+}
+
 // first position (min over the row's entries) and length of every row; one wave per row
 __global__ __launch_bounds__(256) void k_row_first(i32 n_frag, const i64 *__restrict__ base, const u64 *__restrict__ w1,
                                                    unsigned long long *__restrict__ first_pos, i32 *__restrict__ row_len) {
@@ -310,77 +422,94 @@ __global__ __launch_bounds__(256) void k_len_by_index(i32 n_frag, const i32 *__r
     for (i32 f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frag; f += gridDim.x * blockDim.x)
         if (frag_index[f] >= 0) cnt[frag_index[f]] += row_len[f];           // one writer per index
 }
-// one workgroup per linked fragment: CSR row in column order (LDS bitmap rank; columns of a row are unique)
-__global__ __launch_bounds__(256) void k_row_emit(i32 n_frag, i32 W, int self_loop, const i64 *__restrict__ base, const u64 *__restrict__ w0,
-                                                  const u64 *__restrict__ w1, const i32 *__restrict__ frag_index,
-                                                  const i32 *__restrict__ indptr, i32 *__restrict__ oj, float *__restrict__ ox) {
+template <bool PACKED>
+__device__ __forceinline__ u32 entry_col(u64 w0) { return PACKED ? ((u32)(w0 >> PK_CNT_BITS) & PK_ID_MASK) : (u32)(w0 & ID_MASK); }
+template <bool PACKED>
+__device__ __forceinline__ float entry_val(u64 w0, const u64 *__restrict__ w1, i64 p) {
+    return PACKED ? (float)((u32)w0 & PK_CNT_MASK) : (float)(u32)(w1[p] & 0x7fffffffu);
+}
+// One workgroup per linked fragment: CSR row in column order (LDS bitmap rank; columns of a row are unique).
+// The rows are short (3.3k entries on average at C3), so a row is a chain of dependent round trips — entries, index
+// gather, barriers, stores — and the kernel is latency bound: the entries of the NEXT row of the workgroup are loaded
+// into registers before the current row's gather / rank / store phases begin.
+constexpr int EMIT_T = 512, EMIT_R = 8;
+template <bool PACKED>
+__global__ __launch_bounds__(EMIT_T) void k_row_emit(i32 n_frag, i32 W, int self_loop, const i64 *__restrict__ base, const u64 *__restrict__ w0,
+                                                     const u64 *__restrict__ w1, const i32 *__restrict__ frag_index,
+                                                     const i32 *__restrict__ indptr, i32 *__restrict__ oj, float *__restrict__ ox) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32 *bitmap = (u32 *)smem, *prefix = bitmap + W, *scratch = prefix + W;
-    const int tid = threadIdx.x;
-    for (i32 a = blockIdx.x; a < n_frag; a += gridDim.x) {
-        const i32 r = frag_index[a];
-        if (r < 0) continue;
-        const i64 b = base[a], e = base[a + 1];
-        const i32 ob = indptr[r];
-        for (i32 w = tid; w < W; w += 256) bitmap[w] = 0;
-        // the first EMIT_R entries of every thread stay in registers between the marking and the writing sweep
-        // (loads, then dependent index gathers, issued back to back); longer rows re-read the tail
-        constexpr int EMIT_R = 16;
-        i32 cc[EMIT_R];
-        float vv[EMIT_R];
-        u64 t0[EMIT_R];
+    u32 *bitmap = (u32 *)smem, *prefix = bitmap + W, *wsum = prefix + W;       // wsum[EMIT_T / 64]
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / HHX_WAVE;
+    i32 a = blockIdx.x;
+    if (a >= n_frag) return;
+    // registers of the row about to be processed
+    i32 r = frag_index[a];
+    i64 b = base[a], e = r < 0 ? b : base[a + 1];
+    u64 t0[EMIT_R];
 #pragma unroll
-        for (int u = 0; u < EMIT_R; ++u) { const i64 p = b + tid + (i64)u * 256; t0[u] = p < e ? w0[p] : 0; }
+    for (int u = 0; u < EMIT_R; ++u) { const i64 p = b + tid + (i64)u * EMIT_T; t0[u] = p < e ? w0[p] : 0; }
+    for (;;) {
+        const i32 an = a + gridDim.x;
+        i32 rn = -1;
+        i64 bn = 0, en = 0;
+        u64 tn[EMIT_R];
+        if (an < n_frag) { rn = frag_index[an]; bn = base[an]; en = rn < 0 ? bn : base[an + 1]; }
 #pragma unroll
-        for (int u = 0; u < EMIT_R; ++u) { const i64 p = b + tid + (i64)u * 256; vv[u] = p < e ? (float)(u32)(w1[p] & 0x7fffffffu) : 0.f; }
+        for (int u = 0; u < EMIT_R; ++u) { const i64 p = bn + tid + (i64)u * EMIT_T; tn[u] = p < en ? w0[p] : 0; }
+        if (r >= 0) {
+            const i32 ob = indptr[r];
+            for (i32 w = tid; w < W; w += EMIT_T) bitmap[w] = 0;
+            i32 cc[EMIT_R];
 #pragma unroll
-        for (int u = 0; u < EMIT_R; ++u) { const i64 p = b + tid + (i64)u * 256; cc[u] = p < e ? frag_index[(u32)(t0[u] & ID_MASK)] : -1; }
-        __syncthreads();
+            for (int u = 0; u < EMIT_R; ++u) { const i64 p = b + tid + (i64)u * EMIT_T; cc[u] = p < e ? frag_index[entry_col<PACKED>(t0[u])] : -1; }
+            __syncthreads();
 #pragma unroll
-        for (int u = 0; u < EMIT_R; ++u) if (cc[u] >= 0) atomicOr(&bitmap[cc[u] >> 5], 1u << (cc[u] & 31));
-        for (i64 p = b + tid + (i64)EMIT_R * 256; p < e; p += 256) { const i32 c = frag_index[(u32)(w0[p] & ID_MASK)]; atomicOr(&bitmap[c >> 5], 1u << (c & 31)); }
-        if (self_loop && tid == 0) atomicOr(&bitmap[r >> 5], 1u << (r & 31));
-        __syncthreads();
-        const i32 per = (W + 255) / 256, wa = tid * per, wb = min(W, wa + per);
-        u32 local = 0;
-        for (i32 w = wa; w < wb; ++w) local += __popc(bitmap[w]);
-        scratch[tid] = local;
-        __syncthreads();
-        if (tid < 64) {
-            u32 v0 = scratch[tid * 4], v1 = scratch[tid * 4 + 1], v2 = scratch[tid * 4 + 2], v3 = scratch[tid * 4 + 3];
-            u32 s = v0 + v1 + v2 + v3, incl = s;
+            for (int u = 0; u < EMIT_R; ++u) if (cc[u] >= 0) atomicOr(&bitmap[cc[u] >> 5], 1u << (cc[u] & 31));
+            for (i64 p = b + tid + (i64)EMIT_R * EMIT_T; p < e; p += EMIT_T) { const i32 c = frag_index[entry_col<PACKED>(w0[p])]; atomicOr(&bitmap[c >> 5], 1u << (c & 31)); }
+            if (self_loop && tid == 0) atomicOr(&bitmap[r >> 5], 1u << (r & 31));
+            __syncthreads();
+            // exclusive prefix of the word popcounts: a contiguous chunk of words per thread, wave scan, wave totals in LDS
+            const i32 per = (W + EMIT_T - 1) / EMIT_T, wa = min(W, tid * per), wb = min(W, wa + per);
+            u32 local = 0;
+            for (i32 w = wa; w < wb; ++w) local += __popc(bitmap[w]);
+            u32 incl = local;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                u32 t = __shfl_up(incl, o, 64);
-                if (tid >= o) incl += t;
+            for (int o = 1; o < HHX_WAVE; o <<= 1) {
+                const u32 t = __shfl_up(incl, o, HHX_WAVE);
+                if (lane >= o) incl += t;
             }
-            u32 ex = incl - s;
-            scratch[tid * 4] = ex; scratch[tid * 4 + 1] = ex + v0; scratch[tid * 4 + 2] = ex + v0 + v1; scratch[tid * 4 + 3] = ex + v0 + v1 + v2;
-        }
-        __syncthreads();
-        u32 run = scratch[tid];
-        for (i32 w = wa; w < wb; ++w) { prefix[w] = run; run += __popc(bitmap[w]); }
-        __syncthreads();
+            if (lane == HHX_WAVE - 1) wsum[wave] = incl;
+            __syncthreads();
+            u32 run = incl - local;
+            for (int w = 0; w < wave; ++w) run += wsum[w];
+            for (i32 w = wa; w < wb; ++w) { prefix[w] = run; run += __popc(bitmap[w]); }
+            __syncthreads();
 #pragma unroll
-        for (int u = 0; u < EMIT_R; ++u)
-            if (cc[u] >= 0) {
-                const i32 c = cc[u];
+            for (int u = 0; u < EMIT_R; ++u)
+                if (cc[u] >= 0) {
+                    const i32 c = cc[u];
+                    const i32 k = (i32)(prefix[c >> 5] + __popc(bitmap[c >> 5] & ((1u << (c & 31)) - 1u)));
+                    oj[ob + k] = c;
+                    ox[ob + k] = entry_val<PACKED>(t0[u], w1, b + tid + (i64)u * EMIT_T);
+                }
+            for (i64 p = b + tid + (i64)EMIT_R * EMIT_T; p < e; p += EMIT_T) {
+                const u64 t = w0[p];
+                const i32 c = frag_index[entry_col<PACKED>(t)];
                 const i32 k = (i32)(prefix[c >> 5] + __popc(bitmap[c >> 5] & ((1u << (c & 31)) - 1u)));
                 oj[ob + k] = c;
-                ox[ob + k] = vv[u];
+                ox[ob + k] = entry_val<PACKED>(t, w1, p);
             }
-        for (i64 p = b + tid + (i64)EMIT_R * 256; p < e; p += 256) {
-            const i32 c = frag_index[(u32)(w0[p] & ID_MASK)];
-            const i32 k = (i32)(prefix[c >> 5] + __popc(bitmap[c >> 5] & ((1u << (c & 31)) - 1u)));
-            oj[ob + k] = c;
-            ox[ob + k] = (float)(u32)(w1[p] & 0x7fffffffu);
+            if (self_loop && tid == 0) {
+                const i32 k = (i32)(prefix[r >> 5] + __popc(bitmap[r >> 5] & ((1u << (r & 31)) - 1u)));
+                oj[ob + k] = r;
+                ox[ob + k] = 1.0f;                                  // self loops :362-364
+            }
+            __syncthreads();
         }
-        if (self_loop && tid == 0) {
-            const i32 k = (i32)(prefix[r >> 5] + __popc(bitmap[r >> 5] & ((1u << (r & 31)) - 1u)));
-            oj[ob + k] = r;
-            ox[ob + k] = 1.0f;                                  // self loops :362-364
-        }
-        __syncthreads();
+        if (an >= n_frag) break;
+        a = an; r = rn; b = bn; e = en;
+#pragma unroll
+        for (int u = 0; u < EMIT_R; ++u) t0[u] = tn[u];
     }
 }
 // link-less members of frag_set: a unit self loop only
@@ -388,31 +517,51 @@ __global__ __launch_bounds__(256) void k_rest_rows(i32 r0, i32 shape, const i32 
     for (i32 r = r0 + blockIdx.x * blockDim.x + threadIdx.x; r < shape; r += gridDim.x * blockDim.x) { oj[indptr[r]] = r; ox[indptr[r]] = 1.0f; }
 }
 
-int link_matrix_partitioned(const LinkRun *run, i32 n_frag, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,
+// PACKED: 8-byte entries (see SrcDirectedPacked); returns -2 when a count does not fit 24 bits (the caller takes the 16-byte path)
+template <bool PACKED>
+int link_matrix_partitioned(const LinkRun *run, i32 n_frag, u64 ord_limit, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,
                             i32 *frag_index_host, i32 *n_linked_out, hhx_csr **out) {
+    typedef typename std::conditional<PACKED, NoPayload, u64>::type W1;
     DevBuf<unsigned char> in_set;
     if (in_set.alloc((size_t)n_frag)) return 1;
     HHX_HIP(hipMemcpyAsync(in_set.p, in_set_host, (size_t)n_frag, hipMemcpyHostToDevice, g_stream));
     int row_bits = 0;
     while (((i64)1 << row_bits) < n_frag) ++row_bits;
-    const SrcDirected src{run->key.p, run->ord_flank.p, run->fl.p, in_set.p};
-    Partitioned<u64> part;
-    static const int level_bits = getenv("HHX_D2M_LBITS") ? atoi(getenv("HHX_D2M_LBITS")) : 9;
-    HHX_TRY(partition_records(src, DigRow(), 2 * run->n, row_bits, level_bits, &part, "d2m"));
     DevBuf<unsigned long long> first_pos;
     DevBuf<i32> frag_index, row_len;
     DevBuf<unsigned int> nl;
-    if (first_pos.alloc((size_t)n_frag) || frag_index.alloc((size_t)n_frag) || row_len.alloc((size_t)n_frag) || nl.alloc(1)) return 1;
-    HHX_HIP(hipMemsetAsync(nl.p, 0, sizeof(unsigned int), g_stream));
-    if (part.n_valid == 0) {
-        HHX_HIP(hipMemsetAsync(first_pos.p, 0xff, sizeof(unsigned long long) * (size_t)n_frag, g_stream));
-        HHX_HIP(hipMemsetAsync(row_len.p, 0, sizeof(i32) * (size_t)n_frag, g_stream));
+    if (first_pos.alloc((size_t)n_frag) || frag_index.alloc((size_t)n_frag) || nl.alloc(2)) return 1;
+    HHX_HIP(hipMemsetAsync(nl.p, 0, 2 * sizeof(unsigned int), g_stream));
+    Partitioned<W1> part;
+    static const int level_bits = getenv("HHX_D2M_LBITS") ? atoi(getenv("HHX_D2M_LBITS")) : 9;
+    if constexpr (PACKED) {
+        DevBuf<unsigned long long> per_xcc;
+        if (per_xcc.alloc((size_t)N_XCC * (size_t)n_frag)) return 1;
+        HHX_HIP(hipMemsetAsync(per_xcc.p, 0xff, sizeof(unsigned long long) * (size_t)N_XCC * (size_t)n_frag, g_stream));
+        const SrcDirectedPacked src{run->key.p, run->ord_flank.p, run->fl.p, in_set.p, nullptr, nullptr, n_frag};
+        const SrcDirectedPacked marking{run->key.p, run->ord_flank.p, run->fl.p, in_set.p, per_xcc.p, nl.p + 1, n_frag};
+        HHX_TRY(partition_records(src, DigRowPacked(), 2 * run->n, row_bits, level_bits, &part, "d2m", &marking));
+        k_min_over_xcc<<<grid_for((u64)n_frag), 256, 0, g_stream>>>(n_frag, per_xcc.p, first_pos.p);
+        HHX_LAUNCH_CHECK();
+        unsigned int too_big = 0;
+        HHX_HIP(hipMemcpyAsync(&too_big, nl.p + 1, sizeof too_big, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+        if (too_big) return -2;
     } else {
-        k_row_first<<<grid_for((u64)n_frag * 64), 256, 0, g_stream>>>(n_frag, part.base.p, part.w1.p, first_pos.p, row_len.p);
+        const SrcDirected src{run->key.p, run->ord_flank.p, run->fl.p, in_set.p};
+        HHX_TRY(partition_records(src, DigRow(), 2 * run->n, row_bits, level_bits, &part, "d2m"));
+        if (row_len.alloc((size_t)n_frag)) return 1;
+        if (part.n_valid == 0) {
+            HHX_HIP(hipMemsetAsync(first_pos.p, 0xff, sizeof(unsigned long long) * (size_t)n_frag, g_stream));
+            HHX_HIP(hipMemsetAsync(row_len.p, 0, sizeof(i32) * (size_t)n_frag, g_stream));
+        } else {
+            KTimer kt("d2m_row_first");
+            k_row_first<<<grid_for((u64)n_frag * 64), 256, 0, g_stream>>>(n_frag, part.base.p, part.w1.p, first_pos.p, row_len.p);
+        }
         HHX_LAUNCH_CHECK();
     }
-    k_rank_first<<<(unsigned)((n_frag + 255) / 256), 256, 0, g_stream>>>(n_frag, first_pos.p, frag_index.p, nl.p);
-    HHX_LAUNCH_CHECK();
+    { KTimer kt("d2m_rank");
+    HHX_TRY(rank_first_positions(n_frag, first_pos.p, 2 * ord_limit + 1, frag_index.p, nl.p)); }
     unsigned int n_linked = 0;
     HHX_HIP(hipMemcpyAsync(&n_linked, nl.p, sizeof n_linked, hipMemcpyDeviceToHost, g_stream));
     HHX_HIP(hipStreamSynchronize(g_stream));
@@ -427,7 +576,10 @@ int link_matrix_partitioned(const LinkRun *run, i32 n_frag, const uint8_t *in_se
     DevBuf<i32> cnt, indptr;
     if (cnt.alloc((size_t)shape + 1) || indptr.alloc((size_t)shape + 2)) return 1;
     k_init_counts<<<grid_for((u64)shape + 1), 256, 0, g_stream>>>(shape, cnt.p, add_self_loops ? 1 : 0);
-    k_len_by_index<<<grid_for((u64)n_frag), 256, 0, g_stream>>>(n_frag, frag_index.p, row_len.p, cnt.p);
+    if (part.n_valid) {
+        if (PACKED) k_len_from_base<<<grid_for((u64)n_frag), 256, 0, g_stream>>>(n_frag, part.base.p, frag_index.p, cnt.p);
+        else k_len_by_index<<<grid_for((u64)n_frag), 256, 0, g_stream>>>(n_frag, frag_index.p, row_len.p, cnt.p);
+    }
     HHX_LAUNCH_CHECK();
     i64 nnz = 0;
     HHX_TRY(exclusive_scan_i32(cnt.p, indptr.p, shape, &nnz));
@@ -435,16 +587,18 @@ int link_matrix_partitioned(const LinkRun *run, i32 n_frag, const uint8_t *in_se
     HHX_TRY(hhx_csr_alloc_internal(shape, shape, nnz, &m));
     hipError_t e = hipMemcpyAsync(m->indptr.p, indptr.p, sizeof(i32) * ((size_t)shape + 1), hipMemcpyDeviceToDevice, g_stream);
     const i32 W = (shape + 31) / 32;
-    const size_t lds = (size_t)W * 8 + 256 * 4;
+    const size_t lds = (size_t)W * 8 + (EMIT_T / HHX_WAVE) * 4;
     if (lds > 160 * 1024) { hhx_csr_free(m); return fail("link matrix: order %d exceeds the LDS bitmap capacity", shape); }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_row_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_row_emit<PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (e == hipSuccess && part.n_valid)
-        k_row_emit<<<(unsigned)std::min<i64>(n_frag, 256 * 8), 256, lds, g_stream>>>(n_frag, W, add_self_loops, part.base.p, part.w0.p, part.w1.p,
-                                                                                  frag_index.p, indptr.p, m->indices.p, m->data.p);
+    if (e == hipSuccess && part.n_valid) {
+        KTimer kt("d2m_emit");
+        k_row_emit<PACKED><<<(unsigned)std::min<i64>(n_frag, 256 * 6), EMIT_T, lds, g_stream>>>(n_frag, W, add_self_loops, part.base.p, part.w0.p,
+                                                                                          (const u64 *)part.w1.p, frag_index.p, indptr.p, m->indices.p, m->data.p);
+    }
     if (e == hipSuccess && add_self_loops && shape > (i32)n_linked)
         k_rest_rows<<<grid_for((u64)(shape - (i32)n_linked)), 256, 0, g_stream>>>((i32)n_linked, shape, indptr.p, m->indices.p, m->data.p);
     if (e == hipSuccess) e = hipGetLastError();
@@ -463,8 +617,13 @@ int hhx_link_matrix_from_run(const LinkRun *run, i32 n_frag, u64 ord_limit, cons
                              i32 *frag_index_host, i32 *n_linked_out, hhx_csr **out) {
     if (!out || !in_set_host || n_frag <= 0) return fail("hhx_ingest_link_matrix: bad argument");
     // packed entries hold 2*ordinal+side in 33 bits and the count in 31: true whenever < 2^31 pairs were seen
-    if (run && run->n && n_frag <= (1 << 20) && ord_limit <= ((u64)1 << 31) && !getenv("HHX_D2M_GENERIC"))
-        return link_matrix_partitioned(run, n_frag, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked_out, out);
+    if (run && run->n && n_frag <= (1 << 20) && ord_limit <= ((u64)1 << 31) && !getenv("HHX_D2M_GENERIC")) {
+        if (!getenv("HHX_D2M_WIDE")) {                           // 8-byte entries unless a count needs more than 24 bits
+            const int rc = link_matrix_partitioned<true>(run, n_frag, ord_limit, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked_out, out);
+            if (rc != -2) return rc;
+        }
+        return link_matrix_partitioned<false>(run, n_frag, ord_limit, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked_out, out);
+    }
     const RunView vw{run ? run->key.p : nullptr, run ? run->ord_flank.p : nullptr, run ? run->fl.p : nullptr};
     return build_matrix(vw, run ? run->n : 0, n_frag, in_set_host, n_rest, add_self_loops, frag_index_host, n_linked_out, out);
 }

@@ -1,4 +1,4 @@
-// Radix partition of (w0: u64, w1: u32 | u64) records into 2^total_bits buckets, in levels of at most
+// Radix partition of (w0: u64, w1: u32 | u64 | nothing) records into 2^total_bits buckets, in levels of at most
 // 8-9 bits.  Shared by the link-table group-by (hhx_ingest.hip: bucket = hash of the key) and by the link
 // matrix build (hhx_matrix.hip: bucket = matrix row).
 //
@@ -14,9 +14,12 @@
 namespace hhx {
 
 constexpr int PT = 512, P_MAX_BINS = 512;
-// records per thread and tile: 8 x 512 = 4096 records of 12 B, 7 x 512 of 16 B — both stage in < 80 KB of LDS
-// (two workgroups per CU)
-template <class W1> struct PartTile { static constexpr int ITEMS = sizeof(W1) == 4 ? 8 : 7, TILE = PT * ITEMS; };
+struct NoPayload {};       // w1_t of a source whose records are the bare 64-bit word
+template <class W1> struct PartW1 { static constexpr bool HAS = true; static constexpr size_t BYTES = sizeof(W1); };
+template <> struct PartW1<NoPayload> { static constexpr bool HAS = false; static constexpr size_t BYTES = 0; };
+// records per thread and tile: 8 x 512 = 4096 records of 12 B, 7 x 512 of 16 B, 14 x 512 of 8 B — all stage in < 80 KB
+// of LDS (two workgroups per CU).  The longer the tile, the longer the contiguous run a (tile, bucket) pair writes.
+template <class W1> struct PartTile { static constexpr int ITEMS = !PartW1<W1>::HAS ? 14 : (sizeof(W1) == 4 ? 8 : 7), TILE = PT * ITEMS; };
 
 struct PartLevel {
     int total_bits;     // buckets = 2^total_bits; bucket id comes from the Dig functor
@@ -28,9 +31,14 @@ struct PartLevel {
 template <class W1>
 struct SrcRecs {
     typedef W1 w1_t;
+    static constexpr bool MARK = false;
     const u64 *w0;
     const W1 *w1;
-    __device__ __forceinline__ bool get(i64 idx, u64 &a, W1 &b) const { a = w0[idx]; b = w1[idx]; return true; }
+    __device__ __forceinline__ bool get(i64 idx, u64 &a, W1 &b) const {
+        a = w0[idx];
+        if constexpr (PartW1<W1>::HAS) b = w1[idx];
+        return true;
+    }
 };
 
 template <class Src, class Dig>
@@ -64,6 +72,33 @@ __global__ __launch_bounds__(PT) void k_part_count(Src src, Dig dig, i64 n, Part
             cur = tg;
             __syncthreads();
         }
+        if constexpr (Src::MARK) {
+            // a source with a side effect per record (get_marked / mark_load / mark_apply): the record loads of half a tile
+            // first, then the loads the side effect needs, then its (rare) atomics — an atomic inside the per-record loop
+            // would pin the loads of the following records behind it and serialise a dozen round trips per thread; halves,
+            // because three 64-bit words per record in flight for the whole tile cost the kernel half its occupancy
+            constexpr int HALF = (P_ITEMS + 1) / 2;
+#pragma unroll
+            for (int h = 0; h < P_ITEMS; h += HALF) {
+                u64 w0[HALF], extra[HALF], seen[HALF];
+                bool ok[HALF];
+#pragma unroll
+                for (int k = 0; k < HALF; ++k) {
+                    const i64 idx = base + (i64)(h + k) * PT + tid;
+                    ok[k] = h + k < P_ITEMS && idx < n && src.get_marked(idx, w0[k], extra[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < HALF; ++k) seen[k] = ok[k] ? src.mark_load(w0[k]) : 0;
+#pragma unroll
+                for (int k = 0; k < HALF; ++k)
+                    if (ok[k]) {
+                        src.mark_apply(w0[k], extra[k], seen[k]);
+                        const u32 d = dig(w0[k]) >> L.shift;
+                        if ((d >> L.lds_bits) == tg) atomicAdd(&hist[d & (u32)(nb - 1)], 1u);
+                        else atomicAdd(&ghist[d], 1ull);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < P_ITEMS; ++k) {
             const i64 idx = base + (i64)k * PT + tid;
@@ -74,6 +109,7 @@ __global__ __launch_bounds__(PT) void k_part_count(Src src, Dig dig, i64 n, Part
                 else atomicAdd(&ghist[d], 1ull);
             }
         }
+        }
         __syncthreads();
     }
     if (cur != 0xffffffffu)
@@ -83,7 +119,7 @@ __global__ __launch_bounds__(PT) void k_part_count(Src src, Dig dig, i64 n, Part
 
 template <class W1>
 constexpr size_t part_scatter_lds() {
-    return (size_t)PartTile<W1>::TILE * (8 + sizeof(W1) + 2) + (size_t)P_MAX_BINS * (4 + 4 + 8) + 16;
+    return (size_t)PartTile<W1>::TILE * (8 + PartW1<W1>::BYTES + 2) + (size_t)P_MAX_BINS * (4 + 4 + 8) + 16;
 }
 
 template <class Src, class Dig>
@@ -94,8 +130,8 @@ __global__ __launch_bounds__(PT) void k_part_scatter(Src src, Dig dig, i64 n, Pa
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *s_w0 = (u64 *)smem;                                     // [P_TILE] tile grouped by bucket
     unsigned long long *gbase = (unsigned long long *)(s_w0 + P_TILE);   // [P_MAX_BINS] reserved global run of every bucket
-    W1 *s_w1 = (W1 *)(gbase + P_MAX_BINS);                       // [P_TILE]
-    u32 *hist = (u32 *)(s_w1 + P_TILE);                          // [P_MAX_BINS]
+    W1 *s_w1 = (W1 *)(gbase + P_MAX_BINS);                       // [P_TILE] (nothing for payload-free records)
+    u32 *hist = (u32 *)((unsigned char *)s_w1 + (size_t)P_TILE * PartW1<W1>::BYTES);   // [P_MAX_BINS]
     u32 *lbase = hist + P_MAX_BINS;                              // [P_MAX_BINS] tile-local exclusive prefix
     u32 *s_misc = lbase + P_MAX_BINS;                            // [4]: group, wave sums scratch
     unsigned short *s_bin = (unsigned short *)(s_misc + 4);      // [P_TILE]
@@ -123,7 +159,7 @@ __global__ __launch_bounds__(PT) void k_part_scatter(Src src, Dig dig, i64 n, Pa
                 } else {                                         // straddling record: reserve its slot directly
                     const unsigned long long pos = atomicAdd(&cursor[d], 1ull);
                     out_w0[pos] = w0[k];
-                    out_w1[pos] = w1[k];
+                    if constexpr (PartW1<W1>::HAS) out_w1[pos] = w1[k];
                 }
             }
         }
@@ -153,7 +189,7 @@ __global__ __launch_bounds__(PT) void k_part_scatter(Src src, Dig dig, i64 n, Pa
             if (loc[k] != 0xffffffffu) {
                 const u32 s = lbase[loc[k]] + rank[k];
                 s_w0[s] = w0[k];
-                s_w1[s] = w1[k];
+                if constexpr (PartW1<W1>::HAS) s_w1[s] = w1[k];
                 s_bin[s] = (unsigned short)loc[k];
             }
         __syncthreads();
@@ -162,7 +198,7 @@ __global__ __launch_bounds__(PT) void k_part_scatter(Src src, Dig dig, i64 n, Pa
             const u32 b = s_bin[s];
             const unsigned long long pos = gbase[b] + (s - lbase[b]);
             out_w0[pos] = s_w0[s];
-            out_w1[pos] = s_w1[s];
+            if constexpr (PartW1<W1>::HAS) out_w1[pos] = s_w1[s];
         }
         __syncthreads();
     }
@@ -185,13 +221,21 @@ inline int part_levels(int total_bits, int max_bits, int *bits /* [4] */) {
     int n = total_bits <= 0 ? 1 : (total_bits + max_bits - 1) / max_bits;
     if (n > 4) n = 4;
     int left = total_bits;
-    for (int l = 0; l < n; ++l) { bits[l] = (left + (n - l) - 1) / (n - l); left -= bits[l]; }
+    // the FIRST level gets the smaller share: its (tile, bucket) runs are scattered over the whole output, so they should be
+    // long; a later level writes inside one bucket of the previous one, a region the L2 / Infinity Cache merges
+    static const bool ascending = !getenv("HHX_PART_DESC");
+    for (int l = 0; l < n; ++l) {
+        bits[l] = ascending ? left / (n - l) : (left + (n - l) - 1) / (n - l);
+        left -= bits[l];
+    }
     return n;
 }
 
+// count_src (optional): the source object the level-1 COUNT pass reads through instead of src — same records, but its
+// get() may carry a side effect that has to happen exactly once per record (hhx_matrix.hip: first positions).
 template <class Src, class Dig>
 int partition_records(const Src &src, const Dig &dig, i64 n_items, int total_bits, int max_bits_per_level,
-                      Partitioned<typename Src::w1_t> *out, const char *timer_prefix) {
+                      Partitioned<typename Src::w1_t> *out, const char *timer_prefix, const Src *count_src = nullptr) {
     typedef typename Src::w1_t W1;
     static bool attr_set = false;
     if (!attr_set) {
@@ -225,7 +269,7 @@ int partition_records(const Src &src, const Dig &dig, i64 n_items, int total_bit
         const SrcRecs<W1> rs{cur_w0.p, cur_w1.p};
         snprintf(tname, sizeof tname, "%s_count%d", timer_prefix, l + 1);
         { KTimer kt(tname);
-        if (l == 0) k_part_count<Src, Dig><<<grid, PT, 0, g_stream>>>(src, dig, n_cur, L, hist.p);
+        if (l == 0) k_part_count<Src, Dig><<<grid, PT, 0, g_stream>>>(count_src ? *count_src : src, dig, n_cur, L, hist.p);
         else k_part_count<SrcRecs<W1>, Dig><<<grid, PT, 0, g_stream>>>(rs, dig, n_cur, L, hist.p); }
         HHX_LAUNCH_CHECK();
         i64 n_valid = 0;
@@ -236,7 +280,7 @@ int partition_records(const Src &src, const Dig &dig, i64 n_items, int total_bit
             out->base = std::move(nbase);
             return 0;
         }
-        if (nxt_w0.alloc((size_t)n_valid) || nxt_w1.alloc((size_t)n_valid)) return 1;
+        if (nxt_w0.alloc((size_t)n_valid) || (PartW1<W1>::HAS && nxt_w1.alloc((size_t)n_valid))) return 1;
         u64_copy_async((const unsigned long long *)nbase.p, cursor.p, (i64)nbk + 1);
         snprintf(tname, sizeof tname, "%s_scatter%d", timer_prefix, l + 1);
         { KTimer kt(tname);

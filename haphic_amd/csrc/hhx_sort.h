@@ -15,7 +15,7 @@ namespace hhx {
 
 constexpr int RS_T = 256, RS_ROUNDS = 8, RS_TILE = RS_T * RS_ROUNDS, RS_BINS = 256, RS_WAVES = RS_T / HHX_WAVE;
 
-__global__ __launch_bounds__(RS_T) void k_rs_hist(const u64 *__restrict__ key, i64 n, int shift, i64 n_tiles, i64 *__restrict__ table) {
+static __global__ __launch_bounds__(RS_T) void k_rs_hist(const u64 *__restrict__ key, i64 n, int shift, i64 n_tiles, i64 *__restrict__ table) {
     __shared__ u32 hist[RS_BINS];
     for (i64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         hist[threadIdx.x] = 0;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(RS_T) void k_rs_hist(const u64 *__restrict__ key, i
     }
 }
 
-__global__ __launch_bounds__(RS_T) void k_rs_scatter(const u64 *__restrict__ key, const u64 *__restrict__ val, i64 n, int shift, i64 n_tiles,
+static __global__ __launch_bounds__(RS_T) void k_rs_scatter(const u64 *__restrict__ key, const u64 *__restrict__ val, i64 n, int shift, i64 n_tiles,
                                                      const i64 *__restrict__ table, u64 *__restrict__ okey, u64 *__restrict__ oval) {
     __shared__ i64 base[RS_BINS];                 // global position of the next item of every digit of this tile
     __shared__ u32 wcnt[RS_WAVES][RS_BINS];       // items of every digit per wave, current round

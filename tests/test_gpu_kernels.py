@@ -661,3 +661,58 @@ def test_mcl_links_class_stream_iteration0():
     _lib.normalize_l1(nn)
     r4, n4, c4 = _lib.mcl(nn, 2, 2.0, 30, 1e-4, normalized=True)
     assert (n3, c3) == (n4, c4) and all(np.array_equal(x, y) for x, y in zip(r3.to_arrays(), r4.to_arrays()))
+
+
+def test_link_matrix_packed_and_wide_entries():
+    """hhx_ingest_link_matrix moves 8-byte entries (row, column, count < 2^24) through its partition and 16-byte ones when
+    a count needs more bits: both against the oracle's dict_to_matrix on the fetched tables, > 4096 fragments (the
+    sort-ranked index assignment), then with one contig pair holding 17 M links (the automatic fall-back)"""
+    import os
+    import torch
+    from haphic_amd import synth
+    gen = synth.make_genome(5, 20_000_000, 20_000, seed=8)
+    n = gen.n
+    assert n > 4096
+    t = orc.FragTable(gen.lexical_rank(), gen.length, np.arange(n, dtype=np.int32), np.zeros(n, np.uint8), 0,
+                      gen.lexical_rank(), gen.length, (np.arange(n) % 11 != 0).astype(np.uint8))
+    id1, p1, id2, p2 = synth.sample_pairs(gen, 3_000_000, seed=2, device='cuda')
+    in_set = t.frag_nx.copy()
+
+    def check(ing):
+        out = ing.fetch()
+        linked = np.zeros(n, bool)
+        ok = in_set[out['flank_i']].astype(bool) & in_set[out['flank_j']].astype(bool)
+        linked[out['flank_i'][ok]] = True
+        linked[out['flank_j'][ok]] = True
+        n_rest = int(in_set.sum() - linked.sum())
+        want = orc.dict_to_matrix(out['flank_i'], out['flank_j'], out['flank_cnt'].astype(np.float64), n, in_set, n_rest)
+        got = []
+        for wide in (False, True):
+            if wide:
+                os.environ['HHX_D2M_WIDE'] = '1'
+            try:
+                m, fidx, nl = ing.link_matrix(in_set)
+            finally:
+                os.environ.pop('HHX_D2M_WIDE', None)
+            assert nl == want[4] and np.array_equal(fidx, want[3])
+            assert all(np.array_equal(a, b) for a, b in zip(m.to_arrays(), want[:3])), wide
+            got.append(m)
+        return out
+
+    ing = _lib.Ingest(t, 5000, bins=False, skip_intra=True)
+    ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+    check(ing)
+    ing.destroy()
+    # one heavy contig pair: 17 M read pairs inside the flanks of contigs a, b (both in the Nx set)
+    a, b = 1, 2
+    heavy = 17_000_000
+    ing = _lib.Ingest(t, 5000, bins=False, skip_intra=True)
+    ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+    ha = torch.full((heavy,), a, dtype=torch.int32, device='cuda')
+    hb = torch.full((heavy,), b, dtype=torch.int32, device='cuda')
+    hp = torch.full((heavy,), 10, dtype=torch.int32, device='cuda')
+    ing.push_device(heavy, ha.data_ptr(), hp.data_ptr(), hb.data_ptr(), hp.data_ptr())
+    out = check(ing)
+    k = np.flatnonzero((out['flank_i'] == a) & (out['flank_j'] == b))
+    assert len(k) == 1 and out['flank_cnt'][k[0]] > (1 << 24)
+    ing.destroy()

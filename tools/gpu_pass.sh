@@ -40,6 +40,8 @@ for l in open('gpurun_out/bench_text.log'):
     multirank) timeout 1500 python -m pytest tests/test_gpu_multirank.py -m gpu -x -q --durations=3 > gpurun_out/pytest_multirank.log 2>&1; echo "multirank rc=$?"; tail -15 gpurun_out/pytest_multirank.log;;
     plot) timeout 600 python -m pytest tests/test_plot.py -m gpu -x -q > gpurun_out/pytest_plot.log 2>&1; echo "plot rc=$?"; grep -E "passed|failed|Error|error" gpurun_out/pytest_plot.log | tail -8;;
     cprobe) timeout 600 python tools/contact_probe.py > gpurun_out/contact_probe.jsonl 2> gpurun_out/contact_probe.err; echo "cprobe rc=$?"; cat gpurun_out/contact_probe.jsonl; tail -3 gpurun_out/contact_probe.err;;
+    iprobe) timeout 600 python tools/ingest_probe.py > gpurun_out/ingest_probe.jsonl 2> gpurun_out/ingest_probe.err; echo "iprobe rc=$?"; cat gpurun_out/ingest_probe.jsonl; tail -3 gpurun_out/ingest_probe.err;;
+    k:*) timeout 900 python -m pytest tests -m gpu -x -q -k "${what#k:}" > gpurun_out/pytest_sel.log 2>&1; echo "sel rc=$?"; grep -E "passed|failed|Error|^E " gpurun_out/pytest_sel.log | tail -12;;
     listpmc) rocprofv3 -L > gpurun_out/pmc_list.txt 2>&1; grep -c . gpurun_out/pmc_list.txt;;
     env:*) export "${what#env:}"; echo "set ${what#env:}";;
     *) echo "unknown $what";;
