@@ -143,4 +143,9 @@ __device__ __forceinline__ i64 wave_sum_i64(i64 v) {
     return __shfl(v, 0, HHX_WAVE);
 }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (HHX_WAVE - 1); }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release / acquire over ALL address
+// spaces: on gfx950 it waits for every outstanding global load and store of the wave (s_waitcnt vmcnt(0)), so a prefetch
+// issued before it is no prefetch and every phase of a kernel pays the drain of the stores of the phase before.  Use this
+// where the waves of a workgroup exchange data through LDS alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif

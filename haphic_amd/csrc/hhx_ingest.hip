@@ -169,6 +169,7 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
     constexpr int AG_R = 4;
     u32 b = b0;
     unsigned long long rb = A.base[b], re = A.base[b + 1];
+    unsigned long long rbn = b + 1 < b1 ? A.base[b + 1] : 0ull, ren = b + 1 < b1 ? A.base[b + 2] : 0ull;      // bounds run two buckets ahead
     u64 rec_r[AG_R];
     u32 ord_r[AG_R];
 #pragma unroll
@@ -177,18 +178,24 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
         rec_r[u] = i < re ? A.rec[i] : EMPTY_KEY;
         ord_r[u] = i < re ? A.ord[i] : 0u;
     }
+    // The loop must be entered with these registers DEFINED, not with loads pending on them: the waitcnt pass is static,
+    // so a load pending at the loop entry puts an s_waitcnt vmcnt(0) in front of every use inside the loop — and vmcnt(0)
+    // also waits for the prefetch the iteration has just issued.
+#pragma unroll
+    for (int u = 0; u < AG_R; ++u) { asm volatile("" : "+v"(rec_r[u])); asm volatile("" : "+v"(ord_r[u])); }
+    asm volatile("" : "+v"(rbn)); asm volatile("" : "+v"(ren));
     for (;;) {
         const u32 bn = b + 1;
-        unsigned long long rbn = 0, ren = 0;
         u64 rec_n[AG_R];
         u32 ord_n[AG_R];
-        if (bn < b1) { rbn = A.base[bn]; ren = A.base[bn + 1]; }
 #pragma unroll
         for (int u = 0; u < AG_R; ++u) {
             const unsigned long long i = rbn + tid + (unsigned long long)u * AG_T;
             rec_n[u] = i < ren ? A.rec[i] : EMPTY_KEY;
             ord_n[u] = i < ren ? A.ord[i] : 0u;
         }
+        unsigned long long rbn2 = 0, ren2 = 0;
+        if (bn + 1 < b1) { rbn2 = A.base[bn + 1]; ren2 = A.base[bn + 2]; }
         const u64 n = re - rb;
         if (n) {
         // A bucket holds ~8k records at most (read once from HBM, L2-resident afterwards); it is aggregated in 2^sbits
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
 #pragma unroll
             for (int c = 0; c < 5; ++c) s_cnt[c * AG_CAP + s] = 0;
         }
-        __syncthreads();
+        lds_barrier();
         auto insert = [&](const u64 rec, const u32 ord) {
             const u64 key = rec & KEY_MASK;
             const u64 h = mix64(key);
@@ -214,7 +221,8 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
             u32 slot = (u32)h & (tsize - 1);
             u32 probe = 0;
             for (; probe < tsize; ++probe) {
-                const u64 cur = *(volatile u64 *)&s_key[slot];
+                // (a volatile access would lose the LDS address space: a FLAT load, which waits for every outstanding global load)
+                const u64 cur = __hip_atomic_load(&s_key[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (cur == key) break;
                 if (cur == EMPTY_KEY) {
                     const u64 old = atomicCAS((unsigned long long *)&s_key[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
@@ -248,7 +256,13 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
         for (int u = 0; u < AG_R; ++u)
             if (rec_r[u] != EMPTY_KEY) insert(rec_r[u], ord_r[u]);
         for (unsigned long long i = rb + tid + (unsigned long long)AG_R * AG_T; i < re; i += AG_T) insert(A.rec[i], A.ord[i]);
-        __syncthreads();
+        lds_barrier();
+        // The prefetched registers are pinned HERE, before this bucket's reservation atomic and output stores are issued:
+        // vmcnt completes in order, so a wait for the prefetch placed after the stores (at the loop latch, where the compiler
+        // would put it) would drain the stores too, every bucket.  Here the loads were issued a whole insert phase ago.
+#pragma unroll
+        for (int u = 0; u < AG_R; ++u) { asm volatile("" : "+v"(rec_n[u])); asm volatile("" : "+v"(ord_n[u])); }
+        asm volatile("" : "+v"(rbn2)); asm volatile("" : "+v"(ren2));
         // compaction: contiguous chunk of slots per thread, block exclusive scan of the occupied counts
         const u32 per = tsize >= AG_T ? tsize / AG_T : 1;
         const u32 s0 = min(tsize, (u32)tid * per), s1 = min(tsize, s0 + per);
@@ -261,12 +275,12 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
             if (lane >= o) incl += v;
         }
         if (lane == HHX_WAVE - 1) s_scan[wave] = incl;
-        __syncthreads();
+        lds_barrier();
         u32 woff = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < AG_T / HHX_WAVE; ++w) { if (w < wave) woff += s_scan[w]; total += s_scan[w]; }
         if (tid == 0) s_base = total ? atomicAdd(A.out_cursor, (unsigned long long)total) : 0ull;
-        __syncthreads();
+        lds_barrier();
         unsigned long long o = s_base + woff + incl - mine;
         for (u32 s = s0; s < s1; ++s) {
             const u64 key = s_key[s];
@@ -284,11 +298,15 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
             A.o_fl[o] = s_cnt[4 * AG_CAP + s];
             ++o;
         }
-        __syncthreads();
+        lds_barrier();
         }   // sub-passes
-        }   // n != 0
+        } else {   // empty bucket: same pins, so that no path reaches the latch with loads pending (see above)
+#pragma unroll
+            for (int u = 0; u < AG_R; ++u) { asm volatile("" : "+v"(rec_n[u])); asm volatile("" : "+v"(ord_n[u])); }
+            asm volatile("" : "+v"(rbn2)); asm volatile("" : "+v"(ren2));
+        }
         if (bn >= b1) break;
-        b = bn; rb = rbn; re = ren;
+        b = bn; rb = rbn; re = ren; rbn = rbn2; ren = ren2;
 #pragma unroll
         for (int u = 0; u < AG_R; ++u) { rec_r[u] = rec_n[u]; ord_r[u] = ord_n[u]; }
     }

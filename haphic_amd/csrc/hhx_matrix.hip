@@ -448,6 +448,11 @@ __global__ __launch_bounds__(EMIT_T) void k_row_emit(i32 n_frag, i32 W, int self
     u64 t0[EMIT_R];
 #pragma unroll
     for (int u = 0; u < EMIT_R; ++u) { const i64 p = b + tid + (i64)u * EMIT_T; t0[u] = p < e ? w0[p] : 0; }
+    // the loop is entered with t0 DEFINED (no load pending on it), and inside it the prefetched tn is pinned before the row's
+    // stores are issued: the waitcnt pass is static and vmcnt completes in order, so a pending load at the loop entry puts a
+    // vmcnt(0) in front of every use of t0, and a wait for tn placed after the stores drains the stores, every row
+#pragma unroll
+    for (int u = 0; u < EMIT_R; ++u) asm volatile("" : "+v"(t0[u]));
     for (;;) {
         const i32 an = a + gridDim.x;
         i32 rn = -1;
@@ -462,12 +467,12 @@ __global__ __launch_bounds__(EMIT_T) void k_row_emit(i32 n_frag, i32 W, int self
             i32 cc[EMIT_R];
 #pragma unroll
             for (int u = 0; u < EMIT_R; ++u) { const i64 p = b + tid + (i64)u * EMIT_T; cc[u] = p < e ? frag_index[entry_col<PACKED>(t0[u])] : -1; }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int u = 0; u < EMIT_R; ++u) if (cc[u] >= 0) atomicOr(&bitmap[cc[u] >> 5], 1u << (cc[u] & 31));
             for (i64 p = b + tid + (i64)EMIT_R * EMIT_T; p < e; p += EMIT_T) { const i32 c = frag_index[entry_col<PACKED>(w0[p])]; atomicOr(&bitmap[c >> 5], 1u << (c & 31)); }
             if (self_loop && tid == 0) atomicOr(&bitmap[r >> 5], 1u << (r & 31));
-            __syncthreads();
+            lds_barrier();
             // exclusive prefix of the word popcounts: a contiguous chunk of words per thread, wave scan, wave totals in LDS
             const i32 per = (W + EMIT_T - 1) / EMIT_T, wa = min(W, tid * per), wb = min(W, wa + per);
             u32 local = 0;
@@ -479,11 +484,14 @@ __global__ __launch_bounds__(EMIT_T) void k_row_emit(i32 n_frag, i32 W, int self
                 if (lane >= o) incl += t;
             }
             if (lane == HHX_WAVE - 1) wsum[wave] = incl;
-            __syncthreads();
+            lds_barrier();
             u32 run = incl - local;
             for (int w = 0; w < wave; ++w) run += wsum[w];
             for (i32 w = wa; w < wb; ++w) { prefix[w] = run; run += __popc(bitmap[w]); }
-            __syncthreads();
+            lds_barrier();
+#pragma unroll
+            for (int u = 0; u < EMIT_R; ++u) asm volatile("" : "+v"(tn[u]));
+            asm volatile("" : "+v"(rn)); asm volatile("" : "+v"(bn)); asm volatile("" : "+v"(en));
 #pragma unroll
             for (int u = 0; u < EMIT_R; ++u)
                 if (cc[u] >= 0) {
@@ -504,7 +512,11 @@ __global__ __launch_bounds__(EMIT_T) void k_row_emit(i32 n_frag, i32 W, int self
                 oj[ob + k] = r;
                 ox[ob + k] = 1.0f;                                  // self loops :362-364
             }
-            __syncthreads();
+            lds_barrier();
+        } else {
+#pragma unroll
+            for (int u = 0; u < EMIT_R; ++u) asm volatile("" : "+v"(tn[u]));
+            asm volatile("" : "+v"(rn)); asm volatile("" : "+v"(bn)); asm volatile("" : "+v"(en));
         }
         if (an >= n_frag) break;
         a = an; r = rn; b = bn; e = en;

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(PT) void k_part_count(Src src, Dig dig, i64 n, Part
     for (i64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const i64 base = tile * P_TILE;
         if (tid == 0) s_grp = tile_group(src, dig, base, n, L);
-        __syncthreads();
+        lds_barrier();
         const u32 tg = s_grp;
         if (tg != cur) {                                         // flush the histogram of the previous group
             if (cur != 0xffffffffu)
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(PT) void k_part_count(Src src, Dig dig, i64 n, Part
                     hist[t] = 0;
                 }
             cur = tg;
-            __syncthreads();
+            lds_barrier();
         }
         if constexpr (Src::MARK) {
             // a source with a side effect per record (get_marked / mark_load / mark_apply): the record loads of half a tile
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(PT) void k_part_count(Src src, Dig dig, i64 n, Part
             }
         }
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (cur != 0xffffffffu)
         for (int t = tid; t < nb; t += PT)
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(PT) void k_part_scatter(Src src, Dig dig, i64 n, Pa
         const i64 base = tile * P_TILE;
         for (int t = tid; t < nb; t += PT) hist[t] = 0;
         if (tid == 0) s_misc[0] = tile_group(src, dig, base, n, L);
-        __syncthreads();
+        lds_barrier();
         const u32 tg = s_misc[0];
         u64 w0[P_ITEMS];
         W1 w1[P_ITEMS];
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(PT) void k_part_scatter(Src src, Dig dig, i64 n, Pa
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         // tile-local exclusive scan of the histogram (one bin per thread, nb <= PT) + global reservation
         {
             const u32 c = tid < nb ? hist[tid] : 0;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(PT) void k_part_scatter(Src src, Dig dig, i64 n, Pa
                 if (lane >= o) incl += v;
             }
             if (lane == HHX_WAVE - 1) wsum[wave] = incl;
-            __syncthreads();
+            lds_barrier();
             u32 woff = 0;
             for (int w = 0; w < wave; ++w) woff += wsum[w];
             if (tid < nb) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(PT) void k_part_scatter(Src src, Dig dig, i64 n, Pa
             }
             if (tid == PT - 1) s_misc[1] = woff + incl;          // records staged by this tile
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int k = 0; k < P_ITEMS; ++k)
             if (loc[k] != 0xffffffffu) {
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(PT) void k_part_scatter(Src src, Dig dig, i64 n, Pa
                 if constexpr (PartW1<W1>::HAS) s_w1[s] = w1[k];
                 s_bin[s] = (unsigned short)loc[k];
             }
-        __syncthreads();
+        lds_barrier();
         const u32 staged = s_misc[1];
         for (u32 s = tid; s < staged; s += PT) {                 // linear sweep: lanes write consecutive addresses inside a run
             const u32 b = s_bin[s];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(PT) void k_part_scatter(Src src, Dig dig, i64 n, Pa
             out_w0[pos] = s_w0[s];
             if constexpr (PartW1<W1>::HAS) out_w1[pos] = s_w1[s];
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
