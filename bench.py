@@ -225,7 +225,8 @@ def main():
                'pre_expansion': 'fused into iteration 0', 'clusters': state.get('clusters'),
                'alg_bytes_per_mcl_survey': b_iter, 'alg_GBs_survey': b_iter * K / t_mcl / 1e9 if t_mcl else None,
                'stats_nnzA_nnzC_nnzP_F': stats.tolist(),
-               'kernel_ms_per_step': {'expand_window': win_ms / K, 'expand_window_short': pg('expand_window_short')[0] / K, 'expand_finalize': fin_ms / K, 'expand_compact': cmp_ms / K,
+               'kernel_ms_per_step': {'expand_window': win_ms / K, 'expand_window_short': pg('expand_window_short')[0] / K, 'expand_hash': pg('expand_hash')[0] / K,
+                                      'expand_finalize': fin_ms / K, 'expand_compact': cmp_ms / K,
                                       'expand_tiny': tiny_ms / K,
                                       'convergence': cvg_ms / K}}
         ingest = {'pairs_per_s': value, 'ms_per_step': t_ing / K * 1e3, 'alg_bytes_survey': b_ingest,

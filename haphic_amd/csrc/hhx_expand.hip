@@ -50,6 +50,7 @@ struct ExParams {
     // [count 1][count 2][count 3][other], 75 % / 12 % / 5 % / 8 % of a Hi-C link matrix — and v_c = float(c / rowsum).
     // Sc16 / Sx are the (regrouped) columns / values, rec the records (two int4 per segment).
     const unsigned short *Sc16; const float *Sx; const int4 *rec;
+    const int2 *Bjx;                // hash class: (column, float bits) pairs of B, one 8-byte word per entry (k_pack_jx)
     i32 narrow_classes;             // 1: some records have count-2 / count-3 sub-segments (the class stream); 0: count-1 only; -1: none (general operand)
     i32 wb;                         // A entries per wave batch
     i32 n_rows, n_cols;
@@ -848,16 +849,189 @@ __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i
     if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
 }
 
+// ---- hash class: rows of a few thousand distinct output columns ----------------------------------------------------
+// From iteration 1 on a row of T^2 holds ~10^3 distinct columns out of n (1158 on average at n = 100k) reached by ~10^5
+// products: a dense column window spends its sweeps on empty accumulators (and one launch per window), the compact kernel
+// walks the products twice (bitmap mark, then rank lookup).  Here the products are walked ONCE into an LDS hash table
+// keyed by column — ds_read + (first touch only) ds_cmpst + ds_add_u64, the same exact fixed-point sums, so the order of
+// the adds does not matter — and only the table's few thousand keys go through the bitmap rank that puts the sums in
+// column order; from there on the row is finished by the compact kernel's own epilogue (bit-identical by construction).
+// A row that turns out to hold more than HASH_LIMIT distinct columns is handed to the window / compact class lists.
+constexpr int HASH_T = 512, HASH_C = 4096, HASH_LIMIT = 3072, HASH_STAGE = 256, HASH_PER = HASH_C / HASH_T, HASH_PROBES = 128;
+constexpr int HASH_U = 4;           // 16-byte lane loads (two entries each) per B row and step: 4 x 128 = 512 entries
+constexpr u32 HASH_EMPTY = 0xffffffffu;
+__host__ __device__ inline size_t hash_lds_bytes(i32 W) {
+    return (size_t)HASH_C * (8 + 4) + (size_t)HASH_STAGE * (8 + 4 + 4) + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + (8 + 4) + 16 + (size_t)W * 8;
+}
+__device__ __forceinline__ u32 hash_slot(u32 col) { return (col * 0x9e3779b1u) >> 20; }      // 12 bits = HASH_C slots
+// The 2 * HASH_U entries a lane holds of one B row, inserted in ROUNDS of linear probing over two-slot buckets: a column's
+// home is an even slot, round r reads slots home + 2r and home + 2r + 1 of every entry still pending with one 8-byte LDS
+// read (all the reads of a round first: one LDS latency per round, not one per product), then adds where a slot holds the
+// entry's column — claiming it first if it was empty.  At the table's load (<= 0.75, ~0.3 in practice) round 0 settles
+// ~95 % of the entries.  Keys are never removed, so a column sits before the first empty slot of its probe sequence and a
+// stale read can only make a lane try a compare-and-swap it loses.
+__device__ __forceinline__ bool hash_try(u64 *acc, u32 *keys, i32 *ctr, u32 slot, u32 seen, u32 col, u64 g) {
+    if (seen == HASH_EMPTY) {
+        seen = atomicCAS(&keys[slot], HASH_EMPTY, col);
+        if (seen == HASH_EMPTY) {
+            if (atomicAdd(&ctr[0], 1) >= HASH_LIMIT) ctr[1] = 1;          // too many distinct columns: the row leaves the class
+            seen = col;
+        }
+    }
+    if (seen != col) return false;
+    atomicAdd((unsigned long long *)&acc[slot], (unsigned long long)g);
+    return true;
+}
+__device__ __forceinline__ void hash_consume(u64 *acc, u32 *keys, i32 *ctr, const int4 (&t)[HASH_U], i32 q_first, i32 qb, i32 qe, double da) {
+    constexpr int K = 2 * HASH_U;
+    u32 pend = 0;
+#pragma unroll
+    for (int u = 0; u < HASH_U; ++u) {
+        const i32 q = q_first + u * 2 * HHX_WAVE;
+        if (q >= qb && q < qe) pend |= 1u << (2 * u);
+        if (q + 1 < qe) pend |= 1u << (2 * u + 1);
+    }
+    for (int round = 0; __ballot(pend != 0) != 0; ++round) {
+        if (round > HASH_PROBES) { ctr[1] = 1; break; }          // a cluster this long means the table is filling up
+        uint2 cur[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const u32 col = (u32)((k & 1) ? t[k >> 1].z : t[k >> 1].x);
+            cur[k] = make_uint2(0, 0);
+            if (round == 0 || ((pend >> k) & 1u)) cur[k] = *reinterpret_cast<const uint2 *>(&keys[(hash_slot(col) + 2 * round) & (HASH_C - 2)]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if ((pend >> k) & 1u) {
+                const u32 col = (u32)((k & 1) ? t[k >> 1].z : t[k >> 1].x);
+                const u32 slot = (hash_slot(col) + 2 * round) & (HASH_C - 2);
+                const u64 g = fx_bits(da * (double)__int_as_float((k & 1) ? t[k >> 1].w : t[k >> 1].y));
+                if (hash_try(acc, keys, ctr, slot, cur[k].x, col, g) || hash_try(acc, keys, ctr, slot + 1, cur[k].y, col, g)) pend &= ~(1u << k);
+            }
+    }
+}
+__global__ __launch_bounds__(256) void k_pack_jx(i64 n, const i32 *__restrict__ j, const float *__restrict__ x, int2 *__restrict__ out) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) out[k] = make_int2(j[k], __float_as_int(x[k]));
+}
+__global__ __launch_bounds__(HASH_T, 4) void k_expand_hash(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 W, const i64 *__restrict__ row_f,
+                                                        i64 window_min, i32 *__restrict__ list_window, i32 *__restrict__ list_compact,
+                                                        unsigned int *__restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ExLds l;
+    unsigned char *p = smem;
+    l.acc = (u64 *)p; p += (size_t)HASH_C * 8;
+    l.st_da = (double *)p; p += HASH_STAGE * 8;
+    l.red_d = (double *)p; p += EX_WAVES_MAX * 8;
+    l.bcast = (i64 *)p; p += 8;
+    l.win_off = (i64 *)p; p += 8;
+    u32 *keys = (u32 *)p; p += (size_t)HASH_C * 4;
+    l.st_qb = (i32 *)p; p += HASH_STAGE * 4;
+    l.st_qe = (i32 *)p; p += HASH_STAGE * 4;
+    l.red_i = (i32 *)p; p += EX_WAVES_MAX * 4;
+    l.red_f = (float *)p; p += EX_WAVES_MAX * 4;
+    l.win_cnt = (i32 *)p; p += 4;
+    l.ctr = (i32 *)p; p += 12;                                // [0] distinct columns so far, [1] the row does not fit
+    l.bitmap = (u32 *)p; p += (size_t)W * 4;
+    l.prefix = (u32 *)p;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / HHX_WAVE;
+    i64 nnzc = 0;
+    for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const i32 row = rows[li];
+        const i32 a_b = P.Ap[row], a_e = P.Ap[row + 1];
+        for (i32 t = tid; t < HASH_C; t += HASH_T) { keys[t] = HASH_EMPTY; l.acc[t] = 0; }
+        for (i32 w = tid; w < W; w += HASH_T) l.bitmap[w] = 0;
+        if (tid == 0) { l.ctr[0] = 0; l.ctr[1] = 0; }
+        __syncthreads();
+        bool fits = true;
+        for (i32 a0 = a_b; a0 < a_e && fits; a0 += HASH_STAGE) {
+            const i32 len = min(HASH_STAGE, a_e - a0);
+            stage_chunk(P, l, a0, len);
+            __syncthreads();
+            // A wave takes the staged entries two at a time.  A lane loads two consecutive entries of B per 16-byte load
+            // (column, value, column, value), HASH_U loads per B row and step = 512 entries, a whole row of the later
+            // iterations; the loads of both rows are issued back to back, then consumed — nothing loaded is live across a
+            // loop back-edge.  Rows start at any parity: the first load is aligned down and the entry before the row masked.
+            for (i32 e = 2 * wave; e < len; e += 2 * (HASH_T / HHX_WAVE)) {
+                const bool two = e + 1 < len;
+                const double da0 = l.st_da[e], da1 = two ? l.st_da[e + 1] : 0.0;
+                const i32 qb0 = l.st_qb[e], qe0 = l.st_qe[e], qb1 = two ? l.st_qb[e + 1] : 0, qe1 = two ? l.st_qe[e + 1] : 0;
+                const i32 s0 = qb0 & ~1, s1 = qb1 & ~1;
+                const i32 span = max(qe0 - s0, qe1 - s1);
+                for (i32 off = 0; off < span; off += HASH_U * 2 * HHX_WAVE) {
+                    int4 t0[HASH_U], t1[HASH_U];
+#pragma unroll
+                    for (int u = 0; u < HASH_U; ++u) {
+                        const i32 q = s0 + off + u * 2 * HHX_WAVE + 2 * lane;
+                        t0[u] = q < qe0 ? *reinterpret_cast<const int4 *>(P.Bjx + q) : make_int4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < HASH_U; ++u) {
+                        const i32 q = s1 + off + u * 2 * HHX_WAVE + 2 * lane;
+                        t1[u] = q < qe1 ? *reinterpret_cast<const int4 *>(P.Bjx + q) : make_int4(0, 0, 0, 0);
+                    }
+                    if (__hip_atomic_load(&l.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    hash_consume(l.acc, keys, l.ctr, t0, s0 + off + 2 * lane, qb0, qe0, da0);
+                    hash_consume(l.acc, keys, l.ctr, t1, s1 + off + 2 * lane, qb1, qe1, da1);
+                }
+                if (__hip_atomic_load(&l.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+            }
+            __syncthreads();
+            fits = l.ctr[1] == 0;
+            __syncthreads();
+        }
+        if (!fits) {                                         // uniform: the row goes to the class its product count names
+            if (tid == 0) {
+                const i64 f = row_f[row];
+                if (f >= window_min) {
+                    list_window[atomicAdd(&counts[0], 1u)] = row;
+                    atomicAdd(&P.cursors[5], (unsigned long long)f);
+                    atomicAdd(&P.cursors[6], (unsigned long long)(a_e - a_b));
+                } else list_compact[atomicAdd(&counts[1], 1u)] = row;
+            }
+            continue;
+        }
+        // the table's keys -> bitmap; (key, sum) pairs wait in registers while the accumulator array changes its meaning
+        u32 kk[HASH_PER];
+        u64 aa[HASH_PER];
+#pragma unroll
+        for (int u = 0; u < HASH_PER; ++u) {
+            const i32 t = tid + u * HASH_T;
+            kk[u] = keys[t];
+            aa[u] = l.acc[t];
+            if (kk[u] != HASH_EMPTY) atomicOr(&l.bitmap[kk[u] >> 5], 1u << (kk[u] & 31));
+        }
+        __syncthreads();
+        const i32 nnz_row = bitmap_prefix_total(l, W);       // ends with a barrier
+#pragma unroll
+        for (int u = 0; u < HASH_PER; ++u)
+            if (kk[u] != HASH_EMPTY) l.acc[rank_of(l, (i32)kk[u])] = aa[u];
+        __syncthreads();
+        nnzc += (tid == 0) ? nnz_row : 0;
+        if (nnz_row == 0) {
+            if (tid == 0) { P.row_off[row] = 0; P.row_cnt[row] = 0; }
+        } else {
+            i32 nz;
+            const double s_run = window_power_sum<true>(P, l, nnz_row, &nz);
+            window_emit_candidates<true>(P, l, nnz_row, 0, 0, s_run, &l.win_off[0], &l.win_cnt[0]);
+            __syncthreads();
+            finalize_row(P, l, row, 1, s_run, l.win_off, l.win_cnt);
+        }
+        __syncthreads();
+    }
+    nnzc = wave_sum_i64(nnzc);
+    if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
+}
+
 // ---- classification: product count per row, three row lists -----------------------------------------
 // A block takes 64 consecutive rows at a time: its waves count the products of one row each (coalesced),
 // then the first wave sorts the 64 rows into the class lists with ONE atomic per class and chunk (a
 // per-row atomicAdd on a single counter costs ~11 ns each: 1.1 ms for 100k rows, per iteration).
 constexpr int TINY_MAX = 32;        // rows with at most this many products go to the thread-per-row kernel
 __global__ __launch_bounds__(256) void k_classify(i32 n_rows, const i32 *__restrict__ Ap, const i32 *__restrict__ Aj,
-                                                  const i32 *__restrict__ Bp, i64 window_min_products,
+                                                  const i32 *__restrict__ Bp, i64 window_min_products, i64 hash_max_products,
                                                   i32 *__restrict__ list_window, i32 *__restrict__ list_compact,
-                                                  i32 *__restrict__ list_tiny, unsigned int *__restrict__ counts,
-                                                  unsigned long long *__restrict__ cursors) {
+                                                  i32 *__restrict__ list_tiny, i32 *__restrict__ list_hash, i64 *__restrict__ row_f,
+                                                  unsigned int *__restrict__ counts, unsigned long long *__restrict__ cursors) {
     __shared__ i64 fs[64];
     const int lane = lane_id(), wave = threadIdx.x / HHX_WAVE;
     i64 total = 0, total_w = 0, entries_w = 0;
@@ -876,10 +1050,13 @@ __global__ __launch_bounds__(256) void k_classify(i32 n_rows, const i32 *__restr
         if (wave == 0) {
             const i64 f = fs[lane];
             const i32 row = chunk + lane;
-            const int cls = f < 0 ? -1 : (f >= window_min_products ? 0 : (f <= TINY_MAX ? 2 : 1));
-            i32 *const lists[3] = {list_window, list_compact, list_tiny};
+            // hash class (3): everything between the tiny rows and hash_max_products, whatever window_min says — the hash kernel
+            // hands back the rows with too many distinct columns (hash_max_products = 0 switches the class off)
+            const int cls = f < 0 ? -1 : (f <= TINY_MAX ? 2 : (f <= hash_max_products ? 3 : (f >= window_min_products ? 0 : 1)));
+            if (row < n_rows) row_f[row] = f;
+            i32 *const lists[4] = {list_window, list_compact, list_tiny, list_hash};
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < 4; ++c) {
                 const u64 mask = __ballot(cls == c);
                 if (mask) {
                     unsigned int base = 0;
@@ -1075,13 +1252,19 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     // rows whose product count is well above the number of accumulator slots a dense sweep touches
     static const double wfac = getenv("HHX_WINDOW_FACTOR") ? atof(getenv("HHX_WINDOW_FACTOR")) : 0.5;
     const i64 window_min = std::max<i64>(4096, (i64)((double)n_cols * wfac));
-    DevBuf<i32> list_w, list_c, list_t, row_cnt, indptr, g_win_cnt;
-    DevBuf<i64> row_off, g_win_off;
+    DevBuf<i32> list_w, list_c, list_t, list_h, row_cnt, indptr, g_win_cnt;
+    DevBuf<i64> row_off, g_win_off, row_f;
+    // hash class: rows of at most hash_max products (tune "hash_max", 0 = off); needs the bitmap next to a 64 KB table
+    const size_t lds_hash = hash_lds_bytes(W);
+    // off when B's rows are longer than the table can hold distinct columns anyway (iteration 0: the link matrix itself)
+    const bool hash_fits = lds_hash <= 160 * 1024 && b->n_rows > 0 && b->nnz / b->n_rows <= HASH_LIMIT / 2;
+    const i64 hash_max = hash_fits ? std::max<i64>(0, tune_get("hash_max", 4000000)) : 0;
+    DevBuf<int2> bjx;
     DevBuf<double> s_run;
     DevBuf<unsigned int> counts;
     DevBuf<unsigned long long> cursors;
     if (list_w.alloc((size_t)n_rows + 1) || list_c.alloc((size_t)n_rows + 1) || list_t.alloc((size_t)n_rows + 1) ||
-        row_cnt.alloc((size_t)n_rows + 1) ||
+        list_h.alloc((size_t)n_rows + 1) || row_f.alloc((size_t)n_rows + 1) || row_cnt.alloc((size_t)n_rows + 1) ||
         indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || counts.alloc(4) || cursors.alloc(8) ||
         s_run.alloc((size_t)n_rows + 1) || g_win_off.alloc((size_t)n_rows * n_win + 1) || g_win_cnt.alloc((size_t)n_rows * n_win + 1))
         return 1;
@@ -1097,7 +1280,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         HHX_HIP(hipMemsetAsync(counts.p, 0, 4 * sizeof(unsigned int), g_stream));
         HHX_HIP(hipMemsetAsync(cursors.p, 0, 8 * sizeof(unsigned long long), g_stream));
         k_classify<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 63) / 64, 4096)), 256, 0, g_stream>>>(
-            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, list_w.p, list_c.p, list_t.p, counts.p, cursors.p);
+            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, (i64)0, list_w.p, list_c.p, list_t.p, list_h.p, row_f.p, counts.p, cursors.p);
         HHX_LAUNCH_CHECK();
         unsigned long long products = 0;
         HHX_HIP(hipMemcpyAsync(&products, cursors.p + 4, sizeof products, hipMemcpyDeviceToHost, g_stream));
@@ -1113,18 +1296,13 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         HHX_HIP(hipMemsetAsync(counts.p, 0, 4 * sizeof(unsigned int), g_stream));
         HHX_HIP(hipMemsetAsync(cursors.p, 0, 8 * sizeof(unsigned long long), g_stream));
         k_classify<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 63) / 64, 4096)), 256, 0, g_stream>>>(
-            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, list_w.p, list_c.p, list_t.p, counts.p, cursors.p);
+            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, hash_max, list_w.p, list_c.p, list_t.p, list_h.p, row_f.p, counts.p, cursors.p);
         HHX_LAUNCH_CHECK();
         unsigned int hc[4];
         unsigned long long hw[2];                            // products / A entries of the window class
         HHX_HIP(hipMemcpyAsync(hc, counts.p, sizeof hc, hipMemcpyDeviceToHost, g_stream));
         HHX_HIP(hipMemcpyAsync(hw, cursors.p + 5, sizeof hw, hipMemcpyDeviceToHost, g_stream));
         HHX_HIP(hipStreamSynchronize(g_stream));
-        // mean length of a B-row segment inside one column window: tiles of 2 / 4 / 8 entries per lane
-        const int tile_env = (int)tune_get("tile_u", 0);
-        const double seg_len = hw[1] ? (double)hw[0] / (double)hw[1] / (double)n_win : 0.0;
-        int tile_u = 0;
-        const bool long_segments = seg_len >= 192.0;          // iteration 0 (the link matrix is the operand) vs the pruned iterations: timed apart
         ExParams P;
         P.Ap = a->indptr.p; P.Aj = a->indices.p; P.Ax = a->data.p;
         P.Bp = b->indptr.p; P.Bj = b->indices.p; P.Bx = b->data.p;
@@ -1137,7 +1315,36 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
         P.n_win = n_win;
         P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
-        P.Sc16 = nullptr; P.Sx = nullptr; P.rec = nullptr; P.narrow_classes = 0; P.wb = WB_MAX;
+        P.Sc16 = nullptr; P.Sx = nullptr; P.rec = nullptr; P.Bjx = nullptr; P.narrow_classes = 0; P.wb = WB_MAX;
+        if (hc[3]) {                                      // hash class first: it may add rows to the window / compact lists
+            if (!bjx.p) {                                 // B as 8-byte (column, value) words, built once per call
+                if (bjx.alloc((size_t)b->nnz + 4)) return 1;
+                k_pack_jx<<<(unsigned)std::max<i64>(1, std::min<i64>((b->nnz + 255) / 256, 256 * 16)), 256, 0, g_stream>>>(b->nnz, b->indices.p, b->data.p, bjx.p);
+                HHX_LAUNCH_CHECK();
+            }
+            P.Bjx = bjx.p;
+            static bool hash_attr = false;
+            if (!hash_attr) {
+                HHX_HIP(hipFuncSetAttribute((const void *)k_expand_hash, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                hash_attr = true;
+            }
+            {
+                KTimer kt("expand_hash");
+                const unsigned per_cu = lds_hash > 80 * 1024 ? 1 : 2;
+                k_expand_hash<<<std::min<unsigned>(hc[3], 256 * per_cu * 4), HASH_T, lds_hash, g_stream>>>(P, list_h.p, (i32)hc[3], W, row_f.p, window_min,
+                                                                                                      list_w.p, list_c.p, counts.p);
+            }
+            HHX_LAUNCH_CHECK();
+            HHX_HIP(hipMemcpyAsync(hc, counts.p, sizeof hc, hipMemcpyDeviceToHost, g_stream));
+            HHX_HIP(hipMemcpyAsync(hw, cursors.p + 5, sizeof hw, hipMemcpyDeviceToHost, g_stream));
+            HHX_HIP(hipStreamSynchronize(g_stream));
+        }
+        const unsigned n_hash_rows = hc[3];
+        // mean length of a B-row segment inside one column window: tiles of 2 / 4 / 8 entries per lane
+        const int tile_env = (int)tune_get("tile_u", 0);
+        const double seg_len = hw[1] ? (double)hw[0] / (double)hw[1] / (double)n_win : 0.0;
+        int tile_u = 0;
+        const bool long_segments = seg_len >= 192.0;          // iteration 0 (the link matrix is the operand) vs the pruned iterations: timed apart
         if (hc[0]) {
             const unsigned grid = std::min<unsigned>(hc[0], 256);
             if (!rec.p) {                                 // the operand stream of b, built once per call
@@ -1209,9 +1416,9 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         HHX_HIP(hipMemcpyAsync(cur, cursors.p, sizeof cur, hipMemcpyDeviceToHost, g_stream));
         HHX_HIP(hipStreamSynchronize(g_stream));
         if (debug)
-            fprintf(stderr, "[hhx expand] %d x %d, nnzA %lld nnzB %lld: window rows %u (n_win %d x %d cols, lds %zu), compact rows %u; "
+            fprintf(stderr, "[hhx expand] %d x %d, nnzA %lld nnzB %lld: window rows %u (n_win %d x %d cols, lds %zu), hash rows %u, compact rows %u; "
                     "candidates %llu / %lld, survivors %llu / %lld, tile %d (segments of %.0f), %.1f ms since entry%s\n", n_rows, n_cols, (long long)a->nnz, (long long)b->nnz, hc[0], n_win,
-                    cap_win, lds_win, hc[1], cur[0], (long long)cand_cap, cur[1], (long long)pool_cap, tile_u, seg_len,
+                    cap_win, lds_win, n_hash_rows, hc[1], cur[0], (long long)cand_cap, cur[1], (long long)pool_cap, tile_u, seg_len,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count(), cur[2] ? "  OVERFLOW -> retry" : "");
         if (cur[2]) {                                  // a pool overflowed: grow and redo the launches
             if ((i64)cur[0] > cand_cap) cand_cap = std::max<i64>(cand_cap * 2, (i64)cur[0] + (i64)n_rows);

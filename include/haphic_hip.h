@@ -43,11 +43,13 @@ int hhx_synchronize(void);
 int hhx_pool_trim(void);                       /* release cached device memory */
 /* per-kernel device timing with HIP events on the launch stream (bench.py's roofline leg):
  * names: "ingest" (map + partition + aggregate of one push), "aggregate", "ingest_merge", "link_matrix",
- * "spgemm_symbolic", "spgemm_numeric", "expand_window", "expand_compact", "inflate_stats", "prune_write",
- * "convergence", "class_layout" */
+ * "spgemm_symbolic", "spgemm_numeric", "expand_window", "expand_window_short", "expand_hash", "expand_compact",
+ * "expand_tiny", "inflate_stats", "prune_write", "convergence", "class_layout", "d2m_*" (the stages of the link-matrix
+ * build), "bin_contacts" */
 /* measurement / experiment switches of the kernels (tools/ and bench.py only; no reference counterpart): e.g.
  * "cls" 0 = stream iteration 0 as (column, value) pairs instead of the class stream, "probe" 1 = no LDS atomics (garbage
- * results).  Unset knobs fall back to the environment variable HHX_<NAME>. */
+ * results), "hash_max" = largest product count of a row that tries the LDS hash table first (0: window / compact classes
+ * only).  Unset knobs fall back to the environment variable HHX_<NAME>. */
 int hhx_tune(const char *name, int64_t value);
 int hhx_profile_enable(int on);
 int hhx_profile_reset(void);
