@@ -754,10 +754,46 @@ __global__ __launch_bounds__(256) void k_layout_sizes(i32 n_rows, i32 n_win, i32
     }
     if (lane == 0 && uni) atomicAdd(n_uniform, (unsigned long long)uni);
 }
+// BALANCE: the count-1 sub-segment (consumed by the wide tiles: lane l of a 512-entry unit holds entries 8 l .. 8 l + 7 and
+// LDS-atomic instruction j of the unit adds entry 8 l + j of every lane) is stored, unit by unit, in the order of
+// (column mod 32) = the pair of LDS banks the 8-byte accumulator of the column occupies.  Instruction j then takes every
+// eighth entry of that order: two lanes per bank pair, the conflict-free pattern (6.9 clk per ds_add_u64 against 12.8 on
+// random slots, profiles/r02_lds_atomic_bench.jsonl).  The order of the adds is free — exact integer sums.
+constexpr int LAY_UNIT = 512;
+struct LayoutLds {                  // per wave
+    unsigned short stage[LAY_UNIT + HHX_WAVE], sorted[LAY_UNIT];
+    u32 hist[32];
+};
+__device__ __forceinline__ void layout_flush_unit(LayoutLds &L, i32 n, unsigned short *__restrict__ out) {
+    const int lane = lane_id();
+    if (lane < 32) L.hist[lane] = 0;
+    i32 key[LAY_UNIT / HHX_WAVE];
+#pragma unroll
+    for (int i = 0; i < LAY_UNIT / HHX_WAVE; ++i) {
+        const i32 p = lane + i * HHX_WAVE;
+        key[i] = p < n ? (i32)L.stage[p] : -1;
+        if (key[i] >= 0) atomicAdd(&L.hist[key[i] & 31], 1u);
+    }
+    // exclusive scan of the 32 counts (lanes 0..31), in place: hist becomes the cursor of every bank pair
+    u32 c = lane < 32 ? L.hist[lane] : 0u, incl = c;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const u32 v = __shfl_up(incl, o, HHX_WAVE);
+        if (lane >= o) incl += v;
+    }
+    if (lane < 32) L.hist[lane] = incl - c;
+#pragma unroll
+    for (int i = 0; i < LAY_UNIT / HHX_WAVE; ++i)
+        if (key[i] >= 0) L.sorted[atomicAdd(&L.hist[key[i] & 31], 1u)] = (unsigned short)key[i];
+    for (i32 p = lane; p < n; p += HHX_WAVE) out[p] = L.sorted[p];
+}
+template <bool BALANCE>
 __global__ __launch_bounds__(256) void k_layout_write(i32 n_rows, i32 n_win, i32 cap, i32 nc, const i32 *__restrict__ Bp, const i32 *__restrict__ Bj,
                                                       const float *__restrict__ Bx, const unsigned short *__restrict__ n16,
                                                       const double *__restrict__ row_sum, const int4 *__restrict__ cnt4, const i64 *__restrict__ off,
                                                       unsigned short *__restrict__ oc, float *__restrict__ ox, int4 *__restrict__ rec) {
+    __shared__ LayoutLds s_lay[BALANCE ? 4 : 1];
+    LayoutLds &L = s_lay[BALANCE ? threadIdx.x / HHX_WAVE : 0];
     const int lane = lane_id();
     const u64 lt = (1ull << lane) - 1ull;
     const i64 total = (i64)n_rows * n_win;
@@ -774,6 +810,7 @@ __global__ __launch_bounds__(256) void k_layout_write(i32 n_rows, i32 n_win, i32
             rec[2 * sg] = make_int4(base[0], base[1], base[2], base[2] + c4.z);
             rec[2 * sg + 1] = make_int4(base[3] + c4.w, __float_as_int((float)(1.0 / s)), __float_as_int((float)(2.0 / s)), __float_as_int((float)(3.0 / s)));
         }
+        i32 fill = 0;                                        // count-1 entries waiting in the staging buffer (BALANCE)
         for (i32 q0 = qb; q0 < qe; q0 += HHX_WAVE) {
             const i32 q = q0 + lane;
             int cls = -1;
@@ -782,6 +819,17 @@ __global__ __launch_bounds__(256) void k_layout_write(i32 n_rows, i32 n_win, i32
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const u64 m = __ballot(cls == c);
+                if (BALANCE && c == 0) {                     // through the wave's staging buffer, a unit at a time
+                    if (cls == 0) L.stage[fill + __popcll(m & lt)] = (unsigned short)(col - w * cap);
+                    fill += __popcll(m);
+                    if (fill >= LAY_UNIT) {
+                        layout_flush_unit(L, LAY_UNIT, oc + base[0]);
+                        base[0] += LAY_UNIT;
+                        fill -= LAY_UNIT;
+                        if (lane < fill) L.stage[lane] = L.stage[LAY_UNIT + lane];     // the spill-over (< 64 entries) moves to the front
+                    }
+                    continue;
+                }
                 if (cls == c) {
                     const i32 o = base[c] + __popcll(m & lt);
                     oc[o] = (unsigned short)(col - w * cap);
@@ -790,6 +838,7 @@ __global__ __launch_bounds__(256) void k_layout_write(i32 n_rows, i32 n_win, i32
                 base[c] += __popcll(m);
             }
         }
+        if (BALANCE && fill) layout_flush_unit(L, fill, oc + base[0]);
     }
 }
 
@@ -1369,8 +1418,12 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 explicit_frac = b->nnz ? 1.0 - (double)h / (double)b->nnz : 1.0;
                 // slack: a wide tile reads up to 8 entries past a sub-segment end, an exhausted cursor entry 0
                 if (c16.alloc((size_t)slots + 64) || cls_x.alloc((size_t)slots + 64)) return 1;
-                k_layout_write<<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win, cap_win, n_classes, b->indptr.p, b->indices.p, b->data.p,
-                                                            use_cls ? coded.n16 : nullptr, use_cls ? coded.row_sum : nullptr, cnt4.p, offs.p, c16.p, cls_x.p, rec.p);
+                if (use_cls && tune_get("cls_balance", 1))
+                    k_layout_write<true><<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win, cap_win, n_classes, b->indptr.p, b->indices.p, b->data.p, coded.n16,
+                                                                      coded.row_sum, cnt4.p, offs.p, c16.p, cls_x.p, rec.p);
+                else
+                    k_layout_write<false><<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win, cap_win, n_classes, b->indptr.p, b->indices.p, b->data.p,
+                                                                       use_cls ? coded.n16 : nullptr, use_cls ? coded.row_sum : nullptr, cnt4.p, offs.p, c16.p, cls_x.p, rec.p);
                 HHX_LAUNCH_CHECK();
                 HHX_HIP(hipStreamSynchronize(g_stream));         // cnt4 / sizes / offs die here
             }
