@@ -530,32 +530,42 @@ def oracle_fused(A, B, infl, pruning=1e-4, shift=52):
     return orc.prune((c[0], c[1], x), pruning), int(c[0][-1])
 
 
+@pytest.mark.parametrize('hash_max', [0, 4_000_000])          # 0: the window / compact / tiny classes alone; default: rows try the LDS hash table first
 @pytest.mark.parametrize('n,block,deg_in,deg_out,infl', [
     (3000, 100, 20, 1, 2.0),        # window mode, one window
     (40000, 400, 60, 1, 2.0),       # window mode, several column windows (n_cols > LDS capacity)
     (40000, 50, 4, 0, 2.0),         # compact (bitmap-rank) mode
     (5000, 100, 10, 2, 1.4),        # pow() path
     (70000, 10, 2, 1, 3.0),         # tiny rows
+    (8000, 8000, 40, 0, 2.0),       # ~4500 distinct columns per row: leaves the hash class for the window class
+    (20000, 10000, 40, 0, 2.0),     # the same, below the window class's product count: leaves it for the compact class
 ])
-def test_fused_expand_inflate_prune(n, block, deg_in, deg_out, infl):
+def test_fused_expand_inflate_prune(n, block, deg_in, deg_out, infl, hash_max):
     A = clustered_stochastic(n, block, deg_in, deg_out, 31)
     d = _lib.DeviceCSR.from_arrays(*A)
-    p, f, nnz_c = _lib.expand_inflate_prune(d, d, infl, 1e-4)
-    ref, ref_nnz_c = oracle_fused(A, A, infl)
-    got = p.to_arrays()
-    assert nnz_c == ref_nnz_c
-    assert f == int(np.diff(A[0])[A[1]].sum())
-    assert_close_csr(got, ref, RTOL, 'fused iteration')
-    # row-block (multi-GPU shard) gives the same rows
-    r0, r1 = n // 3, n // 3 + n // 5
-    pb, _, _ = _lib.expand_inflate_prune(d.row_block(r0, r1), d, infl, 1e-4)
-    gb = pb.to_arrays()
-    lo, hi = got[0][r0], got[0][r1]
-    assert np.array_equal(gb[0], got[0][r0:r1 + 1] - lo)
-    assert np.array_equal(gb[1], got[1][lo:hi]) and np.array_equal(gb[2], got[2][lo:hi])
-    # deterministic
-    p2, _, _ = _lib.expand_inflate_prune(d, d, infl, 1e-4)
-    assert all(np.array_equal(x, y) for x, y in zip(p2.to_arrays(), got))
+    _lib.tune('hash_max', hash_max)
+    try:
+        p, f, nnz_c = _lib.expand_inflate_prune(d, d, infl, 1e-4)
+        ref, ref_nnz_c = oracle_fused(A, A, infl)
+        got = p.to_arrays()
+        assert nnz_c == ref_nnz_c
+        assert f == int(np.diff(A[0])[A[1]].sum())
+        assert_close_csr(got, ref, RTOL, 'fused iteration')
+        # row-block (multi-GPU shard) gives the same rows
+        r0, r1 = n // 3, n // 3 + n // 5
+        pb, _, _ = _lib.expand_inflate_prune(d.row_block(r0, r1), d, infl, 1e-4)
+        gb = pb.to_arrays()
+        lo, hi = got[0][r0], got[0][r1]
+        assert np.array_equal(gb[0], got[0][r0:r1 + 1] - lo)
+        assert np.array_equal(gb[1], got[1][lo:hi]) and np.array_equal(gb[2], got[2][lo:hi])
+        # deterministic, and the same bits whichever class took the rows
+        p2, _, _ = _lib.expand_inflate_prune(d, d, infl, 1e-4)
+        assert all(np.array_equal(x, y) for x, y in zip(p2.to_arrays(), got))
+        _lib.tune('hash_max', 0 if hash_max else 4_000_000)
+        p3, _, _ = _lib.expand_inflate_prune(d, d, infl, 1e-4)
+        assert all(np.array_equal(x, y) for x, y in zip(p3.to_arrays(), got))
+    finally:
+        _lib.tune('hash_max', 4_000_000)
 
 
 def test_mcl_normalized_fuses_pre_expansion(golden_mcl):
