@@ -225,6 +225,8 @@ __device__ __forceinline__ void acc_add(u64 *slot, double p) {
 // tools/stream_bench.hip is the prototype of this loop.
 constexpr int WB_MAX = 32;          // A entries per wave batch: P.wb <= WB_MAX (short rows take smaller batches so that every wave gets one)
 constexpr int WIDE_UNIT = 512;      // entries per 16-byte lane load of a wave
+constexpr int STREAM_PREFIX = 512;  // Sc16[8 l .. 8 l + 7] = cap + l: what lane l of a wide tile loads when its entries lie past the sub-segment (scratch
+                                    // accumulator l), so that the consume loop needs no per-entry range test
 
 struct BatchRegs {                  // one A entry per lane (lanes >= cnt: empty segments)
     i32 b0, b1, b2, b3, b4;         // record boundaries
@@ -266,26 +268,45 @@ __device__ __forceinline__ void wtile_fetch(const ExParams &P, const BatchRegs &
     t.g_lo = c.g_lo; t.g_hi = c.g_hi;
     const i32 base = t.valid ? c.q : 0;
     const i32 e0 = base + lane_id() * 8, e1 = e0 + WIDE_UNIT;
-    t.x0 = *reinterpret_cast<const uint4 *>(P.Sc16 + (lane_id() * 8 < t.hi ? e0 : 0));
-    t.x1 = *reinterpret_cast<const uint4 *>(P.Sc16 + (lane_id() * 8 + WIDE_UNIT < t.hi ? e1 : 0));
+    t.x0 = *reinterpret_cast<const uint4 *>(P.Sc16 + (lane_id() * 8 < t.hi ? e0 : lane_id() * 8));
+    t.x1 = *reinterpret_cast<const uint4 *>(P.Sc16 + (lane_id() * 8 + WIDE_UNIT < t.hi ? e1 : lane_id() * 8));
     c.q += 2 * WIDE_UNIT;
 }
+// No range test per entry: a sub-segment starts on a tile boundary (64-slot aligned), the slots between its end and the next
+// multiple of 8 hold the reading lane's scratch column (k_layout_write), and a lane whose 8 entries lie past the end loaded
+// its block of the stream prefix instead — every column a lane holds is either real or its own scratch accumulator.
 template <int PROBE>
-__device__ __forceinline__ void wunit_consume(const ExLds &l, const uint4 &x, i32 pos0, i32 lo, i32 hi, u64 g, i32 dummy, u64 &sink) {
+__device__ __forceinline__ void wunit_consume(const ExLds &l, const uint4 &x, u64 g, u64 &sink) {
     const u32 w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const u32 col = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu);
-        const bool ok = pos0 + j >= lo && pos0 + j < hi;
+        if (PROBE == 1) sink += g + col;
+        else atomicAdd((unsigned long long *)&l.acc[col], (unsigned long long)g);
+    }
+}
+// (with count-2 / count-3 sub-segments behind it — hhx_tune("cls_nc") — the count-1 sub-segment is not padded: range test per entry)
+template <int PROBE>
+__device__ __forceinline__ void wunit_consume_masked(const ExLds &l, const uint4 &x, i32 pos0, i32 hi, u64 g, i32 dummy, u64 &sink) {
+    const u32 w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u32 col = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu);
+        const bool ok = pos0 + j < hi;
         if (PROBE == 1) sink += ok ? g + col : 0;
         else atomicAdd((unsigned long long *)&l.acc[ok ? (i32)col : dummy], (unsigned long long)g);
     }
 }
 template <int PROBE>
-__device__ __forceinline__ void wtile_consume(const ExLds &l, const WTile &t, i32 dummy, u64 &sink) {
+__device__ __forceinline__ void wtile_consume(const ExLds &l, const WTile &t, bool padded, i32 dummy, u64 &sink) {
     const u64 g = ((u64)t.g_hi << 32) | t.g_lo;
-    wunit_consume<PROBE>(l, t.x0, lane_id() * 8, t.lo, t.hi, g, dummy, sink);
-    if (t.hi > WIDE_UNIT) wunit_consume<PROBE>(l, t.x1, lane_id() * 8 + WIDE_UNIT, t.lo, t.hi, g, dummy, sink);   // wave-uniform
+    if (padded) {
+        wunit_consume<PROBE>(l, t.x0, g, sink);
+        if (t.hi > WIDE_UNIT) wunit_consume<PROBE>(l, t.x1, g, sink);   // wave-uniform
+    } else {
+        wunit_consume_masked<PROBE>(l, t.x0, lane_id() * 8, t.hi, g, dummy, sink);
+        if (t.hi > WIDE_UNIT) wunit_consume_masked<PROBE>(l, t.x1, lane_id() * 8 + WIDE_UNIT, t.hi, g, dummy, sink);
+    }
 }
 // G tiles per group: the loads of the whole group are issued back to back, then the tiles are consumed in order while
 // the later ones are still in flight (s_waitcnt vmcnt(2 (G - 1)), vmcnt(2 (G - 2)), ...).  Nothing that was loaded is
@@ -309,7 +330,8 @@ template <int PROBE, int G>
 __device__ __forceinline__ void pass_wide(const ExParams &P, const ExLds &l, const BatchRegs &r, i32 cnt, i32 dummy, u64 &sink) {
     WCursor c = {-1, 0, 0, 0, 0u, 0u};
     auto fetch = [&](WTile &t) { wtile_fetch(P, r, cnt, c, t); };
-    auto consume = [&](const WTile &t) { wtile_consume<PROBE>(l, t, dummy, sink); };
+    const bool padded = P.narrow_classes == 0;          // count 1 is the only uniform class: its sub-segment is padded to whole lanes
+    auto consume = [&](const WTile &t) { wtile_consume<PROBE>(l, t, padded, dummy, sink); };
     for (;;) {
         WTile t[G];
         group_fetch<0, G>(t, fetch);
@@ -803,7 +825,7 @@ __global__ __launch_bounds__(256) void k_layout_write(i32 n_rows, i32 n_win, i32
         const i32 qb = w == 0 ? rb : lower_bound_i32(Bj, rb, re, w * cap);
         const i32 qe = w == n_win - 1 ? re : lower_bound_i32(Bj, rb, re, (w + 1) * cap);
         const int4 c4 = cnt4[sg];
-        const i32 s0 = (i32)off[sg];
+        const i32 s0 = (i32)off[sg] + STREAM_PREFIX;
         i32 base[4] = {s0, s0 + c4.x, s0 + c4.x + c4.y, s0 + ceil64(c4.x + c4.y + c4.z)};
         if (lane == 0) {
             const double s = row_sum ? row_sum[k] : 1.0;
@@ -839,7 +861,11 @@ __global__ __launch_bounds__(256) void k_layout_write(i32 n_rows, i32 n_win, i32
             }
         }
         if (BALANCE && fill) layout_flush_unit(L, fill, oc + base[0]);
+        // the slots between the end of the count-1 sub-segment and the next multiple of 8 belong to the last lane that reads it
+        if (n16 && nc == 1 && (c4.x & 7) && lane < 8 - (c4.x & 7)) oc[s0 + c4.x + lane] = (unsigned short)(cap + ((c4.x >> 3) & 63));
     }
+    if (blockIdx.x == 0 && threadIdx.x < HHX_WAVE)           // the stream prefix: eight copies of lane l's scratch column
+        for (int j = 0; j < 8; ++j) oc[threadIdx.x * 8 + j] = (unsigned short)(cap + threadIdx.x);
 }
 
 __global__ __launch_bounds__(EX_T_CMP) void k_expand_window_finalize(ExParams P, const i32 *__restrict__ rows, i32 n_list) {
@@ -1321,7 +1347,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     DevBuf<unsigned short> c16;
     DevBuf<float> cls_x;
     double explicit_frac = 1.0;         // share of B's entries outside the value-uniform sub-segments
-    if (cap_win > 65536) return fail("expand: column window wider than 16 bits");
+    if (cap_win + N_DUMMY > 65536) return fail("expand: column window wider than 16 bits");
     // candidate pool: early windows test against a partial row sum and admit more than finally survive
     i64 pool_cap = std::max<i64>(4 * a->nnz + 16 * (i64)n_rows, (i64)1 << 22);
     i64 cand_cap = n_win > 1 ? 2 * pool_cap : pool_cap;
@@ -1417,7 +1443,8 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 HHX_HIP(hipStreamSynchronize(g_stream));
                 explicit_frac = b->nnz ? 1.0 - (double)h / (double)b->nnz : 1.0;
                 // slack: a wide tile reads up to 8 entries past a sub-segment end, an exhausted cursor entry 0
-                if (c16.alloc((size_t)slots + 64) || cls_x.alloc((size_t)slots + 64)) return 1;
+                if (slots + STREAM_PREFIX > (i64)INT32_MAX - 4096) return fail("expand: the padded operand stream needs %lld slots (int32 cursors)", (long long)slots);
+                if (c16.alloc((size_t)slots + STREAM_PREFIX + 64) || cls_x.alloc((size_t)slots + STREAM_PREFIX + 64)) return 1;
                 if (use_cls && tune_get("cls_balance", 1))
                     k_layout_write<true><<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win, cap_win, n_classes, b->indptr.p, b->indices.p, b->data.p, coded.n16,
                                                                       coded.row_sum, cnt4.p, offs.p, c16.p, cls_x.p, rec.p);
