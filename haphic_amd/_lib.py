@@ -319,13 +319,14 @@ def mem_info():
     return f.value, t.value
 
 
-def mcl_resume(m, done, expansion, inflation, max_iter, pruning):
+def mcl_resume(m, done, expansion, inflation, max_iter, pruning, want_stats=False):
     out = C.c_void_p()
     n_iter, conv = C.c_int(0), C.c_int(0)
     stats = np.zeros((max(int(max_iter), 1), 4), np.int64)
     check(load().hhx_mcl_resume(m.h, int(done), int(expansion), float(inflation), int(max_iter), float(pruning),
                                 C.byref(out), C.byref(n_iter), C.byref(conv), ptr(stats)))
-    return DeviceCSR(out), n_iter.value, bool(conv.value)
+    res = (DeviceCSR(out), n_iter.value, bool(conv.value))
+    return res + (stats[int(done):n_iter.value],) if want_stats else res
 
 
 def spgemm(a, b, fx_shift=-1, want_products=False):

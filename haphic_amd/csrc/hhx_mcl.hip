@@ -348,7 +348,7 @@ static int mcl_impl(const hhx_csr *m, int pre_expanded, int expansion, double in
         *n_iter = it + 1;
         if (it > 1) {                                               // step 5), :2044-2050
             float d = 0.f;
-            rc = hhx_convergence_stat(p, cur, &d);
+            rc = hhx_convergence_stat(p, cur ? cur : m, &d);          // resumed at it >= 2: `m` is what the previous iteration left
             if (!rc && d <= (float)1e-8) {
                 *converged = 1;
                 if (cur) hhx_csr_free(cur);
@@ -371,8 +371,9 @@ extern "C" int hhx_mcl(const hhx_csr *pre, int expansion, double inflation, int 
 }
 
 // mcl() :2026-2062 picked up after its first `done` iterations: `m` is the matrix those iterations left (for the
-// inflation sweep: iteration 0 = inflate + prune of the blocked M^e, hhx_inflate_prune_keep per row block).  done >= 1;
-// the convergence test needs two computed iterations, so it first runs at iteration max(done, 1) + 1 as in the loop.
+// inflation sweep: iteration 0 = inflate + prune of the blocked M^e, hhx_inflate_prune_keep per row block; for the multi-GPU
+// driver: the iterations left once the matrix is small enough to be replicated).  done >= 1; the convergence test needs
+// two computed iterations: it runs from iteration max(done, 2) on, at iteration `done` against `m` itself.
 extern "C" int hhx_mcl_resume(const hhx_csr *m, int done, int expansion, double inflation, int max_iter, double pruning,
                               hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
     if (done < 1) return fail("hhx_mcl_resume: done must be >= 1");

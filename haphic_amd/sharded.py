@@ -75,6 +75,10 @@ class HipEngine:
     def convergence_stat(self, m, last):
         return _lib.convergence_stat(m, last)
 
+    def mcl_resume(self, m, done, expansion, inflation, iters, pruning):
+        """the iterations after `done` on the whole matrix `m` (replicated tail): (matrix, n_iter, converged, stats rows)"""
+        return _lib.mcl_resume(m, done, expansion, inflation, iters, pruning, want_stats=True)
+
     def copy(self, m):
         return m.copy()
 
@@ -270,14 +274,24 @@ def allgather_rows(engine, local, n_cols, dist):
     return engine.from_tensors(n_rows, n_cols, indptr, torch.cat(ix_all).contiguous(), torch.cat(dx_all).contiguous())
 
 
-def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, dist, local_block=None, n=None, local_links=None):
+REPLICATE_NNZ = 4_000_000      # below this many entries the iterations are cheaper than their collectives: every rank runs them whole
+
+
+def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, dist, local_block=None, n=None, local_links=None,
+                       replicate_nnz=None):
     """run_mcl_clustering's pre-expansion (:2146-2147) + mcl() (:2026-2062) with T sharded by row block.
     Three ways in:  full_norm = the L1-normalised link matrix, replicated;  local_block = this rank's rows
     [row_ranges(n)[rank], ...) of it (the right operand of iteration 0 is then all-gathered once);  local_links = this
     rank's rows of the RAW link matrix as build_link_matrix_sharded leaves them: the raw blocks are all-gathered and
     iteration 0 goes through the class stream (hhx_expand_links), the normalisation (:2144) being row-local.
     The pre-expansion is fused into iteration 0 (the expanded rows are consumed in LDS, never materialised).
+    Once the all-gathered matrix has at most replicate_nnz entries (after the first few iterations T has a handful of
+    entries per row: an iteration is a fraction of a millisecond, an all-gather(v) + all-reduce is not) every rank runs
+    the remaining iterations on the whole matrix — same kernels on the same values, so the same bits on every rank and
+    for every GPU count, and no collective at all.
     Returns (full result, n_iter, converged, stats)."""
+    if replicate_nnz is None:
+        replicate_nnz = REPLICATE_NNZ
     torch = engine.torch
     world, rank = dist.get_world_size(), dist.get_rank()
     own_full = False
@@ -349,6 +363,12 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
         if it > 1 and np.float32(mx.item()) <= np.float32(1e-8):
             converged = True
             break
+        if world > 1 and it + 1 < iters and engine.shape(cur_full)[2] <= replicate_nnz and hasattr(engine, 'mcl_resume'):
+            res, n_iter, converged, tail = engine.mcl_resume(cur_full, it + 1, expansion, inflation, iters, pruning)
+            stats.extend(np.asarray(tail, np.int64).tolist())
+            engine.free(cur_full)
+            cur_full = res
+            break
     engine.free(cur_local)
     if links_full is not None:                         # iters == 0
         engine.free(links_full)
@@ -359,9 +379,10 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
 
 
 # ------------------------------------------------------------------ product entry points (HIP engine)
-def mcl_sharded(full_norm, expansion, inflation, iters, pruning, dist, device, local_block=None, n=None, local_links=None):
+def mcl_sharded(full_norm, expansion, inflation, iters, pruning, dist, device, local_block=None, n=None, local_links=None, replicate_nnz=None):
     eng = HipEngine(device)
-    return mcl_sharded_engine(eng, full_norm, expansion, inflation, iters, pruning, dist, local_block=local_block, n=n, local_links=local_links)
+    return mcl_sharded_engine(eng, full_norm, expansion, inflation, iters, pruning, dist, local_block=local_block, n=n, local_links=local_links,
+                              replicate_nnz=replicate_nnz)
 
 
 def gather_tables(engine, tensors, dist):

@@ -65,7 +65,9 @@ def _worker(rank, world, port, q):
         block, fi, n_linked, shape = sharded.build_link_matrix_sharded(eng, ing, in_set, hd)
         ing.destroy()
         blk = block.to_arrays()
-        res, n_iter, conv, stats = sharded.mcl_sharded_engine(eng, None, 2, 2.0, 200, 1e-4, hd, local_links=block, n=shape)
+        # world 2: every iteration sharded; world 3: the row-block iterations until the matrix has < 300k entries, the rest replicated
+        res, n_iter, conv, stats = sharded.mcl_sharded_engine(eng, None, 2, 2.0, 200, 1e-4, hd, local_links=block, n=shape,
+                                                              replicate_nnz=0 if world == 2 else 300_000)
         q.put((rank, blk, fi, n_linked, shape, res.to_arrays(), n_iter, conv, stats))
         hd.barrier()
     finally:

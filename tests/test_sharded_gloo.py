@@ -53,6 +53,23 @@ class OracleEngine:
     def convergence_stat(self, m, last):
         return orc.convergence_stat(m, last)
 
+    def mcl_resume(self, m, done, expansion, inflation, iters, pruning):
+        """mcl() :2026-2062 from iteration `done` on the whole matrix (hhx_mcl_resume)"""
+        cur, n_iter, conv, stats = m, done, False, []
+        for it in range(done, iters):
+            run = cur
+            for _ in range(2, expansion):
+                run, _f = self.spgemm(run, cur)
+            p, f, st_c = self.expand_inflate_prune(run, cur, inflation, pruning)
+            stats.append([self.shape(cur)[2], st_c, self.shape(p)[2], f])
+            n_iter = it + 1
+            stop = it > 1 and np.float32(self.convergence_stat(p, cur)) <= np.float32(1e-8)
+            cur = p
+            if stop:
+                conv = True
+                break
+        return cur, n_iter, conv, stats
+
     def copy(self, m):
         return tuple(a.copy() for a in m)
 
@@ -133,7 +150,12 @@ def _worker(rank, world, port, q):
         assert all(torch.equal(parts[r], torch.cat([piece(r, d) for d in range(world)])) for r in range(world))
         # ---- MCL row-block shard
         T = stochastic(400, 6, 5)
-        res, n_iter, conv, stats = sharded.mcl_sharded_engine(eng, T, 2, 2.0, 100, 1e-4, dist)
+        res, n_iter, conv, stats = sharded.mcl_sharded_engine(eng, T, 2, 2.0, 100, 1e-4, dist, replicate_nnz=0)     # every iteration sharded
+        # replicated tail: the row-block iterations until the matrix is small, then every rank finishes alone — same everything
+        thr = int(stats[2][0])                                # entries of the matrix that enters iteration 2
+        res_r, n_iter_r, conv_r, stats_r = sharded.mcl_sharded_engine(eng, T, 2, 2.0, 100, 1e-4, dist, replicate_nnz=thr)
+        assert (n_iter_r, conv_r) == (n_iter, conv) and all(np.array_equal(x, y) for x, y in zip(res_r, res))
+        assert np.array_equal(np.asarray(stats_r), np.asarray(stats))
         # ---- sharded ingest: each rank owns one contiguous chunk of the stream
         gen = synth.make_genome(3, 400_000, 10_000, seed=2)
         n = gen.n
