@@ -232,8 +232,9 @@ def main():
         ingest = {'pairs_per_s': value, 'ms_per_step': t_ing / K * 1e3, 'alg_bytes_survey': b_ingest,
                   'alg_GBs_survey': b_ingest * K / t_ing / 1e9,
                   'kernels_ms_per_step': {k: pg(k)[0] / K for k in ('ingest', 'map', 'part_count1', 'part_scatter1', 'part_count2',
-                                                                   'part_scatter2', 'part_count3', 'part_scatter3', 'aggregate', 'compact',
-                                                                   'ingest_merge', 'link_matrix')},
+                                                                   'part_scatter2', 'part_count3', 'part_scatter3', 'aggregate',
+                                                                   'ingest_merge', 'link_matrix', 'd2m_count1', 'd2m_scatter1', 'd2m_count2',
+                                                                   'd2m_scatter2', 'd2m_rank', 'd2m_emit')},
                   'roofline': ing_roofline}
         out = {'metric': 'Hi-C pairs/s ingested (link-matrix build) + MCL iters/s', 'value': value, 'unit': 'pairs/s',
                'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': elapsed / K * 1e3,

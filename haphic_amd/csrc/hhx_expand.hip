@@ -251,7 +251,7 @@ __device__ __forceinline__ void batch_load(const ExParams &P, i32 a_b, i32 a_e, 
 }
 
 // wide tiles -------------------------------------------------------------------------------------------------
-struct WTile { uint4 x0, x1; i32 lo, hi; u32 g_lo, g_hi; bool valid; };   // valid positions lo <= lane * 8 + j (+ 512) < hi
+struct WTile { uint4 x0, x1; i32 hi; u32 g_lo, g_hi; bool valid; };       // valid positions lane * 8 + j (+ 512) < hi (a sub-segment starts on a tile boundary)
 struct WCursor { i32 l, q, qb, qe; u32 g_lo, g_hi; };                     // all wave-uniform
 __device__ __forceinline__ void wtile_fetch(const ExParams &P, const BatchRegs &r, i32 cnt, WCursor &c, WTile &t) {
     while (c.q >= c.qe && c.l + 1 < cnt) {            // next A entry of the batch with a uniform sub-segment
@@ -263,7 +263,6 @@ __device__ __forceinline__ void wtile_fetch(const ExParams &P, const BatchRegs &
         c.q = c.qb & ~7;
     }
     t.valid = c.q < c.qe;
-    t.lo = t.valid ? c.qb - c.q : 0;                  // negative on the follow-up tiles of a long segment: no masking
     t.hi = t.valid ? c.qe - c.q : 0;
     t.g_lo = c.g_lo; t.g_hi = c.g_hi;
     const i32 base = t.valid ? c.q : 0;
