@@ -938,12 +938,15 @@ __host__ __device__ inline size_t hash_lds_bytes(i32 W) {
     return (size_t)HASH_C * (8 + 4) + (size_t)HASH_STAGE * (8 + 4 + 4) + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + (8 + 4) + 16 + (size_t)W * 8;
 }
 __device__ __forceinline__ u32 hash_slot(u32 col) { return (col * 0x9e3779b1u) >> 20; }      // 12 bits = HASH_C slots
-// The 2 * HASH_U entries a lane holds of one B row, inserted in ROUNDS of linear probing over two-slot buckets: a column's
-// home is an even slot, round r reads slots home + 2r and home + 2r + 1 of every entry still pending with one 8-byte LDS
-// read (all the reads of a round first: one LDS latency per round, not one per product), then adds where a slot holds the
-// entry's column — claiming it first if it was empty.  At the table's load (<= 0.75, ~0.3 in practice) round 0 settles
-// ~95 % of the entries.  Keys are never removed, so a column sits before the first empty slot of its probe sequence and a
-// stale read can only make a lane try a compare-and-swap it loses.
+// Inserting the 2 * HASH_U entries a lane holds of one B row.  A column's home is a two-slot bucket (an even slot and its
+// neighbour, one 8-byte LDS read); keys are never removed, so a column sits before the first empty slot of its probe
+// sequence and a stale read can only make a lane try a compare-and-swap it loses.
+//   fast round   all the bucket reads first (one LDS latency for the batch, not one per product), then a predicated
+//                ds_add_u64 wherever the bucket already holds the entry's column: ~95 % of the products of a row whose
+//                ~10^3 columns are each hit ~10^2 times, in ~15 branch-free lane-instructions per product;
+//   slow loop    what is left (first touches, columns pushed out of their home bucket) is handled per LANE — each lane
+//                walks its own pending entries with the general probe / claim sequence, so the wave pays for the lane with
+//                the most leftovers (two or three), not for eight wave-wide rounds with a few lanes active in each.
 __device__ __forceinline__ bool hash_try(u64 *acc, u32 *keys, i32 *ctr, u32 slot, u32 seen, u32 col, u64 g) {
     if (seen == HASH_EMPTY) {
         seen = atomicCAS(&keys[slot], HASH_EMPTY, col);
@@ -965,23 +968,37 @@ __device__ __forceinline__ void hash_consume(u64 *acc, u32 *keys, i32 *ctr, cons
         if (q >= qb && q < qe) pend |= 1u << (2 * u);
         if (q + 1 < qe) pend |= 1u << (2 * u + 1);
     }
-    for (int round = 0; __ballot(pend != 0) != 0; ++round) {
-        if (round > HASH_PROBES) { ctr[1] = 1; break; }          // a cluster this long means the table is filling up
-        uint2 cur[K];
+    uint2 cur[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const u32 col = (u32)((k & 1) ? t[k >> 1].z : t[k >> 1].x);
-            cur[k] = make_uint2(0, 0);
-            if (round == 0 || ((pend >> k) & 1u)) cur[k] = *reinterpret_cast<const uint2 *>(&keys[(hash_slot(col) + 2 * round) & (HASH_C - 2)]);
+    for (int k = 0; k < K; ++k) {
+        const u32 col = (u32)((k & 1) ? t[k >> 1].z : t[k >> 1].x);
+        cur[k] = *reinterpret_cast<const uint2 *>(&keys[hash_slot(col) & (HASH_C - 2)]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const u32 col = (u32)((k & 1) ? t[k >> 1].z : t[k >> 1].x);
+        const bool m0 = cur[k].x == col, m1 = cur[k].y == col;
+        if (((pend >> k) & 1u) && (m0 || m1)) {
+            const u64 g = fx_bits(da * (double)__int_as_float((k & 1) ? t[k >> 1].w : t[k >> 1].y));
+            atomicAdd((unsigned long long *)&acc[(hash_slot(col) & (HASH_C - 2)) + (m0 ? 0u : 1u)], (unsigned long long)g);
+            pend &= ~(1u << k);
         }
+    }
+    while (pend) {                                           // per lane: its leftovers, one after the other
+        const int k = __ffs((int)pend) - 1;
+        pend &= pend - 1;
+        u32 col = 0, xb = 0;
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-            if ((pend >> k) & 1u) {
-                const u32 col = (u32)((k & 1) ? t[k >> 1].z : t[k >> 1].x);
-                const u32 slot = (hash_slot(col) + 2 * round) & (HASH_C - 2);
-                const u64 g = fx_bits(da * (double)__int_as_float((k & 1) ? t[k >> 1].w : t[k >> 1].y));
-                if (hash_try(acc, keys, ctr, slot, cur[k].x, col, g) || hash_try(acc, keys, ctr, slot + 1, cur[k].y, col, g)) pend &= ~(1u << k);
-            }
+        for (int kk = 0; kk < K; ++kk)
+            if (kk == k) { col = (u32)((kk & 1) ? t[kk >> 1].z : t[kk >> 1].x); xb = (u32)((kk & 1) ? t[kk >> 1].w : t[kk >> 1].y); }
+        const u64 g = fx_bits(da * (double)__uint_as_float(xb));
+        u32 slot = hash_slot(col) & (HASH_C - 2);
+        for (int probes = 0;; ++probes) {
+            const uint2 c2 = *reinterpret_cast<const uint2 *>(&keys[slot]);
+            if (hash_try(acc, keys, ctr, slot, c2.x, col, g) || hash_try(acc, keys, ctr, slot + 1, c2.y, col, g)) break;
+            if (probes >= HASH_PROBES) { ctr[1] = 1; break; }    // a cluster this long means the table is filling up
+            slot = (slot + 2) & (HASH_C - 2);
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_pack_jx(i64 n, const i32 *__restrict__ j, const float *__restrict__ x, int2 *__restrict__ out) {
