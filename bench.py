@@ -348,6 +348,21 @@ def parity_leg(args, m, rows=64):
     t0 = time.perf_counter()
     one = _lib.mcl(m, 2, args.inflation, 1, 1e-4, links=True)[0]
     gp, gj, gx = one.to_arrays()
+    # iteration 1 (T1 x T1, the hash class) on sampled rows of the real T1
+    n1 = one.shape3[0]
+    rows1 = np.sort(np.random.default_rng(6).choice(n1, min(rows, n1), replace=False))
+    bad1 = 0
+    prod1 = 0
+    for r in rows1:
+        blk = one.row_block(int(r), int(r) + 1)
+        got1 = _lib.expand_inflate_prune(blk, one, args.inflation, 1e-4)[0].to_arrays()
+        blk.free()
+        lo, hi = gp[r], gp[r + 1]
+        c1 = orc.spgemm((np.array([0, hi - lo], np.int32), gj[lo:hi], gx[lo:hi]), (gp, gj, gx), n_cols=n1, mode=1, fx_shift=52)
+        w1 = orc.prune((c1[0], c1[1], orc.normalize_l1(c1[0], orc.power(c1[2], args.inflation))), 1e-4)
+        prod1 += int(np.diff(gp)[gj[lo:hi]].sum())
+        if not (np.array_equal(got1[1], w1[1]) and np.array_equal(got1[2], w1[2])):
+            bad1 += 1
     one.free()
     mp, mj, mx = m.to_arrays()
     n = m.shape3[0]
@@ -367,6 +382,7 @@ def parity_leg(args, m, rows=64):
             bad += 1
     return {'what': 'iteration 0 (fused pre-expansion + inflate + prune, class stream) vs oracle, sampled rows of the real operand',
             'rows_checked': int(len(pick_rows)), 'rows_differing': int(bad), 'bit_identical': bad == 0, 'products_checked': int(c[0][-1] and np.diff(mp)[mj[take]].sum()),
+            'iteration1_hash_class': {'rows_checked': int(len(rows1)), 'rows_differing': int(bad1), 'bit_identical': bad1 == 0, 'products_checked': prod1},
             'oracle_threads': orc.get_threads(), 'seconds': time.perf_counter() - t0,
             'full_size_tests': 'tests/test_gpu_scale.py: C2 whole mcl() bit equal, C3 256 rows + 20 M-pair ingest prefix, C4 40k-contig containers'}
 

@@ -134,8 +134,27 @@ def test_c3_iteration0_sampled_rows_and_ingest_prefix():
         _lib.tune('cls', 0)
         two = _lib.mcl(m, 2, 2.0, 1, 1e-4, links=True)[0]
         assert all(np.array_equal(u, v) for u, v in zip(two.to_arrays(), (gp, gj, gx)))
+        two.free()
     finally:
         _lib.tune('cls', 1)
+    # iteration 1 — T1 x T1, the hash class (rows of ~1000 distinct columns reached by ~160k products) — on 128 sampled rows
+    # of the real T1 against the oracle, and the same rows through the window / compact classes
+    m.free()
+    n1 = one.shape3[0]
+    rows1 = np.sort(np.random.default_rng(6).choice(n1, 128, replace=False))
+    sub_p = np.zeros(len(rows1) + 1, np.int32)
+    sub_p[1:] = np.cumsum(gp[rows1 + 1] - gp[rows1])
+    take = np.concatenate([np.arange(gp[r], gp[r + 1]) for r in rows1])
+    c = orc.spgemm((sub_p, gj[take], gx[take]), (gp, gj, gx), n_cols=n1, mode=1, fx_shift=52)
+    want = orc.prune((c[0], c[1], orc.normalize_l1(c[0], orc.power(c[2], 2.0))), 1e-4)
+    sub = _lib.DeviceCSR.from_arrays(sub_p, gj[take], gx[take], n_cols=n1)
+    for hash_max in (4_000_000, 0):
+        _lib.tune('hash_max', hash_max)
+        try:
+            got1 = _lib.expand_inflate_prune(sub, one, 2.0, 1e-4)[0].to_arrays()
+        finally:
+            _lib.tune('hash_max', 4_000_000)
+        assert all(np.array_equal(u, v) for u, v in zip(got1, want)), 'C3 iteration 1, hash_max %d' % hash_max
 
 
 def test_c4_40k_contigs_allele_aware_containers():
