@@ -209,6 +209,27 @@ def test_patch_plot_rebinds_the_reference_seams():
     finally:
         sys.path.remove('/root/reference/scripts')
     from haphic_amd import plot
+    # the reference's own containers (parse_agp :41-103, generate_contact_matrix :106-150) == the oracle restatement's,
+    # contents and dict orders, on every fixture case: what plot.ContactTable flattens is what the reference would hand it
+    import tempfile
+    P.logger.setLevel('CRITICAL')
+    for name, (kw, min_len, specified) in pf.CASES.items():
+        case = pf.make_case(**kw)
+        with tempfile.NamedTemporaryFile('w', suffix='.agp') as f:
+            f.write(case['agp'])
+            f.flush()
+            r_cd, r_cad, r_sizes, r_frags, r_gfd = P.parse_agp(f.name, case['bin_size'])
+        o_cd, o_cad, o_sizes, o_frags, o_gfd = po.parse_agp(case['agp'], case['bin_size'])
+        assert list(r_cd) == list(o_cd) and all(list(r_cd[c].items()) == list(o_cd[c].items()) for c in r_cd), name
+        assert list(r_cad) == list(o_cad) and all(list(r_cad[c].items()) == list(o_cad[c].items()) for c in r_cad), name
+        assert list(r_sizes.items()) == list(o_sizes.items()) and r_frags == o_frags and dict(r_gfd) == dict(o_gfd), name
+        r_out = P.generate_contact_matrix(r_sizes, r_frags, r_gfd, case['bin_size'], min_len, specified)
+        o_out = po.generate_contact_matrix(o_sizes, o_frags, o_gfd, case['bin_size'], min_len, specified)
+        assert r_out[0].shape == o_out[0].shape and r_out[0].dtype == o_out[0].dtype
+        assert list(r_out[1].items()) == list(o_out[1].items()) and r_out[2] == o_out[2] and r_out[3] == o_out[3], name
+        t_ref = plot.ContactTable(r_cd, r_cad, case['bin_size'], r_out[1], r_out[2], r_out[3], r_out[0].shape[0])
+        t_orc = plot.ContactTable(o_cd, o_cad, case['bin_size'], o_out[1], o_out[2], o_out[3], o_out[0].shape[0])
+        assert t_ref.names == t_orc.names and all(np.array_equal(a, b) for a, b in zip(t_ref.arrays, t_orc.arrays)), name
     want = {n: list(inspect.signature(getattr(P, n)).parameters) for n in ('parse_pairs', 'parse_bam')}
     saved = plot.patch_plot(P)
     try:
