@@ -293,8 +293,7 @@ __global__ __launch_bounds__(AG_T) void k_aggregate(AggParams A) {
                 A.o_ord_full[o] = (u64)s_of[s];
                 A.o_ord_flank[o] = (u64)s_ok[s];
             }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) A.o_ht[o * 4 + c] = s_cnt[c * AG_CAP + s];
+            *reinterpret_cast<uint4 *>(A.o_ht + o * 4) = make_uint4(s_cnt[s], s_cnt[AG_CAP + s], s_cnt[2 * AG_CAP + s], s_cnt[3 * AG_CAP + s]);   // one 16-byte store
             A.o_fl[o] = s_cnt[4 * AG_CAP + s];
             ++o;
         }
