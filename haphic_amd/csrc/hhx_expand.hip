@@ -806,7 +806,13 @@ __device__ __forceinline__ void layout_flush_unit(LayoutLds &L, i32 n, unsigned 
 #pragma unroll
     for (int i = 0; i < LAY_UNIT / HHX_WAVE; ++i)
         if (key[i] >= 0) L.sorted[atomicAdd(&L.hist[key[i] & 31], 1u)] = (unsigned short)key[i];
-    for (i32 p = lane; p < n; p += HHX_WAVE) out[p] = L.sorted[p];
+    // chunk c of the order (8 consecutive entries = one lane's share) goes to lane (c / 2) + ceil(C / 2) * (c % 2): the two
+    // chunks of a bank pair land half a wave apart, so the lanes an LDS pass serves together hold different bank pairs
+    const i32 full = n >> 3, half = (full + 1) >> 1;
+    for (i32 p = lane; p < n; p += HHX_WAVE) {
+        const i32 c = p >> 3;
+        out[c < full ? 8 * ((c >> 1) + half * (c & 1)) + (p & 7) : p] = L.sorted[p];
+    }
 }
 template <bool BALANCE>
 __global__ __launch_bounds__(256) void k_layout_write(i32 n_rows, i32 n_win, i32 cap, i32 nc, const i32 *__restrict__ Bp, const i32 *__restrict__ Bj,
