@@ -784,6 +784,7 @@ constexpr int LAY_UNIT = 512;
 struct LayoutLds {                  // per wave
     unsigned short stage[LAY_UNIT + HHX_WAVE], sorted[LAY_UNIT];
     u32 hist[32];
+    u32 nb[32], start[32], spill_pre[33], hole_pre[33];      // full units: exact dealing (see layout_flush_unit)
 };
 __device__ __forceinline__ void layout_flush_unit(LayoutLds &L, i32 n, unsigned short *__restrict__ out) {
     const int lane = lane_id();
@@ -806,8 +807,37 @@ __device__ __forceinline__ void layout_flush_unit(LayoutLds &L, i32 n, unsigned 
 #pragma unroll
     for (int i = 0; i < LAY_UNIT / HHX_WAVE; ++i)
         if (key[i] >= 0) L.sorted[atomicAdd(&L.hist[key[i] & 31], 1u)] = (unsigned short)key[i];
-    // chunk c of the order (8 consecutive entries = one lane's share) goes to lane (c / 2) + ceil(C / 2) * (c % 2): the two
-    // chunks of a bank pair land half a wave apart, so the lanes an LDS pass serves together hold different bank pairs
+    if (n == LAY_UNIT) {
+        // A full unit is DEALT: lane b and lane b + 32 take the first and the second eight entries of bank pair b, so no two
+        // lanes of a half-wave share a bank pair; what a bank holds beyond sixteen entries fills the slots the short banks leave.
+        const u32 over = c > 16u ? c - 16u : 0u, under = c < 16u ? 16u - c : 0u;
+        u32 so = over, su = under;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const u32 v1 = __shfl_up(so, o, HHX_WAVE), v2 = __shfl_up(su, o, HHX_WAVE);
+            if (lane >= o) { so += v1; su += v2; }
+        }
+        if (lane < 32) { L.nb[lane] = c; L.start[lane] = incl - c; L.spill_pre[lane + 1] = so; L.hole_pre[lane + 1] = su; }
+        if (lane == 0) { L.spill_pre[0] = 0; L.hole_pre[0] = 0; }
+        const u32 b = (u32)lane & 31u, r0 = 8u * ((u32)lane >> 5);
+        const u32 nbb = L.nb[b], st = L.start[b], hp = L.hole_pre[b];
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) {
+            const u32 r = r0 + j;
+            u32 src;
+            if (r < nbb) src = st + r;
+            else {                                           // a hole: the (hp + r - nbb)-th entry of the spill, in bank order
+                const u32 h = hp + (r - nbb);
+                u32 bb = 0;
+                while (L.spill_pre[bb + 1] <= h) ++bb;
+                src = L.start[bb] + 16u + (h - L.spill_pre[bb]);
+            }
+            out[8 * lane + j] = L.sorted[src];
+        }
+        return;
+    }
+    // a partial unit: chunk c of the order (8 consecutive entries = one lane's share) goes to lane (c / 2) + ceil(C / 2) * (c % 2):
+    // the two chunks of a bank pair land half a wave apart, so the lanes an LDS pass serves together hold different bank pairs
     const i32 full = n >> 3, half = (full + 1) >> 1;
     for (i32 p = lane; p < n; p += HHX_WAVE) {
         const i32 c = p >> 3;
