@@ -49,11 +49,38 @@ def parse():
     ap.add_argument('--text-file-tile', type=int, default=110, help='a1 leg: copies of that text written to the .pairs file of the end-to-end figure (110 x 96 MB = a 10.6 GB file; reduced automatically when the temporary directory is short of space)')
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle check of sampled rows of iteration 0')
     ap.add_argument('--text-tile', type=int, default=16, help='a1 leg: copies of that text concatenated in HBM')
+    ap.add_argument('--sweep', type=int, default=20, help='after the timed region: the inflation sweep of run_mcl_clustering :2155-2158 (1.1, 1.2, ... this many '
+                    'values) with ONE expansion — iteration 0 of every inflation from the dense row blocks of M^2 (0 = skip)')
+    ap.add_argument('--sweep-tail-seconds', type=float, default=20.0, help='sweep leg: wall-time budget for the mcl() tails (run from the highest inflation down)')
+    ap.add_argument('--transport', choices=('rccl', 'host'), default='rccl',
+                    help='rccl: one rank per GPU over RCCL / xGMI (the product path).  host: the same ranks and the same exchanges, every collective '
+                         'staged through host memory over gloo (sharded.HostStagedCollectives) — runs N ranks on ONE GPU, a functional proof of '
+                         'the multi-rank path on a box without xGMI; its timings say nothing about scaling')
+    ap.add_argument('--master-port', type=int, default=0, help='rendezvous port of the self-launch (0: pick a free one)')
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no rendezvous in the environment: become `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` (the command the driver itself uses).
+    Under torchrun (RANK / WORLD_SIZE set) this is a no-op."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
+        return
+    port = args.master_port
+    if not port:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def main():
     args = parse()
+    self_launch(args)
     import torch
     import torch.distributed as dist
     from haphic_amd import _lib, synth
@@ -63,16 +90,25 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
-    torch.cuda.set_device(local_rank)
-    _lib.check(_lib.load().hhx_set_device(local_rank))
-    dev = 'cuda:%d' % local_rank
+        raise SystemExit('--gpus %d but WORLD_SIZE is %d' % (args.gpus, world))
+    n_dev = torch.cuda.device_count()
+    if args.transport == 'rccl' and world > n_dev:
+        raise SystemExit('%d ranks but %d GPU(s): RCCL needs one device per rank (use --transport host for a functional run on one GPU)' % (world, n_dev))
+    gpu = local_rank % max(1, n_dev)
+    torch.cuda.set_device(gpu)
+    _lib.check(_lib.load().hhx_set_device(gpu))
+    dev = 'cuda:%d' % gpu
     sharded_path = world > 1 or args.force_sharded
     if sharded_path:
         if world == 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29533')
+        if args.transport == 'host':
+            from haphic_amd import sharded as _sh
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            raw_dist, dist = dist, _sh.HostStagedCollectives(dist)
+            dist.destroy_process_group = raw_dist.destroy_process_group
+        elif world == 1:
             dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(dev))
         else:
             dist.init_process_group('nccl', device_id=torch.device(dev))
@@ -155,7 +191,7 @@ def main():
     t_ing = t_mcl = t_pre = 0.0
     iters = 0
     for k_step in range(args.steps):
-        state['keep_matrix'] = (k_step == args.steps - 1) and world == 1 and not sharded_path and not args.no_parity
+        state['keep_matrix'] = (k_step == args.steps - 1) and world == 1 and not sharded_path and not (args.no_parity and args.sweep <= 1)
         step()
         t_ing += state['t_ingest']; t_mcl += state['t_mcl']; t_pre += state['t_pre']; iters += state['n_iter']
     barrier()
@@ -187,7 +223,7 @@ def main():
         if win_n:
             alg = 2.0 * F_u + 6.0 * (F_w - F_u) + 24.0 * A_w
             ach = alg / (win_ms * 1e-3) / 1e9
-            roofline = {'kernel': 'k_expand_window', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            roofline = {'kernel': 'k_expand_window', 'bound': 'hbm (fabric behind L2: Infinity Cache + HBM, not separable by the TCC counters)', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': ach / HBM_PEAK_GBS, 'traffic': pick(traffic, 'k_expand_window<0'),
                         'alg_bytes_per_launch': alg / win_n, 'avg_launch_ms': win_ms / win_n, 'launches_per_step': win_n / K,
                         'products_per_step': F_w / K, 'uniform_products_per_step': F_u / K, 'bytes_per_product': alg / F_w if F_w else None,
@@ -202,18 +238,19 @@ def main():
                                 'ceiling is the LDS atomic rate (ds_add_u64 on random slots: 12.8 clk per wave instruction, '
                                 'profiles/r02_lds_atomic_bench.jsonl).  traffic = fabric bytes per launch from rocprofv3 PMC (profiles/), '
                                 'null if no profile matches this workload'}
-        # ---- ingest: the kernel that bounds `value` is the level-1 scatter of the group-by
-        sc_ms, sc_n = pg('map')
-        ing_roofline = None
-        if sc_n:
-            n_rec = _lib.profile_counter('ingest_records') / K                 # pairs that survive the map (inter-contig, known contigs)
-            alg = 16.0 * local_pairs + 8.0 * local_pairs                        # read a pair, write an 8-byte record slot
-            ach = alg / (sc_ms / sc_n * 1e-3) / 1e9
-            ing_roofline = {'kernel': 'k_map_records', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                            'frac': ach / HBM_PEAK_GBS, 'traffic': pick(traffic, 'k_map_records'), 'alg_bytes_per_launch': alg,
-                            'avg_launch_ms': sc_ms / sc_n}
         # whole link-matrix build against SURVEY §8d's B_ingest = 16 P + 12 (K_full + K_flank) + 4 n
         b_ingest = 16.0 * local_pairs + 12.0 * (state['n_full'] + state['n_flank']) + 4.0 * n
+        # no single kernel bounds `value` (map 5.0, three radix levels 10.8, aggregation 7.9, matrix 14.4 of ~40 ms): the roofline
+        # of the link-matrix build is the WHOLE build against B_ingest; traffic = the sum over its kernels
+        build_kernels = ('k_map_records', 'k_part_count', 'k_part_scatter', 'k_aggregate', 'k_run_stats', 'k_row_emit', 'k_min_over_xcc',
+                         'k_index_from_sorted', 'k_len_from_base', 'k_iota_u64', 'k_init_counts')
+        build_traffic = sum(v for name, v in traffic.items() if any(bk in name for bk in build_kernels)) or None
+        ach_build = b_ingest * K / t_ing / 1e9
+        ing_roofline = {'kernel': 'link-matrix build, all kernels (k_map_records, k_part_count/scatter x5, k_aggregate, k_row_emit, ...)', 'bound': 'hbm',
+                        'achieved': ach_build, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach_build / HBM_PEAK_GBS,
+                        'traffic': build_traffic, 'alg_bytes_per_launch': b_ingest, 'avg_launch_ms': t_ing / K * 1e3,
+                        'note': 'achieved = SURVEY 8d B_ingest (16 B per pair + 12 B per key + 4 B per fragment) / wall time of the build; the group-by '
+                                'moves several times B_ingest by construction (map record + 3 radix levels + aggregated run + 2 matrix levels)'}
         cmp_ms, _ = pg('expand_compact')
         fin_ms, _ = pg('expand_finalize')
         tiny_ms, _ = pg('expand_tiny')
@@ -238,6 +275,7 @@ def main():
                   'roofline': ing_roofline}
         out = {'metric': 'Hi-C pairs/s ingested (link-matrix build) + MCL iters/s', 'value': value, 'unit': 'pairs/s',
                'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': elapsed / K * 1e3,
+               'transport': ('RCCL' if args.transport == 'rccl' else 'host-staged gloo, %d rank(s) on %d GPU(s): functional run, not a scaling figure' % (world, n_dev)) if sharded_path else None,
                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
                'dtype': 'u64 keys + u32 counts (ingest); f32 values, exact u64 fixed-point accumulation (MCL)',
                'data': 'synthetic',
@@ -250,8 +288,15 @@ def main():
             out['ingest']['text'] = text_leg(args, gen, id1, p1, id2, p2, dev)
         if sharded_path:
             out['ingest']['sharded_build_ms_last_step'] = state.get('shard_ms')
-        if state.get('matrix') is not None:
+        if state.get('matrix') is not None and args.sweep > 1:
+            try:
+                out['sweep'] = sweep_leg(args, state['matrix'], t_mcl / K)
+            except RuntimeError as e:
+                out['sweep'] = {'error': str(e)[:300]}
+        if state.get('matrix') is not None and not args.no_parity:
             out['parity'] = parity_leg(args, state.pop('matrix'))
+        elif state.get('matrix') is not None:
+            state.pop('matrix').free()
         if not args.no_cpu_baseline and world == 1:          # a reported baseline of the N = 1 line only
             out['cpu_baseline'] = cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state)
         print(json.dumps(out))
@@ -338,6 +383,87 @@ def text_leg(args, gen, id1, p1, id2, p2, dev):
     return res
 
 
+def sweep_leg(args, m, one_mcl_s):
+    """Outside the timed region: run_mcl_clustering's inflation sweep (:2155-2158 — every inflation restarts mcl() from the matrix
+    pre-expanded at :2146-2147) on the link matrix of the last step, with ONE expansion: the rows of M^2 are stored as float32
+    row blocks by the window kernel's dense mode (cluster.DenseSweep / hhx_expand_links_dense), iteration 0 of each inflation is
+    the epilogue over them (hhx_dense_inflate_prune), the loop resumes with hhx_mcl_resume.  Low inflations prune little: their
+    tails are long by nature (the reference's too), so the tails run from the highest inflation down within a time budget."""
+    from decimal import Decimal
+    from haphic_amd import _lib, cluster
+    sync = lambda: _lib.check(_lib.load().hhx_synchronize())
+    inflations = [Decimal('1.1') + Decimal('0.1') * k for k in range(args.sweep)]
+    n = m.shape3[0]
+    t0 = time.perf_counter()
+    sw = cluster.DenseSweep(m, 1e-4)
+    order = inflations[::-1]                                         # highest inflation first: the small matrices first
+    out = {'inflations': [str(x) for x in order], 'row_blocks': len(sw.bounds) - 1}
+    firsts, errors = [], {}
+    ta = time.perf_counter()
+    if len(sw.bounds) == 2:                                          # M^2 fits as one resident block (n = 100k: 40 GB)
+        blk = _lib.DenseRows(m, 0, n)                                # the expansion, once
+        sw.n_products = blk.n_products
+        sync()
+        tb = time.perf_counter()
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        for infl in order:
+            try:
+                firsts.append(blk.inflate_prune(float(infl), 1e-4))
+            except RuntimeError as e:                                # e.g. a first iteration of more than 2^31 entries at inflation 1.1
+                firsts.append(None)
+                errors[str(infl)] = str(e)[:200]
+        sync()
+        tc = time.perf_counter()
+        _lib.profile_enable(False)
+        blk.free()
+        out['expansion_ms'] = (tb - ta) * 1e3
+        out['epilogues_all_inflations_ms'] = (tc - tb) * 1e3
+    else:                                                            # several row blocks, each expanded once and used by every inflation
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        firsts = list(sw.first_iterations(order))
+        sync()
+        tc = time.perf_counter()
+        _lib.profile_enable(False)
+    ep_ms, ep_n = _lib.profile_get('dense_epilogue')
+    out.update(iteration0_all_inflations_ms=(tc - ta) * 1e3, dense_epilogue_kernel_ms_avg=ep_ms / ep_n if ep_n else None,
+               dense_bytes=4.0 * n * n, t1_nnz=[f.nnz if f is not None else None for f in firsts], products_walked=sw.n_products,
+               one_fused_mcl_ms=one_mcl_s * 1e3, errors=errors,
+               note='iteration 0 of all inflations = ONE pass over the products (expansion_ms) + one epilogue per inflation; the per-inflation '
+                    'alternative (hhx_mcl_links at every inflation) walks the products %d times' % args.sweep)
+    # iteration 0 at 2.0 must be the fused kernel's bits
+    if Decimal('2.0') in inflations:
+        k = inflations[::-1].index(Decimal('2.0'))
+        one = _lib.mcl(m, 2, 2.0, 1, 1e-4, links=True)[0]
+        out['iteration0_bit_identical_to_fused_at_2.0'] = bool(firsts[k] is not None and all(np.array_equal(x, y) for x, y in zip(one.to_arrays(), firsts[k].to_arrays())))
+        one.free()
+    tails = {}
+    t_budget = time.perf_counter()
+    for infl, first in zip(order, firsts):
+        if first is None:
+            continue
+        if time.perf_counter() - t_budget > args.sweep_tail_seconds or first.nnz > 300_000_000:      # (a first iteration that large: minutes of tail)
+            first.free()
+            continue
+        t1 = time.perf_counter()
+        try:
+            res, n_iter, conv = _lib.mcl_resume(first, 1, 2, float(infl), 200, 1e-4)
+        except RuntimeError as e:
+            errors['tail ' + str(infl)] = str(e)[:200]
+            first.free()
+            continue
+        first.free()
+        att, ptr, mem = _lib.interpret(res)
+        res.free()
+        tails[str(infl)] = {'ms': (time.perf_counter() - t1) * 1e3, 'iterations': int(n_iter), 'converged': bool(conv), 'clusters': int(len(att))}
+    sw.close()
+    out['tails'] = tails
+    out['tails_skipped_time_or_size_budget'] = [str(x) for x in order if str(x) not in tails and str(x) not in errors and 'tail ' + str(x) not in errors]
+    out['seconds'] = time.perf_counter() - t0
+    return out
+
+
 def parity_leg(args, m, rows=64):
     """Outside the timed region: iteration 0 of the MCL on the link matrix of the last step (the kernel instantiation the
     roofline is quoted on) against the oracle — the C restatement of the reference's expand / inflate / prune in the
@@ -397,6 +523,9 @@ def pmc_traffic(n_contigs, pairs):
     except (OSError, ValueError):
         return {}
     if d.get('contigs') != int(n_contigs) or d.get('pairs_per_gpu') != int(pairs):
+        return {}
+    from haphic_amd import build
+    if d.get('kernel_source_sha16') != build.source_hash():      # counters of other kernels than the ones running now: not reported
         return {}
     return d.get('bytes_per_launch', {})
 

@@ -84,8 +84,14 @@ SIGNATURES = {
     'hhx_ingest_keep_pairs': (C.c_int, [C.c_void_p, C.c_int]),
     'hhx_csr_vstack': (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), c_vpp]),
     'hhx_mem_info': (C.c_int, [c_i64p, c_i64p]),
+    'hhx_csr_pack_block': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    'hhx_csr_unpack_blocks': (C.c_int, [C.c_int32, c_i64p, c_i64p, C.c_void_p, C.c_int64, C.c_int32, c_vpp]),
     'hhx_inflate_prune_keep': (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_vpp]),
     'hhx_mcl_resume': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, c_vpp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
+    'hhx_expand_links_dense': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int, c_vpp, c_i64p, c_i64p]),
+    'hhx_dense_inflate_prune': (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_vpp]),
+    'hhx_dense_shape': (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i64p]),
+    'hhx_dense_free': (C.c_int, [C.c_void_p]),
     'hhx_shard_create': (C.c_int, [C.c_void_p, C.c_void_p, c_vpp]),
     'hhx_shard_first': (C.c_int, [C.c_void_p, c_vpp]),
     'hhx_rank_first': (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, c_i32p]),
@@ -317,6 +323,33 @@ def mem_info():
     f, t = C.c_int64(0), C.c_int64(0)
     check(load().hhx_mem_info(C.byref(f), C.byref(t)))
     return f.value, t.value
+
+
+class DenseRows:
+    """hhx_dense: rows [r0, r1) of the pre-expanded matrix M^2 as float32 in HBM — one expansion for a whole inflation sweep"""
+
+    def __init__(self, links, r0, r1, fx_shift=52):
+        self.h = C.c_void_p()
+        f, z = C.c_int64(0), C.c_int64(0)
+        check(load().hhx_expand_links_dense(links.h, int(r0), int(r1), int(fx_shift), C.byref(self.h), C.byref(f), C.byref(z)))
+        self.n_products, self.nnz_expanded = f.value, z.value
+
+    def inflate_prune(self, inflation, pruning):
+        """iteration 0 of mcl() (:2037-2042) of these rows at `inflation`"""
+        out = C.c_void_p()
+        check(load().hhx_dense_inflate_prune(self.h, float(inflation), float(pruning), C.byref(out)))
+        return DeviceCSR(out)
+
+    def free(self):
+        if self.h is not None and self.h.value:
+            load().hhx_dense_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def mcl_resume(m, done, expansion, inflation, max_iter, pruning, want_stats=False):

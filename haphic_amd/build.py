@@ -15,6 +15,17 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources: ties a rocprofv3 / PMC record to the code it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources() + sorted(glob.glob(os.path.join(CSRC, '*.h'))):
+        h.update(os.path.basename(f).encode() + b'\0')
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(SO):
         return True

@@ -516,16 +516,62 @@ def _log_mcl(n_iter, converged, expansion, inflation, iters, pruning):
                         n_iter, expansion, inflation, iters, pruning))
 
 
-def mcl_device_blocked(blocks, expansion, inflation, iters, pruning):
-    """mcl() on a pre-expanded matrix that is held as row blocks (more than 2^31 entries in total): iteration 0
-    (:2030-2042 without the expansion) is row-local — inflate + prune per block, the blocks are left untouched for
-    the next inflation — and the pruned blocks stacked are an ordinary matrix from which the loop resumes."""
-    parts = [_lib.inflate_prune_keep(b, inflation, pruning) for b in blocks]
-    try:
-        first = _lib.vstack(parts)
-    finally:
-        for p in parts:
-            p.free()
+class DenseSweep:
+    """The inflation sweep of run_mcl_clustering :2155-2158 with ONE expansion.  Every inflation restarts mcl() from the matrix
+    pre-expanded at :2146-2147; M^2 of a link matrix is nearly dense, so its rows are kept in HBM as float32 row blocks
+    (_lib.DenseRows, 4 B x n^2 in total — 40 GB at n = 100k) filled by a single pass over the products, and iteration 0 of each
+    inflation (:2037-2042) is the row-local epilogue over those blocks.  When n^2 floats do not fit the budget the blocks are
+    produced and consumed one after the other: the first inflations of every block are formed while it is resident and the
+    pieces of every inflation wait (pruned: small) until the last block is done."""
+
+    def __init__(self, links, pruning, block_rows=None, budget_bytes=None):
+        self.links, self.pruning = links, pruning
+        n = links.shape3[0]
+        self.n = n
+        if block_rows is None:
+            if budget_bytes is None:
+                _lib.check(_lib.load().hhx_pool_trim())
+                free_bytes, _total = _lib.mem_info()
+                budget_bytes = 0.45 * free_bytes             # the rest: candidate pools, operand stream, the tails of the inflations
+            block_rows = max(1, min(n, int(budget_bytes // (4 * max(n, 1)))))
+        self.bounds = list(range(0, n, int(block_rows))) + [n]
+        self.resident = None                                 # the only block when the whole M^2 fits: kept for the whole sweep
+        self.n_products = 0
+
+    def first_iterations(self, inflations):
+        """iteration 0 of mcl() at every inflation -> one matrix per inflation (generator when M^2 is one resident block:
+        an inflation's matrix is formed when asked for, so that at most one of them exists at a time)"""
+        if len(self.bounds) == 2:
+            if self.resident is None:
+                self.resident = _lib.DenseRows(self.links, 0, self.n)
+                self.n_products = self.resident.n_products
+            for infl in inflations:
+                yield self.resident.inflate_prune(float(infl), self.pruning)
+            return
+        pieces = [[] for _ in inflations]
+        for r0, r1 in zip(self.bounds[:-1], self.bounds[1:]):
+            blk = _lib.DenseRows(self.links, r0, r1)
+            self.n_products += blk.n_products
+            try:
+                for k, infl in enumerate(inflations):
+                    pieces[k].append(blk.inflate_prune(float(infl), self.pruning))
+            finally:
+                blk.free()
+        for k in range(len(inflations)):
+            try:
+                yield _lib.vstack(pieces[k])
+            finally:
+                for p in pieces[k]:
+                    p.free()
+
+    def close(self):
+        if self.resident is not None:
+            self.resident.free()
+            self.resident = None
+
+
+def mcl_resume_device(first, expansion, inflation, iters, pruning):
+    """mcl() :2026-2062 picked up after iteration 0 (`first`, consumed); logs like the reference (:2047 :2058)"""
     if iters <= 1:
         _log_mcl(min(iters, 1), False, expansion, inflation, iters, pruning)
         return first
@@ -1057,7 +1103,8 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
                        max_inflation, inflation_step, max_iter, pruning, fa_dict, nchrs, dense_matrix=False,
                        outdir_root='.', dist=None, _block_rows=None):
     """run_mcl_clustering() :2132-2242.  link_matrix: scipy CSC or a DeviceCSR.  The normalised,
-    pre-expanded matrix is built once and stays in HBM for the whole inflation sweep.  With a torch.distributed
+    pre-expanded matrix is built once and stays in HBM for the whole inflation sweep (_block_rows: rows per float32 block of
+    the dense sweep — tests force the blocked path at small orders with it).  With a torch.distributed
     group (`dist`, one process per GPU, every rank holding the link matrix) the inflations are dealt round-robin
     to the ranks (sharded.inflation_sweep); every rank gets all results, rank 0 writes the files."""
     if dense_matrix:
@@ -1067,31 +1114,18 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
     own = not isinstance(link_matrix, _lib.DeviceCSR)
     m = _to_device(link_matrix) if own else link_matrix.copy()
     n = m.shape3[0]
-    # The reference pre-expands once (:2146-2147) and restarts every inflation from that matrix.  M^e is
-    # nearly dense: it is materialised only while it is guaranteed to fit scipy's int32 index range
-    # (n^2 < 2^31); beyond that every inflation starts from the link matrix and the pre-expansion is fused
-    # into its iteration 0 (hhx_mcl_links) — same results, the n^2-entry matrix never exists.
+    # The reference pre-expands once (:2146-2147) and restarts every inflation from that matrix.  M^e is nearly dense: as a
+    # CSR matrix it is materialised only while it is guaranteed to fit scipy's int32 index range (n^2 < 2^31).  Beyond that
+    # (and always when a sweep of several inflations is asked for with expansion 2 on a matrix of that size) the rows of M^2
+    # are kept as float32 row blocks filled by ONE pass over the products (DenseSweep), and iteration 0 of every inflation is the
+    # row-local epilogue over them; a single inflation starts from the link matrix with the pre-expansion fused into its
+    # iteration 0 (hhx_mcl_links) — same results, the n^2-entry CSR matrix never exists.
     materialise = expansion > 1 and n * n < 2 ** 31 and not _block_rows
     inflations = _inflation_values(min_inflation, max_inflation, inflation_step)
     pre = None
-    blocks = None
+    sweep = None
     if expansion == 2 and not materialise and len(inflations) > 1 and max_iter >= 1:
-        # Beyond the int32 range M^2 still fits HBM (n = 100k: ~10^10 entries, 80 GB of 288): keep it as row blocks of
-        # at most 2^31 / n rows, so that the expansion of the link matrix is paid once for the whole sweep.
-        rows_per = int(_block_rows) if _block_rows else max(1, (2 ** 31 - 1) // n)
-        _lib.check(_lib.load().hhx_pool_trim())
-        free_bytes, _total = _lib.mem_info()
-        if _block_rows or 8.0 * n * n + 40.0 * rows_per * n < 0.85 * free_bytes:     # the blocks + one block's work pools
-            _lib.normalize_l1(m)                                     # :2144
-            blocks = []
-            for r0 in range(0, n, rows_per):
-                a = m.row_block(r0, min(n, r0 + rows_per))
-                try:
-                    blocks.append(_lib.spgemm(a, m, fx_shift=52))    # :2146-2147, rows [r0, r1) of M^2
-                finally:
-                    a.free()
-    if blocks is not None:
-        pass
+        sweep = DenseSweep(m, pruning, block_rows=_block_rows)
     elif materialise:
         _lib.normalize_l1(m)                                         # :2144
         pre = m
@@ -1105,10 +1139,15 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
         pre = m
     result_clusters_list = []
     mcl_nrounds = 0
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    # with several ranks the inflations are dealt round-robin; a rank forms iteration 0 only of its own inflations
+    mine = [infl for k, infl in enumerate(inflations) if k % world == rank] if world > 1 else inflations
+    firsts = sweep.first_iterations(mine) if sweep is not None else None
 
     def run_one(inflation):
-        if blocks is not None:
-            res = mcl_device_blocked(blocks, expansion, float(inflation), max_iter, pruning)
+        if sweep is not None:
+            res = mcl_resume_device(next(firsts), expansion, float(inflation), max_iter, pruning)
         elif pre is not None:
             res = mcl_device(pre, expansion, float(inflation), max_iter, pruning)
         else:
@@ -1168,8 +1207,8 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
         result_clusters_list.append((inflation, result_clusters))
     if pre is not None and pre is not m:
         pre.free()
-    for b in blocks or ():
-        b.free()
+    if sweep is not None:
+        sweep.close()
     m.free()
     max_nclusters = max([len(rc) for _, rc in result_clusters_list])
     if max_nclusters < nchrs:

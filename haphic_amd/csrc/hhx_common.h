@@ -118,6 +118,13 @@ struct hhx_csr {
     hhx::DevBuf<float> data;
 };
 
+// rows of the expanded matrix M^e as plain float32 (the inflation sweep; hhx_expand.hip): 0 = no entry
+struct hhx_dense {
+    i32 n_rows = 0, n_cols = 0;
+    i32 cap_win = 0, n_win = 0;         // the column-window plan of the expansion that filled it (summation order of the epilogue)
+    hhx::DevBuf<float> x;
+};
+
 // ------------------------------------------------------------------ device helpers
 #ifdef __HIPCC__
 #define HHX_WAVE 64

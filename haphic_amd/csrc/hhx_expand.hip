@@ -66,6 +66,9 @@ struct ExParams {
     // window class, one launch per column window: per-row state carried between the launches
     double *s_run;                  // [n_rows] running sum of p over the windows done so far
     i64 *g_win_off; i32 *g_win_cnt; // [n_rows][n_win] candidate segment of every (row, window)
+    // dense mode (the inflation sweep, run_mcl_clustering :2155-2158): the window kernel stores x = float(acc) of every column
+    // into row `row` of this n_rows x dense_ld float32 block instead of inflating / pruning (0 = no entry)
+    float *dense; i64 dense_ld;
 };
 
 struct ExLds {
@@ -501,7 +504,8 @@ __device__ __forceinline__ i32 bitmap_prefix_total(const ExLds &l, i32 W) {
 
 // ---- window epilogue: slots [0, wlen) hold the accumulators of columns col_of(slot) (ascending).
 // Turns them into p = x^r (stored back as float bits, -1 = absent), returns the window sum.
-template <bool COMPACT>
+// FROM_X: the slot's low word already holds x as float32 bits (k_dense_epilogue: the expanded row comes back from HBM)
+template <bool COMPACT, bool FROM_X = false>
 __device__ __forceinline__ double window_power_sum(const ExParams &P, const ExLds &l, i32 wlen, i32 *nnz_local) {
     const int tid = threadIdx.x;
     const i32 per = (wlen + EX_T - 1) / EX_T;
@@ -512,7 +516,7 @@ __device__ __forceinline__ double window_power_sum(const ExParams &P, const ExLd
         const u64 ai = l.acc[t];                          // exact: the sum is below 2^53
         float p = -1.0f;
         if (COMPACT || ai != 0) {
-            const float x = (float)((double)(long long)ai * 0x1p-52 * P.inv_scale);
+            const float x = FROM_X ? __uint_as_float((u32)ai) : (float)((double)(long long)ai * 0x1p-52 * P.inv_scale);
             p = P.raw ? x : ex_inflate(x, P.r, P.square);
             s += (double)p;
             ++nz;
@@ -715,6 +719,16 @@ __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__re
             batch = nb;
         }
         __syncthreads();
+        if (P.dense) {                              // the sweep: the expanded row leaves as float32, inflation-independent
+            float *dst = P.dense + (size_t)row * (size_t)P.dense_ld + c0;
+            for (i32 t = tid; t < wlen; t += EX_T) {
+                const u64 ai = l.acc[t];
+                dst[t] = (float)((double)(long long)ai * 0x1p-52 * P.inv_scale);      // the x of window_power_sum, bit for bit
+                nnzc += ai != 0;
+            }
+            __syncthreads();
+            continue;
+        }
         i32 nz;
         const double sw = window_power_sum<false>(P, l, wlen, &nz);
         nnzc += nz;
@@ -907,10 +921,40 @@ __global__ __launch_bounds__(EX_T_CMP) void k_expand_window_finalize(ExParams P,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ExLds l = ex_carve(smem, 0, 0, 0);
     for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
-        const i32 row = rows[li];
+        const i32 row = rows ? rows[li] : li;
         finalize_row(P, l, row, P.n_win, P.s_run[row], &P.g_win_off[(size_t)row * P.n_win], &P.g_win_cnt[(size_t)row * P.n_win]);
         __syncthreads();
     }
+}
+
+// The epilogue of k_expand_window alone, fed from a dense float32 row block (hhx_dense: rows of M^2 stored once by the window
+// kernel's dense mode): per (row, column window) the same x -> p = x^r, block sum, candidate emission against the running row
+// sum, in the same slot order with the same workgroup shape — so that one expansion serves every inflation of the sweep
+// (run_mcl_clustering :2155-2158 restarts each inflation from the same pre-expanded matrix) and gives the bits the fused
+// single-inflation iteration gives.  k_expand_window_finalize then finishes the rows.
+__global__ __launch_bounds__(EX_T_WIN) void k_dense_epilogue(ExParams P, const float *__restrict__ X, i64 ld, i32 cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ExLds l = win_carve(smem, cap);
+    const int tid = threadIdx.x;
+    i64 nnzc = 0;
+    for (i32 row = blockIdx.x; row < P.n_rows; row += gridDim.x) {
+        double s_run = 0.0;
+        for (i32 wv = 0; wv < P.n_win; ++wv) {
+            const i32 c0 = wv * cap, wlen = min(P.n_cols, c0 + cap) - c0;
+            const float *src = X + (size_t)row * (size_t)ld + c0;
+            for (i32 t = tid; t < wlen; t += EX_T) l.acc[t] = (u64)__float_as_uint(src[t]);
+            __syncthreads();
+            i32 nz;
+            const double sw = window_power_sum<false, true>(P, l, wlen, &nz);
+            nnzc += nz;
+            s_run = (wv == 0 ? 0.0 : s_run) + sw;
+            window_emit_candidates<false>(P, l, wlen, c0, 0, s_run, &P.g_win_off[(size_t)row * P.n_win + wv], &P.g_win_cnt[(size_t)row * P.n_win + wv]);
+            __syncthreads();
+        }
+        if (tid == 0) P.s_run[row] = s_run;
+    }
+    nnzc = wave_sum_i64(nnzc);
+    if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
 }
 
 __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 W) {
@@ -1155,7 +1199,7 @@ __global__ __launch_bounds__(HASH_T, 4) void k_expand_hash(ExParams P, const i32
 // per-row atomicAdd on a single counter costs ~11 ns each: 1.1 ms for 100k rows, per iteration).
 constexpr int TINY_MAX = 32;        // rows with at most this many products go to the thread-per-row kernel
 __global__ __launch_bounds__(256) void k_classify(i32 n_rows, const i32 *__restrict__ Ap, const i32 *__restrict__ Aj,
-                                                  const i32 *__restrict__ Bp, i64 window_min_products, i64 hash_max_products,
+                                                  const i32 *__restrict__ Bp, i64 window_min_products, i64 hash_max_products, i64 tiny_max,
                                                   i32 *__restrict__ list_window, i32 *__restrict__ list_compact,
                                                   i32 *__restrict__ list_tiny, i32 *__restrict__ list_hash, i64 *__restrict__ row_f,
                                                   unsigned int *__restrict__ counts, unsigned long long *__restrict__ cursors) {
@@ -1179,7 +1223,8 @@ __global__ __launch_bounds__(256) void k_classify(i32 n_rows, const i32 *__restr
             const i32 row = chunk + lane;
             // hash class (3): everything between the tiny rows and hash_max_products, whatever window_min says — the hash kernel
             // hands back the rows with too many distinct columns (hash_max_products = 0 switches the class off)
-            const int cls = f < 0 ? -1 : (f <= TINY_MAX ? 2 : (f <= hash_max_products ? 3 : (f >= window_min_products ? 0 : 1)));
+            // (dense mode: tiny_max = hash_max = -1, window_min = 0 — every row, empty ones included, takes the window class)
+            const int cls = f < 0 ? -1 : (f <= tiny_max ? 2 : (f <= hash_max_products ? 3 : (f >= window_min_products ? 0 : 1)));
             if (row < n_rows) row_f[row] = f;
             i32 *const lists[4] = {list_window, list_compact, list_tiny, list_hash};
 #pragma unroll
@@ -1319,6 +1364,8 @@ struct CodedOperand {
     const unsigned short *n16 = nullptr;
     const double *row_sum = nullptr;
     int raw = 0;                        // plain product (no inflation / pruning): hhx_spgemm's fast path
+    float *dense_out = nullptr;         // dense mode: n_rows x n_cols float32 block that receives the expanded rows; no CSR result
+    i32 *plan_out = nullptr;            // dense mode: [cap_win, n_win] of the column-window plan, for k_dense_epilogue
 };
 
 template <int PROBE, int UX, int RX, int RW, int T = EX_T_WIN>
@@ -1332,9 +1379,27 @@ static int launch_window(const ExParams &P, const i32 *rows, i32 n_list, i32 cap
     return 0;
 }
 
+// the bump-allocated rows -> CSR: scan of the row counts, ordered copy
+static int pack_rows_to_csr(i32 n_rows, i32 n_cols, const i32 *row_cnt, i32 *indptr, const i64 *row_off, const i32 *pool_col, const float *pool_val,
+                            hhx_csr **out) {
+    i64 total = 0;
+    HHX_TRY(exclusive_scan_i32(row_cnt, indptr, n_rows, &total));
+    hhx_csr *p = nullptr;
+    HHX_TRY(hhx_csr_alloc_internal(n_rows, n_cols, total, &p));
+    HHX_HIP(hipMemcpyAsync(p->indptr.p, indptr, sizeof(i32) * ((size_t)n_rows + 1), hipMemcpyDeviceToDevice, g_stream));
+    k_pack_rows<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 3) / 4, 8192)), 256, 0, g_stream>>>(
+        n_rows, row_off, p->indptr.p, pool_col, pool_val, p->indices.p, p->data.p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);       // the caller's pools are released on return
+    if (e != hipSuccess) { hhx_csr_free(p); return fail("expand pack: %s", hipGetErrorString(e)); }
+    *out = p;
+    return 0;
+}
+
 int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &coded, int fx_shift, double inflation, double pruning,
                     hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
-    if (!a || !b || !out) return fail("null pointer");
+    const bool dense = coded.dense_out != nullptr;
+    if (!a || !b || (!out && !dense)) return fail("null pointer");
     if (a->n_cols != b->n_rows) return fail("expand shape mismatch");
     if (!(inflation > 0)) return fail("inflation must be positive");
     if (b->nnz > (i64)INT32_MAX - 4096) return fail("expand: right operand has %lld entries; the tile cursors need 4096 below 2^31", (long long)b->nnz);
@@ -1378,14 +1443,14 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     const int probe = (int)tune_get("probe", 0);
     // rows whose product count is well above the number of accumulator slots a dense sweep touches
     static const double wfac = getenv("HHX_WINDOW_FACTOR") ? atof(getenv("HHX_WINDOW_FACTOR")) : 0.5;
-    const i64 window_min = std::max<i64>(4096, (i64)((double)n_cols * wfac));
+    const i64 window_min = dense ? 0 : std::max<i64>(4096, (i64)((double)n_cols * wfac));
     DevBuf<i32> list_w, list_c, list_t, list_h, row_cnt, indptr, g_win_cnt;
     DevBuf<i64> row_off, g_win_off, row_f;
     // hash class: rows of at most hash_max products (tune "hash_max", 0 = off); needs the bitmap next to a 64 KB table
     const size_t lds_hash = hash_lds_bytes(W);
     // off when B's rows are longer than the table can hold distinct columns anyway (iteration 0: the link matrix itself)
     const bool hash_fits = lds_hash <= 160 * 1024 && b->n_rows > 0 && b->nnz / b->n_rows <= HASH_LIMIT / 2;
-    const i64 hash_max = hash_fits ? std::max<i64>(0, tune_get("hash_max", 4000000)) : 0;
+    const i64 hash_max = dense ? -1 : (hash_fits ? std::max<i64>(0, tune_get("hash_max", 4000000)) : 0);
     DevBuf<int2> bjx;
     DevBuf<double> s_run;
     DevBuf<unsigned int> counts;
@@ -1401,13 +1466,14 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     double explicit_frac = 1.0;         // share of B's entries outside the value-uniform sub-segments
     if (cap_win + N_DUMMY > 65536) return fail("expand: column window wider than 16 bits");
     // candidate pool: early windows test against a partial row sum and admit more than finally survive
-    i64 pool_cap = std::max<i64>(4 * a->nnz + 16 * (i64)n_rows, (i64)1 << 22);
-    i64 cand_cap = n_win > 1 ? 2 * pool_cap : pool_cap;
+    i64 pool_cap = dense ? 64 : std::max<i64>(4 * a->nnz + 16 * (i64)n_rows, (i64)1 << 22);
+    i64 cand_cap = dense ? 64 : (n_win > 1 ? 2 * pool_cap : pool_cap);
+    if (coded.plan_out) { coded.plan_out[0] = cap_win; coded.plan_out[1] = n_win; }
     if (coded.raw) {                    // every entry is kept: at most dense, and at most one entry per product
         HHX_HIP(hipMemsetAsync(counts.p, 0, 4 * sizeof(unsigned int), g_stream));
         HHX_HIP(hipMemsetAsync(cursors.p, 0, 8 * sizeof(unsigned long long), g_stream));
         k_classify<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 63) / 64, 4096)), 256, 0, g_stream>>>(
-            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, (i64)0, list_w.p, list_c.p, list_t.p, list_h.p, row_f.p, counts.p, cursors.p);
+            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, (i64)0, (i64)TINY_MAX, list_w.p, list_c.p, list_t.p, list_h.p, row_f.p, counts.p, cursors.p);
         HHX_LAUNCH_CHECK();
         unsigned long long products = 0;
         HHX_HIP(hipMemcpyAsync(&products, cursors.p + 4, sizeof products, hipMemcpyDeviceToHost, g_stream));
@@ -1423,7 +1489,8 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         HHX_HIP(hipMemsetAsync(counts.p, 0, 4 * sizeof(unsigned int), g_stream));
         HHX_HIP(hipMemsetAsync(cursors.p, 0, 8 * sizeof(unsigned long long), g_stream));
         k_classify<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 63) / 64, 4096)), 256, 0, g_stream>>>(
-            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, hash_max, list_w.p, list_c.p, list_t.p, list_h.p, row_f.p, counts.p, cursors.p);
+            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, hash_max, dense ? (i64)-1 : (i64)TINY_MAX, list_w.p, list_c.p, list_t.p, list_h.p, row_f.p,
+            counts.p, cursors.p);
         HHX_LAUNCH_CHECK();
         unsigned int hc[4];
         unsigned long long hw[2];                            // products / A entries of the window class
@@ -1442,6 +1509,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
         P.n_win = n_win;
         P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
+        P.dense = coded.dense_out; P.dense_ld = n_cols;
         P.Sc16 = nullptr; P.Sx = nullptr; P.rec = nullptr; P.Bjx = nullptr; P.narrow_classes = 0; P.wb = WB_MAX;
         if (hc[3]) {                                      // hash class first: it may add rows to the window / compact lists
             if (!bjx.p) {                                 // B as 8-byte (column, value) words, built once per call
@@ -1529,8 +1597,10 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 else HHX_TRY((launch_window<0, 1, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
             }
             HHX_LAUNCH_CHECK();
-            KTimer kt("expand_finalize");
-            k_expand_window_finalize<<<std::min<unsigned>(hc[0], 256 * 8), EX_T_CMP, ex_fixed_bytes(0, 0), g_stream>>>(P, list_w.p, (i32)hc[0]);
+            if (!dense) {
+                KTimer kt("expand_finalize");
+                k_expand_window_finalize<<<std::min<unsigned>(hc[0], 256 * 8), EX_T_CMP, ex_fixed_bytes(0, 0), g_stream>>>(P, list_w.p, (i32)hc[0]);
+            }
         }
         HHX_LAUNCH_CHECK();
         if (hc[2]) {
@@ -1552,6 +1622,17 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                     "candidates %llu / %lld, survivors %llu / %lld, tile %d (segments of %.0f), %.1f ms since entry%s\n", n_rows, n_cols, (long long)a->nnz, (long long)b->nnz, hc[0], n_win,
                     cap_win, lds_win, n_hash_rows, hc[1], cur[0], (long long)cand_cap, cur[1], (long long)pool_cap, tile_u, seg_len,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count(), cur[2] ? "  OVERFLOW -> retry" : "");
+        if (dense) {                                   // the rows are in coded.dense_out; nothing to pack
+            if (hc[0] != (unsigned)n_rows) return fail("expand (dense): %u of %d rows took the window class", hc[0], n_rows);
+            if (prof_enabled()) {
+                prof_count("expand_window_products", (i64)cur[5]);
+                prof_count("expand_window_a_reads", (i64)cur[6] * n_win);
+                if (use_cls) prof_count("expand_window_uniform_products", (i64)cur[7]);
+            }
+            if (n_products) *n_products = (i64)cur[4];
+            if (nnz_expanded) *nnz_expanded = (i64)cur[3];
+            return 0;
+        }
         if (cur[2]) {                                  // a pool overflowed: grow and redo the launches
             if ((i64)cur[0] > cand_cap) cand_cap = std::max<i64>(cand_cap * 2, (i64)cur[0] + (i64)n_rows);
             if ((i64)cur[1] > pool_cap) pool_cap = std::max<i64>(pool_cap * 2, (i64)cur[1] + (i64)n_rows);
@@ -1565,20 +1646,100 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         }
         if (n_products) *n_products = (i64)cur[4];
         if (nnz_expanded) *nnz_expanded = (i64)cur[3];
-        i64 total = 0;
-        HHX_TRY(exclusive_scan_i32(row_cnt.p, indptr.p, n_rows, &total));
-        hhx_csr *p = nullptr;
-        HHX_TRY(hhx_csr_alloc_internal(n_rows, n_cols, total, &p));
-        HHX_HIP(hipMemcpyAsync(p->indptr.p, indptr.p, sizeof(i32) * ((size_t)n_rows + 1), hipMemcpyDeviceToDevice, g_stream));
-        k_pack_rows<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 3) / 4, 8192)), 256, 0, g_stream>>>(
-            n_rows, row_off.p, p->indptr.p, out_col.p, out_val.p, p->indices.p, p->data.p);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);   // the pools are released on return
-        if (e != hipSuccess) { hhx_csr_free(p); return fail("expand pack: %s", hipGetErrorString(e)); }
-        *out = p;
-        return 0;
+        return pack_rows_to_csr(n_rows, n_cols, row_cnt.p, indptr.p, row_off.p, out_col.p, out_val.p, out);
     }
     return fail("expand: survivor pool kept overflowing");
+}
+
+// ---- the inflation sweep: one expansion, every inflation (run_mcl_clustering :2146-2158) ------------------------------
+// The reference pre-expands once (:2146-2147) and restarts mcl() at every inflation from that matrix.  M^2 of a Hi-C link matrix is
+// (nearly) dense — n^2 entries at n = 100k — so here a ROW BLOCK of it is stored as plain float32 (4 B per entry instead of the 8 of a
+// CSR entry, no index traffic) by the window kernel's dense mode, and iteration 0 of every inflation is the epilogue alone over that
+// block (k_dense_epilogue + k_expand_window_finalize): the 1.15e12 products of the expansion are walked once for the whole sweep.
+int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift, hhx_dense **out,
+                          i64 *n_products, i64 *nnz_expanded) {
+    if (!a || !b || !out) return fail("null pointer");
+    hhx_dense *d = new hhx_dense();
+    d->n_rows = a->n_rows; d->n_cols = b->n_cols;
+    if (d->x.alloc((size_t)a->n_rows * (size_t)b->n_cols + 1)) { delete d; return 1; }
+    CodedOperand c;
+    c.n16 = n16; c.row_sum = row_sum; c.dense_out = d->x.p;
+    i32 plan[2] = {0, 0};
+    c.plan_out = plan;
+    const int rc = hhx_expand_impl(a, b, c, fx_shift, 2.0, 0.0, nullptr, n_products, nnz_expanded);
+    if (rc) { delete d; return rc; }
+    d->cap_win = plan[0]; d->n_win = plan[1];
+    *out = d;
+    return 0;
+}
+
+extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, double pruning, hhx_csr **out) {
+    if (!d || !out) return fail("null pointer");
+    if (!(inflation > 0)) return fail("inflation must be positive");
+    const i32 n_rows = d->n_rows, n_cols = d->n_cols, n_win = d->n_win, cap = d->cap_win;
+    DevBuf<i32> row_cnt, indptr, g_win_cnt;
+    DevBuf<i64> row_off, g_win_off;
+    DevBuf<double> s_run;
+    DevBuf<unsigned long long> cursors;
+    if (row_cnt.alloc((size_t)n_rows + 1) || indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || cursors.alloc(8) ||
+        s_run.alloc((size_t)n_rows + 1) || g_win_off.alloc((size_t)n_rows * n_win + 1) || g_win_cnt.alloc((size_t)n_rows * n_win + 1)) return 1;
+    static int attr_dev = -1;
+    int dev = 0;
+    HHX_HIP(hipGetDevice(&dev));
+    if (attr_dev != dev) {
+        HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_dev = dev;
+    }
+    // a pruned row holds at most 1 / pruning entries; an early window tests against a partial row sum and admits more
+    i64 pool_cap = std::max<i64>((i64)n_rows * 512, (i64)1 << 22), cand_cap = 2 * pool_cap;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        DevBuf<i32> cand_col, out_col;
+        DevBuf<float> cand_val, out_val;
+        if (cand_col.alloc((size_t)cand_cap) || cand_val.alloc((size_t)cand_cap) || out_col.alloc((size_t)pool_cap) || out_val.alloc((size_t)pool_cap)) return 1;
+        HHX_HIP(hipMemsetAsync(cursors.p, 0, 8 * sizeof(unsigned long long), g_stream));
+        ExParams P;
+        memset(&P, 0, sizeof P);
+        P.n_rows = n_rows; P.n_cols = n_cols;
+        P.scale = 1.0; P.inv_scale = 1.0;
+        P.r = (double)(float)inflation; P.square = inflation == 2.0; P.thr = (float)pruning;
+        P.cand_col = cand_col.p; P.cand_val = cand_val.p; P.cand_cap = cand_cap;
+        P.out_col = out_col.p; P.out_val = out_val.p; P.out_cap = pool_cap;
+        P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
+        P.n_win = n_win; P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
+        if (n_rows) {
+            {
+                KTimer kt("dense_epilogue");
+                k_dense_epilogue<<<std::min<unsigned>((unsigned)n_rows, 256), EX_T_WIN, (size_t)cap * 8 + win_fixed_bytes(), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
+            }
+            HHX_LAUNCH_CHECK();
+            KTimer kt("expand_finalize");
+            k_expand_window_finalize<<<std::min<unsigned>((unsigned)n_rows, 256 * 8), EX_T_CMP, ex_fixed_bytes(0, 0), g_stream>>>(P, nullptr, n_rows);
+        }
+        HHX_LAUNCH_CHECK();
+        unsigned long long cur[8];
+        HHX_HIP(hipMemcpyAsync(cur, cursors.p, sizeof cur, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+        if (cur[2]) {                                  // a pool overflowed: the cursors hold the demand
+            if ((i64)cur[0] > cand_cap) cand_cap = (i64)cur[0] + (i64)n_rows;
+            if ((i64)cur[1] > pool_cap) pool_cap = std::max<i64>(pool_cap * 2, (i64)cur[1] + (i64)n_rows);
+            continue;
+        }
+        return pack_rows_to_csr(n_rows, n_cols, row_cnt.p, indptr.p, row_off.p, out_col.p, out_val.p, out);
+    }
+    return fail("dense inflate / prune: survivor pool kept overflowing");
+}
+
+extern "C" int hhx_dense_shape(const hhx_dense *d, i32 *n_rows, i32 *n_cols, i64 *bytes) {
+    if (!d) return fail("null handle");
+    if (n_rows) *n_rows = d->n_rows;
+    if (n_cols) *n_cols = d->n_cols;
+    if (bytes) *bytes = (i64)sizeof(float) * (i64)d->n_rows * (i64)d->n_cols;
+    return 0;
+}
+
+extern "C" int hhx_dense_free(hhx_dense *d) {
+    delete d;
+    return 0;
 }
 
 extern "C" int hhx_row_products(const hhx_csr *a, const hhx_csr *b, i64 *products_host) {

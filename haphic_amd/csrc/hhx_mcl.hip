@@ -13,6 +13,9 @@ int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
 int hhx_expand_class_stream(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
                      double inflation, double pruning, hhx_csr **out, i64 *n_products, i64 *nnz_expanded);
 
+int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift, hhx_dense **out,
+                          i64 *n_products, i64 *nnz_expanded);
+
 namespace {
 
 // Stochastic operands: every row of T sums to 1 and every entry is <= 1, so |C| <= 1 and products rounded on
@@ -435,6 +438,22 @@ extern "C" int hhx_expand_links(const hhx_csr *a, const hhx_csr *links, int fx_s
     HHX_TRY(normalise_links(links, &nl));
     if (!nl.usable) return hhx_expand_inflate_prune(a, nl.norm, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
     return hhx_expand_class_stream(a, nl.norm, nl.n16.p, nl.row_sum.p, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
+}
+
+// run_mcl_clustering :2144-2147 for rows [r0, r1) of the link matrix, kept for the whole inflation sweep: L1 normalisation, then the
+// rows of M^2 = T[r0:r1, :] * T as a dense float32 block (hhx_dense).  hhx_dense_inflate_prune then gives iteration 0 of mcl()
+// (:2037-2042) of these rows at any inflation without walking the products again.
+extern "C" int hhx_expand_links_dense(const hhx_csr *links, i32 r0, i32 r1, int fx_shift, hhx_dense **out, i64 *n_products, i64 *nnz_expanded) {
+    if (!links || !out) return fail("null pointer");
+    if (links->n_rows != links->n_cols) return fail("hhx_expand_links_dense needs the square link matrix");
+    if (r0 < 0 || r1 < r0 || r1 > links->n_rows) return fail("row block [%d,%d) out of range", r0, r1);
+    NormalisedLinks nl;
+    HHX_TRY(normalise_links(links, &nl));
+    hhx_csr *a = nullptr;
+    HHX_TRY(hhx_csr_row_block(nl.norm, r0, r1, &a));
+    const int rc = hhx_expand_dense_impl(a, nl.norm, nl.usable ? nl.n16.p : nullptr, nl.usable ? nl.row_sum.p : nullptr, fx_shift, out, n_products, nnz_expanded);
+    hhx_csr_free(a);
+    return rc;
 }
 
 // interpret_result(), array half.  The final matrix holds ~n entries, so this is a host pass over a

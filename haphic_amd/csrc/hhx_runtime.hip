@@ -452,6 +452,59 @@ extern "C" int hhx_csr_vstack(i32 n_blocks, const hhx_csr *const *blocks, hhx_cs
     return 0;
 }
 
+// ---- the per-iteration exchange of the row-block MCL (haphic_amd/sharded.py exchange_rows): a CSR row block as ONE int32 message
+// [row lengths (n_rows) | column indices (nnz) | float32 value bits (nnz)], and the world's messages back into one CSR matrix
+__global__ __launch_bounds__(256) void k_row_lengths(const i32 *__restrict__ indptr, i32 n, i32 *__restrict__ out) {
+    for (i32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = indptr[i + 1] - indptr[i];
+}
+extern "C" int hhx_csr_pack_block(const hhx_csr *m, void *dst_dev, i64 capacity_words) {
+    if (!m || !dst_dev) return fail("hhx_csr_pack_block: null pointer");
+    const i64 need = (i64)m->n_rows + 2 * m->nnz;
+    if (capacity_words < need) return fail("hhx_csr_pack_block: message of %lld words, buffer of %lld", (long long)need, (long long)capacity_words);
+    i32 *dst = (i32 *)dst_dev;
+    if (m->n_rows) k_row_lengths<<<(unsigned)std::min<i64>(((i64)m->n_rows + 255) / 256, 4096), 256, 0, g_stream>>>(m->indptr.p, m->n_rows, dst);
+    HHX_LAUNCH_CHECK();
+    if (m->nnz) {
+        HHX_HIP(hipMemcpyAsync(dst + m->n_rows, m->indices.p, sizeof(i32) * (size_t)m->nnz, hipMemcpyDeviceToDevice, g_stream));
+        HHX_HIP(hipMemcpyAsync(dst + m->n_rows + m->nnz, m->data.p, sizeof(float) * (size_t)m->nnz, hipMemcpyDeviceToDevice, g_stream));
+    }
+    return 0;
+}
+// message b starts at packed + b * stride_words and holds rows[b] rows / nnz[b] entries; the blocks are stacked in order.
+// The row pointer is ONE device scan over the concatenated row lengths (no host-side cumsum, no per-block rebase).
+extern "C" int hhx_csr_unpack_blocks(i32 n_blocks, const i64 *rows, const i64 *nnz, const void *packed_dev, i64 stride_words, i32 n_cols,
+                                     hhx_csr **out) {
+    if (n_blocks < 1 || !rows || !nnz || !packed_dev || !out) return fail("hhx_csr_unpack_blocks: bad argument");
+    i64 R = 0, Z = 0;
+    for (i32 b = 0; b < n_blocks; ++b) {
+        if (rows[b] < 0 || nnz[b] < 0 || rows[b] + 2 * nnz[b] > stride_words) return fail("hhx_csr_unpack_blocks: message %d does not fit its stride", b);
+        R += rows[b];
+        Z += nnz[b];
+    }
+    if (R > INT32_MAX || Z > INT32_MAX) return fail("hhx_csr_unpack_blocks: %lld rows / %lld entries exceed int32", (long long)R, (long long)Z);
+    hhx_csr *m = nullptr;
+    HHX_TRY(csr_alloc((i32)R, n_cols, Z, &m));
+    DevBuf<i32> lens;
+    if (lens.alloc((size_t)R + 1)) { delete m; return 1; }
+    const i32 *src = (const i32 *)packed_dev;
+    i64 r = 0, z = 0;
+    hipError_t e = hipSuccess;
+    for (i32 b = 0; b < n_blocks && e == hipSuccess; ++b) {
+        const i32 *msg = src + (size_t)b * (size_t)stride_words;
+        if (rows[b]) e = hipMemcpyAsync(lens.p + r, msg, sizeof(i32) * (size_t)rows[b], hipMemcpyDeviceToDevice, g_stream);
+        if (e == hipSuccess && nnz[b]) e = hipMemcpyAsync(m->indices.p + z, msg + rows[b], sizeof(i32) * (size_t)nnz[b], hipMemcpyDeviceToDevice, g_stream);
+        if (e == hipSuccess && nnz[b]) e = hipMemcpyAsync(m->data.p + z, msg + rows[b] + nnz[b], sizeof(float) * (size_t)nnz[b], hipMemcpyDeviceToDevice, g_stream);
+        r += rows[b];
+        z += nnz[b];
+    }
+    if (e != hipSuccess) { delete m; return fail("hhx_csr_unpack_blocks: %s", hipGetErrorString(e)); }
+    i64 total = 0;
+    if (exclusive_scan_i32(lens.p, m->indptr.p, R, &total)) { delete m; return 1; }        // synchronises: `lens` dies with this frame
+    if (total != Z) { delete m; return fail("hhx_csr_unpack_blocks: the row lengths add up to %lld, the headers to %lld", (long long)total, (long long)Z); }
+    *out = m;
+    return 0;
+}
+
 extern "C" int hhx_mem_info(i64 *free_bytes, i64 *total_bytes) {
     size_t f = 0, t = 0;
     HHX_HIP(hipMemGetInfo(&f, &t));

@@ -9,8 +9,10 @@ SURVEY §8e:
     counts add, ordinals take the minimum == the reference loop run over the whole stream.
   * MCL shards T = M^T by row block (== column block of the reference's M).  Everything except the
     right operand of the expansion is row-local, so per iteration there is ONE all-gather(v) of the
-    pruned row blocks (indices + values + row lengths) and ONE all-reduce(max) of the convergence
-    statistic.  Fixed-point accumulation makes the result bit-identical for any GPU count.
+    pruned row blocks — one packed message per rank: row lengths | indices | values — preceded by ONE
+    48-byte header all-gather that carries the sizes, the convergence statistic (its max over ranks is
+    the all-reduce(max) of :2044-2050) and the bookkeeping counts (exchange_rows).  Fixed-point
+    accumulation makes the result bit-identical for any GPU count.
 
 The collective logic is written against a small `engine` interface so that tests/ can drive it on
 CPU (gloo, world_size 2) with an oracle-backed engine; the product engine is HipEngine (no fallback).
@@ -49,6 +51,22 @@ class HipEngine:
         self.torch.cuda.current_stream(self.device).synchronize()
         return _lib.DeviceCSR.from_device(n_rows, n_cols, int(indices.numel()), indptr.data_ptr(), indices.data_ptr(),
                                           data.data_ptr())
+
+    def pack_block(self, m, words):
+        """m's exchange message [row lengths | column indices | value bits] in an int32 tensor of `words` elements"""
+        buf = self.torch.empty(int(words), dtype=self.torch.int32, device=self.device)
+        _lib.check(_lib.load().hhx_csr_pack_block(m.h, _lib.C.c_void_p(buf.data_ptr()), int(words)))
+        return buf
+
+    def unpack_blocks(self, rows, nnzs, packed, stride, n_cols):
+        """the gathered messages (message b at packed[b * stride:]) stacked into one matrix"""
+        rows = np.ascontiguousarray(rows, np.int64)
+        nnzs = np.ascontiguousarray(nnzs, np.int64)
+        self.torch.cuda.current_stream(self.device).synchronize()
+        out = _lib.C.c_void_p()
+        _lib.check(_lib.load().hhx_csr_unpack_blocks(len(rows), rows.ctypes.data_as(_lib.c_i64p), nnzs.ctypes.data_as(_lib.c_i64p),
+                                                     _lib.C.c_void_p(packed.data_ptr()), int(stride), int(n_cols), _lib.C.byref(out)))
+        return _lib.DeviceCSR(out)
 
     def shape(self, m):
         return m.shape3
@@ -254,24 +272,55 @@ def balanced_ranges(cost, world):
     bounds = [0]
     for k in range(1, world):
         cut = int(np.searchsorted(c, total * k / world, side='left')) + 1 if total else n * k // world
-        bounds.append(max(bounds[-1], min(n, cut)))
+        # a few very heavy rows must not leave a rank without rows (every rank runs the same kernels and collectives; an
+        # empty block is legal but pointless): at least one row per rank while there are rows to give
+        cut = max(cut, bounds[-1] + 1)
+        bounds.append(max(bounds[-1], min(n - min(n, world - k), cut) if n >= world else min(n, cut)))
     bounds.append(n)
     return bounds
 
 
+HEADER = 6     # doubles per rank: rows, entries, convergence statistic, nnz of the expanded rows, survivors, products
+
+
+def exchange_rows(engine, local, n_cols, dist, stat=0.0, counts=(0, 0, 0)):
+    """The exchange of the row-block MCL — all-gather(v) of the row blocks, all-reduce(max) of the convergence statistic
+    (:2044-2050) and the sums of the per-iteration counts — in TWO collectives:
+      1. all-gather of a 6-double header per rank: the sizes of the variable-length blocks, the convergence statistic (a
+         float32, exact in a double) and the bookkeeping counts (< 2^53, exact) ride in the same 48 bytes, so the max and
+         the sums are formed locally from the gathered headers — no separate all-reduce;
+      2. all-gather of ONE packed int32 message per rank, [row lengths | column indices | value bits] (hhx_csr_pack_block),
+         padded to the longest message; hhx_csr_unpack_blocks stacks the world's messages into the CSR triple with the row
+         pointer formed by one device scan.
+    A message longer than MAX_MESSAGE_BYTES goes in slices (the raw link matrix at 2 ranks: 1.3 GB per rank).
+    Returns (the full matrix, rows in rank order; the headers as a [world, 6] float64 numpy array)."""
+    torch = engine.torch
+    world = dist.get_world_size()
+    r, _c, z = engine.shape(local)
+    head = torch.tensor([float(r), float(z), float(stat)] + [float(c) for c in counts], dtype=torch.float64, device=engine.device)
+    heads = torch.empty(world * HEADER, dtype=torch.float64, device=engine.device)
+    dist.all_gather_into_tensor(heads, head)
+    heads = heads.cpu().numpy().reshape(world, HEADER)               # the one host sync of the exchange
+    rows, nnzs = heads[:, 0].astype(np.int64), heads[:, 1].astype(np.int64)
+    stride = int(max(1, (rows + 2 * nnzs).max()))
+    msg = engine.pack_block(local, stride)
+    out = torch.empty(world * stride, dtype=torch.int32, device=msg.device)
+    step = max(1, MAX_MESSAGE_BYTES // 4)
+    if stride <= step:
+        dist.all_gather_into_tensor(out, msg)
+    else:
+        out2 = out.view(world, stride)
+        for lo in range(0, stride, step):
+            hi = min(stride, lo + step)
+            piece = torch.empty(world * (hi - lo), dtype=torch.int32, device=msg.device)
+            dist.all_gather_into_tensor(piece, msg[lo:hi].contiguous())
+            out2[:, lo:hi] = piece.view(world, hi - lo)
+    return engine.unpack_blocks(rows, nnzs, out, stride, n_cols), heads
+
+
 def allgather_rows(engine, local, n_cols, dist):
     """all-gather(v) of row blocks -> the full matrix on every rank (rows in rank order)"""
-    torch = engine.torch
-    ip, ix, dx = engine.tensors(local)
-    lens = (ip[1:] - ip[:-1]).contiguous()
-    lens_all = _all_gather_var(lens, dist, torch)
-    ix_all = _all_gather_var(ix.contiguous(), dist, torch)
-    dx_all = _all_gather_var(dx.contiguous(), dist, torch)
-    lens_cat = torch.cat(lens_all)
-    n_rows = int(lens_cat.numel())
-    indptr = torch.zeros(n_rows + 1, dtype=torch.int32, device=lens_cat.device)
-    indptr[1:] = torch.cumsum(lens_cat, 0).to(torch.int32)
-    return engine.from_tensors(n_rows, n_cols, indptr, torch.cat(ix_all).contiguous(), torch.cat(dx_all).contiguous())
+    return exchange_rows(engine, local, n_cols, dist)[0]
 
 
 REPLICATE_NNZ = 4_000_000      # below this many entries the iterations are cheaper than their collectives: every rank runs them whole
@@ -344,15 +393,11 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
         if run is not cur_local:
             engine.free(run)
         n_iter = it + 1
-        red = torch.tensor([0.0, float(st_c), float(engine.shape(p)[2]), float(st_f)], dtype=torch.float64,
-                           device=engine.device)
-        if it > 1:
-            red[0] = engine.convergence_stat(p, cur_local)
-        mx = red[:1].clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)            # convergence: one float, max over ranks
-        dist.all_reduce(red[1:], op=dist.ReduceOp.SUM)       # bookkeeping only (nnz / product counts)
-        full = allgather_rows(engine, p, n, dist)            # the per-iteration all-gather(v)
-        stats.append([st_a, int(red[1].item()), int(red[2].item()), int(red[3].item())])
+        stat = engine.convergence_stat(p, cur_local) if it > 1 else 0.0
+        # the per-iteration exchange: header all-gather (sizes + convergence max + counts) and one packed all-gather(v)
+        full, heads = exchange_rows(engine, p, n, dist, stat=stat, counts=(st_c, engine.shape(p)[2], st_f))
+        mx = np.float32(heads[:, 2].max())
+        stats.append([st_a] + [int(v) for v in heads[:, 3:].sum(axis=0)])
         engine.free(cur_local)
         if links_full is not None:
             engine.free(links_full)
@@ -360,7 +405,7 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
         elif own_full:
             engine.free(cur_full)
         cur_local, cur_full, own_full = p, full, True
-        if it > 1 and np.float32(mx.item()) <= np.float32(1e-8):
+        if it > 1 and mx <= np.float32(1e-8):
             converged = True
             break
         if world > 1 and it + 1 < iters and engine.shape(cur_full)[2] <= replicate_nnz and hasattr(engine, 'mcl_resume'):

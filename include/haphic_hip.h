@@ -74,6 +74,14 @@ int hhx_csr_copy(const hhx_csr *m, hhx_csr **out);
 int hhx_csr_row_block(const hhx_csr *m, int32_t r0, int32_t r1, hhx_csr **out);
 /* row blocks stacked in order (same column count; fewer than 2^31 entries in total) */
 int hhx_csr_vstack(int32_t n_blocks, const hhx_csr *const *blocks, hhx_csr **out);
+/* SURVEY §8e, the per-iteration all-gather(v) of the pruned row blocks (mcl :2026-2062 with T sharded by row block): RCCL has no
+ * all-gather-v, so a block travels as ONE int32 message [row lengths | column indices | float32 value bits] padded to the longest
+ * message of the world.  hhx_csr_pack_block writes m's message (n_rows + 2 nnz words) into a caller-owned device buffer;
+ * hhx_csr_unpack_blocks turns the gathered messages (message b at packed + b * stride_words, rows[b] rows / nnz[b] entries — host
+ * arrays, from the header exchange) into the stacked matrix: three device copies per block and one scan for the row pointer. */
+int hhx_csr_pack_block(const hhx_csr *m, void *dst_dev, int64_t capacity_words);
+int hhx_csr_unpack_blocks(int32_t n_blocks, const int64_t *rows, const int64_t *nnz, const void *packed_dev, int64_t stride_words,
+                          int32_t n_cols, hhx_csr **out);
 /* free / total device memory in bytes (memory cached by the library's pool counts as used: hhx_pool_trim first) */
 int hhx_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 int hhx_csr_free(hhx_csr *m);
@@ -131,6 +139,17 @@ int hhx_mcl_resume(const hhx_csr *m, int done, int expansion, double inflation, 
                    hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
 int hhx_mcl_normalized(const hhx_csr *normalized, int expansion, double inflation, int max_iter, double pruning,
                        hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
+/* The inflation sweep of run_mcl_clustering :2155-2158 (every inflation restarts from the matrix pre-expanded at :2146-2147) with ONE
+ * expansion.  hhx_expand_links_dense: rows [r0, r1) of M^2 — M the L1-normalised (:2144) raw link matrix of dict_to_matrix — as a
+ * dense float32 row block in HBM (4 B x (r1 - r0) x n; hhx_dense_shape reports the bytes).  hhx_dense_inflate_prune: iteration 0 of
+ * mcl() (:2037-2042: power, normalise, prune, restore the maximum, normalise) of those rows at one inflation, bit for bit what
+ * hhx_mcl_links computes in its first iteration; stack the blocks (hhx_csr_vstack) and continue with hhx_mcl_resume(done = 1). */
+typedef struct hhx_dense hhx_dense;
+int hhx_expand_links_dense(const hhx_csr *links, int32_t r0, int32_t r1, int fx_shift, hhx_dense **out, int64_t *n_products,
+                           int64_t *nnz_expanded);
+int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, double pruning, hhx_csr **out);
+int hhx_dense_shape(const hhx_dense *d, int32_t *n_rows, int32_t *n_cols, int64_t *bytes);
+int hhx_dense_free(hhx_dense *d);
 
 /* run_mcl_clustering :2144-2158 for one inflation straight from the RAW link matrix that dict_to_matrix
  * returns (:362-368): the L1 normalisation (:2144), the pre-expansion (:2146-2147, fused into iteration 0) and

@@ -200,10 +200,10 @@ static i64 count_products(i32 n, const i32 *Ap, const i32 *Aj, const i32 *Bp) {
     return f;
 }
 
-i64 orc_mcl(i32 n, const i32 *indptr, const i32 *indices, const float *data, int expansion,
-            double inflation, int iters, double pruning, int spgemm_mode, int fx_shift, i64 cap,
-            i32 *out_indptr, i32 *out_indices, float *out_data, int *n_iter, int *converged,
-            i64 *stats) {
+i64 orc_mcl_from(i32 n, const i32 *indptr, const i32 *indices, const float *data, int expansion,
+                 double inflation, int iters, double pruning, int spgemm_mode, int fx_shift, i64 cap,
+                 i32 *out_indptr, i32 *out_indices, float *out_data, int *n_iter, int *converged,
+                 i64 *stats, int first_it) {
     i64 nnz = indptr[n];
     i32 *cp = (i32 *)malloc(sizeof(i32) * ((size_t)n + 1));
     i32 *cj = (i32 *)malloc(sizeof(i32) * (size_t)(nnz ? nnz : 1));
@@ -214,8 +214,16 @@ i64 orc_mcl(i32 n, const i32 *indptr, const i32 *indices, const float *data, int
     i32 *lp = NULL, *lj = NULL;
     float *lx = NULL;
     *converged = 0;
-    *n_iter = 0;
-    for (int it = 0; it < iters; ++it) {
+    *n_iter = first_it;
+    if (first_it >= 2) {         /* picked up after `first_it` iterations: the input is what the last of them left (last_matrix) */
+        lp = (i32 *)malloc(sizeof(i32) * ((size_t)n + 1));
+        lj = (i32 *)malloc(sizeof(i32) * (size_t)(nnz ? nnz : 1));
+        lx = (float *)malloc(sizeof(float) * (size_t)(nnz ? nnz : 1));
+        memcpy(lp, cp, sizeof(i32) * ((size_t)n + 1));
+        memcpy(lj, cj, sizeof(i32) * (size_t)nnz);
+        memcpy(lx, cx, sizeof(float) * (size_t)nnz);
+    }
+    for (int it = first_it; it < iters; ++it) {
         i64 st_a = cp[n], st_f = 0;
         if (it != 0 && expansion > 1) { /* 2) expand, :2030-2035 */
             /* mkl_matrix_power(M, e) = M * M^(e-1) on CSC (:2017-2023)  ==  T^(e-1) * T on CSR(T) */
@@ -269,6 +277,14 @@ i64 orc_mcl(i32 n, const i32 *indptr, const i32 *indices, const float *data, int
     } else out_nnz = -1;
     free(cp); free(cj); free(cx); free(lp); free(lj); free(lx);
     return out_nnz;
+}
+
+i64 orc_mcl(i32 n, const i32 *indptr, const i32 *indices, const float *data, int expansion,
+            double inflation, int iters, double pruning, int spgemm_mode, int fx_shift, i64 cap,
+            i32 *out_indptr, i32 *out_indices, float *out_data, int *n_iter, int *converged,
+            i64 *stats) {
+    return orc_mcl_from(n, indptr, indices, data, expansion, inflation, iters, pruning, spgemm_mode, fx_shift, cap,
+                        out_indptr, out_indices, out_data, n_iter, converged, stats, 0);
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -54,6 +54,8 @@ def lib():
                               C.c_int, C.c_int, C.c_int64, _i32p, _i32p, _f32p, C.POINTER(C.c_int),
                               C.POINTER(C.c_int), C.c_void_p]
         L.orc_mcl.restype = C.c_int64
+        L.orc_mcl_from.argtypes = L.orc_mcl.argtypes + [C.c_int]
+        L.orc_mcl_from.restype = C.c_int64
         L.orc_interpret.argtypes = [C.c_int32, _i32p, _i32p, _f32p, _i32p, _i32p, _i32p]
         L.orc_interpret.restype = C.c_int32
         L.orc_ingest_new.argtypes = [C.c_int32, C.c_int, C.c_int]
@@ -136,23 +138,28 @@ def convergence_stat(A, B):
     return float(lib().orc_convergence_stat(len(ap) - 1, ap, aj, ax, bp, bj, bx))
 
 
-def mcl(A, expansion, inflation, iters, pruning, spgemm_mode=0, fx_shift=62, want_stats=False):
-    """mcl() :2026-2062 on the pre-expanded matrix.  Returns (indptr, indices, data, n_iter, converged[, stats])."""
+def mcl(A, expansion, inflation, iters, pruning, spgemm_mode=0, fx_shift=62, want_stats=False, first_it=0):
+    """mcl() :2026-2062 on the pre-expanded matrix.  Returns (indptr, indices, data, n_iter, converged[, stats]).
+    first_it >= 1: A is what the first `first_it` iterations of the loop left; the loop is picked up there (iteration
+    `first_it` expands; the convergence test of :2044 runs from iteration max(first_it, 2) on, at first_it against A)."""
     ap, aj, ax = _csr(*A)
     n = len(ap) - 1
     cap = max(int(ax.size), 1)
+    if n:               # a pruned row holds at most 1 / pruning entries (+ the restored maximum); np.zeros pages are lazy
+        per_row = n if pruning <= 0 else min(n, int(1.0 / pruning) + 1)
+        cap = max(cap, n * per_row)
     op = np.zeros(n + 1, np.int32)
     oj = np.zeros(cap, np.int32)
     ox = np.zeros(cap, np.float32)
     n_iter, conv = C.c_int(0), C.c_int(0)
     stats = np.zeros((max(iters, 1), 4), np.int64)
-    nnz = lib().orc_mcl(n, ap, aj, ax, int(expansion), float(inflation), int(iters), float(pruning),
-                        int(spgemm_mode), int(fx_shift), cap, op, oj, ox, C.byref(n_iter), C.byref(conv),
-                        stats.ctypes.data)
+    nnz = lib().orc_mcl_from(n, ap, aj, ax, int(expansion), float(inflation), int(iters), float(pruning),
+                             int(spgemm_mode), int(fx_shift), cap, op, oj, ox, C.byref(n_iter), C.byref(conv),
+                             stats.ctypes.data, int(first_it))
     if nnz < 0:
         raise RuntimeError('oracle mcl: output larger than input (unexpected)')
     res = (op, oj[:nnz], ox[:nnz], n_iter.value, bool(conv.value))
-    return res + (stats[:n_iter.value],) if want_stats else res
+    return res + (stats[int(first_it):n_iter.value],) if want_stats else res
 
 
 def interpret(A):

@@ -92,6 +92,24 @@ def inflate_prune_keep(c, inflation, pruning):
     return DeviceCSR(*orc.prune((c.a[0], c.a[1], x), pruning), n_cols=c.n_cols)
 
 
+class DenseRows:
+    """rows [r0, r1) of M^2 (M = the L1-normalised link matrix), the stand-in of hhx_dense"""
+
+    def __init__(self, links, r0, r1, fx_shift=52):
+        p, j, x = links.a
+        norm = (p, j, orc.normalize_l1(p, x))
+        blk = (p[r0:r1 + 1] - p[r0], j[p[r0]:p[r1]], norm[2][p[r0]:p[r1]])
+        self.c = DeviceCSR(*orc.spgemm(blk, norm, n_cols=links.n_cols, mode=1, fx_shift=52), n_cols=links.n_cols)
+        self.n_products = int(np.diff(p)[blk[1]].sum())
+        self.nnz_expanded = self.c.nnz
+
+    def inflate_prune(self, inflation, pruning):
+        return inflate_prune_keep(self.c, inflation, pruning)
+
+    def free(self):
+        pass
+
+
 def vstack(blocks):
     ps = [b.a[0] for b in blocks]
     off = np.cumsum([0] + [p[-1] for p in ps])

@@ -22,6 +22,18 @@ def test_oracle_bam_restatement_and_fixture():
     assert len(orc.parse_bam(data, 0, False)[2]) == len(recs)
 
 
+def test_oracle_bam_rich_fixture():
+    """optional fields of every type, multi-operation and > 65535-operation CIGARs (CG tag), records larger than a BGZF
+    block, more than 65535 references: the record walk must rely on block_size alone"""
+    refs, recs, data = bf.random_case(n_ref=70_000, n_rec=4000, seed=11, block_payload=0xff00, rich=True)
+    raw = gzip.decompress(data)
+    assert raw[:4] == b'BAM\x01' and b'CGBI' in raw
+    text, names, tup = orc.parse_bam(data, 0x40, False)
+    read1 = [x for x in recs if x[4] & 0x40]
+    assert len(names) == 70_000 and max(x[0] for x in read1) > 65_535
+    assert tup == [(refs[r][0] if r >= 0 else None, refs[m][0] if m >= 0 else None, p, q) for r, p, m, q, f in read1]
+
+
 def test_check_sorting_order_mirror(caplog):
     from haphic_amd import cluster
     with caplog.at_level(logging.INFO, logger='HapHiC_cluster'):
@@ -44,6 +56,17 @@ def test_bam_front_end_against_oracle(tmp_path):
             gen = cluster.bam_generator(str(path), 3, opts)
             gen.batch_bytes = batch
             assert list(gen) == want, (opts, batch)
+    # what real BAMs carry beyond the fixed fields: optional fields ('B' arrays too), long CIGARs (CG tag), records larger
+    # than a BGZF block and than the batch limit, 70k references
+    refs2, recs2, data2 = bf.random_case(n_ref=70_000, n_rec=20000, seed=12, block_payload=0xff00, rich=True)
+    rich = tmp_path / 'rich.bam'
+    rich.write_bytes(data2)
+    for drop, opts in ((False, [b'filter=flag.read1']), (True, [b'filter=flag.read1 && refid != mrefid'])):
+        want2 = orc.parse_bam(data2, 0x40, drop)[2]
+        for batch in (256 << 20, 1 << 16, 1_000_000):
+            gen = cluster.bam_generator(str(rich), 4, opts)
+            gen.batch_bytes = batch
+            assert list(gen) == want2, ('rich', opts, batch)
     # through the ingest: some BAM references are not in the FASTA (dropped like `ref not in fa_dict`), FASTA order differs
     rng = np.random.default_rng(9)
     keep = [k for k in range(len(refs)) if k % 5 != 3]

@@ -673,6 +673,107 @@ def test_mcl_links_class_stream_iteration0():
     assert (n3, c3) == (n4, c4) and all(np.array_equal(x, y) for x, y in zip(r3.to_arrays(), r4.to_arrays()))
 
 
+def test_dense_sweep_equals_fused_iteration0():
+    """The inflation sweep with one expansion (hhx_expand_links_dense + hhx_dense_inflate_prune): rows of M^2 stored once as
+    float32, iteration 0 of every inflation from them — bit for bit the first iteration of hhx_mcl_links at that inflation, with
+    the rows in one block, in ragged blocks, through the generic stream (non-integer values), and against the oracle on a slice."""
+    import torch
+    from haphic_amd import cluster, synth
+    gen = synth.make_genome(8, 60_000_000, 20_000, seed=8)          # ~24k contigs -> 2 column windows
+    n = gen.n
+    lex = gen.lexical_rank()
+    t = orc.FragTable(lex, gen.length, np.arange(n, dtype=np.int32), np.zeros(n, np.uint8), 0, lex, gen.length, np.ones(n, np.uint8))
+    id1, p1, id2, p2 = synth.sample_pairs(gen, 8_000_000, seed=9, device='cuda')
+    ing = _lib.Ingest(t, 500_000, bins=False, skip_intra=True)
+    ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+    torch.cuda.synchronize()
+    links, fidx, n_linked = ing.link_matrix(np.ones(n, np.uint8))
+    ing.destroy()
+    n = links.shape3[0]
+    inflations = (2.0, 1.4, 3.0)
+    want = {r: _lib.mcl(links, 2, r, 1, 1e-4, want_stats=True, links=True) for r in inflations}
+    whole = _lib.DenseRows(links, 0, n)
+    assert whole.n_products == want[2.0][3][0, 3] and whole.nnz_expanded == want[2.0][3][0, 1]
+    for r in inflations:
+        got = whole.inflate_prune(r, 1e-4)
+        assert all(np.array_equal(x, y) for x, y in zip(got.to_arrays(), want[r][0].to_arrays())), 'dense sweep, one block, inflation %r' % r
+        got.free()
+    whole.free()
+    # ragged row blocks through the host driver (cluster.DenseSweep), the pieces stacked
+    sweep = cluster.DenseSweep(links, 1e-4, block_rows=7001)
+    assert len(sweep.bounds) == 5
+    for r, first in zip(inflations, sweep.first_iterations(inflations)):
+        assert all(np.array_equal(x, y) for x, y in zip(first.to_arrays(), want[r][0].to_arrays())), 'dense sweep, 4 blocks, inflation %r' % r
+        # ... and the loop resumed from it ends where the fused mcl() ends
+        if r == 2.0:
+            a, na, ca = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4)
+            b, nb, cb = _lib.mcl(links, 2, r, 200, 1e-4, links=True)
+            assert (na, ca) == (nb, cb) and all(np.array_equal(x, y) for x, y in zip(a.to_arrays(), b.to_arrays()))
+            a.free(); b.free()
+        first.free()
+    sweep.close()
+    # against the oracle on a slice of rows (mode 1: the kernels' own specification)
+    mp, mj, mx = links.to_arrays()
+    norm = orc.normalize_l1(mp, mx)
+    r0, r1 = 5000, 5040
+    blk = _lib.DenseRows(links, r0, r1)
+    lo, hi = mp[r0], mp[r1]
+    c = orc.spgemm(((mp[r0:r1 + 1] - lo).astype(np.int32), mj[lo:hi], norm[lo:hi]), (mp, mj, norm), n_cols=n, mode=1, fx_shift=52)
+    for r in (2.0, 1.7):
+        ref = orc.prune((c[0], c[1], orc.normalize_l1(c[0], orc.power(c[2], r))), 1e-4)
+        got = blk.inflate_prune(r, 1e-4).to_arrays()
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        if r == 2.0:
+            assert np.array_equal(got[2], ref[2])
+        else:
+            np.testing.assert_allclose(got[2], ref[2], rtol=RTOL)      # powf (oracle) vs float(pow) (device)
+    blk.free()
+    # an empty row block, and values that are not integer counts (generic stream)
+    empty = _lib.DenseRows(links, 100, 100)
+    e = empty.inflate_prune(2.0, 1e-4)
+    assert e.shape3 == (0, n, 0)
+    x2 = (mx * np.float32(0.37)).astype(np.float32)
+    l2 = _lib.DeviceCSR.from_arrays(mp, mj, x2)
+    w2 = _lib.mcl(l2, 2, 2.0, 1, 1e-4, links=True)[0]
+    d2 = _lib.DenseRows(l2, 0, n)
+    g2 = d2.inflate_prune(2.0, 1e-4)
+    assert all(np.array_equal(x, y) for x, y in zip(g2.to_arrays(), w2.to_arrays()))
+    for x in (e, g2, w2, l2, links):
+        x.free()
+    d2.free()
+    empty.free()
+
+
+def test_pack_unpack_row_blocks_and_empty_blocks():
+    """the packed exchange message of the row-block MCL (hhx_csr_pack_block / hhx_csr_unpack_blocks) — blocks of different
+    sizes, an EMPTY block among them (balanced_ranges can leave a rank without rows) — and a fused iteration on a
+    block without rows"""
+    import torch
+    A = clustered_stochastic(3000, 60, 6, 1, 3)
+    d = _lib.DeviceCSR.from_arrays(*A)
+    cuts = [0, 700, 700, 2100, 3000]
+    blocks = [d.row_block(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    rows = np.array([b.shape3[0] for b in blocks], np.int64)
+    nnzs = np.array([b.shape3[2] for b in blocks], np.int64)
+    stride = int((rows + 2 * nnzs).max()) + 5
+    packed = torch.zeros(len(blocks) * stride, dtype=torch.int32, device='cuda')
+    for k, b in enumerate(blocks):
+        _lib.check(_lib.load().hhx_csr_pack_block(b.h, _lib.C.c_void_p(packed[k * stride:].data_ptr()), stride))
+    torch.cuda.synchronize()
+    out = _lib.C.c_void_p()
+    _lib.check(_lib.load().hhx_csr_unpack_blocks(len(blocks), rows.ctypes.data_as(_lib.c_i64p), nnzs.ctypes.data_as(_lib.c_i64p),
+                                                 _lib.C.c_void_p(packed.data_ptr()), stride, 3000, _lib.C.byref(out)))
+    back = _lib.DeviceCSR(out)
+    assert all(np.array_equal(x, y) for x, y in zip(back.to_arrays(), d.to_arrays()))
+    with pytest.raises(RuntimeError, match='buffer of'):
+        _lib.check(_lib.load().hhx_csr_pack_block(blocks[0].h, _lib.C.c_void_p(packed.data_ptr()), 10))
+    got, f, z = _lib.expand_inflate_prune(blocks[1], d, 2.0, 1e-4)        # the empty block through the fused iteration
+    assert got.shape3 == (0, 3000, 0) and f == 0 and z == 0
+    assert _lib.row_products(blocks[1], d).size == 0
+    for x in blocks + [back, got, d]:
+        x.free()
+
+
 def test_link_matrix_packed_and_wide_entries():
     """hhx_ingest_link_matrix moves 8-byte entries (row, column, count < 2^24) through its partition and 16-byte ones when
     a count needs more bits: both against the oracle's dict_to_matrix on the fetched tables, > 4096 fragments (the

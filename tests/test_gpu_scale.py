@@ -3,9 +3,17 @@
   C2 (configs[1], 10k contigs / 50 M pairs, full size): ingest tables, dict_to_matrix triples — bit exact; whole
      mcl(): same iteration count, same convergence flag, identical cluster sets, every matrix value equal (the oracle
      runs the kernels' own specification, mode 1: exact fixed-point sums) and within 1e-6 of it by construction.
+     The knife-edge audit (was tools/flip_count.py): the reference-like float32 accumulation (oracle mode 0) run beside it —
+     same iteration count, same clusters, final matrix within 1e-6; entries kept by one and pruned by the other are counted.
   C3 (configs[2], 100k contigs / 500 M pairs): the fused iteration 0 — the kernel instantiation the roofline is quoted on
-     (5 column windows, the class stream) — against the oracle on 256 sampled rows of the real operand; ingest parity
-     on a 20 M-pair prefix against the full 100k-contig table.
+     (5 column windows, the class stream) — against the oracle on 2048 rows of the real operand stratified by product
+     count; ingest parity on a 20 M-pair prefix against the full 100k-contig table; THE WHOLE mcl(): the oracle picks the
+     loop up from the device's (sample-verified) iteration-0 output and runs it to convergence — iteration count,
+     convergence flag, survivors per iteration, final pattern + values and the cluster sets must be bit equal; the same
+     tail in float32 accumulation (mode 0) must end in the same clusters and a final matrix within 1e-6.
+  C5 (configs[4], 200k contigs / 2 G pairs in four pushes, one GPU): iteration 0 under the n_win = 10 instantiation on sampled
+     rows; ingest parity of a prefix pushed in two ragged batches (the merge of pushed runs) against the full 200k-contig table;
+     size-independent invariants of the full four-push table.
   C4 (configs[3] at 40k contigs): the device ingest with --remove_allelic_links containers (coordinate lists, CLM
      distances, HT counts) against the oracle, entry for entry.
 
@@ -38,6 +46,43 @@ def _oracle_ingest(t, h, flank=500_000, **kw):
 
 def _clusters(att, ptr, mem):
     return {tuple(mem[ptr[a]:ptr[a + 1]].tolist()) for a in range(len(att))}
+
+
+def _keys(A, n):
+    return np.repeat(np.arange(n, dtype=np.int64), np.diff(A[0])) * n + A[1]
+
+
+def _flips(a, b, n):
+    """entries of one pattern missing from the other, largest relative difference on the common ones"""
+    ka, kb = _keys(a, n), _keys(b, n)
+    only_a = np.setdiff1d(ka, kb, assume_unique=True)
+    only_b = np.setdiff1d(kb, ka, assume_unique=True)
+    va = a[2][np.isin(ka, kb, assume_unique=True)].astype(np.float64)
+    vb = b[2][np.isin(kb, ka, assume_unique=True)].astype(np.float64)
+    rel = float(np.max(np.abs(va - vb) / np.maximum(np.abs(vb), 1e-300))) if len(va) else 0.0
+    return len(only_a), len(only_b), rel
+
+
+def _sample_rows_oracle(mp, mj, norm, rows, n, inflation=2.0, mode=1):
+    """iteration 0 of the oracle (expand, inflate, prune) on the given rows of the normalised link matrix"""
+    sub_p = np.zeros(len(rows) + 1, np.int32)
+    sub_p[1:] = np.cumsum(mp[rows + 1] - mp[rows])
+    take = np.concatenate([np.arange(mp[r], mp[r + 1]) for r in rows])
+    c = orc.spgemm((sub_p, mj[take], norm[take]), (mp, mj, norm), n_cols=n, mode=mode, fx_shift=52)
+    x = orc.normalize_l1(c[0], orc.power(c[2], inflation))
+    return orc.prune((c[0], c[1], x), 1e-4)
+
+
+def _stratified_rows(products, count, seed):
+    """`count` rows spread evenly over the rows sorted by product count, plus the 32 lightest and the 32 heaviest"""
+    order = np.argsort(products, kind='stable')
+    n = len(order)
+    pick = set(order[np.linspace(0, n - 1, count).astype(np.int64)].tolist())
+    pick.update(order[:32].tolist())
+    pick.update(order[-32:].tolist())
+    extra = np.random.default_rng(seed).choice(n, 64, replace=False)
+    pick.update(extra.tolist())
+    return np.array(sorted(pick), np.int64)
 
 
 def test_c2_full_size_against_oracle():
@@ -79,6 +124,21 @@ def test_c2_full_size_against_oracle():
     np.testing.assert_allclose(gx, o[2], rtol=1e-6, atol=0)
     assert np.array_equal(gx, o[2]), 'C2 mcl: final values (same specification: expected bit equal)'
     assert _clusters(*_lib.interpret(res)) == _clusters(*orc.interpret(o[:3])), 'C2 clusters'
+    # knife-edge audit: the reference-like float32 accumulation (mode 0: scipy's sequential float32 sums, the stand-in for
+    # sparse_dot_mkl) beside the exact fixed-point one.  Intermediate iterations of two float trajectories differ by the
+    # float32 accumulation noise of the REFERENCE (k * eps over 2-3 k terms, ~1e-4 at iteration 0); north_star's bar is the
+    # outcome: same iteration count, identical clusters, final matrix within 1e-6.
+    pre0 = orc.spgemm((rp, rj, rn), (rp, rj, rn), mode=0)
+    one = _lib.mcl(m, 2, 2.0, 1, 1e-4, links=True)[0]
+    t1_f32 = orc.mcl(pre0, 2, 2.0, 1, 1e-4, spgemm_mode=0)[:3]
+    only_f32, only_exact, rel0 = _flips(t1_f32, one.to_arrays(), n)
+    one.free()
+    assert only_f32 + only_exact <= 16 and rel0 < 1e-3, 'C2 iteration 0: %d + %d entries decided differently, rel %g' % (only_f32, only_exact, rel0)
+    o0 = orc.mcl(pre0, 2, 2.0, 200, 1e-4, spgemm_mode=0)
+    assert (o0[3], o0[4]) == (n_iter, conv), 'C2 float32 trajectory: iteration count'
+    assert _clusters(*orc.interpret(o0[:3])) == _clusters(*_lib.interpret(res)), 'C2 float32 trajectory: clusters'
+    assert np.array_equal(o0[0], gp) and np.array_equal(o0[1], gj), 'C2 float32 trajectory: final pattern'
+    np.testing.assert_allclose(gx, o0[2], rtol=1e-6, atol=0)
 
 
 def test_c3_iteration0_sampled_rows_and_ingest_prefix():
@@ -111,24 +171,51 @@ def test_c3_iteration0_sampled_rows_and_ingest_prefix():
     m, fidx, n_linked = ing.link_matrix(np.ones(n, np.uint8))
     ing.destroy()
     assert m.shape3[0] > 99_000 and m.nnz > 300_000_000
+    n = m.shape3[0]
+    # the whole mcl() as bench.py times it (normalisation + pre-expansion fused into iteration 0, class stream)
+    res, n_iter_full, conv_full, stats_full = _lib.mcl(m, 2, 2.0, 200, 1e-4, want_stats=True, links=True)
+    fp, fj, fx = res.to_arrays()
+    dev_clusters = _clusters(*_lib.interpret(res))
+    res.free()
     one, n_iter, conv, stats = _lib.mcl(m, 2, 2.0, 1, 1e-4, want_stats=True, links=True)        # iteration 0 only
     assert n_iter == 1 and stats[0, 3] > 10 ** 12
+    assert np.array_equal(stats[0], stats_full[0])
     gp, gj, gx = one.to_arrays()
     mp, mj, mx = m.to_arrays()
     assert (mx == np.rint(mx)).all() and mx.max() < 65536                # integer link counts: the class stream was taken
     norm = orc.normalize_l1(mp, mx)
-    rows = np.sort(np.random.default_rng(5).choice(m.shape3[0], 256, replace=False))
-    sub_p = np.zeros(len(rows) + 1, np.int32)
-    sub_p[1:] = np.cumsum(mp[rows + 1] - mp[rows])
-    take = np.concatenate([np.arange(mp[r], mp[r + 1]) for r in rows])
-    c = orc.spgemm((sub_p, mj[take], norm[take]), (mp, mj, norm), n_cols=m.shape3[0], mode=1, fx_shift=52)
-    x = orc.normalize_l1(c[0], orc.power(c[2], 2.0))
-    want = orc.prune((c[0], c[1], x), 1e-4)
+    # iteration 0: 2048 rows spread over the product-count distribution (+ the lightest, the heaviest, 64 random ones)
+    rows = _stratified_rows(_lib.row_products(m, m), 2048, seed=5)
+    assert len(rows) >= 2048
+    want = _sample_rows_oracle(mp, mj, norm, rows, n)
     for k, r in enumerate(rows):
         lo, hi = gp[r], gp[r + 1]
         wl, wh = want[0][k], want[0][k + 1]
         assert np.array_equal(gj[lo:hi], want[1][wl:wh]), 'C3 iteration 0: pattern of row %d' % r
         assert np.array_equal(gx[lo:hi], want[2][wl:wh]), 'C3 iteration 0: values of row %d' % r
+    # the same rows in the reference's float32 accumulation: how far apart the two specifications are after one iteration
+    rows0 = rows[:: max(1, len(rows) // 256)]
+    want0 = _sample_rows_oracle(mp, mj, norm, rows0, n, mode=0)
+    got0_p = np.zeros(len(rows0) + 1, np.int32)
+    got0_p[1:] = np.cumsum(gp[rows0 + 1] - gp[rows0])
+    take0 = np.concatenate([np.arange(gp[r], gp[r + 1]) for r in rows0])
+    only_f32, only_exact, rel0 = _flips(want0, (got0_p, gj[take0], gx[take0]), n)
+    assert only_f32 + only_exact <= 8 and rel0 < 2e-3, 'C3 iteration 0 (%d rows): %d + %d entries decided differently, rel %g' % (
+        len(rows0), only_f32, only_exact, rel0)
+    # THE TAIL: the oracle continues mcl() :2026-2062 from the device's iteration-0 output (iteration 1 = 1.6e10 products,
+    # row-parallel on the host cores) to convergence; the device's own full run must agree bit for bit
+    o = orc.mcl((gp, gj, gx), 2, 2.0, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
+    assert (n_iter_full, conv_full) == (o[3], o[4]), 'C3 mcl: iteration count / convergence flag'
+    assert np.array_equal(stats_full[1:], o[5]), 'C3 mcl: nnz_A, nnz_C, survivors, products of every iteration'
+    assert np.array_equal(fp, o[0]) and np.array_equal(fj, o[1]), 'C3 mcl: final pattern'
+    assert np.array_equal(fx, o[2]), 'C3 mcl: final values'
+    assert dev_clusters == _clusters(*orc.interpret(o[:3])), 'C3 mcl: clusters'
+    # the same tail in float32 accumulation: the outcome north_star asks for — identical clusters, final matrix within 1e-6
+    o0 = orc.mcl((gp, gj, gx), 2, 2.0, 200, 1e-4, spgemm_mode=0, first_it=1)
+    assert dev_clusters == _clusters(*orc.interpret(o0[:3])), 'C3 float32 tail: clusters'
+    assert o0[3] == n_iter_full, 'C3 float32 tail: iteration count'
+    assert np.array_equal(fp, o0[0]) and np.array_equal(fj, o0[1]), 'C3 float32 tail: final pattern'
+    np.testing.assert_allclose(fx, o0[2], rtol=1e-6, atol=0)
     # the generic (column, value) stream gives the same matrix
     try:
         _lib.tune('cls', 0)
@@ -155,6 +242,71 @@ def test_c3_iteration0_sampled_rows_and_ingest_prefix():
         finally:
             _lib.tune('hash_max', 4_000_000)
         assert all(np.array_equal(u, v) for u, v in zip(got1, want)), 'C3 iteration 1, hash_max %d' % hash_max
+
+
+def test_c5_200k_contigs_four_pushes():
+    """configs[4] on one GPU: 200k contigs / 2 G pairs handed over in four pushes (bench.py --contigs 200000 --pairs 2000000000
+    --pushes 4).  What the C3 test cannot reach: the merge of pushed runs, the 3-level radix partition of 5 x 10^8-record
+    batches behind one another, iteration 0 with n_win = 10 column windows."""
+    import torch
+    from haphic_amd import _lib, synth
+    gen = synth.make_genome(24, (200_000 // 24) * 30_000, 30_000, seed=12345)
+    n = gen.n
+    assert n > 199_000
+    t = _table(gen)
+    P, per = 2_000_000_000, 500_000_000
+    # ingest parity across a push boundary: a 24 M-pair prefix in two ragged pushes against the full 200k-contig table
+    first = synth.sample_pairs(gen, per, seed=12345, device='cuda:0')
+    S, cut = 24_000_000, 13_999_999
+    pre = _lib.Ingest(t, 500_000, bins=False, skip_intra=True)
+    pre.push_device(cut, *[x[:cut].data_ptr() for x in first])
+    pre.push_device(S - cut, *[x[cut:S].data_ptr() for x in first])
+    torch.cuda.synchronize()
+    pre.finalize()
+    got = pre.fetch()
+    ref = _oracle_ingest(t, _host([x[:S] for x in first]))
+    for k in TABLES:
+        assert np.array_equal(got[k], ref[k]), 'C5 ingest (24 M-pair prefix, two pushes) differs: ' + k
+    pre.destroy()
+    del got, ref
+    # the whole stream: four pushes of 500 M pairs
+    ing = _lib.Ingest(t, 500_000, bins=False, skip_intra=True)
+    inter = 0
+    for k in range(P // per):
+        part = first if k == 0 else synth.sample_pairs(gen, per, seed=12345 + 1000 * k, device='cuda:0')
+        inter += int((part[0] != part[2]).sum().item())
+        ing.push_device(per, *[x.data_ptr() for x in part])
+        torch.cuda.synchronize()
+        del part
+    del first
+    torch.cuda.empty_cache()
+    n_full, n_flank = ing.finalize()
+    tab = ing.fetch()
+    # size-independent invariants of the merged table: every inter-contig pair counted once, keys unique and oriented,
+    # flank == full (every contig is shorter than twice the flank), per-fragment totals consistent
+    assert int(tab['full_cnt'].sum()) == inter, 'C5: pairs counted'
+    assert (tab['full_i'] != tab['full_j']).all()
+    key = tab['full_i'].astype(np.int64) * n + tab['full_j']
+    assert len(np.unique(key)) == n_full, 'C5: duplicate keys after the run merge'
+    assert n_flank == n_full and np.array_equal(tab['flank_cnt'], tab['full_cnt'])
+    assert int(tab['ht_cnt'].sum()) == inter
+    assert int(tab['frag_links'].sum()) == 2 * inter
+    del tab, key
+    m, fidx, n_linked = ing.link_matrix(np.ones(n, np.uint8))
+    ing.destroy()
+    assert m.shape3[0] == n and m.nnz == 2 * n_flank + n
+    one, n_iter, conv, stats = _lib.mcl(m, 2, 2.0, 1, 1e-4, want_stats=True, links=True)        # iteration 0, n_win = 10
+    gp, gj, gx = one.to_arrays()
+    one.free()
+    mp, mj, mx = m.to_arrays()
+    rows = _stratified_rows(_lib.row_products(m, m), 192, seed=7)
+    m.free()
+    want = _sample_rows_oracle(mp, mj, orc.normalize_l1(mp, mx), rows, n)
+    for k, r in enumerate(rows):
+        lo, hi = gp[r], gp[r + 1]
+        wl, wh = want[0][k], want[0][k + 1]
+        assert np.array_equal(gj[lo:hi], want[1][wl:wh]), 'C5 iteration 0: pattern of row %d' % r
+        assert np.array_equal(gx[lo:hi], want[2][wl:wh]), 'C5 iteration 0: values of row %d' % r
 
 
 def test_c4_40k_contigs_allele_aware_containers():

@@ -40,3 +40,27 @@ def test_inflation_values_match_numpy_decimal_arange():
     for lo, hi, st in ((1.0, 3.0, 0.1), (1.1, 1.7, 0.2), (2.0, 2.0, 0.5), (1.2, 2.4, 0.4)):
         want = list(np.arange(Decimal(str(lo)), Decimal(str(hi)) + Decimal(str(st)), Decimal(str(st))))
         assert cluster._inflation_values(lo, hi, st) == want
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without a rendezvous in the environment re-executes itself under torch.distributed.run with
+    the driver's own flags; under torchrun (WORLD_SIZE set) or at N = 1 it does nothing"""
+    import argparse
+    import os
+    import sys
+    import bench
+    calls = []
+    monkeypatch.setattr(os, 'execv', lambda exe, argv: calls.append((exe, argv)))
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    bench.self_launch(argparse.Namespace(gpus=4, master_port=0))
+    (exe, argv), = calls
+    assert exe == sys.executable and argv[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in argv and argv[argv.index('--nproc-per-node') + 1] == '4' and argv[argv.index('--master-addr') + 1] == '127.0.0.1'
+    assert int(argv[argv.index('--master-port') + 1]) > 0
+    assert argv[-7] == os.path.abspath(bench.__file__) and argv[-6:] == ['--gpus', '4', '--steps', '3', '--warmup', '1']
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    bench.self_launch(argparse.Namespace(gpus=4, master_port=0))
+    monkeypatch.delenv('WORLD_SIZE')
+    bench.self_launch(argparse.Namespace(gpus=1, master_port=0))
+    assert len(calls) == 1

@@ -25,6 +25,24 @@ class OracleEngine:
     def from_tensors(self, n_rows, n_cols, indptr, indices, data):
         return (indptr.numpy().copy(), indices.numpy().copy(), data.numpy().copy())
 
+    def pack_block(self, m, words):
+        buf = torch.zeros(int(words), dtype=torch.int32)
+        r, z = len(m[0]) - 1, int(m[0][-1])
+        buf[:r] = torch.from_numpy(np.diff(m[0]).astype(np.int32))
+        buf[r:r + z] = torch.from_numpy(np.ascontiguousarray(m[1], np.int32))
+        buf[r + z:r + 2 * z] = torch.from_numpy(np.ascontiguousarray(m[2], np.float32).view(np.int32))
+        return buf
+
+    def unpack_blocks(self, rows, nnzs, packed, stride, n_cols):
+        p = packed.numpy()
+        lens, ix, dx = [], [], []
+        for b, (r, z) in enumerate(zip(rows.tolist(), nnzs.tolist())):
+            msg = p[b * stride:(b + 1) * stride]
+            lens.append(msg[:r]); ix.append(msg[r:r + z]); dx.append(msg[r + z:r + 2 * z].view(np.float32))
+        indptr = np.zeros(int(sum(rows)) + 1, np.int32)
+        indptr[1:] = np.cumsum(np.concatenate(lens))
+        return indptr, np.concatenate(ix).astype(np.int32), np.concatenate(dx).astype(np.float32)
+
     def shape(self, m):
         return len(m[0]) - 1, None, int(m[0][-1])
 
@@ -334,6 +352,14 @@ def test_row_ranges():
     assert sharded.balanced_ranges([5, 1, 1, 1, 1, 1], 2) == [0, 1, 6]
     assert sharded.balanced_ranges([1, 1, 1, 1, 1, 5], 2) == [0, 5, 6]
     assert sharded.balanced_ranges([0, 0, 0], 2) == [0, 1, 3] and sharded.balanced_ranges([], 3) == [0, 0, 0, 0]
+    # a few very heavy rows: no rank is left without rows while there are rows to give
+    assert sharded.balanced_ranges([100, 1], 2) == [0, 1, 2]
+    assert sharded.balanced_ranges([100, 1, 1, 1], 4) == [0, 1, 2, 3, 4]
+    assert sharded.balanced_ranges([1, 1, 1, 100], 4) == [0, 1, 2, 3, 4]
+    assert sharded.balanced_ranges([100, 1], 4) == [0, 1, 2, 2, 2]
+    for w in (2, 3, 8):
+        bb = sharded.balanced_ranges([10 ** 9, 10 ** 9] + [1] * 20, w)
+        assert bb[0] == 0 and bb[-1] == 22 and all(y > x for x, y in zip(bb, bb[1:])), bb
     b = sharded.balanced_ranges(np.arange(1000), 4)
     c = np.cumsum(np.arange(1000))
     assert b[0] == 0 and b[-1] == 1000 and all(x <= y for x, y in zip(b, b[1:]))

@@ -45,7 +45,9 @@ def main(root, contigs, pairs, out_json, out_txt):
         f.write('kernel, launches, read_bytes(FETCH_SIZE*1024*2), write_bytes(WRITE_SIZE*1024), TCC_MISS*128B, L2_hit_rate\n')
         for _, k, n, fetch, write, miss, hr in rows[:40]:
             f.write('%s, %d, %.4g, %.4g, %.4g, %.3f\n' % (k, n, fetch, write, miss, hr))
-    json.dump({'contigs': int(contigs), 'pairs_per_gpu': int(pairs), 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes',
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from haphic_amd import build
+    json.dump({'contigs': int(contigs), 'pairs_per_gpu': int(pairs), 'kernel_source_sha16': build.source_hash(), 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes',
                'bytes_per_launch': per_launch}, open(out_json, 'w'), indent=1)
     print(open(out_txt).read())
 
