@@ -407,12 +407,18 @@ def sweep_leg(args, m, one_mcl_s):
         tb = time.perf_counter()
         _lib.profile_reset()
         _lib.profile_enable(True)
-        for infl in order:
+        ep = {}
+        for infl in inflations:                                      # ascending: the pools sized by the previous (larger) demand fit
+            te = time.perf_counter()
             try:
                 firsts.append(blk.inflate_prune(float(infl), 1e-4))
             except RuntimeError as e:                                # e.g. a first iteration of more than 2^31 entries at inflation 1.1
                 firsts.append(None)
                 errors[str(infl)] = str(e)[:200]
+            sync()
+            ep[str(infl)] = (time.perf_counter() - te) * 1e3
+        firsts = firsts[::-1]
+        out['epilogue_ms'] = ep
         sync()
         tc = time.perf_counter()
         _lib.profile_enable(False)

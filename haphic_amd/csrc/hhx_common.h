@@ -122,6 +122,7 @@ struct hhx_csr {
 struct hhx_dense {
     i32 n_rows = 0, n_cols = 0;
     i32 cap_win = 0, n_win = 0;         // the column-window plan of the expansion that filled it (summation order of the epilogue)
+    mutable i64 last_cand = 0, last_out = 0;    // pool demand of the previous hhx_dense_inflate_prune (sizes the next call's pools)
     hhx::DevBuf<float> x;
 };
 

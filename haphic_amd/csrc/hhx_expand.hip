@@ -1692,6 +1692,10 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
     }
     // a pruned row holds at most 1 / pruning entries; an early window tests against a partial row sum and admits more
     i64 pool_cap = std::max<i64>((i64)n_rows * 512, (i64)1 << 22), cand_cap = 2 * pool_cap;
+    if (d->last_out) {                                 // a sweep: the demand of the previous inflation, with room for a neighbouring one
+        pool_cap = d->last_out + d->last_out / 2 + n_rows;
+        cand_cap = d->last_cand + d->last_cand / 2 + n_rows;
+    }
     for (int attempt = 0; attempt < 4; ++attempt) {
         DevBuf<i32> cand_col, out_col;
         DevBuf<float> cand_val, out_val;
@@ -1724,6 +1728,8 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
             if ((i64)cur[1] > pool_cap) pool_cap = std::max<i64>(pool_cap * 2, (i64)cur[1] + (i64)n_rows);
             continue;
         }
+        d->last_cand = (i64)cur[0];
+        d->last_out = (i64)cur[1];
         return pack_rows_to_csr(n_rows, n_cols, row_cnt.p, indptr.p, row_off.p, out_col.p, out_val.p, out);
     }
     return fail("dense inflate / prune: survivor pool kept overflowing");

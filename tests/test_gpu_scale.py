@@ -49,7 +49,7 @@ def _clusters(att, ptr, mem):
 
 
 def _keys(A, n):
-    return np.repeat(np.arange(n, dtype=np.int64), np.diff(A[0])) * n + A[1]
+    return np.repeat(np.arange(len(A[0]) - 1, dtype=np.int64), np.diff(A[0])) * n + A[1]
 
 
 def _flips(a, b, n):

@@ -22,6 +22,10 @@ for line in open(sys.argv[1]):
         print('  ingest roofline %s: %.0f GB/s (frac %.3f) launch %.2f ms, traffic %s' % (r['kernel'], r['achieved'], r['frac'], r['avg_launch_ms'], r['traffic']))
     if 'parity' in d:
         print('  parity', d['parity'])
+    if d.get('sweep'):
+        print('  sweep', json.dumps(d['sweep'])[:1800])
+    if d.get('transport'):
+        print('  transport', d['transport'])
     t = g.get('text')
     if t:
         print('  text: parse %.2e pairs/s, with bed %.2e | file->matrix %.2e pairs/s (%.1f GB file), with alignments.bed %.2e pairs/s' % (

@@ -7,7 +7,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 C3="--contigs 100000 --pairs 500000000 --nchrs 24 --mean-len 30000"
 for what in "$@"; do
   case $what in
-    tests) timeout 700 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; grep -A8 "slowest" gpurun_out/pytest_gpu.log | head -9; tail -2 gpurun_out/pytest_gpu.log;;
+    tests) timeout 1500 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; grep -A8 "slowest" gpurun_out/pytest_gpu.log | head -9; tail -2 gpurun_out/pytest_gpu.log;;
     c2) timeout 600 python bench.py --contigs 10000 --pairs 50000000 --nchrs 16 --mean-len 50000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_c2.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c2.log; python tools/bench_brief.py gpurun_out/bench_c2.log;;
     c3) timeout 900 python bench.py $C3 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/bench_c3.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3.log; grep "hhx expand" gpurun_out/bench_c3.log | head -3; python tools/bench_brief.py gpurun_out/bench_c3.log;;
     c3w) HHX_DEBUG=1 timeout 900 python bench.py $C3 --steps 1 --warmup 1 --no-cpu-baseline --text-lines 0 > gpurun_out/bench_c3w.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3w.log; grep "hhx expand" gpurun_out/bench_c3w.log | cut -c150-420 | tail -26 | head -4; python tools/bench_brief.py gpurun_out/bench_c3w.log | head -2;;
@@ -42,6 +42,9 @@ for l in open('gpurun_out/bench_text.log'):
     cprobe) timeout 600 python tools/contact_probe.py > gpurun_out/contact_probe.jsonl 2> gpurun_out/contact_probe.err; echo "cprobe rc=$?"; cat gpurun_out/contact_probe.jsonl; tail -3 gpurun_out/contact_probe.err;;
     iprobe) timeout 600 python tools/ingest_probe.py > gpurun_out/ingest_probe.jsonl 2> gpurun_out/ingest_probe.err; echo "iprobe rc=$?"; cat gpurun_out/ingest_probe.jsonl; tail -3 gpurun_out/ingest_probe.err;;
     k:*) timeout 900 python -m pytest tests -m gpu -x -q -k "${what#k:}" > gpurun_out/pytest_sel.log 2>&1; echo "sel rc=$?"; grep -E "passed|failed|Error|^E " gpurun_out/pytest_sel.log | tail -12;;
+    rccl) timeout 600 python tools/rccl_probe.py > gpurun_out/rccl_probe.jsonl 2> gpurun_out/rccl_probe.err; echo "rccl rc=$?"; cat gpurun_out/rccl_probe.jsonl; tail -3 gpurun_out/rccl_probe.err;;
+    host2) timeout 900 python bench.py --gpus 2 --transport host --contigs 10000 --pairs 50000000 --nchrs 16 --mean-len 50000 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_host2.log 2>&1; echo "host2 rc=$?"; python tools/bench_brief.py gpurun_out/bench_host2.log; tail -3 gpurun_out/bench_host2.log | cut -c1-400;;
+    c5) timeout 1500 python bench.py --contigs 200000 --pairs 2000000000 --pushes 4 --steps 1 --warmup 1 --no-cpu-baseline --text-lines 0 --sweep 0 > gpurun_out/bench_c5.log 2>&1; echo "c5 rc=$?"; python tools/bench_brief.py gpurun_out/bench_c5.log; tail -2 gpurun_out/bench_c5.log | cut -c1-300;;
     listpmc) rocprofv3 -L > gpurun_out/pmc_list.txt 2>&1; grep -c . gpurun_out/pmc_list.txt;;
     env:*) export "${what#env:}"; echo "set ${what#env:}";;
     *) echo "unknown $what";;
