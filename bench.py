@@ -231,7 +231,10 @@ def main():
                         'achieved_survey_8B_model': (8.0 * F_w + 16.0 * A_w) / (win_ms * 1e-3) / 1e9,
                         'measured_stream_ceiling_GBs': 6290.0, 'frac_of_measured_ceiling': ach / 6290.0,
                         'lds_atomic_ceiling_products_per_s': 256 * 2.4e9 * 64 / 12.77,
-                        'note': 'iteration 0 (the link matrix is the operand; long segments); the launches of later iterations are in '
+                        'full_products_per_step': float(stats[0, 3]) if len(stats) else None,
+                        'note': 'iteration 0 (the link matrix is the operand; long segments) in the integer arithmetic of the link matrix: S = L D^-1 L is '
+                                'exactly symmetric, so the launches walk only the blocks J >= I (products_per_step of full_products_per_step) into a dense '
+                                'float32 block; the rest is transposed (dense_transpose) and the rows are finished by dense_epilogue.  The launches of later iterations are in '
                                 'mcl.kernel_ms_per_step.expand_window_short.  The stream is served by the fabric behind L2 (HBM + the 256 MB '
                                 'Infinity Cache: one column-window slice of the class stream is ~200 MB), so the HBM peak is the contract '
                                 'denominator and the float4-copy ceiling of MI355X_MICROARCH.md (6.29 TB/s) the practical one; the second '
@@ -263,6 +266,7 @@ def main():
                'alg_bytes_per_mcl_survey': b_iter, 'alg_GBs_survey': b_iter * K / t_mcl / 1e9 if t_mcl else None,
                'stats_nnzA_nnzC_nnzP_F': stats.tolist(),
                'kernel_ms_per_step': {'expand_window': win_ms / K, 'expand_window_short': pg('expand_window_short')[0] / K, 'expand_hash': pg('expand_hash')[0] / K,
+                                      'dense_transpose': pg('dense_transpose')[0] / K, 'dense_epilogue': pg('dense_epilogue')[0] / K,
                                       'expand_finalize': fin_ms / K, 'expand_compact': cmp_ms / K,
                                       'expand_tiny': tiny_ms / K,
                                       'convergence': cvg_ms / K}}
@@ -499,12 +503,16 @@ def parity_leg(args, m, rows=64):
     mp, mj, mx = m.to_arrays()
     n = m.shape3[0]
     m.free()
-    norm = orc.normalize_l1(mp, mx)
     pick_rows = np.sort(np.random.default_rng(5).choice(n, min(rows, n), replace=False))
-    sub_p = np.zeros(len(pick_rows) + 1, np.int32)
-    sub_p[1:] = np.cumsum(mp[pick_rows + 1] - mp[pick_rows])
-    take = np.concatenate([np.arange(mp[r], mp[r + 1]) for r in pick_rows])
-    c = orc.spgemm((sub_p, mj[take], norm[take]), (mp, mj, norm), n_cols=n, mode=1, fx_shift=52)
+    integer = orc.links_shift((mp, mj, mx)) > 0           # the kernels took the integer arithmetic (symmetric counts, row sums < 2^18)
+    if integer:
+        c = orc.expand_links((mp, mj, mx), rows=pick_rows)
+    else:
+        norm = orc.normalize_l1(mp, mx)
+        sub_p = np.zeros(len(pick_rows) + 1, np.int32)
+        sub_p[1:] = np.cumsum(mp[pick_rows + 1] - mp[pick_rows])
+        take = np.concatenate([np.arange(mp[r], mp[r + 1]) for r in pick_rows])
+        c = orc.spgemm((sub_p, mj[take], norm[take]), (mp, mj, norm), n_cols=n, mode=1, fx_shift=52)
     x = orc.normalize_l1(c[0], orc.power(c[2], args.inflation))
     want = orc.prune((c[0], c[1], x), 1e-4)
     bad = 0
@@ -512,11 +520,14 @@ def parity_leg(args, m, rows=64):
         lo, hi, wl, wh = gp[r], gp[r + 1], want[0][k], want[0][k + 1]
         if not (np.array_equal(gj[lo:hi], want[1][wl:wh]) and np.array_equal(gx[lo:hi], want[2][wl:wh])):
             bad += 1
-    return {'what': 'iteration 0 (fused pre-expansion + inflate + prune, class stream) vs oracle, sampled rows of the real operand',
-            'rows_checked': int(len(pick_rows)), 'rows_differing': int(bad), 'bit_identical': bad == 0, 'products_checked': int(c[0][-1] and np.diff(mp)[mj[take]].sum()),
+    return {'what': 'iteration 0 (pre-expansion: integer arithmetic, upper block triangle + transposition; inflate + prune from the dense rows) vs oracle, sampled rows of the real operand',
+            'rows_checked': int(len(pick_rows)), 'rows_differing': int(bad), 'bit_identical': bad == 0,
+            'products_checked': int(sum(int(np.diff(mp)[mj[mp[r]:mp[r + 1]]].sum()) for r in pick_rows)),
+            'specification': 'integer (S = L D^-1 L exact, orc_expand_links)' if integer else 'fixed point 2^-52 (orc_spgemm mode 1)',
             'iteration1_hash_class': {'rows_checked': int(len(rows1)), 'rows_differing': int(bad1), 'bit_identical': bad1 == 0, 'products_checked': prod1},
             'oracle_threads': orc.get_threads(), 'seconds': time.perf_counter() - t0,
-            'full_size_tests': 'tests/test_gpu_scale.py: C2 whole mcl() bit equal, C3 256 rows + 20 M-pair ingest prefix, C4 40k-contig containers'}
+            'full_size_tests': 'tests/test_gpu_scale.py: C2 whole mcl() bit equal; C3 2k stratified rows of iteration 0 + the whole tail continued by the '
+                               'oracle to convergence, bit equal; C5 (4 pushes) sampled rows + cross-push ingest prefix; C4 40k-contig containers'}
 
 
 def pmc_traffic(n_contigs, pairs):

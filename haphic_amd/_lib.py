@@ -61,7 +61,7 @@ SIGNATURES = {
                                    C.c_double, c_i64p]),
     'hhx_group_link_sums': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'hhx_row_products': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    'hhx_expand_links': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, c_vpp, c_i64p, c_i64p]),
+    'hhx_expand_links': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_double, C.c_double, c_vpp, c_i64p, c_i64p]),
     'hhx_convergence_stat': (C.c_int, [C.c_void_p, C.c_void_p, c_f32p]),
     'hhx_mcl': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, c_vpp, C.POINTER(C.c_int),
                           C.POINTER(C.c_int), C.c_void_p]),
@@ -420,11 +420,11 @@ def row_products(a, b):
     return out[:a.shape3[0]]
 
 
-def expand_links(a, links, inflation, pruning, fx_shift=52):
-    """iteration 0 for a row block: a = rows of the normalised link matrix, links = the whole RAW link matrix"""
+def expand_links(links, r0, r1, inflation, pruning, fx_shift=52):
+    """iteration 0 of mcl() for the rows [r0, r1) of the RAW link matrix `links` (the whole matrix: the right operand)"""
     out = C.c_void_p()
     f, z = C.c_int64(0), C.c_int64(0)
-    check(load().hhx_expand_links(a.h, links.h, int(fx_shift), float(inflation), float(pruning), C.byref(out), C.byref(f), C.byref(z)))
+    check(load().hhx_expand_links(links.h, int(r0), int(r1), int(fx_shift), float(inflation), float(pruning), C.byref(out), C.byref(f), C.byref(z)))
     return DeviceCSR(out), f.value, z.value
 
 

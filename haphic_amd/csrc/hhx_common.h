@@ -123,7 +123,20 @@ struct hhx_dense {
     i32 n_rows = 0, n_cols = 0;
     i32 cap_win = 0, n_win = 0;         // the column-window plan of the expansion that filled it (summation order of the epilogue)
     mutable i64 last_cand = 0, last_out = 0;    // pool demand of the previous hhx_dense_inflate_prune (sizes the next call's pools)
+    bool integer = false;               // x holds y = float(S_ij) of the integer arithmetic; the entry of M^2 is float(y / row_div[i])
     hhx::DevBuf<float> x;
+    hhx::DevBuf<double> row_div;
+};
+
+// the right operand of iteration 0 described as a link matrix (hhx_mcl.hip normalise_links -> hhx_expand.hip)
+struct hhx_links_operand {
+    const unsigned short *n16 = nullptr;    // link count of every entry of the matrix
+    const double *row_sum = nullptr;        // d_k: L1 row sums
+    const u64 *W = nullptr;                 // rint(2^shift / d_k): non-null selects the integer arithmetic (symmetric matrix, d_max <= 2^18)
+    int shift = 0;
+    i32 a_row0 = 0;                         // the left operand is rows [a_row0, a_row0 + n_rows) of the same matrix ...
+    i64 a_off = 0;                          // ... whose first entry is entry a_off of the matrix
+    int sym = 0;                            // dense mode over all rows: compute the upper block triangle, transpose the rest
 };
 
 // ------------------------------------------------------------------ device helpers

@@ -69,6 +69,11 @@ struct ExParams {
     // dense mode (the inflation sweep, run_mcl_clustering :2155-2158): the window kernel stores x = float(acc) of every column
     // into row `row` of this n_rows x dense_ld float32 block instead of inflating / pruning (0 = no entry)
     float *dense; i64 dense_ld;
+    // INTEGER arithmetic of iteration 0 on the raw link matrix (specification: DESIGN.md 4.1, "integer arithmetic").  A = rows of L, B = L, integer link counts c:
+    // the addend of product (i, k, j) is c_ik * W_k * c_kj with W_k = rint(2^s / d_k) — S = L D^-1 L, a symmetric matrix, in exact
+    // 64-bit integers; y = float(acc * 2^-s), x = float(y / d_i).  W == nullptr: the float arithmetic above (fx_bits).
+    const u64 *W; const unsigned short *A16; const double *row_div; double fx_inv;
+    i32 sym;                        // dense + whole matrix: launch wv covers rows [0, (wv + 1) * cap) only (blocks J >= I); the rest is transposed
 };
 
 struct ExLds {
@@ -231,26 +236,34 @@ constexpr int WIDE_UNIT = 512;      // entries per 16-byte lane load of a wave
 constexpr int STREAM_PREFIX = 512;  // Sc16[8 l .. 8 l + 7] = cap + l: what lane l of a wide tile loads when its entries lie past the sub-segment (scratch
                                     // accumulator l), so that the consume loop needs no per-entry range test
 
+__device__ __forceinline__ i32 ceil64(i32 x) { return (x + 63) & ~63; }
 struct BatchRegs {                  // one A entry per lane (lanes >= cnt: empty segments)
     i32 b0, b1, b2, b3, b4;         // record boundaries
     u32 g_lo, g_hi;                 // fx_bits(a_ik * scale * v1): the count-1 sub-segment's fixed-point product
     u32 v2, v3;                     // float bits of the count-2 / count-3 values (their products are formed when the pass gets there)
     u32 da_lo, da_hi;               // a_ik * scale (double bits)
 };
+template <bool FX>
 __device__ __forceinline__ void batch_load(const ExParams &P, i32 a_b, i32 a_e, i32 batch, i32 wv, BatchRegs &r) {
     const i32 e = a_b + batch * P.wb + lane_id();
     const bool ok = lane_id() < P.wb && e < a_e;
     const i32 ec = ok ? e : a_b;                      // unconditional loads (a_b < a_e whenever a batch exists)
     const i32 k = P.Aj[ec];
-    const double da = (double)P.Ax[ec] * P.scale;
     const int4 *rp = P.rec + ((size_t)k * P.n_win + wv) * 2;
     const int4 r0 = rp[0], r1 = rp[1];
     r.b0 = ok ? r0.x : 0; r.b1 = ok ? r0.y : 0; r.b2 = ok ? r0.z : 0; r.b3 = ok ? r0.w : 0; r.b4 = ok ? r1.x : 0;
-    const u64 g = fx_bits(da * (double)__int_as_float(r1.y));
-    r.g_lo = (u32)g; r.g_hi = (u32)(g >> 32);
     r.v2 = (u32)r1.z; r.v3 = (u32)r1.w;
-    const u64 d = (u64)__double_as_longlong(da);
-    r.da_lo = (u32)d; r.da_hi = (u32)(d >> 32);
+    if (FX) {                                         // integer arithmetic: c_ik * W_k, the addend of a count-1 entry of row k; the explicit
+        const u64 g = (u64)P.A16[ec] * P.W[k];        // entries multiply it by their own count (xtile_consume)
+        r.g_lo = (u32)g; r.g_hi = (u32)(g >> 32);
+        r.da_lo = r.g_lo; r.da_hi = r.g_hi;
+    } else {
+        const double da = (double)P.Ax[ec] * P.scale;
+        const u64 g = fx_bits(da * (double)__int_as_float(r1.y));
+        r.g_lo = (u32)g; r.g_hi = (u32)(g >> 32);
+        const u64 d = (u64)__double_as_longlong(da);
+        r.da_lo = (u32)d; r.da_hi = (u32)(d >> 32);
+    }
 }
 
 // wide tiles -------------------------------------------------------------------------------------------------
@@ -367,22 +380,23 @@ __device__ __forceinline__ void xtile_fetch(const ExParams &P, const BatchRegs &
     }
     c.q += UX * HHX_WAVE;
 }
-template <int PROBE, int UX>
+template <int PROBE, int UX, bool FX>
 __device__ __forceinline__ void xtile_consume(const ExLds &l, const XTile<UX> &t, i32 dummy, u64 &sink) {
-    const double da = __longlong_as_double((long long)(((u64)t.da_hi << 32) | t.da_lo));
+    const u64 ga = ((u64)t.da_hi << 32) | t.da_lo;               // FX: c_ik * W_k; else the bits of double(a_ik * scale)
+    const double da = __longlong_as_double((long long)ga);
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
         const bool ok = lane_id() + u * HHX_WAVE < t.n;
-        const u64 g = fx_bits(da * (double)__uint_as_float(t.v[u]));
+        const u64 g = FX ? ga * (u64)t.v[u] : fx_bits(da * (double)__uint_as_float(t.v[u]));     // FX: the slot holds the link count c_kj
         if (PROBE == 1) sink += ok ? g + t.j[u] : 0;
         else atomicAdd((unsigned long long *)&l.acc[ok ? (i32)t.j[u] : dummy], (unsigned long long)g);
     }
 }
-template <int PROBE, int UX, int G>
+template <int PROBE, int UX, int G, bool FX>
 __device__ __forceinline__ void pass_explicit(const ExParams &P, const ExLds &l, const BatchRegs &r, i32 cnt, i32 dummy, u64 &sink) {
     XCursor c = {-1, 0, 0, 0u, 0u};
     auto fetch = [&](XTile<UX> &t) { xtile_fetch<UX>(P, r, cnt, c, t); };
-    auto consume = [&](const XTile<UX> &t) { xtile_consume<PROBE, UX>(l, t, dummy, sink); };
+    auto consume = [&](const XTile<UX> &t) { xtile_consume<PROBE, UX, FX>(l, t, dummy, sink); };
     for (;;) {
         XTile<UX> t[G];
         group_fetch<0, G>(t, fetch);
@@ -505,8 +519,9 @@ __device__ __forceinline__ i32 bitmap_prefix_total(const ExLds &l, i32 W) {
 // ---- window epilogue: slots [0, wlen) hold the accumulators of columns col_of(slot) (ascending).
 // Turns them into p = x^r (stored back as float bits, -1 = absent), returns the window sum.
 // FROM_X: the slot's low word already holds x as float32 bits (k_dense_epilogue: the expanded row comes back from HBM)
+// row_div != 0: the integer arithmetic of the link matrix — the slot holds acc (or, FROM_X, y = float(acc * 2^-s)) and x = float(y / d_i)
 template <bool COMPACT, bool FROM_X = false>
-__device__ __forceinline__ double window_power_sum(const ExParams &P, const ExLds &l, i32 wlen, i32 *nnz_local) {
+__device__ __forceinline__ double window_power_sum(const ExParams &P, const ExLds &l, i32 wlen, i32 *nnz_local, double row_div = 0.0) {
     const int tid = threadIdx.x;
     const i32 per = (wlen + EX_T - 1) / EX_T;
     const i32 s0 = min(wlen, tid * per), s1 = min(wlen, s0 + per);
@@ -516,7 +531,11 @@ __device__ __forceinline__ double window_power_sum(const ExParams &P, const ExLd
         const u64 ai = l.acc[t];                          // exact: the sum is below 2^53
         float p = -1.0f;
         if (COMPACT || ai != 0) {
-            const float x = FROM_X ? __uint_as_float((u32)ai) : (float)((double)(long long)ai * 0x1p-52 * P.inv_scale);
+            float x;
+            if (row_div != 0.0) {
+                const float y = FROM_X ? __uint_as_float((u32)ai) : (float)((double)(long long)ai * P.fx_inv);
+                x = (float)((double)y / row_div);
+            } else x = FROM_X ? __uint_as_float((u32)ai) : (float)((double)(long long)ai * 0x1p-52 * P.inv_scale);
             p = P.raw ? x : ex_inflate(x, P.r, P.square);
             s += (double)p;
             ++nz;
@@ -682,18 +701,19 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
 // UX / RX: entries per lane of an explicit tile and explicit tiles per group; RW: wide tiles per group.  Measured at
 // n = 100k, iteration 0 (tools/expand_probe.py): groups of 3 wide / 8 explicit tiles 590 ms, 3 / 5 597, 2 / 3 636; 512-thread
 // workgroups with twice the group sizes 806 ms — the sixteen waves per CU, not the depth of a wave's group, hide the latency.
-template <int PROBE, int UX, int RX, int RW, int T = EX_T_WIN>
+template <int PROBE, int UX, int RX, int RW, bool FX = false, int T = EX_T_WIN>
 __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 wv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ExLds l = win_carve(smem, cap);
     const int tid = threadIdx.x;
     i64 nnzc = 0, n_uni = 0;                    // n_uni: products streamed as 16-bit columns only (cursors[7])
+    i64 n_prod = 0, n_a = 0;                    // products walked / A entries staged by this launch (cursors[8], [9])
     u64 sink = 0;
     const i32 n_win = P.n_win;
     const i32 c0 = wv * cap, c1 = min(P.n_cols, c0 + cap), wlen = c1 - c0;
     const i32 dummy = cap + lane_id();
     for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
-        const i32 row = rows[li];
+        const i32 row = rows ? rows[li] : li;
         const i32 a_b = P.Ap[row], a_e = P.Ap[row + 1];
         const i32 n_batches = (a_e - a_b + P.wb - 1) / P.wb;
         if (tid == 0) l.ctr[0] = 0;
@@ -704,18 +724,20 @@ __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__re
         if (lane_id() == 0) batch = atomicAdd(&l.ctr[0], 1);
         batch = __builtin_amdgcn_readfirstlane(batch);
         BatchRegs nxt;
-        if (batch < n_batches) batch_load(P, a_b, a_e, batch, wv, nxt);
+        if (batch < n_batches) batch_load<FX>(P, a_b, a_e, batch, wv, nxt);
         while (batch < n_batches) {
             const BatchRegs cur = nxt;
             const i32 cnt = min(P.wb, a_e - (a_b + batch * P.wb));
             i32 nb = 0;
             if (lane_id() == 0) nb = atomicAdd(&l.ctr[0], 1);
             nb = __builtin_amdgcn_readfirstlane(nb);
-            if (nb < n_batches) batch_load(P, a_b, a_e, nb, wv, nxt);
+            if (nb < n_batches) batch_load<FX>(P, a_b, a_e, nb, wv, nxt);
             n_uni += cur.b3 - cur.b0;
+            n_prod += (cur.b3 - cur.b0) + max(0, cur.b4 - ceil64(cur.b3));
+            n_a += lane_id() == 0 ? cnt : 0;
             if (P.narrow_classes >= 0) pass_wide<PROBE, RW>(P, l, cur, cnt, dummy, sink);      // -1: a general operand, every segment is explicit
-            if (P.narrow_classes > 0) pass_narrow<PROBE, 2, 8>(P, l, cur, cnt, dummy, sink);
-            pass_explicit<PROBE, UX, RX>(P, l, cur, cnt, dummy, sink);
+            if (!FX && P.narrow_classes > 0) pass_narrow<PROBE, 2, 8>(P, l, cur, cnt, dummy, sink);
+            pass_explicit<PROBE, UX, RX, FX>(P, l, cur, cnt, dummy, sink);
             batch = nb;
         }
         __syncthreads();
@@ -723,14 +745,16 @@ __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__re
             float *dst = P.dense + (size_t)row * (size_t)P.dense_ld + c0;
             for (i32 t = tid; t < wlen; t += EX_T) {
                 const u64 ai = l.acc[t];
-                dst[t] = (float)((double)(long long)ai * 0x1p-52 * P.inv_scale);      // the x of window_power_sum, bit for bit
-                nnzc += ai != 0;
+                // float arithmetic: the x of window_power_sum, bit for bit.  Integer arithmetic: y = float(S_ij), symmetric — the
+                // division by d_i is the epilogue's (k_dense_epilogue)
+                dst[t] = FX ? (float)((double)(long long)ai * P.fx_inv) : (float)((double)(long long)ai * 0x1p-52 * P.inv_scale);
+                nnzc += ai != 0 ? (P.sym && row / cap != wv ? 2 : 1) : 0;       // symmetric mode: an off-diagonal block stands for its mirror image too
             }
             __syncthreads();
             continue;
         }
         i32 nz;
-        const double sw = window_power_sum<false>(P, l, wlen, &nz);
+        const double sw = window_power_sum<false>(P, l, wlen, &nz, FX ? P.row_div[row] : 0.0);
         nnzc += nz;
         const double s_run = (wv == 0 ? 0.0 : P.s_run[row]) + sw;        // windows are launched in order
         window_emit_candidates<false>(P, l, wlen, c0, 0, s_run, &P.g_win_off[(size_t)row * n_win + wv],
@@ -742,6 +766,10 @@ __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__re
     if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
     n_uni = wave_sum_i64(n_uni);
     if (lane_id() == 0 && n_uni) atomicAdd(&P.cursors[7], (unsigned long long)n_uni);
+    n_prod = wave_sum_i64(n_prod);
+    if (lane_id() == 0 && n_prod) atomicAdd(&P.cursors[8], (unsigned long long)n_prod);
+    n_a = wave_sum_i64(n_a);
+    if (lane_id() == 0 && n_a) atomicAdd(&P.cursors[9], (unsigned long long)n_a);
     if (PROBE == 1 && sink == 0x123456789abcdefull) l.acc[0] = sink;
 }
 
@@ -754,7 +782,6 @@ __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__re
 // fabric, profiles/r02_pmc_c3.txt).  The padding slots are never read.
 //   record (two int4): {b0, b1, b2, b3 | b4, v1, v2, v3}: count-c entries in [b(c-1), b(c)), explicit entries in
 //   [ceil64(b3), b4); v_c = float(double(c) / row_sum) is bit for bit what the normalised matrix holds for a count-c entry.
-__device__ __forceinline__ i32 ceil64(i32 x) { return (x + 63) & ~63; }
 __device__ __forceinline__ int class_of(const unsigned short *__restrict__ n16, i32 q, i32 nc) {
     if (!n16) return 3;
     const i32 c = n16[q];
@@ -862,7 +889,7 @@ template <bool BALANCE>
 __global__ __launch_bounds__(256) void k_layout_write(i32 n_rows, i32 n_win, i32 cap, i32 nc, const i32 *__restrict__ Bp, const i32 *__restrict__ Bj,
                                                       const float *__restrict__ Bx, const unsigned short *__restrict__ n16,
                                                       const double *__restrict__ row_sum, const int4 *__restrict__ cnt4, const i64 *__restrict__ off,
-                                                      unsigned short *__restrict__ oc, float *__restrict__ ox, int4 *__restrict__ rec) {
+                                                      unsigned short *__restrict__ oc, float *__restrict__ ox, int4 *__restrict__ rec, int fx) {
     __shared__ LayoutLds s_lay[BALANCE ? 4 : 1];
     LayoutLds &L = s_lay[BALANCE ? threadIdx.x / HHX_WAVE : 0];
     const int lane = lane_id();
@@ -886,7 +913,7 @@ __global__ __launch_bounds__(256) void k_layout_write(i32 n_rows, i32 n_win, i32
             const i32 q = q0 + lane;
             int cls = -1;
             i32 col = 0; float x = 0.f;
-            if (q < qe) { cls = class_of(n16, q, nc); col = Bj[q]; x = Bx[q]; }
+            if (q < qe) { cls = class_of(n16, q, nc); col = Bj[q]; x = fx ? __int_as_float((int)n16[q]) : Bx[q]; }      // fx: the link count itself
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const u64 m = __ballot(cls == c);
@@ -945,7 +972,7 @@ __global__ __launch_bounds__(EX_T_WIN) void k_dense_epilogue(ExParams P, const f
             for (i32 t = tid; t < wlen; t += EX_T) l.acc[t] = (u64)__float_as_uint(src[t]);
             __syncthreads();
             i32 nz;
-            const double sw = window_power_sum<false, true>(P, l, wlen, &nz);
+            const double sw = window_power_sum<false, true>(P, l, wlen, &nz, P.row_div ? P.row_div[row] : 0.0);
             nnzc += nz;
             s_run = (wv == 0 ? 0.0 : s_run) + sw;
             window_emit_candidates<false>(P, l, wlen, c0, 0, s_run, &P.g_win_off[(size_t)row * P.n_win + wv], &P.g_win_cnt[(size_t)row * P.n_win + wv]);
@@ -1193,6 +1220,25 @@ __global__ __launch_bounds__(HASH_T, 4) void k_expand_hash(ExParams P, const i32
     if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
 }
 
+// The symmetric pre-expansion computes the blocks (I, J >= I) of Y = float(S) only; block (J, I), J > I, is the transpose of (I, J)
+// bit for bit (S is an exact integer matrix).  One workgroup per 64 x 64 tile of the strictly lower block triangle: the source
+// tile is read row-wise (coalesced), turned in LDS and written row-wise.  cap is a multiple of 64, so a tile never straddles blocks.
+__global__ __launch_bounds__(256) void k_transpose_lower(float *__restrict__ Y, i64 ld, i32 n, i32 cap) {
+    __shared__ float tile[64][65];
+    const i32 r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;          // destination tile: rows r0.., columns c0..
+    if (r0 / cap <= c0 / cap) return;                               // on or above the block diagonal: computed, not copied
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4) {                              // source tile: rows c0.., columns r0..
+        const i32 sr = c0 + k, sc = r0 + tx;
+        tile[k][tx] = (sr < n && sc < n) ? Y[(size_t)sr * (size_t)ld + sc] : 0.0f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4) {
+        const i32 dr = r0 + k, dc = c0 + tx;
+        if (dr < n && dc < n) Y[(size_t)dr * (size_t)ld + dc] = tile[tx][k];
+    }
+}
+
 // ---- classification: product count per row, three row lists -----------------------------------------
 // A block takes 64 consecutive rows at a time: its waves count the products of one row each (coalesced),
 // then the first wave sorts the 64 rows into the class lists with ONE atomic per class and chunk (a
@@ -1366,17 +1412,34 @@ struct CodedOperand {
     int raw = 0;                        // plain product (no inflation / pruning): hhx_spgemm's fast path
     float *dense_out = nullptr;         // dense mode: n_rows x n_cols float32 block that receives the expanded rows; no CSR result
     i32 *plan_out = nullptr;            // dense mode: [cap_win, n_win] of the column-window plan, for k_dense_epilogue
+    // integer arithmetic (ExParams::W): a = rows [a_row0, a_row0 + a->n_rows) of the link matrix whose normalised form is b
+    const u64 *W = nullptr;
+    const unsigned short *a16 = nullptr;     // link counts of a's entries
+    const double *a_row_sum = nullptr;       // d_i of a's rows
+    int shift = 0;
+    int sym = 0;                        // dense mode, a == all rows: compute the blocks J >= I only, transpose the rest
 };
 
-template <int PROBE, int UX, int RX, int RW, int T = EX_T_WIN>
-static int launch_window(const ExParams &P, const i32 *rows, i32 n_list, i32 cap, size_t lds, unsigned grid) {
-    static bool attr = false;
-    if (!attr) {
-        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window<PROBE, UX, RX, RW, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+template <int PROBE, int UX, int RX, int RW, bool FX, int T = EX_T_WIN>
+static int launch_window_fx(const ExParams &P, const i32 *rows, i32 n_list, i32 cap, size_t lds, unsigned grid) {
+    static int attr_dev = -1;           // the attribute is per device: keyed on the current ordinal
+    int dev = 0;
+    HHX_HIP(hipGetDevice(&dev));
+    if (attr_dev != dev) {
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window<PROBE, UX, RX, RW, FX, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_dev = dev;
     }
-    for (i32 wv = 0; wv < P.n_win; ++wv) k_expand_window<PROBE, UX, RX, RW, T><<<grid, T, lds, g_stream>>>(P, rows, n_list, cap, wv);
+    for (i32 wv = 0; wv < P.n_win; ++wv) {
+        // symmetric mode: the rows are in identity order and launch wv takes the row blocks I <= wv (blocks J >= I of S)
+        const i32 n_w = P.sym ? (i32)std::min<i64>(n_list, (i64)(wv + 1) * cap) : n_list;
+        k_expand_window<PROBE, UX, RX, RW, FX, T><<<std::min<unsigned>(grid, (unsigned)std::max(n_w, 1)), T, lds, g_stream>>>(P, P.sym ? nullptr : rows, n_w, cap, wv);
+    }
     return 0;
+}
+template <int PROBE, int UX, int RX, int RW>
+static int launch_window(const ExParams &P, const i32 *rows, i32 n_list, i32 cap, size_t lds, unsigned grid) {
+    if (P.W) return launch_window_fx<PROBE, UX, RX, RW, true>(P, rows, n_list, cap, lds, grid);
+    return launch_window_fx<PROBE, UX, RX, RW, false>(P, rows, n_list, cap, lds, grid);
 }
 
 // the bump-allocated rows -> CSR: scan of the row counts, ordered copy
@@ -1409,10 +1472,13 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     const i32 W = (n_cols + 31) / 32;
     // ---- plans
     const bool use_cls = coded.n16 != nullptr && !coded.raw && tune_get("cls", 1) != 0;
+    const bool fx = use_cls && coded.W != nullptr;           // integer arithmetic of the link matrix: every row through the window class
+    if (coded.W && !fx) return fail("expand: the integer arithmetic needs the class stream");
+    if (coded.sym && !(dense && fx && a->n_rows == b->n_rows)) return fail("expand: the symmetric mode needs the whole link matrix in dense integer mode");
     // link counts 1..n_classes are streamed as columns only.  Measured at n = 100k (profiles/r02_expand_probe_c3.jsonl): counts 1-3
     // move 17 % fewer bytes than count 1 alone but run 20 % longer (the count-2 / count-3 sub-segments are a few dozen entries:
     // tiles of 128 that are mostly empty), so the default is 1
-    const i32 n_classes = (i32)std::min<i64>(3, std::max<i64>(1, tune_get("cls_nc", 1)));
+    const i32 n_classes = fx ? 1 : (i32)std::min<i64>(3, std::max<i64>(1, tune_get("cls_nc", 1)));
     const size_t fixed_win = win_fixed_bytes(), fixed_cmp = ex_fixed_bytes(W, MAX_WIN);
     // window class: the column window must fit LDS (8 B per column).  Measured on MI355X (n = 100k, 330M
     // entries): the fewest, widest windows win — 6 windows 1.41 s, 13 windows 1.54 s, 27 windows 2.24 s —
@@ -1441,23 +1507,25 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     }
     static const bool debug = getenv("HHX_DEBUG") != nullptr;
     const int probe = (int)tune_get("probe", 0);
+    (void)probe;
     // rows whose product count is well above the number of accumulator slots a dense sweep touches
     static const double wfac = getenv("HHX_WINDOW_FACTOR") ? atof(getenv("HHX_WINDOW_FACTOR")) : 0.5;
-    const i64 window_min = dense ? 0 : std::max<i64>(4096, (i64)((double)n_cols * wfac));
+    const bool all_window = dense || fx;
+    const i64 window_min = all_window ? 0 : std::max<i64>(4096, (i64)((double)n_cols * wfac));
     DevBuf<i32> list_w, list_c, list_t, list_h, row_cnt, indptr, g_win_cnt;
     DevBuf<i64> row_off, g_win_off, row_f;
     // hash class: rows of at most hash_max products (tune "hash_max", 0 = off); needs the bitmap next to a 64 KB table
     const size_t lds_hash = hash_lds_bytes(W);
     // off when B's rows are longer than the table can hold distinct columns anyway (iteration 0: the link matrix itself)
     const bool hash_fits = lds_hash <= 160 * 1024 && b->n_rows > 0 && b->nnz / b->n_rows <= HASH_LIMIT / 2;
-    const i64 hash_max = dense ? -1 : (hash_fits ? std::max<i64>(0, tune_get("hash_max", 4000000)) : 0);
+    const i64 hash_max = all_window ? -1 : (hash_fits ? std::max<i64>(0, tune_get("hash_max", 4000000)) : 0);
     DevBuf<int2> bjx;
     DevBuf<double> s_run;
     DevBuf<unsigned int> counts;
     DevBuf<unsigned long long> cursors;
     if (list_w.alloc((size_t)n_rows + 1) || list_c.alloc((size_t)n_rows + 1) || list_t.alloc((size_t)n_rows + 1) ||
         list_h.alloc((size_t)n_rows + 1) || row_f.alloc((size_t)n_rows + 1) || row_cnt.alloc((size_t)n_rows + 1) ||
-        indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || counts.alloc(4) || cursors.alloc(8) ||
+        indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || counts.alloc(4) || cursors.alloc(12) ||
         s_run.alloc((size_t)n_rows + 1) || g_win_off.alloc((size_t)n_rows * n_win + 1) || g_win_cnt.alloc((size_t)n_rows * n_win + 1))
         return 1;
     DevBuf<int4> rec;                   // window kernel: records + stream of the right operand, built once per call
@@ -1471,7 +1539,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     if (coded.plan_out) { coded.plan_out[0] = cap_win; coded.plan_out[1] = n_win; }
     if (coded.raw) {                    // every entry is kept: at most dense, and at most one entry per product
         HHX_HIP(hipMemsetAsync(counts.p, 0, 4 * sizeof(unsigned int), g_stream));
-        HHX_HIP(hipMemsetAsync(cursors.p, 0, 8 * sizeof(unsigned long long), g_stream));
+        HHX_HIP(hipMemsetAsync(cursors.p, 0, 12 * sizeof(unsigned long long), g_stream));
         k_classify<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 63) / 64, 4096)), 256, 0, g_stream>>>(
             n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, (i64)0, (i64)TINY_MAX, list_w.p, list_c.p, list_t.p, list_h.p, row_f.p, counts.p, cursors.p);
         HHX_LAUNCH_CHECK();
@@ -1487,9 +1555,9 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         if (cand_col.alloc((size_t)cand_cap) || cand_val.alloc((size_t)cand_cap) || out_col.alloc((size_t)pool_cap) ||
             out_val.alloc((size_t)pool_cap)) return 1;
         HHX_HIP(hipMemsetAsync(counts.p, 0, 4 * sizeof(unsigned int), g_stream));
-        HHX_HIP(hipMemsetAsync(cursors.p, 0, 8 * sizeof(unsigned long long), g_stream));
+        HHX_HIP(hipMemsetAsync(cursors.p, 0, 12 * sizeof(unsigned long long), g_stream));
         k_classify<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)n_rows + 63) / 64, 4096)), 256, 0, g_stream>>>(
-            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, hash_max, dense ? (i64)-1 : (i64)TINY_MAX, list_w.p, list_c.p, list_t.p, list_h.p, row_f.p,
+            n_rows, a->indptr.p, a->indices.p, b->indptr.p, window_min, hash_max, all_window ? (i64)-1 : (i64)TINY_MAX, list_w.p, list_c.p, list_t.p, list_h.p, row_f.p,
             counts.p, cursors.p);
         HHX_LAUNCH_CHECK();
         unsigned int hc[4];
@@ -1510,6 +1578,8 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         P.n_win = n_win;
         P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
         P.dense = coded.dense_out; P.dense_ld = n_cols;
+        P.W = fx ? coded.W : nullptr; P.A16 = coded.a16; P.row_div = coded.a_row_sum; P.fx_inv = ldexp(1.0, -coded.shift);
+        P.sym = coded.sym;
         P.Sc16 = nullptr; P.Sx = nullptr; P.rec = nullptr; P.Bjx = nullptr; P.narrow_classes = 0; P.wb = WB_MAX;
         if (hc[3]) {                                      // hash class first: it may add rows to the window / compact lists
             if (!bjx.p) {                                 // B as 8-byte (column, value) words, built once per call
@@ -1567,10 +1637,10 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 if (c16.alloc((size_t)slots + STREAM_PREFIX + 64) || cls_x.alloc((size_t)slots + STREAM_PREFIX + 64)) return 1;
                 if (use_cls && tune_get("cls_balance", 1))
                     k_layout_write<true><<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win, cap_win, n_classes, b->indptr.p, b->indices.p, b->data.p, coded.n16,
-                                                                      coded.row_sum, cnt4.p, offs.p, c16.p, cls_x.p, rec.p);
+                                                                      coded.row_sum, cnt4.p, offs.p, c16.p, cls_x.p, rec.p, fx ? 1 : 0);
                 else
                     k_layout_write<false><<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win, cap_win, n_classes, b->indptr.p, b->indices.p, b->data.p,
-                                                                       use_cls ? coded.n16 : nullptr, use_cls ? coded.row_sum : nullptr, cnt4.p, offs.p, c16.p, cls_x.p, rec.p);
+                                                                       use_cls ? coded.n16 : nullptr, use_cls ? coded.row_sum : nullptr, cnt4.p, offs.p, c16.p, cls_x.p, rec.p, fx ? 1 : 0);
                 HHX_LAUNCH_CHECK();
                 HHX_HIP(hipStreamSynchronize(g_stream));         // cnt4 / sizes / offs die here
             }
@@ -1588,15 +1658,24 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             tile_u = ux;
             {
                 KTimer kt(long_segments ? "expand_window" : "expand_window_short", n_win);
+#ifdef HHX_PROBE_BUILD             // measurement build only (-DHHX_PROBE_BUILD): the atomics switched off, results are garbage
                 if (probe == 1 && ux >= 4) HHX_TRY((launch_window<1, 8, 3, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else if (probe == 1) HHX_TRY((launch_window<1, 3, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
-                else if (ux >= 8) HHX_TRY((launch_window<0, 8, 3, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
+                else
+#endif
+                if (ux >= 8) HHX_TRY((launch_window<0, 8, 3, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else if (ux == 4) HHX_TRY((launch_window<0, 4, 4, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else if (ux == 3) HHX_TRY((launch_window<0, 3, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else if (ux == 2) HHX_TRY((launch_window<0, 2, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else HHX_TRY((launch_window<0, 1, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
             }
             HHX_LAUNCH_CHECK();
+            if (coded.sym && n_win > 1) {
+                KTimer kt("dense_transpose");
+                const unsigned tiles = (unsigned)((n_cols + 63) / 64);
+                k_transpose_lower<<<dim3(tiles, tiles), 256, 0, g_stream>>>(coded.dense_out, (i64)n_cols, n_cols, cap_win);
+                HHX_LAUNCH_CHECK();
+            }
             if (!dense) {
                 KTimer kt("expand_finalize");
                 k_expand_window_finalize<<<std::min<unsigned>(hc[0], 256 * 8), EX_T_CMP, ex_fixed_bytes(0, 0), g_stream>>>(P, list_w.p, (i32)hc[0]);
@@ -1614,7 +1693,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             k_expand_compact<<<std::min<unsigned>(hc[1], 256 * per_cu * 4), EX_T_CMP, lds_cmp, g_stream>>>(P, list_c.p, (i32)hc[1], cap_cmp, W);
         }
         HHX_LAUNCH_CHECK();
-        unsigned long long cur[8];
+        unsigned long long cur[12];
         HHX_HIP(hipMemcpyAsync(cur, cursors.p, sizeof cur, hipMemcpyDeviceToHost, g_stream));
         HHX_HIP(hipStreamSynchronize(g_stream));
         if (debug)
@@ -1624,9 +1703,9 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count(), cur[2] ? "  OVERFLOW -> retry" : "");
         if (dense) {                                   // the rows are in coded.dense_out; nothing to pack
             if (hc[0] != (unsigned)n_rows) return fail("expand (dense): %u of %d rows took the window class", hc[0], n_rows);
-            if (prof_enabled()) {
-                prof_count("expand_window_products", (i64)cur[5]);
-                prof_count("expand_window_a_reads", (i64)cur[6] * n_win);
+            if (prof_enabled()) {                      // what the launches actually walked (the symmetric mode skips the blocks J < I)
+                prof_count("expand_window_products", (i64)cur[8]);
+                prof_count("expand_window_a_reads", (i64)cur[9]);
                 if (use_cls) prof_count("expand_window_uniform_products", (i64)cur[7]);
             }
             if (n_products) *n_products = (i64)cur[4];
@@ -1640,8 +1719,8 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         }
         if (prof_enabled() && hc[0]) {
             const bool longseg = long_segments;
-            prof_count(longseg ? "expand_window_products" : "expand_window_short_products", (i64)cur[5]);
-            prof_count(longseg ? "expand_window_a_reads" : "expand_window_short_a_reads", (i64)cur[6] * n_win);
+            prof_count(longseg ? "expand_window_products" : "expand_window_short_products", (i64)cur[8]);
+            prof_count(longseg ? "expand_window_a_reads" : "expand_window_short_a_reads", (i64)cur[9]);
             if (use_cls) prof_count("expand_window_uniform_products", (i64)cur[7]);
         }
         if (n_products) *n_products = (i64)cur[4];
@@ -1656,14 +1735,24 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
 // (nearly) dense — n^2 entries at n = 100k — so here a ROW BLOCK of it is stored as plain float32 (4 B per entry instead of the 8 of a
 // CSR entry, no index traffic) by the window kernel's dense mode, and iteration 0 of every inflation is the epilogue alone over that
 // block (k_dense_epilogue + k_expand_window_finalize): the 1.15e12 products of the expansion are walked once for the whole sweep.
-int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift, hhx_dense **out,
-                          i64 *n_products, i64 *nnz_expanded) {
+int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const hhx_links_operand *lk, int fx_shift, hhx_dense **out, i64 *n_products,
+                          i64 *nnz_expanded) {
     if (!a || !b || !out) return fail("null pointer");
     hhx_dense *d = new hhx_dense();
     d->n_rows = a->n_rows; d->n_cols = b->n_cols;
     if (d->x.alloc((size_t)a->n_rows * (size_t)b->n_cols + 1)) { delete d; return 1; }
     CodedOperand c;
-    c.n16 = n16; c.row_sum = row_sum; c.dense_out = d->x.p;
+    c.dense_out = d->x.p;
+    if (lk) {
+        c.n16 = lk->n16; c.row_sum = lk->row_sum;
+        if (lk->W) {                                   // integer arithmetic: the block holds y = float(S); its epilogue divides by d_i
+            c.W = lk->W; c.shift = lk->shift; c.a16 = lk->n16 + lk->a_off; c.a_row_sum = lk->row_sum + lk->a_row0;
+            c.sym = lk->sym;
+            if (d->row_div.alloc((size_t)a->n_rows + 1)) { delete d; return 1; }
+            if (a->n_rows) HHX_HIP(hipMemcpyAsync(d->row_div.p, c.a_row_sum, sizeof(double) * (size_t)a->n_rows, hipMemcpyDeviceToDevice, g_stream));
+            d->integer = true;
+        }
+    }
     i32 plan[2] = {0, 0};
     c.plan_out = plan;
     const int rc = hhx_expand_impl(a, b, c, fx_shift, 2.0, 0.0, nullptr, n_products, nnz_expanded);
@@ -1681,7 +1770,7 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
     DevBuf<i64> row_off, g_win_off;
     DevBuf<double> s_run;
     DevBuf<unsigned long long> cursors;
-    if (row_cnt.alloc((size_t)n_rows + 1) || indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || cursors.alloc(8) ||
+    if (row_cnt.alloc((size_t)n_rows + 1) || indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || cursors.alloc(12) ||
         s_run.alloc((size_t)n_rows + 1) || g_win_off.alloc((size_t)n_rows * n_win + 1) || g_win_cnt.alloc((size_t)n_rows * n_win + 1)) return 1;
     static int attr_dev = -1;
     int dev = 0;
@@ -1700,7 +1789,7 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
         DevBuf<i32> cand_col, out_col;
         DevBuf<float> cand_val, out_val;
         if (cand_col.alloc((size_t)cand_cap) || cand_val.alloc((size_t)cand_cap) || out_col.alloc((size_t)pool_cap) || out_val.alloc((size_t)pool_cap)) return 1;
-        HHX_HIP(hipMemsetAsync(cursors.p, 0, 8 * sizeof(unsigned long long), g_stream));
+        HHX_HIP(hipMemsetAsync(cursors.p, 0, 12 * sizeof(unsigned long long), g_stream));
         ExParams P;
         memset(&P, 0, sizeof P);
         P.n_rows = n_rows; P.n_cols = n_cols;
@@ -1710,6 +1799,7 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
         P.out_col = out_col.p; P.out_val = out_val.p; P.out_cap = pool_cap;
         P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
         P.n_win = n_win; P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
+        P.row_div = d->integer ? d->row_div.p : nullptr;
         if (n_rows) {
             {
                 KTimer kt("dense_epilogue");
@@ -1766,11 +1856,13 @@ extern "C" int hhx_expand_inflate_prune(const hhx_csr *a, const hhx_csr *b, int 
     return hhx_expand_impl(a, b, CodedOperand(), fx_shift, inflation, pruning, out, n_products, nnz_expanded);
 }
 
-// b is the L1-normalised link matrix whose entry p equals float(n16[p] / row_sum[row]) (checked by the caller)
-int hhx_expand_class_stream(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
+// b is the L1-normalised link matrix whose entry p equals float(n16[p] / row_sum[row]) (checked by the caller); with lk->W the
+// products are formed in the integer arithmetic of the link matrix (a = rows [a_row0, ...) of it)
+int hhx_expand_class_stream(const hhx_csr *a, const hhx_csr *b, const hhx_links_operand *lk, int fx_shift,
                      double inflation, double pruning, hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
     CodedOperand c;
-    c.n16 = n16; c.row_sum = row_sum;
+    c.n16 = lk->n16; c.row_sum = lk->row_sum;
+    if (lk->W) { c.W = lk->W; c.shift = lk->shift; c.a16 = lk->n16 + lk->a_off; c.a_row_sum = lk->row_sum + lk->a_row0; }
     return hhx_expand_impl(a, b, c, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
 }
 

@@ -10,11 +10,11 @@
 using namespace hhx;
 
 int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
-int hhx_expand_class_stream(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift,
+int hhx_expand_class_stream(const hhx_csr *a, const hhx_csr *b, const hhx_links_operand *lk, int fx_shift,
                      double inflation, double pruning, hhx_csr **out, i64 *n_products, i64 *nnz_expanded);
-
-int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const unsigned short *n16, const double *row_sum, int fx_shift, hhx_dense **out,
-                          i64 *n_products, i64 *nnz_expanded);
+int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const hhx_links_operand *lk, int fx_shift, hhx_dense **out, i64 *n_products,
+                          i64 *nnz_expanded);
+namespace hhx { i64 pool_cached_bytes(); }
 
 namespace {
 
@@ -203,6 +203,39 @@ __global__ __launch_bounds__(256) void k_link_counts(i64 nnz, const float *__res
     }
     if (__any(bad) && lane_id() == 0) atomicExch(flags, 1u);
 }
+// Symmetry of the link matrix (dict_to_matrix mirrors every key, :350-356; a caller's own matrix need not be): the multiset of
+// (row, column, count) must equal the multiset of (column, row, count).  Two independent 64-bit mixes of every entry are summed in
+// both orientations; equal sums in both mixes <=> symmetric, up to a 2^-128 collision.  One streaming pass.
+__device__ __forceinline__ u64 mix64(u64 x, u64 salt) {
+    x += salt;
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void k_symmetry_sums(i32 n_rows, const i32 *__restrict__ indptr, const i32 *__restrict__ indices,
+                                                       const unsigned short *__restrict__ n16, unsigned long long *__restrict__ sums) {
+    const int lane = lane_id();
+    u64 s0 = 0, s1 = 0, t0 = 0, t1 = 0;
+    for (i32 row = blockIdx.x * 4 + threadIdx.x / HHX_WAVE; row < n_rows; row += gridDim.x * 4)
+        for (i32 p = indptr[row] + lane; p < indptr[row + 1]; p += HHX_WAVE) {
+            const u64 j = (u64)(u32)indices[p], c = (u64)n16[p] << 48;
+            const u64 fwd = ((u64)(u32)row << 24 | j) ^ c, rev = (j << 24 | (u64)(u32)row) ^ c;     // n < 2^24 (checked by the caller)
+            s0 += mix64(fwd, 0x9e3779b97f4a7c15ull); s1 += mix64(fwd, 0xd1b54a32d192ed03ull);
+            t0 += mix64(rev, 0x9e3779b97f4a7c15ull); t1 += mix64(rev, 0xd1b54a32d192ed03ull);
+        }
+    s0 = (u64)wave_sum_i64((i64)s0); s1 = (u64)wave_sum_i64((i64)s1); t0 = (u64)wave_sum_i64((i64)t0); t1 = (u64)wave_sum_i64((i64)t1);
+    if (lane == 0) { atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[2], t0); atomicAdd(&sums[3], t1); }
+}
+// W_k = rint(2^shift / d_k) and the largest row sum (as the bits of a non-negative double: ordered like integers)
+__global__ __launch_bounds__(256) void k_max_row_sum(i32 n, const double *__restrict__ d, unsigned long long *__restrict__ max_bits) {
+    unsigned long long m = 0;
+    for (i32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, (unsigned long long)__double_as_longlong(d[i]));
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned long long)__shfl_down((long long)m, o, HHX_WAVE));
+    if (lane_id() == 0) atomicMax(max_bits, m);
+}
+__global__ __launch_bounds__(256) void k_fx_weights(i32 n, const double *__restrict__ d, double two_s, u64 *__restrict__ W) {
+    for (i32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) W[i] = (u64)rint(two_s / d[i]);
+}
 __global__ __launch_bounds__(256) void k_any_zero(i32 n, const double *__restrict__ v, unsigned int *flags) {
     bool bad = false;
     for (i32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bad |= !(v[i] > 0.0);
@@ -304,9 +337,11 @@ extern "C" int hhx_convergence_stat(const hhx_csr *m, const hhx_csr *last, float
 // mcl() driver.  pre_expanded != 0: `m` is the pre-expanded matrix (the reference seam, :2026);
 // pre_expanded == 0: `m` is the L1-normalised link matrix and the pre-expansion of :2146-2147 is
 // fused into iteration 0.  Every expansion that feeds an inflate+prune goes through the fused kernel.
+struct NormalisedLinks;
+static int expand_links_iteration0(const hhx_csr *norm, const NormalisedLinks &nl, double inflation, double pruning, hhx_csr **out, i64 *n_products,
+                                   i64 *nnz_expanded);
 static int mcl_impl(const hhx_csr *m, int pre_expanded, int expansion, double inflation, int max_iter, double pruning,
-                    hhx_csr **out, int *n_iter, int *converged, i64 *stats, const unsigned short *n16 = nullptr,
-                    const double *row_sum = nullptr, int first_it = 0) {
+                    hhx_csr **out, int *n_iter, int *converged, i64 *stats, const NormalisedLinks *nl = nullptr, int first_it = 0) {
     if (!m || !out || !n_iter || !converged) return fail("null pointer");
     if (m->n_rows != m->n_cols) return fail("mcl needs a square matrix");
     if (expansion < 1) return fail("expansion must be >= 1");
@@ -338,8 +373,8 @@ static int mcl_impl(const hhx_csr *m, int pre_expanded, int expansion, double in
             }
             if (!rc) {
                 i64 f = 0;
-                if (it == 0 && n16)   // iteration 0 right operand = the normalised link matrix itself: 4-byte count-coded stream
-                    rc = hhx_expand_class_stream(run, src, n16, row_sum, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);
+                if (it == 0 && nl && run == src)   // iteration 0, expansion 2: both operands are the link matrix itself
+                    rc = expand_links_iteration0(src, *nl, inflation, pruning, &p, &f, &st_c);
                 else
                     rc = hhx_expand_inflate_prune(run, src, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);   // :2030-2042
                 st_f += f;
@@ -380,7 +415,7 @@ extern "C" int hhx_mcl(const hhx_csr *pre, int expansion, double inflation, int 
 extern "C" int hhx_mcl_resume(const hhx_csr *m, int done, int expansion, double inflation, int max_iter, double pruning,
                               hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
     if (done < 1) return fail("hhx_mcl_resume: done must be >= 1");
-    return mcl_impl(m, 1, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats, nullptr, nullptr, done);
+    return mcl_impl(m, 1, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats, nullptr, done);
 }
 
 extern "C" int hhx_mcl_normalized(const hhx_csr *norm, int expansion, double inflation, int max_iter, double pruning,
@@ -391,12 +426,22 @@ extern "C" int hhx_mcl_normalized(const hhx_csr *norm, int expansion, double inf
 // The raw link matrix normalised (:2144) together with what the class stream needs: the L1 row sums the
 // normalisation divided by and the 16-bit link counts.  *usable = 0 if some value is not an integer in [0, 65535] or
 // some row sum is zero (then only the normalised matrix is meaningful).
+// integer: the matrix is symmetric and its row sums stay below 2^18 — iteration 0 can run in the integer arithmetic of
+// DESIGN.md 4.1 (W, shift), whose accumulators are an exactly symmetric matrix.
 struct NormalisedLinks {
     hhx_csr *norm = nullptr;
     DevBuf<double> row_sum;
     DevBuf<unsigned short> n16;
-    bool usable = false;
+    DevBuf<u64> W;
+    int shift = 0;
+    bool usable = false, integer = false;
     ~NormalisedLinks() { if (norm) hhx_csr_free(norm); }
+    hhx_links_operand operand(i32 a_row0 = 0, i64 a_off = 0, int sym = 0) const {
+        hhx_links_operand lk;
+        lk.n16 = n16.p; lk.row_sum = row_sum.p; lk.W = integer ? W.p : nullptr; lk.shift = shift; lk.a_row0 = a_row0; lk.a_off = a_off;
+        lk.sym = integer ? sym : 0;
+        return lk;
+    }
 };
 static int normalise_links(const hhx_csr *links, NormalisedLinks *o) {
     HHX_TRY(hhx_csr_copy(links, &o->norm));
@@ -415,29 +460,88 @@ static int normalise_links(const hhx_csr *links, NormalisedLinks *o) {
     HHX_HIP(hipMemcpyAsync(&bad, flags.p, sizeof bad, hipMemcpyDeviceToHost, g_stream));
     HHX_HIP(hipStreamSynchronize(g_stream));
     o->usable = !bad;
+    o->integer = false;
+    if (!o->usable || links->n_rows != links->n_cols || links->n_rows >= (1 << 24) || tune_get("links_integer", 1) == 0) return 0;
+    // the integer arithmetic applies to a symmetric matrix whose weights keep 24 bits: shift = 61 - lg, lg = ceil(log2(d_max)) <= 18
+    DevBuf<unsigned long long> red;
+    if (red.alloc(5) || o->W.alloc((size_t)links->n_rows + 1)) return 1;
+    HHX_HIP(hipMemsetAsync(red.p, 0, 5 * sizeof(unsigned long long), g_stream));
+    k_symmetry_sums<<<row_grid(links->n_rows), ROW_T, 0, g_stream>>>(links->n_rows, links->indptr.p, links->indices.p, o->n16.p, red.p);
+    k_max_row_sum<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)links->n_rows + 255) / 256, 1024)), 256, 0, g_stream>>>(links->n_rows, o->row_sum.p, red.p + 4);
+    HHX_LAUNCH_CHECK();
+    unsigned long long h[5];
+    HHX_HIP(hipMemcpyAsync(h, red.p, sizeof h, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    if (h[0] != h[2] || h[1] != h[3]) return 0;                 // not symmetric
+    double d_max;
+    memcpy(&d_max, &h[4], sizeof d_max);
+    int lg = 0;
+    while (ldexp(1.0, lg) < d_max) ++lg;
+    if (61 - 2 * lg < 24) return 0;                              // a weight would keep fewer than 24 bits
+    o->shift = 61 - lg;
+    k_fx_weights<<<(unsigned)std::max<i64>(1, std::min<i64>(((i64)links->n_rows + 255) / 256, 1024)), 256, 0, g_stream>>>(
+        links->n_rows, o->row_sum.p, ldexp(1.0, o->shift), o->W.p);
+    HHX_LAUNCH_CHECK();
+    o->integer = true;
     return 0;
+}
+
+// Iteration 0 of mcl() on the link matrix itself (expansion 2).  In the integer arithmetic S = L D^-1 L is exactly symmetric: when
+// n^2 floats fit the device the upper block triangle of Y = float(S) is computed (60 % of the products at 5 column windows), the
+// rest transposed, and the rows are finished by the dense epilogue; otherwise every row walks all its products into the fused
+// epilogue.  Same bits either way.
+static int expand_links_iteration0(const hhx_csr *norm, const NormalisedLinks &nl, double inflation, double pruning, hhx_csr **out, i64 *n_products,
+                                   i64 *nnz_expanded) {
+    if (!nl.usable) return hhx_expand_inflate_prune(norm, norm, HHX_MCL_FX_SHIFT, inflation, pruning, out, n_products, nnz_expanded);
+    if (nl.integer && tune_get("links_sym", 1) != 0) {
+        size_t free_b = 0, total_b = 0;
+        HHX_HIP(hipMemGetInfo(&free_b, &total_b));
+        const double need = 4.0 * (double)norm->n_rows * (double)norm->n_cols;
+        if (need * 2.0 + 4e9 < (double)free_b + (double)pool_cached_bytes()) {       // the block + room for the operand stream and the pools
+            const hhx_links_operand lk = nl.operand(0, 0, 1);
+            hhx_dense *d = nullptr;
+            HHX_TRY(hhx_expand_dense_impl(norm, norm, &lk, HHX_MCL_FX_SHIFT, &d, n_products, nnz_expanded));
+            const int rc = hhx_dense_inflate_prune(d, inflation, pruning, out);
+            hhx_dense_free(d);
+            return rc;
+        }
+    }
+    const hhx_links_operand lk = nl.operand();
+    return hhx_expand_class_stream(norm, norm, &lk, HHX_MCL_FX_SHIFT, inflation, pruning, out, n_products, nnz_expanded);
 }
 
 // run_mcl_clustering :2144-2158 for one inflation straight from the RAW link matrix of dict_to_matrix
 // (:362-368): L1 normalisation (:2144), pre-expansion (:2146-2147) fused into iteration 0, mcl().  When the
 // matrix holds integer link counts <= 65535 (always, unless --normalize_by_nlinks / GFA weights were applied)
-// iteration 0 streams its right operand as the class stream (hhx_expand.hip).
+// iteration 0 streams its right operand as the class stream (hhx_expand.hip), in integer arithmetic when it is symmetric.
 extern "C" int hhx_mcl_links(const hhx_csr *links, int expansion, double inflation, int max_iter, double pruning,
                              hhx_csr **out, int *n_iter, int *converged, i64 *stats) {
     if (!links || !out) return fail("null pointer");
     NormalisedLinks nl;
     HHX_TRY(normalise_links(links, &nl));
-    return mcl_impl(nl.norm, 0, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats, nl.usable ? nl.n16.p : nullptr,
-                    nl.usable ? nl.row_sum.p : nullptr);
+    return mcl_impl(nl.norm, 0, expansion, inflation, max_iter, pruning, out, n_iter, converged, stats, &nl);
 }
 
-extern "C" int hhx_expand_links(const hhx_csr *a, const hhx_csr *links, int fx_shift, double inflation, double pruning,
+// iteration 0 for the rows [r0, r1) of the link matrix (the row block of one rank): the bits of hhx_mcl_links' first iteration
+extern "C" int hhx_expand_links(const hhx_csr *links, i32 r0, i32 r1, int fx_shift, double inflation, double pruning,
                                 hhx_csr **out, i64 *n_products, i64 *nnz_expanded) {
-    if (!a || !links || !out) return fail("null pointer");
+    if (!links || !out) return fail("null pointer");
+    if (r0 < 0 || r1 < r0 || r1 > links->n_rows) return fail("row block [%d,%d) out of range", r0, r1);
     NormalisedLinks nl;
     HHX_TRY(normalise_links(links, &nl));
-    if (!nl.usable) return hhx_expand_inflate_prune(a, nl.norm, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
-    return hhx_expand_class_stream(a, nl.norm, nl.n16.p, nl.row_sum.p, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
+    hhx_csr *a = nullptr;
+    HHX_TRY(hhx_csr_row_block(nl.norm, r0, r1, &a));
+    int rc;
+    if (!nl.usable) rc = hhx_expand_inflate_prune(a, nl.norm, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
+    else {
+        i32 off = 0;
+        HHX_HIP(hipMemcpyAsync(&off, links->indptr.p + r0, sizeof off, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+        const hhx_links_operand lk = nl.operand(r0, off);
+        rc = hhx_expand_class_stream(a, nl.norm, &lk, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
+    }
+    hhx_csr_free(a);
+    return rc;
 }
 
 // run_mcl_clustering :2144-2147 for rows [r0, r1) of the link matrix, kept for the whole inflation sweep: L1 normalisation, then the
@@ -451,7 +555,12 @@ extern "C" int hhx_expand_links_dense(const hhx_csr *links, i32 r0, i32 r1, int 
     HHX_TRY(normalise_links(links, &nl));
     hhx_csr *a = nullptr;
     HHX_TRY(hhx_csr_row_block(nl.norm, r0, r1, &a));
-    const int rc = hhx_expand_dense_impl(a, nl.norm, nl.usable ? nl.n16.p : nullptr, nl.usable ? nl.row_sum.p : nullptr, fx_shift, out, n_products, nnz_expanded);
+    i32 off = 0;
+    HHX_HIP(hipMemcpyAsync(&off, links->indptr.p + r0, sizeof off, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    const bool whole = r0 == 0 && r1 == links->n_rows;
+    const hhx_links_operand lk = nl.operand(r0, off, whole && tune_get("links_sym", 1) != 0 ? 1 : 0);       // all rows: the symmetric half + transposition
+    const int rc = hhx_expand_dense_impl(a, nl.norm, nl.usable ? &lk : nullptr, fx_shift, out, n_products, nnz_expanded);
     hhx_csr_free(a);
     return rc;
 }

@@ -66,6 +66,13 @@ void pool_free(void *p) {
     g_live.erase(it);
 }
 
+i64 pool_cached_bytes() {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    i64 b = 0;
+    for (auto &kv : g_free) b += (i64)kv.first;
+    return b;
+}
+
 void pool_trim() {
     std::vector<void *> blocks;
     {

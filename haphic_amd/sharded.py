@@ -83,9 +83,9 @@ class HipEngine:
     def expand_inflate_prune(self, a, b, inflation, pruning):
         return _lib.expand_inflate_prune(a, b, inflation, pruning, fx_shift=52)
 
-    def expand_links(self, a, links, inflation, pruning):
-        """iteration 0: a = this rank's rows of the normalised link matrix, links = the whole RAW link matrix"""
-        return _lib.expand_links(a, links, inflation, pruning, fx_shift=52)
+    def expand_links(self, links, r0, r1, inflation, pruning):
+        """iteration 0 for this rank's rows [r0, r1) of the whole RAW link matrix `links`"""
+        return _lib.expand_links(links, r0, r1, inflation, pruning, fx_shift=52)
 
     def row_products(self, a, b):
         return _lib.row_products(a, b)
@@ -381,7 +381,7 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
             run = nxt
         if expansion > 1:
             if links_full is not None:
-                p, f, st_c = engine.expand_links(run, links_full, inflation, pruning)          # iteration 0, class stream
+                p, f, st_c = engine.expand_links(links_full, r0, r1, inflation, pruning)       # iteration 0, class stream
             else:
                 p, f, st_c = engine.expand_inflate_prune(run, cur_full, inflation, pruning)   # :2030-2042 fused
             st_f += f

@@ -153,20 +153,24 @@ int hhx_dense_free(hhx_dense *d);
 
 /* run_mcl_clustering :2144-2158 for one inflation straight from the RAW link matrix that dict_to_matrix
  * returns (:362-368): the L1 normalisation (:2144), the pre-expansion (:2146-2147, fused into iteration 0) and
- * mcl().  Same results as hhx_normalize_l1 + hhx_mcl_normalized; when the matrix holds integer link counts
- * <= 65535 (always, unless --normalize_by_nlinks / GFA weights were applied) iteration 0 streams its right operand
- * as the CLASS STREAM: the count-1 entries of every (row, column window) segment — 75 % of a Hi-C link matrix —
- * share the value float(1 / rowsum) and go as 16-bit columns alone, 2 B per product instead of 6; bit-identical. */
+ * mcl().  When the matrix holds integer link counts <= 65535 (always, unless --normalize_by_nlinks / GFA weights
+ * were applied) iteration 0 streams its right operand as the CLASS STREAM: the count-1 entries of every (row, column
+ * window) segment — 75 % of a Hi-C link matrix — go as 16-bit columns alone, 2 B per product instead of 6.
+ * When it is also SYMMETRIC with row sums below 2^18 (every matrix of dict_to_matrix at the sizes of BASELINE.json) the
+ * pre-expansion runs in INTEGER arithmetic, (M^2)_ij = S_ij / d_i with S = L D^-1 L evaluated exactly (DESIGN.md
+ * 4.1; within 3e-7 of the float32-normalised product, far inside the float32 accumulation noise of the
+ * reference's own SpGEMM): S is symmetric bit for bit, so only its upper block triangle is computed and the rest is
+ * transposed — 60 % of the products at five column windows.  Other matrices take the float arithmetic of
+ * hhx_normalize_l1 + hhx_mcl_normalized (bit-identical to it). */
 int hhx_mcl_links(const hhx_csr *links, int expansion, double inflation, int max_iter, double pruning,
                   hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
-/* Iteration 0 of the above for ONE ROW BLOCK (multi-GPU shard): a = rows [r0, r1) of the L1-normalised
- * link matrix (hhx_normalize_l1 on the rank's block of the raw matrix: row-local), links = the WHOLE raw link matrix
- * (all-gathered).  out = prune(normalize(power(a * normalize(links), inflation))) — hhx_expand_inflate_prune(a,
- * normalize(links)) bit for bit, through the class stream when the counts allow it. */
 /* products_host[i] = sum over the entries (i, k) of a of nnz(row k of b): the cost of row i of a * b.  The multi-GPU driver
  * cuts the row blocks of the expansion at equal product counts with it (SURVEY §8e "row-block ... by balanced nnz"). */
 int hhx_row_products(const hhx_csr *a, const hhx_csr *b, int64_t *products_host);
-int hhx_expand_links(const hhx_csr *a, const hhx_csr *links, int fx_shift, double inflation, double pruning,
+/* Iteration 0 of hhx_mcl_links for ONE ROW BLOCK (multi-GPU shard): rows [r0, r1) of the result, links = the WHOLE raw
+ * link matrix (all-gathered).  Same arithmetic, hence the same bits, as the one-GPU call (a row block cannot use the symmetry:
+ * it walks all its products). */
+int hhx_expand_links(const hhx_csr *links, int32_t r0, int32_t r1, int fx_shift, double inflation, double pruning,
                      hhx_csr **out, int64_t *n_products, int64_t *nnz_expanded);
 
 /* ---------------------------------------------------------------- a12: interpret_result :2065-2095

@@ -134,6 +134,92 @@ i64 orc_spgemm(i32 n_rows, i32 n_cols, const i32 *Ap, const i32 *Aj, const float
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Pre-expansion of the link matrix, run_mcl_clustering :2144-2147, in the INTEGER specification of the HIP kernels (mode 2).
+ * L is the raw symmetric link matrix of dict_to_matrix (integer counts c, :362-368), d_i its L1 row sums (:2144), and
+ *     (M^2)_ij = sum_k (c_ik / d_i)(c_kj / d_k) = (1 / d_i) * S_ij,    S_ij = sum_k c_ik c_kj / d_k  — a SYMMETRIC matrix.
+ * The kernels evaluate S in exact integer arithmetic, so that only its upper block triangle has to be computed:
+ *     lg = ceil(log2(max_i d_i)), s = 61 - lg (applicable while s - lg >= 24, i.e. every weight keeps >= 24 bits)
+ *     W_k = rint(2^s / d_k)                          (double division, round to nearest even, as an unsigned 64-bit integer)
+ *     acc_ij = sum_k c_ik * c_kj * W_k               (exact; < 2^63 because c_kj W_k <= 2^s + c_kj / 2 and sum_k c_ik = d_i)
+ *     y_ij = float(double(acc_ij) * 2^-s)            (= S_ij to float32; symmetric bit for bit)
+ *     x_ij = float(double(y_ij) / d_i)               (the entry of the pre-expanded matrix)
+ * Against the reference's float32 product of the float32-normalised matrix this differs by the roundings of the normalised
+ * entries it never forms (<= 2^-23 relative), far inside the float32 accumulation noise of the reference's own SpGEMM.
+ * rows: the output rows wanted (NULL = all).  Two-call pattern like orc_spgemm.  Returns nnz, -2 if the specification is not
+ * applicable (row sums beyond 2^18, a zero row sum, non-integer or negative values).
+ * ---------------------------------------------------------------------------------------------- */
+int orc_links_shift(i32 n, const i32 *Lp, const float *Lx, double *d_out) {
+    double dmax = 0.0;
+    for (i32 r = 0; r < n; ++r) {
+        double s = 0.0;
+        for (i32 p = Lp[r]; p < Lp[r + 1]; ++p) {
+            if (!(Lx[p] >= 0.0f) || Lx[p] != rintf(Lx[p]) || Lx[p] > 65535.0f) return -1;
+            s += (double)Lx[p];
+        }
+        if (s == 0.0) return -1;
+        if (d_out) d_out[r] = s;
+        if (s > dmax) dmax = s;
+    }
+    int lg = 0;
+    while (ldexp(1.0, lg) < dmax) ++lg;
+    const int shift = 61 - lg;
+    return shift - lg >= 24 ? shift : -1;
+}
+
+i64 orc_expand_links(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i32 n_rows, const i32 *rows, i32 *Cp, i32 *Cj, float *Cx) {
+    double *d = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+    const int shift = orc_links_shift(n, Lp, Lx, d);
+    if (shift < 0) { free(d); return -2; }
+    uint64_t *W = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n ? n : 1));
+    for (i32 k = 0; k < n; ++k) W[k] = (uint64_t)rint(ldexp(1.0, shift) / d[k]);
+    const double inv = ldexp(1.0, -shift);
+    const int nt = orc_get_threads();
+    i64 *row_nnz = (i64 *)calloc((size_t)n_rows + 1, sizeof(i64));
+    for (int pass = 0; pass < (Cj ? 2 : 1); ++pass) {
+#pragma omp parallel num_threads(nt)
+        {
+            i32 *mark = (i32 *)malloc(sizeof(i32) * (size_t)n);
+            uint64_t *acc = (uint64_t *)calloc((size_t)n, sizeof(uint64_t));
+            i32 *cols = (i32 *)malloc(sizeof(i32) * (size_t)n);
+            for (i32 c = 0; c < n; ++c) mark[c] = -1;
+#pragma omp for schedule(dynamic, 16)
+            for (i32 t = 0; t < n_rows; ++t) {
+                const i32 i = rows ? rows[t] : t;
+                i32 cnt = 0;
+                for (i32 p = Lp[i]; p < Lp[i + 1]; ++p) {
+                    const i32 k = Lj[p];
+                    const uint64_t g = (uint64_t)Lx[p] * W[k];
+                    for (i32 q = Lp[k]; q < Lp[k + 1]; ++q) {
+                        const i32 j = Lj[q];
+                        if (mark[j] != t) { mark[j] = t; cols[cnt++] = j; acc[j] = 0; }
+                        if (pass == 1) acc[j] += g * (uint64_t)Lx[q];
+                    }
+                }
+                if (pass == 0) row_nnz[t + 1] = cnt;
+                else {
+                    const i64 base = row_nnz[t];
+                    qsort(cols, (size_t)cnt, sizeof(i32), cmp_i32);
+                    for (i32 c = 0; c < cnt; ++c) {
+                        const float y = (float)((double)acc[cols[c]] * inv);
+                        Cj[base + c] = cols[c];
+                        Cx[base + c] = (float)((double)y / d[i]);
+                    }
+                }
+                for (i32 c = 0; c < cnt; ++c) mark[cols[c]] = -1;
+            }
+            free(mark); free(acc); free(cols);
+        }
+        if (pass == 0) {
+            for (i32 t = 0; t < n_rows; ++t) row_nnz[t + 1] += row_nnz[t];
+            for (i32 t = 0; t <= n_rows; ++t) Cp[t] = (i32)row_nnz[t];
+        }
+    }
+    const i64 nnz = row_nnz[n_rows];
+    free(row_nnz); free(W); free(d);
+    return nnz;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * prune(), :1987-2014.  Input = inflated+normalised matrix (sorted rows).  Keep entries >= the
  * float32-rounded threshold (:1994 sparse branch / :2005 dense branch compare float32 data against
  * the python float under numpy scalar promotion -> float32 compare), restore each row's maximum from

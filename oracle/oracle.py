@@ -42,6 +42,10 @@ def lib():
         L.orc_spgemm.argtypes = [C.c_int32, C.c_int32, _i32p, _i32p, _f32p, _i32p, _i32p, _f32p, _i32p,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_spgemm.restype = C.c_int64
+        L.orc_expand_links.argtypes = [C.c_int32, _i32p, _i32p, _f32p, C.c_int32, C.c_void_p, _i32p, C.c_void_p, C.c_void_p]
+        L.orc_expand_links.restype = C.c_int64
+        L.orc_links_shift.argtypes = [C.c_int32, _i32p, _f32p, C.c_void_p]
+        L.orc_links_shift.restype = C.c_int
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_set_threads.restype = None
         L.orc_get_threads.argtypes = []
@@ -119,6 +123,33 @@ def spgemm(A, B, n_cols=None, mode=0, fx_shift=62):
     cj = np.zeros(max(nnz, 1), np.int32)
     cx = np.zeros(max(nnz, 1), np.float32)
     lib().orc_spgemm(n_rows, n_cols, ap, aj, ax, bp, bj, bx, cp, cj.ctypes.data, cx.ctypes.data, mode, fx_shift)
+    return cp, cj[:nnz], cx[:nnz]
+
+
+def links_shift(L):
+    """the fixed-point shift s of the integer specification for the raw link matrix L, or -1 if it is not applicable"""
+    lp, lj, lx = _csr(*L)
+    return int(lib().orc_links_shift(len(lp) - 1, lp, lx, None))
+
+
+def expand_links(L, rows=None):
+    """run_mcl_clustering :2144-2147 on the RAW link matrix L (integer counts, symmetric): the rows `rows` (all if None) of
+    the pre-expanded matrix M^2, M = L1-normalised L, in the kernels' integer specification (hhx_oracle.c: orc_expand_links).
+    Returns the CSR triple (indptr over the selected rows, columns, values)."""
+    lp, lj, lx = _csr(*L)
+    n = len(lp) - 1
+    if rows is None:
+        n_rows, rp = n, None
+    else:
+        rows = np.ascontiguousarray(rows, np.int32)
+        n_rows, rp = len(rows), rows.ctypes.data
+    cp = np.zeros(n_rows + 1, np.int32)
+    nnz = lib().orc_expand_links(n, lp, lj, lx, n_rows, rp, cp, None, None)
+    if nnz == -2:
+        raise ValueError('the integer specification does not apply to this matrix (row sums beyond 2^18, zero rows or non-integer values)')
+    cj = np.zeros(max(nnz, 1), np.int32)
+    cx = np.zeros(max(nnz, 1), np.float32)
+    lib().orc_expand_links(n, lp, lj, lx, n_rows, rp, cp, cj.ctypes.data, cx.ctypes.data)
     return cp, cj[:nnz], cx[:nnz]
 
 

@@ -633,11 +633,31 @@ def test_mcl_links_class_stream_iteration0():
     torch.cuda.synchronize()
     links, fidx, n_linked = ing.link_matrix(np.ones(n, np.uint8))
     assert links.shape3[0] > 17_500
-    r1, n1, c1, st1 = _lib.mcl(links, 2, 2.0, 200, 1e-4, want_stats=True, links=True)      # default class stream
+    r1, n1, c1, st1 = _lib.mcl(links, 2, 2.0, 200, 1e-4, want_stats=True, links=True)      # default: integer arithmetic, symmetric half
+    mp, mj, mx = links.to_arrays()
+    assert orc.links_shift((mp, mj, mx)) > 0
+    one_int = _lib.mcl(links, 2, 2.0, 1, 1e-4, links=True)[0].to_arrays()
+    # iteration 0 against the oracle's integer specification on a slice of rows, through the row-block entry point of the
+    # multi-GPU driver (no symmetry: all products) — and those rows of the symmetric one-GPU result are the same bits
+    c = orc.expand_links((mp, mj, mx), rows=np.arange(100, 140))
+    ref = orc.prune((c[0], c[1], orc.normalize_l1(c[0], orc.power(c[2], 2.0))), 1e-4)
+    got, f_blk, z_blk = _lib.expand_links(links, 100, 140, 2.0, 1e-4)
+    ga = got.to_arrays()
+    got.free()
+    assert all(np.array_equal(x, y) for x, y in zip(ga, ref)), 'integer iteration 0 (row block) vs oracle'
+    lo, hi = one_int[0][100], one_int[0][140]
+    assert np.array_equal(one_int[1][lo:hi], ref[1]) and np.array_equal(one_int[2][lo:hi], ref[2]), 'integer iteration 0 (symmetric) vs oracle'
     try:
+        for sym, tile_u in ((0, 0), (1, 1), (1, 2), (0, 3), (1, 4), (1, 8)):          # without the symmetry; every explicit tile shape
+            _lib.tune('links_sym', sym)
+            _lib.tune('tile_u', tile_u)
+            one = _lib.mcl(links, 2, 2.0, 1, 1e-4, links=True)[0].to_arrays()
+            assert all(np.array_equal(x, y) for x, y in zip(one, one_int)), 'integer iteration 0 changed bits: %r' % ((sym, tile_u),)
+        _lib.tune('links_sym', 1)
+        _lib.tune('tile_u', 0)
+        _lib.tune('links_integer', 0)                                # the float arithmetic: class stream, then generic stream
         _lib.tune('cls', 0)                                          # generic (column, value) stream
         r0, n0, c0 = _lib.mcl(links, 2, 2.0, 200, 1e-4, links=True)
-        assert (n0, c0) == (n1, c1) and all(np.array_equal(x, y) for x, y in zip(r0.to_arrays(), r1.to_arrays()))
         one0 = _lib.mcl(links, 2, 2.0, 1, 1e-4, links=True)[0].to_arrays()
         for cls, nc, tile_u in ((1, 1, 0), (1, 3, 0), (1, 2, 0), (1, 3, 1), (1, 3, 2), (1, 1, 3), (1, 3, 4), (1, 2, 8), (0, 3, 1), (0, 3, 2), (0, 3, 3),
                                 (0, 3, 4)):
@@ -650,11 +670,18 @@ def test_mcl_links_class_stream_iteration0():
         _lib.tune('cls', 1)
         _lib.tune('cls_nc', 1)
         _lib.tune('tile_u', 0)
+        _lib.tune('links_integer', 1)
+        _lib.tune('links_sym', 1)
+    # integer vs float arithmetic: float32 round-off apart after one iteration, the same clusters at the end
+    assert np.array_equal(one_int[0], one0[0]) and np.array_equal(one_int[1], one0[1])
+    np.testing.assert_allclose(one_int[2], one0[2], rtol=2e-6, atol=0)
+    assert clusters_of(*_lib.interpret(r1)) == clusters_of(*_lib.interpret(r0))
     norm = links.copy()
     _lib.normalize_l1(norm)
     r2, n2, c2, st2 = _lib.mcl(norm, 2, 2.0, 200, 1e-4, want_stats=True, normalized=True)
-    assert (n1, c1) == (n2, c2) and np.array_equal(st1, st2)
-    assert all(np.array_equal(x, y) for x, y in zip(r1.to_arrays(), r2.to_arrays())), 'class-stream iteration 0 changed bits'
+    assert (n0, c0) == (n2, c2)
+    assert all(np.array_equal(x, y) for x, y in zip(r0.to_arrays(), r2.to_arrays())), 'class-stream iteration 0 (float arithmetic) changed bits'
+    assert np.array_equal(st1[0, [0, 1, 3]], st2[0, [0, 1, 3]])          # entries, nnz of M^2, products of iteration 0
     # one fused iteration against the oracle on a slice of rows (the oracle is too slow for all of them)
     A = norm.to_arrays()
     blk = norm.row_block(100, 140)
@@ -714,11 +741,9 @@ def test_dense_sweep_equals_fused_iteration0():
     sweep.close()
     # against the oracle on a slice of rows (mode 1: the kernels' own specification)
     mp, mj, mx = links.to_arrays()
-    norm = orc.normalize_l1(mp, mx)
     r0, r1 = 5000, 5040
     blk = _lib.DenseRows(links, r0, r1)
-    lo, hi = mp[r0], mp[r1]
-    c = orc.spgemm(((mp[r0:r1 + 1] - lo).astype(np.int32), mj[lo:hi], norm[lo:hi]), (mp, mj, norm), n_cols=n, mode=1, fx_shift=52)
+    c = orc.expand_links((mp, mj, mx), rows=np.arange(r0, r1))
     for r in (2.0, 1.7):
         ref = orc.prune((c[0], c[1], orc.normalize_l1(c[0], orc.power(c[2], r))), 1e-4)
         got = blk.inflate_prune(r, 1e-4).to_arrays()

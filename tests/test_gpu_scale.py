@@ -63,12 +63,20 @@ def _flips(a, b, n):
     return len(only_a), len(only_b), rel
 
 
-def _sample_rows_oracle(mp, mj, norm, rows, n, inflation=2.0, mode=1):
-    """iteration 0 of the oracle (expand, inflate, prune) on the given rows of the normalised link matrix"""
-    sub_p = np.zeros(len(rows) + 1, np.int32)
-    sub_p[1:] = np.cumsum(mp[rows + 1] - mp[rows])
-    take = np.concatenate([np.arange(mp[r], mp[r + 1]) for r in rows])
-    c = orc.spgemm((sub_p, mj[take], norm[take]), (mp, mj, norm), n_cols=n, mode=mode, fx_shift=52)
+def _sample_rows_oracle(L, rows, inflation=2.0, mode=2):
+    """iteration 0 of the oracle (expand, inflate, prune) on the given rows of the raw link matrix L.  mode 2: the kernels' integer
+    specification of the pre-expansion (orc.expand_links); mode 0: the reference-like float32 accumulation on the normalised matrix"""
+    mp, mj, mx = L
+    n = len(mp) - 1
+    rows = np.asarray(rows, np.int64)
+    if mode == 2:
+        c = orc.expand_links(L, rows=rows)
+    else:
+        norm = orc.normalize_l1(mp, mx)
+        sub_p = np.zeros(len(rows) + 1, np.int32)
+        sub_p[1:] = np.cumsum(mp[rows + 1] - mp[rows])
+        take = np.concatenate([np.arange(mp[r], mp[r + 1]) for r in rows])
+        c = orc.spgemm((sub_p, mj[take], norm[take]), (mp, mj, norm), n_cols=n, mode=mode, fx_shift=52)
     x = orc.normalize_l1(c[0], orc.power(c[2], inflation))
     return orc.prune((c[0], c[1], x), 1e-4)
 
@@ -111,10 +119,12 @@ def test_c2_full_size_against_oracle():
     rp, rj, rx, ridx, rl = orc.dict_to_matrix(ref['flank_i'], ref['flank_j'], ref['flank_cnt'].astype(np.float64), n, in_set, n_rest)
     assert n_linked == rl and np.array_equal(fidx, ridx)
     assert all(np.array_equal(u, v) for u, v in zip(m.to_arrays(), (rp, rj, rx))), 'C2 dict_to_matrix triple differs'
-    # whole mcl(): device (normalisation + pre-expansion fused, class stream) vs oracle (materialised M^2, mode 1)
+    # whole mcl(): device (normalisation + pre-expansion fused: integer arithmetic, upper block triangle + transposition) vs
+    # oracle (materialised M^2 in the integer specification, then mode 1)
     res, n_iter, conv, stats = _lib.mcl(m, 2, 2.0, 200, 1e-4, want_stats=True, links=True)
     rn = orc.normalize_l1(rp, rx)
-    pre = orc.spgemm((rp, rj, rn), (rp, rj, rn), mode=1, fx_shift=52)
+    assert orc.links_shift((rp, rj, rx)) > 0
+    pre = orc.expand_links((rp, rj, rx))
     assert stats[0, 1] == len(pre[1]), 'nnz of the pre-expansion'
     o = orc.mcl(pre, 2, 2.0, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True)
     assert (n_iter, conv) == (o[3], o[4]), 'C2 mcl: iteration count / convergence flag'
@@ -183,11 +193,11 @@ def test_c3_iteration0_sampled_rows_and_ingest_prefix():
     gp, gj, gx = one.to_arrays()
     mp, mj, mx = m.to_arrays()
     assert (mx == np.rint(mx)).all() and mx.max() < 65536                # integer link counts: the class stream was taken
-    norm = orc.normalize_l1(mp, mx)
+    assert orc.links_shift((mp, mj, mx)) > 0                             # ... in the integer arithmetic
     # iteration 0: 2048 rows spread over the product-count distribution (+ the lightest, the heaviest, 64 random ones)
     rows = _stratified_rows(_lib.row_products(m, m), 2048, seed=5)
     assert len(rows) >= 2048
-    want = _sample_rows_oracle(mp, mj, norm, rows, n)
+    want = _sample_rows_oracle((mp, mj, mx), rows)
     for k, r in enumerate(rows):
         lo, hi = gp[r], gp[r + 1]
         wl, wh = want[0][k], want[0][k + 1]
@@ -195,7 +205,7 @@ def test_c3_iteration0_sampled_rows_and_ingest_prefix():
         assert np.array_equal(gx[lo:hi], want[2][wl:wh]), 'C3 iteration 0: values of row %d' % r
     # the same rows in the reference's float32 accumulation: how far apart the two specifications are after one iteration
     rows0 = rows[:: max(1, len(rows) // 256)]
-    want0 = _sample_rows_oracle(mp, mj, norm, rows0, n, mode=0)
+    want0 = _sample_rows_oracle((mp, mj, mx), rows0, mode=0)
     got0_p = np.zeros(len(rows0) + 1, np.int32)
     got0_p[1:] = np.cumsum(gp[rows0 + 1] - gp[rows0])
     take0 = np.concatenate([np.arange(gp[r], gp[r + 1]) for r in rows0])
@@ -216,14 +226,27 @@ def test_c3_iteration0_sampled_rows_and_ingest_prefix():
     assert o0[3] == n_iter_full, 'C3 float32 tail: iteration count'
     assert np.array_equal(fp, o0[0]) and np.array_equal(fj, o0[1]), 'C3 float32 tail: final pattern'
     np.testing.assert_allclose(fx, o0[2], rtol=1e-6, atol=0)
-    # the generic (column, value) stream gives the same matrix
+    # the same iteration WITHOUT the symmetry (every row walks all its products into the fused epilogue — what a multi-GPU row block
+    # does): the same matrix, bit for bit; and in the float arithmetic (class stream, then generic stream): within float32 round-off
     try:
-        _lib.tune('cls', 0)
+        _lib.tune('links_sym', 0)
         two = _lib.mcl(m, 2, 2.0, 1, 1e-4, links=True)[0]
-        assert all(np.array_equal(u, v) for u, v in zip(two.to_arrays(), (gp, gj, gx)))
+        assert all(np.array_equal(u, v) for u, v in zip(two.to_arrays(), (gp, gj, gx))), 'C3 iteration 0: symmetric half + transposition vs all products'
         two.free()
+        _lib.tune('links_integer', 0)
+        flt = _lib.mcl(m, 2, 2.0, 1, 1e-4, links=True)[0]
+        fa = flt.to_arrays()
+        flt.free()
+        only_i, only_f, rel = _flips((gp, gj, gx), fa, n)
+        assert only_i + only_f <= 64 and rel < 2e-6, 'C3 iteration 0, integer vs float arithmetic: %d + %d entries decided differently, rel %g' % (only_i, only_f, rel)
+        _lib.tune('cls', 0)
+        gen_ = _lib.mcl(m, 2, 2.0, 1, 1e-4, links=True)[0]
+        assert all(np.array_equal(u, v) for u, v in zip(gen_.to_arrays(), fa)), 'C3 iteration 0: class stream vs generic stream (float arithmetic)'
+        gen_.free()
     finally:
         _lib.tune('cls', 1)
+        _lib.tune('links_integer', 1)
+        _lib.tune('links_sym', 1)
     # iteration 1 — T1 x T1, the hash class (rows of ~1000 distinct columns reached by ~160k products) — on 128 sampled rows
     # of the real T1 against the oracle, and the same rows through the window / compact classes
     m.free()
@@ -301,7 +324,8 @@ def test_c5_200k_contigs_four_pushes():
     mp, mj, mx = m.to_arrays()
     rows = _stratified_rows(_lib.row_products(m, m), 192, seed=7)
     m.free()
-    want = _sample_rows_oracle(mp, mj, orc.normalize_l1(mp, mx), rows, n)
+    assert orc.links_shift((mp, mj, mx)) > 0
+    want = _sample_rows_oracle((mp, mj, mx), rows)
     for k, r in enumerate(rows):
         lo, hi = gp[r], gp[r + 1]
         wl, wh = want[0][k], want[0][k + 1]

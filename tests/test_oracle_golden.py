@@ -36,6 +36,41 @@ def test_spgemm_matches_scipy_standin(golden_mcl):
         assert_close_csr(F, ref, 1e-6, 'fixed-point spgemm')
 
 
+def test_integer_pre_expansion_against_the_reference(golden_mcl):
+    """The integer specification of the pre-expansion (orc.expand_links: S = L D^-1 L in exact integers, then one division per
+    row — the symmetric form the HIP kernels evaluate) against the reference's own normalize + M @ M (:2144-2147) on every
+    golden link matrix that holds integer counts: same pattern, values within float32 round-off of the float32 product, and the
+    whole mcl() from it ends in the reference's clusters."""
+    g = golden_mcl
+    done = 0
+    for tag in g['cases']:
+        L = tri(g, tag + '_link')
+        sym = (np.asarray(L[2]) == np.rint(L[2])).all()
+        if not sym or orc.links_shift(L) < 0:
+            continue
+        import scipy.sparse as sp
+        m = sp.csr_matrix((L[2], L[1], L[0]), shape=(len(L[0]) - 1,) * 2)
+        if (m != m.T).nnz:
+            continue
+        done += 1
+        ref = tri(g, tag + '_m2')
+        C = orc.expand_links(L)
+        assert_close_csr(C, ref, 2e-6, tag + ': integer pre-expansion vs the reference float32 product')
+        F = orc.spgemm(tri(g, tag + '_norm'), tri(g, tag + '_norm'), mode=1, fx_shift=52)
+        assert_close_csr(C, F, 3e-7, tag + ': integer specification vs the fixed-point one')       # the roundings of the normalised entries
+        infl = float(g[tag + '_inflation'])
+        p, j, x, n_iter, conv = orc.mcl(C, 2, infl, 200, 1e-4, spgemm_mode=1, fx_shift=52)
+        att, ptr, mem = orc.interpret((p, j, x))
+        cp, cl = g[tag + '_clusters_ptr'], g[tag + '_clusters']
+        assert {tuple(mem[ptr[a]:ptr[a + 1]].tolist()) for a in range(len(att))} == {tuple(cl[cp[a]:cp[a + 1]].tolist()) for a in range(len(cp) - 1)}
+        # rows on their own == rows of the whole
+        rows = np.arange(0, len(L[0]) - 1, 7, dtype=np.int32)
+        sub = orc.expand_links(L, rows=rows)
+        for t, r in enumerate(rows):
+            assert np.array_equal(sub[2][sub[0][t]:sub[0][t + 1]], C[2][C[0][r]:C[0][r + 1]])
+    assert done >= 1, 'no golden case holds a symmetric integer link matrix'
+
+
 def test_mcl_iterations(golden_mcl):
     g = golden_mcl
     for tag in g['cases']:

@@ -65,8 +65,9 @@ class OracleEngine:
     def row_products(self, a, b):
         return np.add.reduceat(np.concatenate([np.diff(b[0])[a[1]].astype(np.int64), [0]]), np.minimum(a[0][:-1], len(a[1]))) * (np.diff(a[0]) > 0)
 
-    def expand_links(self, a, links, inflation, pruning):
-        return self.expand_inflate_prune(a, self.normalize_l1(links), inflation, pruning)
+    def expand_links(self, links, r0, r1, inflation, pruning):
+        norm = self.normalize_l1(links)
+        return self.expand_inflate_prune(self.row_block(norm, r0, r1), norm, inflation, pruning)
 
     def convergence_stat(self, m, last):
         return orc.convergence_stat(m, last)
