@@ -221,7 +221,8 @@ def main():
         traffic = pmc_traffic(n, local_pairs)
         roofline = None
         if win_n:
-            alg = 2.0 * F_u + 6.0 * (F_w - F_u) + 24.0 * A_w
+            X_b = _lib.profile_counter('expand_window_explicit_bytes')     # 4 B per explicit product in the integer arithmetic (count << 16 | column), 6 B otherwise
+            alg = 2.0 * F_u + float(X_b) + 24.0 * A_w
             ach = alg / (win_ms * 1e-3) / 1e9
             roofline = {'kernel': 'k_expand_window', 'bound': 'hbm (fabric behind L2: Infinity Cache + HBM, not separable by the TCC counters)', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': ach / HBM_PEAK_GBS, 'traffic': pick(traffic, 'k_expand_window<0'),

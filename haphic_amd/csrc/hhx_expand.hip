@@ -358,7 +358,8 @@ __device__ __forceinline__ void pass_wide(const ExParams &P, const ExLds &l, con
 template <int UX>
 struct XTile { u32 j[UX], v[UX]; i32 n; u32 da_lo, da_hi; bool valid; };      // entry u of the lane: position lane + 64 u < n
 struct XCursor { i32 l, q, qe; u32 da_lo, da_hi; };
-template <int UX>
+// FX: an explicit entry is ONE 32-bit word of Sx, link count << 16 | window-local column (4 B per product, one load)
+template <int UX, bool FX>
 __device__ __forceinline__ void xtile_fetch(const ExParams &P, const BatchRegs &r, i32 cnt, XCursor &c, XTile<UX> &t) {
     while (c.q >= c.qe && c.l + 1 < cnt) {
         ++c.l;
@@ -375,8 +376,14 @@ __device__ __forceinline__ void xtile_fetch(const ExParams &P, const BatchRegs &
     for (int u = 0; u < UX; ++u) {
         const i32 pos = lane_id() + u * HHX_WAVE;
         const i32 qs = pos < t.n ? base + pos : 0;
-        t.j[u] = (u32)P.Sc16[qs];
-        t.v[u] = __float_as_uint(P.Sx[qs]);
+        if (FX) {
+            const u32 w = __float_as_uint(P.Sx[qs]);
+            t.j[u] = w & 0xffffu;
+            t.v[u] = w >> 16;
+        } else {
+            t.j[u] = (u32)P.Sc16[qs];
+            t.v[u] = __float_as_uint(P.Sx[qs]);
+        }
     }
     c.q += UX * HHX_WAVE;
 }
@@ -395,7 +402,7 @@ __device__ __forceinline__ void xtile_consume(const ExLds &l, const XTile<UX> &t
 template <int PROBE, int UX, int G, bool FX>
 __device__ __forceinline__ void pass_explicit(const ExParams &P, const ExLds &l, const BatchRegs &r, i32 cnt, i32 dummy, u64 &sink) {
     XCursor c = {-1, 0, 0, 0u, 0u};
-    auto fetch = [&](XTile<UX> &t) { xtile_fetch<UX>(P, r, cnt, c, t); };
+    auto fetch = [&](XTile<UX> &t) { xtile_fetch<UX, FX>(P, r, cnt, c, t); };
     auto consume = [&](const XTile<UX> &t) { xtile_consume<PROBE, UX, FX>(l, t, dummy, sink); };
     for (;;) {
         XTile<UX> t[G];
@@ -520,7 +527,8 @@ __device__ __forceinline__ i32 bitmap_prefix_total(const ExLds &l, i32 W) {
 // Turns them into p = x^r (stored back as float bits, -1 = absent), returns the window sum.
 // FROM_X: the slot's low word already holds x as float32 bits (k_dense_epilogue: the expanded row comes back from HBM)
 // row_div != 0: the integer arithmetic of the link matrix — the slot holds acc (or, FROM_X, y = float(acc * 2^-s)) and x = float(y / d_i)
-template <bool COMPACT, bool FROM_X = false>
+// SQUARE: inflation 2 known at compile time (no pow call in the instantiation: half the registers, two workgroups per CU)
+template <bool COMPACT, bool FROM_X = false, bool SQUARE = false>
 __device__ __forceinline__ double window_power_sum(const ExParams &P, const ExLds &l, i32 wlen, i32 *nnz_local, double row_div = 0.0) {
     const int tid = threadIdx.x;
     const i32 per = (wlen + EX_T - 1) / EX_T;
@@ -528,7 +536,7 @@ __device__ __forceinline__ double window_power_sum(const ExParams &P, const ExLd
     double s = 0.0;
     i32 nz = 0;
     for (i32 t = s0; t < s1; ++t) {
-        const u64 ai = l.acc[t];                          // exact: the sum is below 2^53
+        const u64 ai = FROM_X ? (u64)((const u32 *)l.acc)[t] : l.acc[t];      // exact: the sum is below 2^53 (FROM_X: 4-byte slots of float bits)
         float p = -1.0f;
         if (COMPACT || ai != 0) {
             float x;
@@ -536,11 +544,11 @@ __device__ __forceinline__ double window_power_sum(const ExParams &P, const ExLd
                 const float y = FROM_X ? __uint_as_float((u32)ai) : (float)((double)(long long)ai * P.fx_inv);
                 x = (float)((double)y / row_div);
             } else x = FROM_X ? __uint_as_float((u32)ai) : (float)((double)(long long)ai * 0x1p-52 * P.inv_scale);
-            p = P.raw ? x : ex_inflate(x, P.r, P.square);
+            p = SQUARE ? x * x : (P.raw ? x : ex_inflate(x, P.r, P.square));
             s += (double)p;
             ++nz;
         }
-        ((float *)&l.acc[t])[0] = p;
+        ((float *)l.acc)[FROM_X ? t : 2 * t] = p;
     }
     *nnz_local = nz;
     return block_sum_f64(s, l.red_d);
@@ -553,7 +561,8 @@ struct BitWalk {
 
 // emits the candidates of one window (entries that may still survive given the running row sum, plus
 // the window maximum) in column order; returns their count (uniform) and records (offset,count)
-template <bool COMPACT>
+// SS: floats per slot (2: the 8-byte accumulator slots with p in the low word; 1: the 4-byte slots of k_dense_epilogue)
+template <bool COMPACT, int SS = 2>
 __device__ __forceinline__ void window_emit_candidates(const ExParams &P, const ExLds &l, i32 wlen, i32 c0, i32 r0,
                                                        double s_run, i64 *seg_off, i32 *seg_cnt) {
     const int tid = threadIdx.x;
@@ -562,13 +571,13 @@ __device__ __forceinline__ void window_emit_candidates(const ExParams &P, const 
     // window maximum (first by column == lowest slot)
     float bq = -1.0f; i32 bs = 0x7fffffff;
     for (i32 t = s0; t < s1; ++t) {
-        const float p = ((float *)&l.acc[t])[0];
+        const float p = ((const float *)l.acc)[SS * t];
         if (p > bq) { bq = p; bs = t; }
     }
     block_argmax(bq, bs, l.red_f, l.red_i);
     i32 cnt = 0;
     for (i32 t = s0; t < s1; ++t) {
-        const float p = ((float *)&l.acc[t])[0];
+        const float p = ((const float *)l.acc)[SS * t];
         if (p >= 0.0f && (P.raw || t == bs || (float)((double)p / s_run) >= P.thr)) ++cnt;
     }
     i32 total;
@@ -604,7 +613,7 @@ __device__ __forceinline__ void window_emit_candidates(const ExParams &P, const 
             col = (w << 5) + (__ffs(bits) - 1);
             bits &= bits - 1;
         } else col = c0 + t;
-        const float p = ((float *)&l.acc[t])[0];
+        const float p = ((const float *)l.acc)[SS * t];
         if (p >= 0.0f && (P.raw || t == bs || (float)((double)p / s_run) >= P.thr)) {
             P.cand_col[o] = col;
             P.cand_val[o] = p;
@@ -913,7 +922,8 @@ __global__ __launch_bounds__(256) void k_layout_write(i32 n_rows, i32 n_win, i32
             const i32 q = q0 + lane;
             int cls = -1;
             i32 col = 0; float x = 0.f;
-            if (q < qe) { cls = class_of(n16, q, nc); col = Bj[q]; x = fx ? __int_as_float((int)n16[q]) : Bx[q]; }      // fx: the link count itself
+            // fx: the explicit entry is one word, link count << 16 | window-local column
+            if (q < qe) { cls = class_of(n16, q, nc); col = Bj[q]; x = fx ? __uint_as_float((u32)n16[q] << 16 | (u32)(col - w * cap)) : Bx[q]; }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const u64 m = __ballot(cls == c);
@@ -959,23 +969,38 @@ __global__ __launch_bounds__(EX_T_CMP) void k_expand_window_finalize(ExParams P,
 // sum, in the same slot order with the same workgroup shape — so that one expansion serves every inflation of the sweep
 // (run_mcl_clustering :2155-2158 restarts each inflation from the same pre-expanded matrix) and gives the bits the fused
 // single-inflation iteration gives.  k_expand_window_finalize then finishes the rows.
-__global__ __launch_bounds__(EX_T_WIN) void k_dense_epilogue(ExParams P, const float *__restrict__ X, i64 ld, i32 cap) {
+__host__ __device__ inline size_t dense_epi_lds_bytes(i32 cap) { return (size_t)cap * 4 + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + 8; }
+template <bool SQUARE>
+__global__ __launch_bounds__(EX_T_WIN, SQUARE ? 8 : 4) void k_dense_epilogue(ExParams P, const float *__restrict__ X, i64 ld, i32 cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ExLds l = win_carve(smem, cap);
+    // 4-byte slots (the expanded row is float32 already): two workgroups share a CU, one loading its window while the other reduces
+    ExLds l;
+    {
+        unsigned char *p = smem;
+        l.red_d = (double *)p; p += EX_WAVES_MAX * 8;
+        l.bcast = (i64 *)p; p += 8;
+        l.red_i = (i32 *)p; p += EX_WAVES_MAX * 4;
+        l.red_f = (float *)p; p += EX_WAVES_MAX * 4;
+        l.ctr = (i32 *)p; p += 8;
+        l.acc = (u64 *)p;                                   // [cap] floats
+        l.st_da = nullptr; l.st_qb = l.st_qe = nullptr; l.win_off = nullptr; l.win_cnt = nullptr; l.bitmap = l.prefix = nullptr;
+    }
+    float *slot = (float *)l.acc;
     const int tid = threadIdx.x;
     i64 nnzc = 0;
     for (i32 row = blockIdx.x; row < P.n_rows; row += gridDim.x) {
         double s_run = 0.0;
+        const double div = P.row_div ? P.row_div[row] : 0.0;
         for (i32 wv = 0; wv < P.n_win; ++wv) {
             const i32 c0 = wv * cap, wlen = min(P.n_cols, c0 + cap) - c0;
             const float *src = X + (size_t)row * (size_t)ld + c0;
-            for (i32 t = tid; t < wlen; t += EX_T) l.acc[t] = (u64)__float_as_uint(src[t]);
+            for (i32 t = tid; t < wlen; t += EX_T) slot[t] = src[t];
             __syncthreads();
             i32 nz;
-            const double sw = window_power_sum<false, true>(P, l, wlen, &nz, P.row_div ? P.row_div[row] : 0.0);
+            const double sw = window_power_sum<false, true, SQUARE>(P, l, wlen, &nz, div);
             nnzc += nz;
             s_run = (wv == 0 ? 0.0 : s_run) + sw;
-            window_emit_candidates<false>(P, l, wlen, c0, 0, s_run, &P.g_win_off[(size_t)row * P.n_win + wv], &P.g_win_cnt[(size_t)row * P.n_win + wv]);
+            window_emit_candidates<false, 1>(P, l, wlen, c0, 0, s_run, &P.g_win_off[(size_t)row * P.n_win + wv], &P.g_win_cnt[(size_t)row * P.n_win + wv]);
             __syncthreads();
         }
         if (tid == 0) P.s_run[row] = s_run;
@@ -1707,6 +1732,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 prof_count("expand_window_products", (i64)cur[8]);
                 prof_count("expand_window_a_reads", (i64)cur[9]);
                 if (use_cls) prof_count("expand_window_uniform_products", (i64)cur[7]);
+                prof_count("expand_window_explicit_bytes", (i64)(fx ? 4 : 6) * ((i64)cur[8] - (use_cls ? (i64)cur[7] : 0)));
             }
             if (n_products) *n_products = (i64)cur[4];
             if (nnz_expanded) *nnz_expanded = (i64)cur[3];
@@ -1721,6 +1747,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             const bool longseg = long_segments;
             prof_count(longseg ? "expand_window_products" : "expand_window_short_products", (i64)cur[8]);
             prof_count(longseg ? "expand_window_a_reads" : "expand_window_short_a_reads", (i64)cur[9]);
+            if (longseg) prof_count("expand_window_explicit_bytes", (i64)(fx ? 4 : 6) * ((i64)cur[8] - (use_cls ? (i64)cur[7] : 0)));
             if (use_cls) prof_count("expand_window_uniform_products", (i64)cur[7]);
         }
         if (n_products) *n_products = (i64)cur[4];
@@ -1776,7 +1803,8 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
     int dev = 0;
     HHX_HIP(hipGetDevice(&dev));
     if (attr_dev != dev) {
-        HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_dev = dev;
     }
     // a pruned row holds at most 1 / pruning entries; an early window tests against a partial row sum and admits more
@@ -1803,7 +1831,8 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
         if (n_rows) {
             {
                 KTimer kt("dense_epilogue");
-                k_dense_epilogue<<<std::min<unsigned>((unsigned)n_rows, 256), EX_T_WIN, (size_t)cap * 8 + win_fixed_bytes(), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
+                if (P.square) k_dense_epilogue<true><<<std::min<unsigned>((unsigned)n_rows, 512), EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
+                else k_dense_epilogue<false><<<std::min<unsigned>((unsigned)n_rows, 512), EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
             }
             HHX_LAUNCH_CHECK();
             KTimer kt("expand_finalize");

@@ -53,12 +53,16 @@ def _keys(A, n):
 
 
 def _flips(a, b, n):
-    """entries of one pattern missing from the other, largest relative difference on the common ones"""
+    """entries of one pattern missing from the other; largest relative difference on the common entries of the rows WITHOUT such
+    a flip (one entry more or less in a row moves its second normalisation sum, hence every value of that row, by up to the
+    pruning threshold)"""
     ka, kb = _keys(a, n), _keys(b, n)
     only_a = np.setdiff1d(ka, kb, assume_unique=True)
     only_b = np.setdiff1d(kb, ka, assume_unique=True)
-    va = a[2][np.isin(ka, kb, assume_unique=True)].astype(np.float64)
-    vb = b[2][np.isin(kb, ka, assume_unique=True)].astype(np.float64)
+    bad_rows = np.union1d(only_a // n, only_b // n)
+    ca = np.isin(ka, kb, assume_unique=True) & ~np.isin(ka // n, bad_rows)
+    cb = np.isin(kb, ka, assume_unique=True) & ~np.isin(kb // n, bad_rows)
+    va, vb = a[2][ca].astype(np.float64), b[2][cb].astype(np.float64)
     rel = float(np.max(np.abs(va - vb) / np.maximum(np.abs(vb), 1e-300))) if len(va) else 0.0
     return len(only_a), len(only_b), rel
 
