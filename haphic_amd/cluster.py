@@ -421,6 +421,10 @@ def parse_link_dict(link_dict, ctg_group_dict, normalize_by_nlinks=False, _origi
     grp = np.fromiter((-1 if ctg_group_dict[c] == 'ungrouped' else groups.setdefault(ctg_group_dict[c], len(groups)) for c in id_names),
                       np.int32, len(id_names))
     group_names = list(groups)
+    # the device path holds two dense int64 [contigs x groups] tables: beyond a budget (or with nothing grouped) the reference's
+    # O(keys) dict loop is the better tool
+    if _original is not None and (not group_names or len(id_names) * len(group_names) > 50_000_000):
+        return _original(link_dict, ctg_group_dict, normalize_by_nlinks)
     sums, first = _lib.group_link_sums(fi, fj, val.astype(np.int64), grp, len(group_names))
     ctg_group_link_dict = defaultdict(dict)
     linked_ctg_dict = defaultdict(set)

@@ -1525,10 +1525,12 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     const i32 cap_cmp = (i32)((budget_cmp - fixed_cmp) / 8) & ~63;
     if (n_cols / 2 / cap_cmp + 2 > MAX_WIN - 1) return fail("expand: %d columns need too many LDS rank windows", n_cols);
     const size_t lds_win = (size_t)cap_win * 8 + fixed_win, lds_cmp = (size_t)cap_cmp * 8 + fixed_cmp;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_set = -1;           // the attribute is per device: keyed on the current ordinal
+    int attr_dev = 0;
+    HHX_HIP(hipGetDevice(&attr_dev));
+    if (attr_set != attr_dev) {
         HHX_HIP(hipFuncSetAttribute((const void *)k_expand_compact, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set = attr_dev;
     }
     static const bool debug = getenv("HHX_DEBUG") != nullptr;
     const int probe = (int)tune_get("probe", 0);
@@ -1613,10 +1615,12 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 HHX_LAUNCH_CHECK();
             }
             P.Bjx = bjx.p;
-            static bool hash_attr = false;
-            if (!hash_attr) {
+            static int hash_attr = -1;
+            int hash_dev = 0;
+            HHX_HIP(hipGetDevice(&hash_dev));
+            if (hash_attr != hash_dev) {
                 HHX_HIP(hipFuncSetAttribute((const void *)k_expand_hash, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                hash_attr = true;
+                hash_attr = hash_dev;
             }
             {
                 KTimer kt("expand_hash");

@@ -331,11 +331,13 @@ struct Payload {            // MODE 1 only
 
 template <class Src, int MODE>
 int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, LinkRun **out) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_set = -1;           // the attribute is per device: keyed on the current ordinal
+    int attr_dev = 0;
+    HHX_HIP(hipGetDevice(&attr_dev));
+    if (attr_set != attr_dev) {
         HHX_HIP(hipFuncSetAttribute((const void *)k_aggregate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_aggregate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set = attr_dev;
     }
     LinkRun *run = new LinkRun();
     if (n_items <= 0) { *out = run; return run->alloc(0) ? (delete run, 1) : 0; }

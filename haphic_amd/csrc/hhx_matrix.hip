@@ -220,10 +220,12 @@ int build_matrix(const View &vw, i64 n_keys, i32 n_frag, const uint8_t *in_set_h
     const i32 W = (shape + 31) / 32;
     const size_t lds = (size_t)W * 8 + 256 * 4;
     if (lds > 160 * 1024) { hhx_csr_free(m); return fail("dict_to_matrix: matrix order %d exceeds the LDS bitmap capacity", shape); }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_set = -1;           // the attribute is per device: keyed on the current ordinal
+    int attr_dev = 0;
+    HHX_HIP(hipGetDevice(&attr_dev));
+    if (attr_set != attr_dev) {
         (void)hipFuncSetAttribute((const void *)k_sort_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set = attr_dev;
     }
     if (shape) k_sort_rows<<<(unsigned)std::min<i64>(shape, 256 * 8), 256, lds, g_stream>>>(shape, W, indptr.p, tj.p, tx.p, m->indices.p, m->data.p);
     e = hipGetLastError();
@@ -601,10 +603,12 @@ int link_matrix_partitioned(const LinkRun *run, i32 n_frag, u64 ord_limit, const
     const i32 W = (shape + 31) / 32;
     const size_t lds = (size_t)W * 8 + (EMIT_T / HHX_WAVE) * 4;
     if (lds > 160 * 1024) { hhx_csr_free(m); return fail("link matrix: order %d exceeds the LDS bitmap capacity", shape); }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_set = -1;           // the attribute is per device: keyed on the current ordinal
+    int attr_dev = 0;
+    HHX_HIP(hipGetDevice(&attr_dev));
+    if (attr_set != attr_dev) {
         (void)hipFuncSetAttribute((const void *)k_row_emit<PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set = attr_dev;
     }
     if (e == hipSuccess && part.n_valid) {
         KTimer kt("d2m_emit");
@@ -875,11 +879,13 @@ extern "C" int hhx_rows_from_entries(i64 n, const void *w0_dev, const void *w1_d
     const bool any = part.n_valid > 0;
     DevBuf<i32> cnt, indptr;
     if (cnt.alloc((size_t)n_local + 1) || indptr.alloc((size_t)n_local + 2)) return 1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_set = -1;           // the attribute is per device: keyed on the current ordinal
+    int attr_dev = 0;
+    HHX_HIP(hipGetDevice(&attr_dev));
+    if (attr_set != attr_dev) {
         HHX_HIP(hipFuncSetAttribute((const void *)k_rows_distinct, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_rows_merge_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set = attr_dev;
     }
     const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(n_local, 256 * 8));
     if (n_local) {

@@ -27,7 +27,9 @@ __global__ __launch_bounds__(256) void k_link_weights(i64 n, const i32 *__restri
             // Python: (int * int) ** 0.5 — the product is exact (< 2^53 for any real link totals); float.__pow__ is C pow(),
             // which glibc rounds correctly in all but a handful of cases, i.e. to the IEEE square root: sqrt() here (the
             // device pow() is 1-2 ulp off, measured against the reference's values)
-            v /= sqrt((double)(per_frag[a] * per_frag[b]));
+            // each factor is converted before the multiplication: an int64 product would wrap beyond ~3e9 links per fragment, where
+            // Python's integers stay exact (the double product is then rounded once, like float(int * int))
+            v /= sqrt((double)per_frag[a] * (double)per_frag[b]);
         } else if (MODE == 1) {
             const double two_flanks = param;
             const double la = (double)per_frag[a], lb = (double)per_frag[b];
