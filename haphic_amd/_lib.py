@@ -97,6 +97,7 @@ SIGNATURES = {
     'hhx_rank_first': (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, c_i32p]),
     'hhx_shard_emit': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, c_i32p, c_vpp, c_vpp, c_i64p]),
     'hhx_rows_from_entries': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int, c_vpp]),
+    'hhx_rows_from_runs': (C.c_int, [C.c_int32, c_i64p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int, c_vpp]),
     'hhx_shard_destroy': (C.c_int, [C.c_void_p]),
     'hhx_pairs_parser_create': (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     'hhx_pairs_parse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, c_i64p, c_i64p]),

@@ -770,6 +770,103 @@ __global__ __launch_bounds__(256) void k_rows_merge_emit(i32 n_local, i32 r0, i3
     }
 }
 
+// ---- the same from SORTED RUNS: what an owner receives is one run per source rank, each already in row order (k_emit_by_row lays a
+// chunk's entries out by matrix row) — so the rows need no partition at all, only the bounds of every row inside every run:
+// a binary search per (row, run), done by the first lanes of the workgroup that owns the row.
+constexpr int MAX_RUNS = 64;
+__device__ __forceinline__ i64 run_lower_bound(const u64 *__restrict__ w0, i64 b, i64 e, u32 row) {
+    while (b < e) {
+        const i64 m = b + ((e - b) >> 1);
+        if ((u32)(w0[m] >> ID_BITS) < row) b = m + 1; else e = m;
+    }
+    return b;
+}
+__device__ __forceinline__ i64 row_segments(i32 n_runs, const i64 *__restrict__ run_off, const u64 *__restrict__ w0, u32 row, i64 *seg_b, i64 *seg_e) {
+    if ((int)threadIdx.x < n_runs) {
+        const i64 b = run_off[threadIdx.x], e = run_off[threadIdx.x + 1];
+        const i64 lo = run_lower_bound(w0, b, e, row);
+        seg_b[threadIdx.x] = lo;
+        seg_e[threadIdx.x] = run_lower_bound(w0, lo, e, row + 1);
+    }
+    __syncthreads();
+    i64 total = 0;
+    for (int s = 0; s < n_runs; ++s) total += seg_e[s] - seg_b[s];
+    return total;
+}
+__device__ __forceinline__ void mark_columns_runs(u32 *bitmap, i32 W, const u64 *__restrict__ w0, i32 n_runs, const i64 *seg_b, const i64 *seg_e, i32 self_col) {
+    for (i32 w = threadIdx.x; w < W; w += 256) bitmap[w] = 0;
+    __syncthreads();
+    for (int s = 0; s < n_runs; ++s)
+        for (i64 p = seg_b[s] + threadIdx.x; p < seg_e[s]; p += 256) { const u32 c = (u32)(w0[p] & ID_MASK); atomicOr(&bitmap[c >> 5], 1u << (c & 31)); }
+    if (self_col >= 0 && threadIdx.x == 0) atomicOr(&bitmap[self_col >> 5], 1u << (self_col & 31));
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void k_rows_distinct_runs(i32 n_local, i32 r0, i32 W, int self_loop, i32 n_runs, const i64 *__restrict__ run_off,
+                                                            const u64 *__restrict__ w0, i32 *__restrict__ cnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    i64 *seg_b = (i64 *)smem, *seg_e = seg_b + MAX_RUNS;
+    u32 *bitmap = (u32 *)(seg_e + MAX_RUNS);
+    i32 *wsum = (i32 *)(bitmap + W);
+    for (i32 a = blockIdx.x; a < n_local; a += gridDim.x) {
+        const i64 total = row_segments(n_runs, run_off, w0, (u32)(r0 + a), seg_b, seg_e);
+        if (total == 0) { if (threadIdx.x == 0) cnt[a] = self_loop ? 1 : 0; __syncthreads(); continue; }
+        mark_columns_runs(bitmap, W, w0, n_runs, seg_b, seg_e, self_loop ? r0 + a : -1);
+        i32 c = 0;
+        for (i32 w = threadIdx.x; w < W; w += 256) c += __popc(bitmap[w]);
+        c = wave_sum_i32(c);
+        if (lane_id() == 0) wsum[threadIdx.x / HHX_WAVE] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) cnt[a] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_rows_merge_emit_runs(i32 n_local, i32 r0, i32 W, int self_loop, i32 n_runs, const i64 *__restrict__ run_off,
+                                                              const u64 *__restrict__ w0, const u64 *__restrict__ w1, const i32 *__restrict__ indptr,
+                                                              i32 *__restrict__ oj, float *__restrict__ ox) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    i64 *seg_b = (i64 *)smem, *seg_e = seg_b + MAX_RUNS;
+    u32 *bitmap = (u32 *)(seg_e + MAX_RUNS), *prefix = bitmap + W, *scratch = prefix + W;
+    const int tid = threadIdx.x;
+    u32 *oxu = reinterpret_cast<u32 *>(ox);
+    for (i32 a = blockIdx.x; a < n_local; a += gridDim.x) {
+        const i32 ob = indptr[a], oe = indptr[a + 1], r = r0 + a;
+        const i64 total = row_segments(n_runs, run_off, w0, (u32)r, seg_b, seg_e);
+        if (total == 0) {                                        // link-less row: the unit self loop only
+            if (tid == 0 && oe > ob) { oj[ob] = r; ox[ob] = 1.0f; }
+            __syncthreads();
+            continue;
+        }
+        mark_columns_runs(bitmap, W, w0, n_runs, seg_b, seg_e, self_loop ? r : -1);
+        const i32 per = (W + 255) / 256, wa = tid * per, wb = min(W, wa + per);
+        u32 local = 0;
+        for (i32 w = wa; w < wb; ++w) local += __popc(bitmap[w]);
+        scratch[tid] = local;
+        for (i32 k = ob + tid; k < oe; k += 256) oxu[k] = 0;
+        __syncthreads();
+        if (tid == 0) { u32 run = 0; for (int t = 0; t < 256; ++t) { const u32 v = scratch[t]; scratch[t] = run; run += v; } }
+        __syncthreads();
+        u32 run = scratch[tid];
+        for (i32 w = wa; w < wb; ++w) { prefix[w] = run; run += __popc(bitmap[w]); }
+        __syncthreads();
+        for (int sg = 0; sg < n_runs; ++sg)
+            for (i64 p = seg_b[sg] + tid; p < seg_e[sg]; p += 256) {
+                const u32 c = (u32)(w0[p] & ID_MASK);
+                const i32 k = ob + (i32)(prefix[c >> 5] + __popc(bitmap[c >> 5] & ((1u << (c & 31)) - 1u)));
+                oj[k] = (i32)c;
+                atomicAdd(&oxu[k], (u32)w1[p]);
+            }
+        __syncthreads();
+        for (i32 k = ob + tid; k < oe; k += 256) ox[k] = (float)atomicOr(&oxu[k], 0u);   // read at L2; int -> float32, the cast of :368
+        __syncthreads();
+        if (self_loop && tid == 0) {
+            const i32 k = ob + (i32)(prefix[r >> 5] + __popc(bitmap[r >> 5] & ((1u << (r & 31)) - 1u)));
+            oj[k] = r;
+            ox[k] = 1.0f;                                        // :362-364 (a flank key never has i == j)
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int hhx_shard_create(hhx_ingest *h, const uint8_t *in_set_host, hhx_shard **out) {
@@ -903,6 +1000,54 @@ extern "C" int hhx_rows_from_entries(i64 n, const void *w0_dev, const void *w1_d
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
     if (e != hipSuccess) { hhx_csr_free(m); return fail("hhx_rows_from_entries: %s", hipGetErrorString(e)); }
+    *out = m;
+    return 0;
+}
+
+// The same row block from what the all-to-all(v) delivers as it is: n_runs runs (one per source rank, run k = entries
+// [run_off[k], run_off[k + 1])), each sorted by row because hhx_shard_emit writes a chunk's entries in matrix-row order.  No
+// partition pass: 19.7 -> (measured below) ms at n = 100k / 330 M entries.
+extern "C" int hhx_rows_from_runs(i32 n_runs, const i64 *run_off_host, const void *w0_dev, const void *w1_dev, i32 r0, i32 r1, i32 shape,
+                                  int add_self_loops, hhx_csr **out) {
+    if (n_runs < 1 || n_runs > MAX_RUNS || !run_off_host || r0 < 0 || r1 < r0 || r1 > shape || !out) return fail("hhx_rows_from_runs: bad argument");
+    const i64 n = run_off_host[n_runs];
+    if (n < 0 || (n && (!w0_dev || !w1_dev))) return fail("hhx_rows_from_runs: bad argument");
+    const i32 n_local = r1 - r0;
+    if (n && !n_local) return fail("hhx_rows_from_runs: entries for an empty row block");
+    const i32 W = (shape + 31) / 32;
+    const size_t lds_fixed = (size_t)MAX_RUNS * 16, lds = lds_fixed + (size_t)W * 8 + 256 * 4;
+    if (lds > 160 * 1024) return fail("hhx_rows_from_runs: order %d exceeds the LDS bitmap capacity", shape);
+    DevBuf<i64> run_off;
+    DevBuf<i32> cnt, indptr;
+    if (run_off.alloc((size_t)n_runs + 1) || cnt.alloc((size_t)n_local + 1) || indptr.alloc((size_t)n_local + 2)) return 1;
+    HHX_HIP(hipMemcpyAsync(run_off.p, run_off_host, sizeof(i64) * ((size_t)n_runs + 1), hipMemcpyHostToDevice, g_stream));
+    static int attr_set = -1;
+    int attr_dev = 0;
+    HHX_HIP(hipGetDevice(&attr_dev));
+    if (attr_set != attr_dev) {
+        HHX_HIP(hipFuncSetAttribute((const void *)k_rows_distinct_runs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_rows_merge_emit_runs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = attr_dev;
+    }
+    const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(n_local, 256 * 8));
+    if (n_local) {
+        KTimer kt("rows_distinct");
+        k_rows_distinct_runs<<<grid, 256, lds_fixed + (size_t)W * 4 + 16, g_stream>>>(n_local, r0, W, add_self_loops, n_runs, run_off.p, (const u64 *)w0_dev, cnt.p);
+        HHX_LAUNCH_CHECK();
+    }
+    i64 nnz = 0;
+    HHX_TRY(exclusive_scan_i32(cnt.p, indptr.p, n_local, &nnz));
+    hhx_csr *m = nullptr;
+    HHX_TRY(hhx_csr_alloc_internal(n_local, shape, nnz, &m));
+    hipError_t e = hipMemcpyAsync(m->indptr.p, indptr.p, sizeof(i32) * ((size_t)n_local + 1), hipMemcpyDeviceToDevice, g_stream);
+    if (e == hipSuccess && n_local) {
+        KTimer kt("rows_emit");
+        k_rows_merge_emit_runs<<<grid, 256, lds, g_stream>>>(n_local, r0, W, add_self_loops, n_runs, run_off.p, (const u64 *)w0_dev, (const u64 *)w1_dev, indptr.p,
+                                                             m->indices.p, m->data.p);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    if (e != hipSuccess) { hhx_csr_free(m); return fail("hhx_rows_from_runs: %s", hipGetErrorString(e)); }
     *out = m;
     return 0;
 }

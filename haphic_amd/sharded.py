@@ -137,9 +137,17 @@ class HipEngine:
     def shard_close(self, st):
         _lib.load().hhx_shard_destroy(st['h'])
 
-    def rows_from_entries(self, w0, w1, r0, r1, shape):
+    def rows_from_entries(self, w0, w1, r0, r1, shape, recv_counts=None):
+        """the owner's CSR row block from the entries it received; recv_counts (entries per source rank, in the order they lie in
+        w0 / w1): every source's run is already in row order, so the rows are merged straight from the runs (hhx_rows_from_runs)"""
         self.torch.cuda.current_stream(self.device).synchronize()
         out = _lib.C.c_void_p()
+        if recv_counts is not None and 1 <= len(recv_counts) <= 64:
+            off = np.zeros(len(recv_counts) + 1, np.int64)
+            off[1:] = np.cumsum(recv_counts)
+            _lib.check(_lib.load().hhx_rows_from_runs(len(recv_counts), off.ctypes.data_as(_lib.c_i64p), _lib.C.c_void_p(w0.data_ptr()),
+                                                      _lib.C.c_void_p(w1.data_ptr()), int(r0), int(r1), int(shape), 1, _lib.C.byref(out)))
+            return _lib.DeviceCSR(out)
         _lib.check(_lib.load().hhx_rows_from_entries(int(w0.numel()), _lib.C.c_void_p(w0.data_ptr()), _lib.C.c_void_p(w1.data_ptr()), int(r0), int(r1),
                                                      int(shape), 1, _lib.C.byref(out)))
         return _lib.DeviceCSR(out)
@@ -496,10 +504,10 @@ def build_link_matrix_sharded(engine, src, in_set, dist, timings=None, rest_orde
         bounds = row_ranges(shape, world)
         w0, w1, counts = engine.shard_emit(st, fidx, bounds)
         mark('emit')
-        e0, _recv = _all_to_all_var(w0, counts, dist, torch)                # exchange 2: the entries, to their row owners
+        e0, recv = _all_to_all_var(w0, counts, dist, torch)                 # exchange 2: the entries, to their row owners
         e1, _recv = _all_to_all_var(w1, counts, dist, torch)
         mark('all_to_all')
-        block = engine.rows_from_entries(e0, e1, bounds[rank], bounds[rank + 1], shape)
+        block = engine.rows_from_entries(e0, e1, bounds[rank], bounds[rank + 1], shape, recv_counts=recv)
         mark('rows')
         if timings is not None:
             for (_, t0), (name, t1) in zip(marks[:-1], marks[1:]):

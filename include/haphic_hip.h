@@ -303,6 +303,10 @@ int hhx_shard_emit(hhx_shard *s, const void *frag_index_dev, int32_t n_bounds, c
                    void **w0_dev, void **w1_dev, int64_t *counts);
 int hhx_rows_from_entries(int64_t n, const void *w0_dev, const void *w1_dev, int32_t r0, int32_t r1, int32_t shape,
                           int add_self_loops, hhx_csr **out);
+/* the same row block from the received entries AS THE ALL-TO-ALL(V) DELIVERS THEM: n_runs runs (one per source rank; run k =
+ * entries [run_off[k], run_off[k + 1]), run_off a host array), each in row order as hhx_shard_emit wrote it — no partition pass */
+int hhx_rows_from_runs(int32_t n_runs, const int64_t *run_off, const void *w0_dev, const void *w1_dev, int32_t r0, int32_t r1, int32_t shape,
+                       int add_self_loops, hhx_csr **out);
 int hhx_shard_destroy(hhx_shard *s);
 
 /* ------------------------------------------------------------------ a1: .pairs text -> id / position arrays

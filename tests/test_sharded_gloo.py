@@ -133,7 +133,7 @@ class OracleEngine:
     def shard_close(self, st):
         pass
 
-    def rows_from_entries(self, w0, w1, r0, r1, shape):
+    def rows_from_entries(self, w0, w1, r0, r1, shape, recv_counts=None):
         import scipy.sparse as sp
         w0, w1 = w0.numpy(), w1.numpy()
         row, col = (w0 >> 29) - r0, w0 & ((1 << 29) - 1)
