@@ -76,6 +76,7 @@ SIGNATURES = {
     'hhx_rank_sums': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'hhx_ingest_create': (C.c_int, [C.POINTER(IngestConfig), c_vpp]),
     'hhx_ingest_push': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    'hhx_ingest_push64': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     'hhx_ingest_finalize': (C.c_int, [C.c_void_p, c_i64p, c_i64p]),
     'hhx_ingest_fetch': (C.c_int, [C.c_void_p] + [C.c_void_p] * 8),
     'hhx_ingest_flank_device': (C.c_int, [C.c_void_p, c_vpp, c_vpp, c_vpp]),
@@ -103,6 +104,8 @@ SIGNATURES = {
     'hhx_pairs_parse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, c_i64p, c_i64p]),
     'hhx_pairs_parser_arrays': (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5),
     'hhx_pairs_parser_fetch': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
+    'hhx_pairs_parser_set_wide': (C.c_int, [C.c_void_p, C.c_int]),
+    'hhx_pairs_parser_fetch64': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     'hhx_pairs_parser_bed_host': (C.c_int, [C.c_void_p, c_vpp, c_i64p]),
     'hhx_pairs_parser_destroy': (C.c_int, [C.c_void_p]),
     'hhx_bam_open': (C.c_int, [C.c_char_p, C.c_int, c_vpp]),
@@ -585,6 +588,12 @@ class PairsParser:
         self.h = C.c_void_p()
         check(load().hhx_pairs_parser_create(len(enc), ptr(blob), ptr(off), C.byref(self.h)))
         self.n_lines = self.bed_bytes = 0
+        self.wide = False
+
+    def set_wide(self, on=True):
+        """positions as int64 from the next parse on (contigs of 2^31 bp and more)"""
+        check(load().hhx_pairs_parser_set_wide(self.h, int(on)))
+        self.wide = bool(on)
 
     def parse(self, text, want_bed=False, device_ptr=None, n_bytes=None):
         """text: bytes-like holding whole lines (or device_ptr + n_bytes); raises IndexError / ValueError like
@@ -610,9 +619,10 @@ class PairsParser:
         return [x.value for x in p]
 
     def fetch(self, want_bed=False):
-        out = [np.empty(self.n_lines, np.int32) for _ in range(4)]
+        out = [np.empty(self.n_lines, np.int64 if self.wide and k in (1, 3) else np.int32) for k in range(4)]
         bed = np.empty(self.bed_bytes if want_bed else 0, np.uint8)
-        check(load().hhx_pairs_parser_fetch(self.h, *[ptr(a) for a in out], ptr(bed) if bed.size else None))
+        fn = load().hhx_pairs_parser_fetch64 if self.wide else load().hhx_pairs_parser_fetch
+        check(fn(self.h, *[ptr(a) for a in out], ptr(bed) if bed.size else None))
         return out + [bed.tobytes()]
 
     def bed_host(self):
@@ -666,12 +676,19 @@ class Ingest:
         self.n_full = self.n_flank = None
 
     def push(self, id1, pos1, id2, pos2):
+        """host arrays; positions of dtype int64 go through hhx_ingest_push64 (contigs of 2^31 bp and more, :116-147)"""
+        if np.asarray(pos1).dtype == np.int64 or np.asarray(pos2).dtype == np.int64:
+            ids = [np.ascontiguousarray(a, np.int32) for a in (id1, id2)]
+            pos = [np.ascontiguousarray(a, np.int64) for a in (pos1, pos2)]
+            check(load().hhx_ingest_push64(self.h, ids[0].size, ptr(ids[0]), ptr(pos[0]), ptr(ids[1]), ptr(pos[1]), 0))
+            return
         arrs = [np.ascontiguousarray(a, np.int32) for a in (id1, pos1, id2, pos2)]
         check(load().hhx_ingest_push(self.h, arrs[0].size, *[ptr(a) for a in arrs], 0))
 
-    def push_device(self, n_pairs, id1_ptr, pos1_ptr, id2_ptr, pos2_ptr):
-        check(load().hhx_ingest_push(self.h, int(n_pairs), C.c_void_p(id1_ptr), C.c_void_p(pos1_ptr),
-                                     C.c_void_p(id2_ptr), C.c_void_p(pos2_ptr), 1))
+    def push_device(self, n_pairs, id1_ptr, pos1_ptr, id2_ptr, pos2_ptr, wide=False):
+        """device arrays (int32 ids; positions int32, or int64 with wide=True)"""
+        fn = load().hhx_ingest_push64 if wide else load().hhx_ingest_push
+        check(fn(self.h, int(n_pairs), C.c_void_p(id1_ptr), C.c_void_p(pos1_ptr), C.c_void_p(id2_ptr), C.c_void_p(pos2_ptr), 1))
 
     def finalize(self):
         a, b = C.c_int64(0), C.c_int64(0)

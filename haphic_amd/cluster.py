@@ -46,6 +46,9 @@ class FragTable:
         self.frag_nx = np.ascontiguousarray(frag_nx, np.uint8)
         self.n_ctg = len(self.ctg_rank)
         self.n_frag = len(self.frag_rank)
+        # determine_int_type :116-147: a contig longer than 2^31 - 1 bp switches the reference's coordinate arrays to int64; here
+        # it switches the position arrays of the device path (tokeniser, ingest) to 64 bits
+        self.wide = bool(self.n_ctg and int(self.ctg_len.max()) > 2 ** 31 - 1)
 
     @staticmethod
     def _rank(names):
@@ -753,13 +756,15 @@ class PairsText:
             if carry:
                 yield carry
 
-    def batches(self, names):
-        """per chunk: (parser, n_lines) with the id / position arrays of the chunk on the device.  The BED bytes of the
+    def batches(self, names, wide=False):
+        """per chunk: (parser, n_lines) with the id / position arrays of the chunk on the device (wide: int64 positions).  The BED bytes of the
         chunk come back through the parser's pinned double buffer (PCIe rate) and are written to alignments.bed by a
         pool of threads, each with its own pwrite() at its own offset of the file, while the next chunk is parsed:
         the reference writes alignments.bed inside its generator loop (:1549-1557), so this is part of the a1 cost."""
         from concurrent.futures import ThreadPoolExecutor, wait
         parser = _lib.PairsParser(names)
+        if wide:
+            parser.set_wide(True)
         fd = os.open(self.bed_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644) if self.bed_path else None
         pool = ThreadPoolExecutor(self.bed_writers) if fd is not None else None
         pending = []                                             # [futures of chunk k - 1, futures of chunk k]
@@ -882,16 +887,17 @@ def bam_generator(bam, threads, format_options):
 
 
 # ------------------------------------------------------------------ S5: ingest
-def _ids_from_alignments(alignments, cid, chunk):
-    """(ref, mref, pos, mpos) iterator -> int32 arrays, `chunk` pairs at a time"""
-    b1, p1, b2, p2 = [np.empty(chunk, np.int32) for _ in range(4)]
+def _ids_from_alignments(alignments, cid, chunk, wide=False):
+    """(ref, mref, pos, mpos) iterator -> id (int32) and position (int32; int64 when wide) arrays, `chunk` pairs at a time"""
+    pos_t = np.int64 if wide else np.int32
+    b1, b2 = np.empty(chunk, np.int32), np.empty(chunk, np.int32)
+    p1, p2 = np.empty(chunk, pos_t), np.empty(chunk, pos_t)
     k = 0
     get = cid.get
-    limit = np.iinfo(np.int32).max
+    limit = np.iinfo(pos_t).max
     for ref, mref, pos, mpos in alignments:
-        if pos >= limit or mpos >= limit:        # the reference switches to int64 positions for contigs beyond 2^31 bp (:116-147)
-            raise RuntimeError('position {} does not fit the int32 coordinates of the MI355X ingest (contigs longer than 2^31 bp '
-                               'are not supported: patch_reference(H, ingest=False) keeps the reference parser)'.format(max(pos, mpos)))
+        if pos >= limit or mpos >= limit:        # int32 positions: every contig is shorter than 2^31 bp (FragTable.wide says otherwise)
+            raise RuntimeError('position {} does not fit the {} coordinates of the MI355X ingest'.format(max(pos, mpos), pos_t.__name__))
         b1[k] = get(ref, -1)
         b2[k] = get(mref, -1)
         p1[k] = pos
@@ -917,15 +923,15 @@ def ingest_links(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False
         if want_frag_pairs:
             ing.keep_frag_pairs()
         if text:                             # a1 on the device: text chunk -> id arrays -> ingest, nothing returns to the host
-            for parser, k in alignments.batches(table.ctg_names):
+            for parser, k in alignments.batches(table.ctg_names, wide=table.wide):
                 if k:
-                    ing.push_device(k, *parser.device_arrays()[:4])
+                    ing.push_device(k, *parser.device_arrays()[:4], wide=table.wide)
         elif bam:                            # f4: BGZF inflate on host threads, record decode on the device
             for _reader, k, ptrs in alignments.batches(table.ctg_names):
                 ing.push_device(k, *ptrs)
         else:
             cid = {n: i for i, n in enumerate(table.ctg_names)}
-            for b1, p1, b2, p2, k in _ids_from_alignments(alignments, cid, chunk):
+            for b1, p1, b2, p2, k in _ids_from_alignments(alignments, cid, chunk, wide=table.wide):
                 ing.push(b1, p1, b2, p2)     # unknown names (-1) and intra-contig pairs are filtered on the device
         ing.finalize()
         out = ing.fetch()

@@ -69,11 +69,11 @@ __device__ __forceinline__ bool pair_admitted(const DevTables &t, i32 r, i32 m) 
 // ... and the part after them: a = t.ctg[r], b = t.ctg[m] are handed in, so that a caller can issue the gathers of
 // several pairs before any of them is consumed (k_map_records)
 template <bool COMBINED>
-__device__ __forceinline__ bool map_pair_with(const DevTables &t, int stream, i32 r, i32 m, i32 p1, i32 p2, UnitInfo a, UnitInfo b, u64 &rec,
+__device__ __forceinline__ bool map_pair_with(const DevTables &t, int stream, i32 r, i32 m, i64 p1, i64 p2, UnitInfo a, UnitInfo b, u64 &rec,
                                               u64 *xy = nullptr) {
     if (!COMBINED && t.bins && r == m && !(a.lenf & SPLIT_BIT)) return false;    // :1699
     i32 ci = r, cj = m;
-    i64 xi = (i64)p1 + 1, xj = (i64)p2 + 1;                                      // 1-based, :1629
+    i64 xi = p1 + 1, xj = p2 + 1;                                                // 1-based, :1629 (int32 or int64 positions, :116-147)
     if (a.rank > b.rank || (r == m && xi > xj)) {
         ci = m; cj = r;
         const i64 tx = xi; xi = xj; xj = tx;
@@ -119,7 +119,7 @@ __device__ __forceinline__ bool map_pair_with(const DevTables &t, int stream, i3
     return true;
 }
 template <bool COMBINED>
-__device__ __forceinline__ bool map_pair(const DevTables &t, int stream, i32 r, i32 m, i32 p1, i32 p2, u64 &rec, u64 *xy = nullptr) {
+__device__ __forceinline__ bool map_pair(const DevTables &t, int stream, i32 r, i32 m, i64 p1, i64 p2, u64 &rec, u64 *xy = nullptr) {
     if (!pair_admitted(t, r, m)) return false;
     return map_pair_with<COMBINED>(t, stream, r, m, p1, p2, t.ctg[r], t.ctg[m], rec, xy);
 }
@@ -157,6 +157,7 @@ struct hhx_ingest {
     std::vector<hhx::DevBuf<u64>> side_key, side_xy;     // one pair of arrays per push: key, (xi << 32 | xj)
     i64 n_side = 0;
     hhx::DevBuf<i32> stage[4];             // staging for host-side inputs
+    hhx::DevBuf<i64> stage64[2];           // ... of 64-bit positions (hhx_ingest_push64)
     ~hhx_ingest() {
         for (auto &v : runs)
             for (auto *r : v) delete r;
@@ -168,7 +169,9 @@ struct hhx_ingest {
 };
 
 // hhx_pairs.hip: stable compaction of the side records of one push; CLM / coordinate lists from them
-int hhx_side_records_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const i32 *pos1, const i32 *id2, const i32 *pos2);
+// (POS = i32 or i64 positions; the records hold 32-bit coordinates: a 64-bit stream must stay below 2^32, checked by the caller)
+template <class POS>
+int hhx_side_records_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const POS *pos1, const i32 *id2, const POS *pos2);
 
 // hhx_matrix.hip: dict_to_matrix on a run (flank rows, first-seen order taken from ord_flank)
 int hhx_link_matrix_from_run(const hhx::LinkRun *run, i32 n_frag, u64 ord_limit, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,

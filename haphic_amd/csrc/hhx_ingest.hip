@@ -38,16 +38,16 @@ __device__ __forceinline__ u32 bucket_of(u64 key, int total_bits) {
 }
 
 // ---- record sources (hhx_partition.h: get(idx, w0, w1)) --------------------------------------------------
-template <bool COMBINED>
+template <bool COMBINED, class POS = i32>
 struct SrcPairs {
     typedef u32 w1_t;
     static constexpr bool MARK = false;
-    const i32 *id1, *pos1, *id2, *pos2;
+    const i32 *id1; const POS *pos1; const i32 *id2; const POS *pos2;
     DevTables t;
     int stream;
     __device__ __forceinline__ bool get(i64 idx, u64 &rec, u32 &ord) const {
         ord = (u32)idx;
-        return map_pair<COMBINED>(t, stream, id1[idx], id2[idx], pos1[idx], pos2[idx], rec);
+        return map_pair<COMBINED>(t, stream, id1[idx], id2[idx], (i64)pos1[idx], (i64)pos2[idx], rec);
     }
 };
 // The map is evaluated ONCE per pair (k_map_records: 16 B read, 8 B written); the count and scatter passes of the
@@ -56,9 +56,9 @@ struct SrcPairs {
 // Four consecutive pairs per lane: the four streams arrive as 16-byte loads, the eight table gathers (clamped ids,
 // unconditional) are all issued before the first is consumed, and the records leave as two 16-byte stores — the
 // kernel is bound by the latency of its dependent loads, not by bytes.  VEC = false: any alignment, any tail.
-template <bool COMBINED, bool VEC>
-__global__ __launch_bounds__(256) void k_map_records(SrcPairs<COMBINED> src, i64 i0, i64 n, u64 *__restrict__ rec) {
-    if (!VEC) {
+template <bool COMBINED, bool VEC, class POS = i32>
+__global__ __launch_bounds__(256) void k_map_records(SrcPairs<COMBINED, POS> src, i64 i0, i64 n, u64 *__restrict__ rec) {
+    if (!VEC || sizeof(POS) != 4) {
         for (i64 idx = i0 + (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (i64)gridDim.x * blockDim.x) {
             u64 w0; u32 w1;
             rec[idx] = src.get(idx, w0, w1) ? w0 : EMPTY_KEY;
@@ -89,12 +89,13 @@ __global__ __launch_bounds__(256) void k_map_records(SrcPairs<COMBINED> src, i64
         reinterpret_cast<ulonglong2 *>(rec)[2 * g + 1] = make_ulonglong2(w[2], w[3]);
     }
 }
-template <bool COMBINED>
-void launch_map(const SrcPairs<COMBINED> &src, i64 n, u64 *rec) {
-    const bool aligned = ((((uintptr_t)src.id1) | ((uintptr_t)src.id2) | ((uintptr_t)src.pos1) | ((uintptr_t)src.pos2) | ((uintptr_t)rec)) & 15) == 0;
+template <bool COMBINED, class POS>
+void launch_map(const SrcPairs<COMBINED, POS> &src, i64 n, u64 *rec) {
+    // (64-bit positions — contigs beyond 2^31 bp, rare — take the scalar kernel: one pair per lane)
+    const bool aligned = sizeof(POS) == 4 && ((((uintptr_t)src.id1) | ((uintptr_t)src.id2) | ((uintptr_t)src.pos1) | ((uintptr_t)src.pos2) | ((uintptr_t)rec)) & 15) == 0;
     const i64 bulk = aligned && src.t.n_ctg > 0 ? (n & ~(i64)3) : 0;
-    if (bulk) k_map_records<COMBINED, true><<<(unsigned)std::max<i64>(1, std::min<i64>((bulk / 4 + 255) / 256, 256 * 16)), 256, 0, g_stream>>>(src, 0, bulk, rec);
-    if (bulk < n) k_map_records<COMBINED, false><<<(unsigned)std::max<i64>(1, std::min<i64>((n - bulk + 255) / 256, 256 * 16)), 256, 0, g_stream>>>(src, bulk, n, rec);
+    if (bulk) k_map_records<COMBINED, true, POS><<<(unsigned)std::max<i64>(1, std::min<i64>((bulk / 4 + 255) / 256, 256 * 16)), 256, 0, g_stream>>>(src, 0, bulk, rec);
+    if (bulk < n) k_map_records<COMBINED, false, POS><<<(unsigned)std::max<i64>(1, std::min<i64>((n - bulk + 255) / 256, 256 * 16)), 256, 0, g_stream>>>(src, bulk, n, rec);
 }
 struct SrcMapped {
     typedef u32 w1_t;
@@ -620,6 +621,40 @@ extern "C" int hhx_ingest_fetch_frag_pairs(hhx_ingest *h, i64 *n_pairs, i32 *fra
     return 0;
 }
 
+__global__ __launch_bounds__(256) void k_max_i64(i64 n, const i64 *__restrict__ a, const i64 *__restrict__ b, unsigned long long *__restrict__ out) {
+    unsigned long long m = 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        m = max(m, (unsigned long long)max(a[i], (i64)0));
+        m = max(m, (unsigned long long)max(b[i], (i64)0));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned long long)__shfl_down((long long)m, o, HHX_WAVE));
+    if (lane_id() == 0) atomicMax(out, m);
+}
+
+// one batch of pairs (device arrays): map -> group-by run(s) (+ the side records); POS = i32 or i64 positions
+template <class POS>
+static int ingest_push_device(hhx_ingest *h, i64 n_pairs, const i32 *id1, const POS *pos1, const i32 *id2, const POS *pos2) {
+    const u64 ord0 = h->ord_base + h->n_pushed;
+    { KTimer kt("ingest");
+    DevBuf<u64> mapped;
+    if (mapped.alloc((size_t)n_pairs)) return 1;
+    for (int stream = 0; stream < 3; ++stream) {
+        if (stream == 1 && h->combined) continue;
+        if (stream == 2 && !h->keep_frag_pairs) continue;
+        { KTimer kt2("map");
+        if (h->combined && stream == 0) launch_map(SrcPairs<true, POS>{id1, pos1, id2, pos2, h->t, 0}, n_pairs, mapped.p);
+        else launch_map(SrcPairs<false, POS>{id1, pos1, id2, pos2, h->t, stream}, n_pairs, mapped.p); }
+        HHX_LAUNCH_CHECK();
+        LinkRun *run = nullptr;
+        HHX_TRY((build_run<SrcMapped, 0>(SrcMapped{mapped.p}, n_pairs, Payload(), ord0, &run)));
+        h->runs[stream].push_back(run);
+    } }
+    if (h->keep_pairs) HHX_TRY(hhx_side_records_push<POS>(h, n_pairs, id1, pos1, id2, pos2));
+    h->n_pushed += (u64)n_pairs;
+    h->ord_limit = std::max<u64>(h->ord_limit, h->ord_base + h->n_pushed);
+    return 0;
+}
+
 extern "C" int hhx_ingest_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const i32 *pos1, const i32 *id2, const i32 *pos2,
                                int on_device) {
     if (!h) return fail("null handle");
@@ -633,25 +668,40 @@ extern "C" int hhx_ingest_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const
             src[k] = h->stage[k].p;
         }
     }
-    const u64 ord0 = h->ord_base + h->n_pushed;
-    { KTimer kt("ingest");
-    DevBuf<u64> mapped;
-    if (mapped.alloc((size_t)n_pairs)) return 1;
-    for (int stream = 0; stream < 3; ++stream) {
-        if (stream == 1 && h->combined) continue;
-        if (stream == 2 && !h->keep_frag_pairs) continue;
-        { KTimer kt2("map");
-        if (h->combined && stream == 0) launch_map(SrcPairs<true>{src[0], src[1], src[2], src[3], h->t, 0}, n_pairs, mapped.p);
-        else launch_map(SrcPairs<false>{src[0], src[1], src[2], src[3], h->t, stream}, n_pairs, mapped.p); }
+    return ingest_push_device<i32>(h, n_pairs, src[0], src[1], src[2], src[3]);
+}
+
+// the same with 64-bit positions: contigs of 2^31 bp and more, where the reference switches its coordinate arrays to int64
+// (determine_int_type :116-147).  The CLM / coordinate side records (hhx_ingest_keep_pairs) hold 32-bit coordinates: with them
+// switched on the positions must stay below 2^32 - 1 (checked here, loudly).
+extern "C" int hhx_ingest_push64(hhx_ingest *h, i64 n_pairs, const i32 *id1, const i64 *pos1, const i32 *id2, const i64 *pos2, int on_device) {
+    if (!h) return fail("null handle");
+    if (h->finalized) return fail("ingest handle already finalized");
+    if (n_pairs <= 0) return 0;
+    const i32 *ids[2] = {id1, id2};
+    const i64 *pos[2] = {pos1, pos2};
+    if (!on_device) {
+        for (int k = 0; k < 2; ++k) {
+            if (h->stage[2 * k].n < (size_t)n_pairs && h->stage[2 * k].alloc((size_t)n_pairs)) return 1;
+            if (h->stage64[k].n < (size_t)n_pairs && h->stage64[k].alloc((size_t)n_pairs)) return 1;
+            HHX_HIP(hipMemcpyAsync(h->stage[2 * k].p, ids[k], sizeof(i32) * (size_t)n_pairs, hipMemcpyHostToDevice, g_stream));
+            HHX_HIP(hipMemcpyAsync(h->stage64[k].p, pos[k], sizeof(i64) * (size_t)n_pairs, hipMemcpyHostToDevice, g_stream));
+            ids[k] = h->stage[2 * k].p;
+            pos[k] = h->stage64[k].p;
+        }
+    }
+    if (h->keep_pairs) {
+        DevBuf<unsigned long long> mx;
+        if (mx.alloc(1)) return 1;
+        HHX_HIP(hipMemsetAsync(mx.p, 0, sizeof(unsigned long long), g_stream));
+        k_max_i64<<<(unsigned)std::max<i64>(1, std::min<i64>((n_pairs + 255) / 256, 4096)), 256, 0, g_stream>>>(n_pairs, pos[0], pos[1], mx.p);
         HHX_LAUNCH_CHECK();
-        LinkRun *run = nullptr;
-        HHX_TRY((build_run<SrcMapped, 0>(SrcMapped{mapped.p}, n_pairs, Payload(), ord0, &run)));
-        h->runs[stream].push_back(run);
-    } }
-    if (h->keep_pairs) HHX_TRY(hhx_side_records_push(h, n_pairs, src[0], src[1], src[2], src[3]));
-    h->n_pushed += (u64)n_pairs;
-    h->ord_limit = std::max<u64>(h->ord_limit, h->ord_base + h->n_pushed);
-    return 0;
+        unsigned long long m = 0;
+        HHX_HIP(hipMemcpyAsync(&m, mx.p, sizeof m, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+        if (m >= 0xfffffffeull) return fail("hhx_ingest_push64: position %llu with the CLM / coordinate side records on (32-bit coordinates: contigs below 2^32 bp)", m);
+    }
+    return ingest_push_device<i64>(h, n_pairs, ids[0], pos[0], ids[1], pos[1]);
 }
 
 extern "C" int hhx_ingest_push_table(hhx_ingest *h, int which, i64 n_rows, const uint64_t *key, const uint64_t *ord_full,
@@ -686,6 +736,7 @@ extern "C" int hhx_ingest_finalize(hhx_ingest *h, i64 *n_full_keys, i64 *n_flank
         h->n_full = a;
         h->n_flank = h->combined ? b : d;
         for (auto &s : h->stage) s.release();
+        for (auto &s : h->stage64) s.release();
         h->finalized = true;
     }
     if (n_full_keys) *n_full_keys = h->n_full;

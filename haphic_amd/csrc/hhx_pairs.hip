@@ -18,7 +18,7 @@ namespace {
 constexpr int SD_T = 256, SD_ITEMS = 4, SD_TILE = SD_T * SD_ITEMS;
 
 template <bool COMBINED>
-__device__ __forceinline__ bool side_rec(const DevTables &t, i32 r, i32 m, i32 p1, i32 p2, u64 &key, u64 &xy) {
+__device__ __forceinline__ bool side_rec(const DevTables &t, i32 r, i32 m, i64 p1, i64 p2, u64 &key, u64 &xy) {
     u64 rec;
     if (!map_pair<COMBINED>(t, 0, r, m, p1, p2, rec, &xy)) return false;
     if (!(rec & FULL_BIT)) return false;
@@ -26,9 +26,9 @@ __device__ __forceinline__ bool side_rec(const DevTables &t, i32 r, i32 m, i32 p
     return true;
 }
 
-template <bool COMBINED>
-__global__ __launch_bounds__(SD_T) void k_side_count(i64 n, const i32 *__restrict__ id1, const i32 *__restrict__ pos1,
-                                                     const i32 *__restrict__ id2, const i32 *__restrict__ pos2, DevTables t, i64 *__restrict__ tile_cnt) {
+template <bool COMBINED, class POS>
+__global__ __launch_bounds__(SD_T) void k_side_count(i64 n, const i32 *__restrict__ id1, const POS *__restrict__ pos1,
+                                                     const i32 *__restrict__ id2, const POS *__restrict__ pos2, DevTables t, i64 *__restrict__ tile_cnt) {
     __shared__ i32 wsum[SD_T / HHX_WAVE];
     const i64 tile = blockIdx.x;
     const i64 base = tile * SD_TILE + (i64)threadIdx.x * SD_ITEMS;
@@ -45,9 +45,9 @@ __global__ __launch_bounds__(SD_T) void k_side_count(i64 n, const i32 *__restric
 }
 
 // stable: thread t owns SD_ITEMS consecutive pairs, positions = tile offset + exclusive scan of the per-thread counts
-template <bool COMBINED>
-__global__ __launch_bounds__(SD_T) void k_side_write(i64 n, const i32 *__restrict__ id1, const i32 *__restrict__ pos1,
-                                                     const i32 *__restrict__ id2, const i32 *__restrict__ pos2, DevTables t,
+template <bool COMBINED, class POS>
+__global__ __launch_bounds__(SD_T) void k_side_write(i64 n, const i32 *__restrict__ id1, const POS *__restrict__ pos1,
+                                                     const i32 *__restrict__ id2, const POS *__restrict__ pos2, DevTables t,
                                                      const i64 *__restrict__ tile_off, u64 *__restrict__ okey, u64 *__restrict__ oxy) {
     __shared__ i32 wsum[SD_T / HHX_WAVE];
     const i64 tile = blockIdx.x;
@@ -165,12 +165,13 @@ int sort_pairs_u64(const u64 *kin, u64 *kout, const u64 *vin, u64 *vout, i64 n) 
 
 }  // namespace
 
-int hhx_side_records_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const i32 *pos1, const i32 *id2, const i32 *pos2) {
+template <class POS>
+int hhx_side_records_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const POS *pos1, const i32 *id2, const POS *pos2) {
     const i64 n_tiles = (n_pairs + SD_TILE - 1) / SD_TILE;
     DevBuf<i64> cnt, off;
     if (cnt.alloc((size_t)n_tiles + 1) || off.alloc((size_t)n_tiles + 2)) return 1;
-    if (h->combined) k_side_count<true><<<(unsigned)n_tiles, SD_T, 0, g_stream>>>(n_pairs, id1, pos1, id2, pos2, h->t, cnt.p);
-    else k_side_count<false><<<(unsigned)n_tiles, SD_T, 0, g_stream>>>(n_pairs, id1, pos1, id2, pos2, h->t, cnt.p);
+    if (h->combined) k_side_count<true, POS><<<(unsigned)n_tiles, SD_T, 0, g_stream>>>(n_pairs, id1, pos1, id2, pos2, h->t, cnt.p);
+    else k_side_count<false, POS><<<(unsigned)n_tiles, SD_T, 0, g_stream>>>(n_pairs, id1, pos1, id2, pos2, h->t, cnt.p);
     HHX_LAUNCH_CHECK();
     i64 total = 0;
     HHX_TRY(exclusive_scan_i64(cnt.p, off.p, n_tiles, &total));
@@ -178,14 +179,17 @@ int hhx_side_records_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const i32 
     h->side_xy.emplace_back();
     if (h->side_key.back().alloc((size_t)total) || h->side_xy.back().alloc((size_t)total)) return 1;
     if (total) {
-        if (h->combined) k_side_write<true><<<(unsigned)n_tiles, SD_T, 0, g_stream>>>(n_pairs, id1, pos1, id2, pos2, h->t, off.p, h->side_key.back().p, h->side_xy.back().p);
-        else k_side_write<false><<<(unsigned)n_tiles, SD_T, 0, g_stream>>>(n_pairs, id1, pos1, id2, pos2, h->t, off.p, h->side_key.back().p, h->side_xy.back().p);
+        if (h->combined) k_side_write<true, POS><<<(unsigned)n_tiles, SD_T, 0, g_stream>>>(n_pairs, id1, pos1, id2, pos2, h->t, off.p, h->side_key.back().p, h->side_xy.back().p);
+        else k_side_write<false, POS><<<(unsigned)n_tiles, SD_T, 0, g_stream>>>(n_pairs, id1, pos1, id2, pos2, h->t, off.p, h->side_key.back().p, h->side_xy.back().p);
         HHX_LAUNCH_CHECK();
     }
     HHX_HIP(hipStreamSynchronize(g_stream));
     h->n_side += total;
     return 0;
 }
+
+template int hhx_side_records_push<i32>(hhx_ingest *, i64, const i32 *, const i32 *, const i32 *, const i32 *);
+template int hhx_side_records_push<i64>(hhx_ingest *, i64, const i32 *, const i64 *, const i32 *, const i64 *);
 
 int hhx_ingest_ordered_full_device(hhx_ingest *h, const i32 **fi, const i32 **fj);   // hhx_ingest.hip
 

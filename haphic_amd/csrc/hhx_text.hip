@@ -35,6 +35,8 @@ struct hhx_pairs_parser {
     DevBuf<unsigned char> text, bed;
     DevBuf<i64> starts, bed_off;
     DevBuf<i32> id1, pos1, id2, pos2;
+    DevBuf<i64> pos1w, pos2w;               // wide mode (hhx_pairs_parser_set_wide): 64-bit positions, contigs beyond 2^31 bp (:116-147)
+    bool wide = false;
     DevBuf<unsigned long long> err;
     i64 n_lines = 0, bed_bytes = 0, lines_before = 0;
     // alignments.bed leaves through two pinned host buffers used in turn (hhx_pairs_parser_bed_host): the device -> host copy
@@ -255,9 +257,9 @@ __device__ __forceinline__ i32 lookup(const NameTable &T, const RD &rd, const To
     }
 }
 
-// int(token): [+-]? digit (_? digit)*   -> false when malformed; *range when value - 1 leaves the int32 window
+// int(token): [+-]? digit (_? digit)*   -> false when malformed; *range = 1 when value - 1 leaves the int32 window, 2 beyond 2^40
 template <class RD>
-__device__ __forceinline__ bool parse_int(const RD &rd, const Tok &k, i64 *val, bool *range) {
+__device__ __forceinline__ bool parse_int(const RD &rd, const Tok &k, i64 *val, int *range) {
     i32 q = 0;
     bool neg = false;
     const unsigned char c0 = rd(k.s);
@@ -278,7 +280,7 @@ __device__ __forceinline__ bool parse_int(const RD &rd, const Tok &k, i64 *val, 
     }
     if (!prev_digit) return false;
     v = neg ? -v : v;
-    *range = big || v - 1 > 2147483647ll || v - 1 < -2147483648ll;
+    *range = big ? 2 : ((v - 1 > 2147483647ll || v - 1 < -2147483648ll) ? 1 : 0);
     *val = v;
     return true;
 }
@@ -308,29 +310,35 @@ struct LineOut {
     i32 *id1, *pos1, *id2, *pos2;
     i64 *bed_len;
     unsigned long long *err;
+    i64 *pos1w, *pos2w;                     // non-null: wide mode, the positions go here as int64
 };
 
 template <class RD>
 __device__ __forceinline__ void parse_one(const RD &rd, i64 k, i64 a, i64 e, const NameTable &T, const LineOut &O) {
     Tok tok[5];
     i32 o1 = -1, o2 = -1, q1 = 0, q2 = 0;
-    i64 blen = 0;
+    i64 blen = 0, w1 = 0, w2 = 0;
     const int nt = rd(a) == '#' ? -1 : first_tokens(rd, a, e, tok);
     if (nt > 0) {                                                // nt == 0: blank, nt == -1: header
         i64 v1 = 0, v2 = 0;
-        bool r1 = false, r2 = false;
+        int r1 = 0, r2 = 0;
+        const int limit = O.pos1w ? 1 : 0;                       // wide mode accepts what does not fit int32
         if (nt < 5) atomicMin(O.err, ((unsigned long long)k << 8) | ERR_COLUMNS);
         else if (!parse_int(rd, tok[2], &v1, &r1) || !parse_int(rd, tok[4], &v2, &r2)) atomicMin(O.err, ((unsigned long long)k << 8) | ERR_INT);
-        else if (r1 || r2) atomicMin(O.err, ((unsigned long long)k << 8) | ERR_RANGE);
+        else if (r1 > limit || r2 > limit) atomicMin(O.err, ((unsigned long long)k << 8) | ERR_RANGE);
         else {
             o1 = lookup(T, rd, tok[1]);
             o2 = lookup(T, rd, tok[3]);
             q1 = (i32)(v1 - 1);
             q2 = (i32)(v2 - 1);
+            w1 = v1 - 1;
+            w2 = v2 - 1;
             if (O.bed_len) blen = tok[1].len + tok[3].len + 2 * (i64)tok[0].len + 2 * dec_len(v1 - 1) + 2 * dec_len(v2 - 1) + 24;
         }
     }
-    O.id1[k] = o1; O.pos1[k] = q1; O.id2[k] = o2; O.pos2[k] = q2;
+    O.id1[k] = o1; O.id2[k] = o2;
+    if (O.pos1w) { O.pos1w[k] = w1; O.pos2w[k] = w2; }
+    else { O.pos1[k] = q1; O.pos2[k] = q2; }
     if (O.bed_len) O.bed_len[k] = blen;
 }
 
@@ -392,8 +400,8 @@ __global__ __launch_bounds__(LN_BLOCK) void k_parse_lines(const unsigned char *_
 // BED records of a block of lines are formatted into LDS at (offset - out_bias), out_bias chosen so that LDS and
 // HBM addresses agree mod 16, then leave with 16-byte stores (bytes at the two ragged ends)
 __global__ __launch_bounds__(LN_BLOCK) void k_bed_write(const unsigned char *__restrict__ t, i64 n, const i64 *__restrict__ starts, i64 n_lines,
-                                                        const i32 *__restrict__ pos1, const i32 *__restrict__ pos2, const i64 *__restrict__ bed_off,
-                                                        unsigned char *__restrict__ bed) {
+                                                        const i32 *__restrict__ pos1, const i32 *__restrict__ pos2, const i64 *__restrict__ pos1w,
+                                                        const i64 *__restrict__ pos2w, const i64 *__restrict__ bed_off, unsigned char *__restrict__ bed) {
     __shared__ __attribute__((aligned(16))) unsigned char s_in[IN_CAP + 16];
     __shared__ __attribute__((aligned(16))) unsigned char s_out[OUT_CAP];
     for (i64 k0 = (i64)blockIdx.x * LN_BLOCK; k0 < n_lines; k0 += (i64)gridDim.x * LN_BLOCK) {
@@ -410,8 +418,9 @@ __global__ __launch_bounds__(LN_BLOCK) void k_bed_write(const unsigned char *__r
         if (k < k1 && bed_off[k + 1] > bed_off[k]) {
             const i64 a = starts[k], e = k + 1 < n_lines ? starts[k + 1] : n;
             unsigned char *o = out_staged ? s_out + (bed_off[k] - out_bias) : bed + bed_off[k];
-            if (staged) bed_one(LdsText{s_in, bias}, a, e, pos1[k], pos2[k], o);
-            else bed_one(HbmText{t}, a, e, pos1[k], pos2[k], o);
+            const i64 p1 = pos1w ? pos1w[k] : (i64)pos1[k], p2 = pos2w ? pos2w[k] : (i64)pos2[k];
+            if (staged) bed_one(LdsText{s_in, bias}, a, e, p1, p2, o);
+            else bed_one(HbmText{t}, a, e, p1, p2, o);
         }
         __syncthreads();
         if (out_staged) {
@@ -500,12 +509,14 @@ extern "C" int hhx_pairs_parse(hhx_pairs_parser *p, const uint8_t *text, i64 n_b
     HHX_LAUNCH_CHECK();
     if (std::min(std::min(p->id1.n, p->pos1.n), std::min(p->id2.n, p->pos2.n)) < (size_t)nl)
         if (p->id1.alloc((size_t)nl) || p->pos1.alloc((size_t)nl) || p->id2.alloc((size_t)nl) || p->pos2.alloc((size_t)nl)) return 1;
+    if (p->wide && std::min(p->pos1w.n, p->pos2w.n) < (size_t)nl && (p->pos1w.alloc((size_t)nl) || p->pos2w.alloc((size_t)nl))) return 1;
     DevBuf<i64> bed_len;
     if (want_bed && bed_len.alloc((size_t)nl)) return 1;
     HHX_HIP(hipMemsetAsync(p->err.p, 0xff, sizeof(unsigned long long), g_stream));      // [0] first error (min), [1] unstaged blocks seen
     HHX_HIP(hipMemsetAsync(p->err.p + 1, 0, sizeof(unsigned long long), g_stream));
     const NameTable T{p->names.p, p->name_off.p, p->name_len.p, p->slot_hash.p, p->slot_id.p, p->mask};
-    const LineOut O{p->id1.p, p->pos1.p, p->id2.p, p->pos2.p, want_bed ? bed_len.p : nullptr, p->err.p};
+    const LineOut O{p->id1.p, p->pos1.p, p->id2.p, p->pos2.p, want_bed ? bed_len.p : nullptr, p->err.p, p->wide ? p->pos1w.p : nullptr,
+                    p->wide ? p->pos2w.p : nullptr};
     { KTimer kt("text_parse");
     k_parse_lines<true><<<grid_for(nl, LN_BLOCK), LN_BLOCK, 0, g_stream>>>(t, n_bytes, p->starts.p, nl, T, O); }
     HHX_LAUNCH_CHECK();
@@ -524,7 +535,7 @@ extern "C" int hhx_pairs_parse(hhx_pairs_parser *p, const uint8_t *text, i64 n_b
         switch ((int)(err & 0xff)) {
             case ERR_COLUMNS: return fail("IndexError: .pairs line %lld has fewer than 5 columns", line);
             case ERR_INT: return fail("ValueError: .pairs line %lld: invalid position literal", line);
-            default: return fail("ValueError: .pairs line %lld: position outside the int32 range", line);
+            default: return fail(p->wide ? "ValueError: .pairs line %lld: position beyond 2^40" : "ValueError: .pairs line %lld: position outside the int32 range", line);
         }
     }
     p->n_lines = nl;
@@ -535,7 +546,8 @@ extern "C" int hhx_pairs_parse(hhx_pairs_parser *p, const uint8_t *text, i64 n_b
         HHX_TRY(exclusive_scan_i64(bed_len.p, p->bed_off.p, nl, &total));
         if (p->bed.n < (size_t)total + 16 && p->bed.alloc((size_t)total + 16)) return 1;
         { KTimer kt("text_bed");
-        k_bed_write<<<grid_for(nl, LN_BLOCK), LN_BLOCK, 0, g_stream>>>(t, n_bytes, p->starts.p, nl, p->pos1.p, p->pos2.p, p->bed_off.p, p->bed.p); }
+        k_bed_write<<<grid_for(nl, LN_BLOCK), LN_BLOCK, 0, g_stream>>>(t, n_bytes, p->starts.p, nl, p->pos1.p, p->pos2.p, p->wide ? p->pos1w.p : nullptr,
+                                                                          p->wide ? p->pos2w.p : nullptr, p->bed_off.p, p->bed.p); }
         HHX_LAUNCH_CHECK();
         p->bed_bytes = total;
         if (bed_bytes) *bed_bytes = total;
@@ -546,9 +558,9 @@ extern "C" int hhx_pairs_parse(hhx_pairs_parser *p, const uint8_t *text, i64 n_b
 extern "C" int hhx_pairs_parser_arrays(hhx_pairs_parser *p, void **id1, void **pos1, void **id2, void **pos2, void **bed) {
     if (!p) return fail("null parser");
     if (id1) *id1 = p->id1.p;
-    if (pos1) *pos1 = p->pos1.p;
+    if (pos1) *pos1 = p->wide ? (void *)p->pos1w.p : (void *)p->pos1.p;        // int64 arrays in wide mode
     if (id2) *id2 = p->id2.p;
-    if (pos2) *pos2 = p->pos2.p;
+    if (pos2) *pos2 = p->wide ? (void *)p->pos2w.p : (void *)p->pos2.p;
     if (bed) *bed = p->bed.p;
     return 0;
 }
@@ -573,8 +585,30 @@ extern "C" int hhx_pairs_parser_bed_host(hhx_pairs_parser *p, void **host, i64 *
     return 0;
 }
 
+// positions as 64-bit integers from the next parse on (contigs beyond 2^31 bp: determine_int_type :116-147 picks int64 there);
+// hhx_pairs_parser_arrays then hands out int64 position arrays (for hhx_ingest_push64) and hhx_pairs_parser_fetch64 copies them
+extern "C" int hhx_pairs_parser_set_wide(hhx_pairs_parser *p, int on) {
+    if (!p) return fail("null parser");
+    p->wide = on != 0;
+    return 0;
+}
+extern "C" int hhx_pairs_parser_fetch64(hhx_pairs_parser *p, i32 *id1, i64 *pos1, i32 *id2, i64 *pos2, uint8_t *bed) {
+    if (!p) return fail("null parser");
+    if (!p->wide) return fail("hhx_pairs_parser_fetch64: the parser is not in wide mode");
+    const size_t n = (size_t)p->n_lines;
+    if (n) {
+        if (id1) HHX_HIP(hipMemcpyAsync(id1, p->id1.p, sizeof(i32) * n, hipMemcpyDeviceToHost, g_stream));
+        if (pos1) HHX_HIP(hipMemcpyAsync(pos1, p->pos1w.p, sizeof(i64) * n, hipMemcpyDeviceToHost, g_stream));
+        if (id2) HHX_HIP(hipMemcpyAsync(id2, p->id2.p, sizeof(i32) * n, hipMemcpyDeviceToHost, g_stream));
+        if (pos2) HHX_HIP(hipMemcpyAsync(pos2, p->pos2w.p, sizeof(i64) * n, hipMemcpyDeviceToHost, g_stream));
+    }
+    if (bed && p->bed_bytes) HHX_HIP(hipMemcpyAsync(bed, p->bed.p, (size_t)p->bed_bytes, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
 extern "C" int hhx_pairs_parser_fetch(hhx_pairs_parser *p, i32 *id1, i32 *pos1, i32 *id2, i32 *pos2, uint8_t *bed) {
     if (!p) return fail("null parser");
+    if (p->wide && (pos1 || pos2)) return fail("hhx_pairs_parser_fetch: wide mode holds int64 positions (hhx_pairs_parser_fetch64)");
     const size_t nb = sizeof(i32) * (size_t)p->n_lines;
     if (nb) {
         if (id1) HHX_HIP(hipMemcpyAsync(id1, p->id1.p, nb, hipMemcpyDeviceToHost, g_stream));

@@ -261,6 +261,10 @@ int hhx_ingest_set_ordinal_base(hhx_ingest *h, int64_t base);
  * (on_device=1) or host memory.  Each push is aggregated on the device into one run of distinct keys. */
 int hhx_ingest_push(hhx_ingest *h, int64_t n_pairs, const int32_t *id1, const int32_t *pos1,
                     const int32_t *id2, const int32_t *pos2, int on_device);
+/* the same with 64-bit positions: contigs of 2^31 bp and more, where the reference switches its coordinate arrays to int64
+ * (determine_int_type :116-147).  With hhx_ingest_keep_pairs on, positions must stay below 2^32 - 1 (32-bit side records). */
+int hhx_ingest_push64(hhx_ingest *h, int64_t n_pairs, const int32_t *id1, const int64_t *pos1, const int32_t *id2,
+                      const int64_t *pos2, int on_device);
 /* close the stream: merges the runs into one table per dict; the numbers of keys are returned */
 int hhx_ingest_finalize(hhx_ingest *h, int64_t *n_full_keys, int64_t *n_flank_keys);
 /* host copies, in dict insertion order: full_link_dict keys/counts, the HT_link_dict counts of each
@@ -324,6 +328,10 @@ int hhx_pairs_parse(hhx_pairs_parser *p, const uint8_t *text, int64_t n_bytes, i
                     int64_t *n_lines, int64_t *bed_bytes);
 int hhx_pairs_parser_arrays(hhx_pairs_parser *p, void **id1, void **pos1, void **id2, void **pos2, void **bed);
 int hhx_pairs_parser_fetch(hhx_pairs_parser *p, int32_t *id1, int32_t *pos1, int32_t *id2, int32_t *pos2, uint8_t *bed);
+/* wide mode: positions as int64 from the next parse on (contigs beyond 2^31 bp, :116-147): hhx_pairs_parser_arrays then hands out
+ * int64 position arrays (for hhx_ingest_push64), hhx_pairs_parser_fetch64 copies them; ids, BED bytes and errors as before */
+int hhx_pairs_parser_set_wide(hhx_pairs_parser *p, int on);
+int hhx_pairs_parser_fetch64(hhx_pairs_parser *p, int32_t *id1, int64_t *pos1, int32_t *id2, int64_t *pos2, uint8_t *bed);
 /* the alignments.bed bytes of the last parse in pinned host memory owned by the parser: two buffers used in turn, so the
  * pointer stays valid until the SECOND following call (the caller writes buffer k to the file while chunk k + 1 is parsed) */
 int hhx_pairs_parser_bed_host(hhx_pairs_parser *p, void **host, int64_t *n_bytes);

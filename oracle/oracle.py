@@ -260,10 +260,10 @@ def ingest(table, id1, pos1, id2, pos2, flank, bins=False, want_clm=False, max_r
     return out
 
 
-def parse_pairs_text(text, names):
+def parse_pairs_text(text, names, wide=False):
     """pairs_generator (scripts/HapHiC_cluster.py:1539-1559) on a bytes object: one (id1, pos1, id2, pos2) row per
     LINE (skipped lines and unknown names -> id -1, so that rows stay aligned with lines) and the alignments.bed
-    bytes (:1557).  Pure-Python restatement, small inputs only."""
+    bytes (:1557).  wide: positions as int64 (contigs beyond 2^31 bp, :116-147).  Pure-Python restatement, small inputs only."""
     import io
     cid = {n: i for i, n in enumerate(names)}
     rows, bed = [], []
@@ -276,7 +276,8 @@ def parse_pairs_text(text, names):
         bed.append('{0}\t{1}\t{2}\t{3}/1\t255\t.\n{4}\t{5}\t{6}\t{3}/2\t255\t.\n'.format(ref, pos, pos, cols[0], mref, mpos, mpos))
         rows.append((cid.get(ref, -1), pos, cid.get(mref, -1), mpos))
     a = np.array(rows, np.int64).reshape(-1, 4)
-    return a[:, 0].astype(np.int32), a[:, 1].astype(np.int32), a[:, 2].astype(np.int32), a[:, 3].astype(np.int32), ''.join(bed).encode()
+    pos_t = np.int64 if wide else np.int32
+    return a[:, 0].astype(np.int32), a[:, 1].astype(pos_t), a[:, 2].astype(np.int32), a[:, 3].astype(pos_t), ''.join(bed).encode()
 
 
 def ht_first(table, id1, pos1, id2, pos2, full_i, full_j):

@@ -622,6 +622,83 @@ def gen_pairs_text(path):
     np.savez_compressed(path, **out)
 
 
+def gen_ingest_wide(path):
+    """Contigs of 2^31 bp and more: determine_int_type :116-147 switches the reference's coordinate containers to
+    int64 there.  An assembly with one 3.0 Gb and one 2.3 Gb contig among ordinary ones (fa_dict entries without sequence: only the
+    lengths matter to the parser), a .pairs TEXT whose positions go up to 3e9 read by the reference's own
+    pairs_generator_inter_ctgs (alignments.bed included), parse_alignments_for_ctgs with the int types the reference itself
+    picks.  Frozen: text, names, lengths, the yielded tuples, alignments.bed, every container of the parser."""
+    import tempfile
+    rng = np.random.default_rng(4242)
+    names = ['chrBig_3Gb', 'ctg_a', 'chrBig_2Gb', 'ctg_b', 'ctg_c', 'ctg_d', 'ctg_e', 'ctg_f']
+    lens = [3_000_000_123, 400_000, 2_300_000_000, 90_000, 1_500_000, 35_000, 2_147_483_647, 700_000]
+    fa_dict = {n_: [None, l_, max(2, l_ // 256)] for n_, l_ in zip(names, lens)}
+    pos_t, dist_t = H.determine_int_type(fa_dict)
+    assert (pos_t, dist_t) == ('int64', 'int64')
+    lines = ['## pairs format v1.0']
+    w = np.array(lens, np.float64) ** 0.5
+    w /= w.sum()
+    for k in range(6000):
+        a, b = rng.choice(len(names), 2, p=w)
+        if rng.random() < 0.1:
+            b = a
+        x = int(rng.integers(1, lens[a] + 1))
+        y = int(rng.integers(1, lens[b] + 1))
+        if rng.random() < 0.3:                                   # near the ends: flank logic on both sides of 2^31 / 2^32 - flank
+            x = int(rng.choice([rng.integers(1, 600_000), lens[a] - rng.integers(0, 600_000)]))
+            x = min(max(x, 1), lens[a])
+        nm_a = names[a] if rng.random() > 0.02 else 'unplaced'
+        lines.append('r%d\t%s\t%d\t%s\t%d\t+\t-' % (k, nm_a, x, names[b], y))
+    raw = ('\n'.join(lines) + '\n').encode()
+    cid = {n_: i for i, n_ in enumerate(names)}
+    args = Args()
+    args.flank = 500
+    args.remove_allelic_links = 4
+    args.remove_concentrated_links = False
+    args.max_read_pairs = 6
+    args.nwindows = 50
+    frag_len_dict = {n_: l_ for n_, l_ in zip(names, lens)}
+    out = dict(text=np.frombuffer(raw, np.uint8), names=np.array(names), ctg_len=np.array(lens, np.int64), flank=np.int64(500_000),
+               max_read_pairs=np.int32(6), pos_int_type=np.array(pos_t), dist_int_type=np.array(dist_t))
+    cwd = os.getcwd()
+    orig_ccr = H.cal_concordance_ratio
+    H.cal_concordance_ratio = lambda coord_list, shorter_len, nwindows: tuple(coord_list)
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        try:
+            with open('in.pairs', 'wb') as f:
+                f.write(raw)
+            tuples = list(H.pairs_generator_inter_ctgs('in.pairs', 'pairs'))
+            with open('alignments.bed', 'rb') as f:
+                out['bed'] = np.frombuffer(f.read(), np.uint8)
+            full, flank, HT, clm, frag_link, coord = H.parse_alignments_for_ctgs(iter(tuples), fa_dict, args, frag_len_dict, set(names), pos_t, dist_t)
+        finally:
+            os.chdir(cwd)
+            H.cal_concordance_ratio = orig_ccr
+    out['tuples'] = np.array([(cid.get(a, -1), x, cid.get(b, -1), y) for a, b, x, y in tuples], np.int64)
+    assert out['tuples'][:, [1, 3]].max() > 2 ** 31 and all(v.typecode == 'l' for v in clm.values())
+    out.update(full_i=np.array([cid[k[0]] for k in full], np.int32), full_j=np.array([cid[k[1]] for k in full], np.int32),
+               full_cnt=np.array(list(full.values()), np.int64),
+               flank_i=np.array([cid[k[0]] for k in flank], np.int32), flank_j=np.array([cid[k[1]] for k in flank], np.int32),
+               flank_cnt=np.array(list(flank.values()), np.int64), frag_links=np.array([frag_link.get(n_, 0) for n_ in names], np.int64))
+    ht = np.zeros((len(full), 4), np.int64)
+    kidx = {k: i for i, k in enumerate(full)}
+    for (a, b), c in HT.items():
+        ht[kidx[(a[:-2], b[:-2])], (a[-1] == 'T') * 2 + (b[-1] == 'T')] = c
+    out['ht_cnt'] = ht
+    clm_ptr, clm_all, crd_ptr, crd_all = [0], [], [0], []
+    for k in full:
+        clm_all += list(clm[k])
+        clm_ptr.append(len(clm_all))
+        v = coord[k]
+        crd_all += list(v[0]) if isinstance(v, list) else list(v)
+        crd_ptr.append(len(crd_all))
+    out.update(clm_ptr=np.array(clm_ptr, np.int64), clm=np.array(clm_all, np.int64), crd_ptr=np.array(crd_ptr, np.int64), crd=np.array(crd_all, np.int64))
+    print('wide ingest case: tuples', len(tuples), 'full keys', len(full), 'flank keys', len(flank), 'max position', int(out['tuples'][:, [1, 3]].max()),
+          'max CLM distance', int(out['clm'].max()))
+    np.savez_compressed(path, **out)
+
+
 def gen_weights(path):
     """a6: the reference's in-place dict rewrites normalize_by_nlinks :718-724, normalize_by_length :727-738 (dead code),
     reduce_inter_hap_HiC_links :695-707 on a synthetic flank_link_dict; inputs as arrays in dict order, outputs as
@@ -748,6 +825,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'reassign':
         gen_reassign(os.path.join(HERE, 'reassign.npz'))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'wide':
+        gen_ingest_wide(os.path.join(HERE, 'ingest_wide.npz'))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'weights':
         gen_weights(os.path.join(HERE, 'weights.npz'))
         sys.exit(0)
@@ -764,3 +844,4 @@ if __name__ == '__main__':
     gen_weights(os.path.join(HERE, 'weights.npz'))
     gen_reassign(os.path.join(HERE, 'reassign.npz'))
     gen_plot(os.path.join(HERE, 'plot.npz'))
+    gen_ingest_wide(os.path.join(HERE, 'ingest_wide.npz'))

@@ -179,9 +179,13 @@ class PairsParser:
     def __init__(self, names):
         self.names = list(names)
         self.n_lines = self.bed_bytes = 0
+        self.wide = False
+
+    def set_wide(self, on=True):
+        self.wide = bool(on)
 
     def parse(self, text, want_bed=False, device_ptr=None, n_bytes=None):
-        *self.arr, self.bed = orc.parse_pairs_text(bytes(text), self.names)
+        *self.arr, self.bed = orc.parse_pairs_text(bytes(text), self.names, wide=self.wide)
         self.n_lines, self.bed_bytes = len(self.arr[0]), len(self.bed) if want_bed else 0
         return self.n_lines
 
@@ -220,7 +224,7 @@ class Ingest:
     def push(self, id1, pos1, id2, pos2):
         self.parts.append([np.array(a, np.int64) for a in (id1, pos1, id2, pos2)])
 
-    def push_device(self, n, id1, pos1, id2, pos2):
+    def push_device(self, n, id1, pos1, id2, pos2, wide=False):
         self.push(id1[:n], pos1[:n], id2[:n], pos2[:n])
 
     def _stream(self):

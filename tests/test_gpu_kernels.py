@@ -799,6 +799,93 @@ def test_pack_unpack_row_blocks_and_empty_blocks():
         x.free()
 
 
+def test_wide_positions_int64_path(tmp_path):
+    """Contigs of 2^31 bp and more (determine_int_type :116-147): the device tokeniser in wide mode (int64 positions,
+    the same alignments.bed bytes), hhx_ingest_push64 through host arrays, device arrays and the .pairs file front end, the CLM /
+    coordinate side records — all against the containers the reference itself produced on an assembly with a 3.0 Gb and a 2.3 Gb
+    contig (tests/golden/ingest_wide.npz), and the mirror parse_alignments_for_ctgs with the reference's int types."""
+    from array import array
+    from haphic_amd import cluster
+    from tests.conftest import load_golden
+    g = load_golden('ingest_wide.npz')
+    names = [str(x) for x in g['names']]
+    n = len(names)
+    table = cluster.FragTable.for_contigs(cluster.FragTable._rank(names), g['ctg_len'], np.ones(n, np.uint8), names=names)
+    assert table.wide
+    text = g['text'].tobytes()
+    # tokeniser, wide mode
+    ps = _lib.PairsParser(names)
+    with pytest.raises(ValueError, match='int32'):
+        ps.parse(text)                                           # positions beyond 2^31 without the wide mode: refused, loudly
+    ps.set_wide(True)
+    assert ps.parse(text, want_bed=True) == text.count(b'\n')
+    i1, p1, i2, p2, bed = ps.fetch(want_bed=True)
+    assert p1.dtype == np.int64 and bed == g['bed'].tobytes()
+    oi1, op1, oi2, op2, _ = orc.parse_pairs_text(text, names, wide=True)
+    assert all(np.array_equal(x, y) for x, y in zip((i1, p1, i2, p2), (oi1, op1, oi2, op2)))
+    tup = g['tuples']
+    tables = ('full_i', 'full_j', 'full_cnt', 'ht_cnt', 'flank_i', 'flank_j', 'flank_cnt', 'frag_links')
+
+    def check(ing):
+        ing.finalize()
+        got = ing.fetch()
+        for k in tables:
+            assert np.array_equal(got[k], g[k]), k
+        clm_ptr, clm, crd_ptr, crd = ing.fetch_pairs(int(g['max_read_pairs']), got['full_cnt'])
+        assert np.array_equal(clm_ptr * 4, g['clm_ptr']) and np.array_equal(clm, g['clm'])
+        assert np.array_equal(crd_ptr * 2, g['crd_ptr']) and np.array_equal(crd, g['crd'])
+        ing.destroy()
+    # host arrays (int64 positions -> hhx_ingest_push64), in two ragged pushes
+    ing = _lib.Ingest(table, int(g['flank']), bins=False, skip_intra=True)
+    ing.keep_pairs()
+    cut = 1777
+    for lo, hi in ((0, cut), (cut, len(tup))):
+        ing.push(tup[lo:hi, 0].astype(np.int32), tup[lo:hi, 1], tup[lo:hi, 2].astype(np.int32), tup[lo:hi, 3])
+    check(ing)
+    # device arrays straight from the tokeniser (every line: headers and intra-contig pairs are dropped on the device)
+    ing = _lib.Ingest(table, int(g['flank']), bins=False, skip_intra=True)
+    ing.keep_pairs()
+    ing.push_device(ps.n_lines, *ps.device_arrays()[:4], wide=True)
+    check(ing)
+    ps.destroy()
+
+
+def test_wide_positions_file_front_end_and_mirror(tmp_path):
+    """the .pairs file front end and the mirror of parse_alignments_for_ctgs on the same wide case, with the int types the
+    reference's determine_int_type picks (int64 containers: array('l'))"""
+    from array import array
+    from haphic_amd import cluster
+    from tests.conftest import load_golden
+    g = load_golden('ingest_wide.npz')
+    names = [str(x) for x in g['names']]
+    text = g['text'].tobytes()
+    path = tmp_path / 'wide.pairs'
+    path.write_bytes(text)
+    fa_dict = {nm: [None, int(l), 5] for nm, l in zip(names, g['ctg_len'])}
+
+    class A:
+        flank = 500
+        remove_allelic_links = 4
+        remove_concentrated_links = False
+        max_read_pairs = int(g['max_read_pairs'])
+        nwindows = 50
+    aln = cluster.pairs_generator_inter_ctgs(str(path), 'pairs')
+    aln.bed_path = str(tmp_path / 'alignments.bed')
+    frag_len = {nm: fa_dict[nm][1] for nm in names}
+    import haphic_amd.cluster as C_
+    orig = C_.cal_concordance_ratio
+    C_.cal_concordance_ratio = lambda coord_list, shorter_len, nwindows: tuple(coord_list)
+    try:
+        full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(aln, fa_dict, A(), frag_len, set(names), 'int64', 'int64')
+    finally:
+        C_.cal_concordance_ratio = orig
+    assert (tmp_path / 'alignments.bed').read_bytes() == g['bed'].tobytes()
+    assert [(names.index(a), names.index(b)) for a, b in full] == list(zip(g['full_i'].tolist(), g['full_j'].tolist()))
+    assert list(full.values()) == g['full_cnt'].tolist() and list(flank.values()) == g['flank_cnt'].tolist()
+    k0 = next(iter(full))
+    assert isinstance(clm[k0], array) and clm[k0].typecode == 'l' and max(max(v) for v in clm.values()) == int(g['clm'].max()) > 2 ** 32
+
+
 def test_link_matrix_packed_and_wide_entries():
     """hhx_ingest_link_matrix moves 8-byte entries (row, column, count < 2^24) through its partition and 16-byte ones when
     a count needs more bits: both against the oracle's dict_to_matrix on the fetched tables, > 4096 fragments (the

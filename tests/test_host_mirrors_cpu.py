@@ -41,6 +41,10 @@ def test_pairs_file_front_end(host_only, tmp_path, monkeypatch):
     tk.test_pairs_text_through_ingest(tmp_path, monkeypatch)
 
 
+def test_wide_positions_mirror(host_only, tmp_path):
+    tk.test_wide_positions_file_front_end_and_mirror(tmp_path)
+
+
 @pytest.fixture
 def host_only_everywhere(monkeypatch, host_only):
     import haphic_amd

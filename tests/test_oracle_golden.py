@@ -146,6 +146,37 @@ def test_pairs_text_restatement_pinned():
     assert bed == g['bed_all'].tobytes()
 
 
+def _wide_case():
+    from tests.conftest import load_golden
+    g = load_golden('ingest_wide.npz')
+    names = [str(x) for x in g['names']]
+    n = len(names)
+    order = sorted(range(n), key=names.__getitem__)
+    rank = np.empty(n, np.int32)
+    rank[order] = np.arange(n, dtype=np.int32)
+    t = orc.FragTable(rank, g['ctg_len'], np.arange(n, dtype=np.int32), np.zeros(n, np.uint8), 0, rank, g['ctg_len'], np.ones(n, np.uint8))
+    return g, names, t
+
+
+def test_wide_positions_restatement_pinned():
+    """contigs of 2^31 bp and more (determine_int_type :116-147 -> int64 containers): the tokeniser's tuples and alignments.bed,
+    and every container of parse_alignments_for_ctgs, frozen from the reference on an assembly with a 3.0 Gb and a 2.3 Gb contig"""
+    g, names, t = _wide_case()
+    assert str(g['pos_int_type']) == 'int64' and g['tuples'][:, [1, 3]].max() > 2 ** 31
+    i1, p1, i2, p2, bed = orc.parse_pairs_text(g['text'].tobytes(), names, wide=True)
+    assert p1.dtype == np.int64 and bed == g['bed'].tobytes()
+    text_names = [ln.split('\t')[1:4:2] for ln in g['text'].tobytes().decode().splitlines() if ln and not ln.startswith('#')]
+    live = np.array([a != b for a, b in text_names])             # pairs_generator_inter_ctgs :1582 compares NAMES
+    rows = np.stack([i1, p1, i2, p2], 1)[1:][live]                # line 0 is the header
+    assert np.array_equal(rows, g['tuples'])
+    tup = g['tuples']
+    got = orc.ingest(t, tup[:, 0].astype(np.int32), tup[:, 1], tup[:, 2].astype(np.int32), tup[:, 3], int(g['flank']), want_clm=True,
+                     max_read_pairs=int(g['max_read_pairs']))
+    for k in ('full_i', 'full_j', 'full_cnt', 'ht_cnt', 'flank_i', 'flank_j', 'flank_cnt', 'frag_links', 'clm', 'crd'):
+        assert np.array_equal(got[k], g[k]), k
+    assert np.array_equal(got['clm_ptr'], g['clm_ptr']) and np.array_equal(got['crd_ptr'], g['crd_ptr'])
+
+
 def test_frag_pairs_restatement_pinned():
     """ctg_pair_to_frag (:1731-1733), frozen from the reference's parse_alignments on split contigs"""
     from tests.conftest import load_golden
