@@ -164,6 +164,13 @@ __device__ __forceinline__ i64 wave_sum_i64(i64 v) {
     return __shfl(v, 0, HHX_WAVE);
 }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (HHX_WAVE - 1); }
+// x^r for the inflation step (`matrix.power(inflation)` :2038 on float32 data -> numpy powf), x >= 0.  exp2(r * log2(x)) in double:
+// relative error ~ |r log2 x| * 2^-52 <= ~1e-14, i.e. the float32 result differs from the correctly rounded power in about one case
+// in 10^6 (numpy's SIMD powf itself is within 1 ulp of libm's) — and it costs a third of the double-double pow() of the device
+// library, which is what the 19 non-quadratic inflations of the sweep spend their time in.  One definition for every kernel.
+__device__ __forceinline__ float hhx_powr(float x, double r) {
+    return x > 0.0f ? (float)exp2(r * log2((double)x)) : 0.0f;
+}
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release / acquire over ALL address
 // spaces: on gfx950 it waits for every outstanding global load and store of the wave (s_waitcnt vmcnt(0)), so a prefetch
 // issued before it is no prefetch and every phase of a kernel pays the drain of the stores of the phase before.  Use this

@@ -132,7 +132,7 @@ __device__ __forceinline__ ExLds win_carve(unsigned char *smem, i32 cap) {
 }
 
 __device__ __forceinline__ float ex_inflate(float x, double r, int square) {
-    return square ? x * x : (float)pow((double)x, r);
+    return square ? x * x : hhx_powr(x, r);
 }
 
 __device__ __forceinline__ i32 lower_bound_i32(const i32 *__restrict__ a, i32 b, i32 e, i32 v) {

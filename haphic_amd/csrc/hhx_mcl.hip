@@ -34,8 +34,8 @@ inline unsigned row_grid(i32 n_rows) {
 
 __device__ __forceinline__ float inflate_one(float x, double r, bool square) {
     // numpy float32 `data ** r`: r == 2 -> x*x; otherwise powf with the exponent rounded to float32.
-    // pow in double then one rounding = correctly rounded powf (numpy's SIMD powf is within 1 ulp).
-    return square ? x * x : (float)pow((double)x, r);
+    // hhx_powr: exp2(r log2 x) in double, one rounding to float32 (hhx_common.h)
+    return square ? x * x : hhx_powr(x, r);
 }
 
 // ---- L1 normalise in place ------------------------------------------------------------------
