@@ -85,6 +85,7 @@ SIGNATURES = {
     'hhx_ingest_keep_pairs': (C.c_int, [C.c_void_p, C.c_int]),
     'hhx_csr_vstack': (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), c_vpp]),
     'hhx_mem_info': (C.c_int, [c_i64p, c_i64p]),
+    'hhx_pool_cached_bytes': (C.c_int, [c_i64p]),
     'hhx_csr_pack_block': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     'hhx_csr_unpack_blocks': (C.c_int, [C.c_int32, c_i64p, c_i64p, C.c_void_p, C.c_int64, C.c_int32, c_vpp]),
     'hhx_inflate_prune_keep': (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_vpp]),
@@ -327,6 +328,12 @@ def mem_info():
     f, t = C.c_int64(0), C.c_int64(0)
     check(load().hhx_mem_info(C.byref(f), C.byref(t)))
     return f.value, t.value
+
+
+def pool_cached_bytes():
+    b = C.c_int64(0)
+    check(load().hhx_pool_cached_bytes(C.byref(b)))
+    return b.value
 
 
 class DenseRows:

@@ -537,9 +537,10 @@ class DenseSweep:
         self.n = n
         if block_rows is None:
             if budget_bytes is None:
-                _lib.check(_lib.load().hhx_pool_trim())
+                # what the driver reports free + what the library's pool holds for reuse (no trim: a cached 40 GB block is worth
+                # seconds of hipMalloc); the rest: candidate pools, operand stream, the tails of the inflations
                 free_bytes, _total = _lib.mem_info()
-                budget_bytes = 0.45 * free_bytes             # the rest: candidate pools, operand stream, the tails of the inflations
+                budget_bytes = 0.45 * (free_bytes + _lib.pool_cached_bytes())
             block_rows = max(1, min(n, int(budget_bytes // (4 * max(n, 1)))))
         self.bounds = list(range(0, n, int(block_rows))) + [n]
         self.resident = None                                 # the only block when the whole M^2 fits: kept for the whole sweep

@@ -512,6 +512,13 @@ extern "C" int hhx_csr_unpack_blocks(i32 n_blocks, const i64 *rows, const i64 *n
     return 0;
 }
 
+// bytes held by the library's caching pool (free for the next allocation of the library, not for the driver's hipMemGetInfo)
+extern "C" int hhx_pool_cached_bytes(i64 *bytes) {
+    if (!bytes) return fail("null pointer");
+    *bytes = pool_cached_bytes();
+    return 0;
+}
+
 extern "C" int hhx_mem_info(i64 *free_bytes, i64 *total_bytes) {
     size_t f = 0, t = 0;
     HHX_HIP(hipMemGetInfo(&f, &t));

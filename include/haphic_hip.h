@@ -84,6 +84,8 @@ int hhx_csr_unpack_blocks(int32_t n_blocks, const int64_t *rows, const int64_t *
                           int32_t n_cols, hhx_csr **out);
 /* free / total device memory in bytes (memory cached by the library's pool counts as used: hhx_pool_trim first) */
 int hhx_mem_info(int64_t *free_bytes, int64_t *total_bytes);
+/* bytes cached by the library's pool: reusable by the library's next allocations without asking the driver */
+int hhx_pool_cached_bytes(int64_t *bytes);
 int hhx_csr_free(hhx_csr *m);
 
 /* ---------------------------------------------------------------- S3: normalize / power / prune

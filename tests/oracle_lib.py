@@ -73,6 +73,10 @@ def mem_info():
     return 1 << 40, 1 << 40
 
 
+def pool_cached_bytes():
+    return 0
+
+
 def normalize_l1(m):
     m.a = (m.a[0], m.a[1], orc.normalize_l1(m.a[0], m.a[2]))
     return m
