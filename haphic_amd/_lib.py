@@ -90,7 +90,9 @@ SIGNATURES = {
     'hhx_csr_unpack_blocks': (C.c_int, [C.c_int32, c_i64p, c_i64p, C.c_void_p, C.c_int64, C.c_int32, c_vpp]),
     'hhx_inflate_prune_keep': (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_vpp]),
     'hhx_mcl_resume': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, c_vpp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
-    'hhx_expand_links_dense': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int, c_vpp, c_i64p, c_i64p]),
+    'hhx_expand_links_dense': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_int, c_vpp, c_i64p, c_i64p]),
+    'hhx_links_integer_ok': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'hhx_dense_device': (C.c_int, [C.c_void_p, c_vpp, c_i32p, c_i32p]),
     'hhx_dense_inflate_prune': (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_vpp]),
     'hhx_dense_shape': (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i64p]),
     'hhx_dense_free': (C.c_int, [C.c_void_p]),
@@ -339,11 +341,19 @@ def pool_cached_bytes():
 class DenseRows:
     """hhx_dense: rows [r0, r1) of the pre-expanded matrix M^2 as float32 in HBM — one expansion for a whole inflation sweep"""
 
-    def __init__(self, links, r0, r1, fx_shift=52):
+    def __init__(self, links, r0, r1, fx_shift=52, upper_only=False):
+        """upper_only: only the blocks (I, J >= I) of the rows are filled (integer arithmetic); the caller mirrors the rest"""
         self.h = C.c_void_p()
         f, z = C.c_int64(0), C.c_int64(0)
-        check(load().hhx_expand_links_dense(links.h, int(r0), int(r1), int(fx_shift), C.byref(self.h), C.byref(f), C.byref(z)))
+        check(load().hhx_expand_links_dense(links.h, int(r0), int(r1), int(fx_shift), int(bool(upper_only)), C.byref(self.h), C.byref(f), C.byref(z)))
         self.n_products, self.nnz_expanded = f.value, z.value
+        self.n_rows, self.n_cols = int(r1) - int(r0), links.shape3[1]
+
+    def device(self):
+        """(device pointer of the n_rows x n_cols float32 block, columns per window, number of windows)"""
+        x, cap, nw = C.c_void_p(), C.c_int32(0), C.c_int32(0)
+        check(load().hhx_dense_device(self.h, C.byref(x), C.byref(cap), C.byref(nw)))
+        return x.value or 0, cap.value, nw.value
 
     def inflate_prune(self, inflation, pruning):
         """iteration 0 of mcl() (:2037-2042) of these rows at `inflation`"""
@@ -361,6 +371,13 @@ class DenseRows:
             self.free()
         except Exception:
             pass
+
+
+def links_integer_ok(links):
+    """does iteration 0 on this raw link matrix run in the integer arithmetic (symmetric integer counts, row sums < 2^18)?"""
+    ok, shift = C.c_int(0), C.c_int(0)
+    check(load().hhx_links_integer_ok(links.h, C.byref(ok), C.byref(shift)))
+    return bool(ok.value)
 
 
 def mcl_resume(m, done, expansion, inflation, max_iter, pruning, want_stats=False):

@@ -73,7 +73,8 @@ struct ExParams {
     // the addend of product (i, k, j) is c_ik * W_k * c_kj with W_k = rint(2^s / d_k) — S = L D^-1 L, a symmetric matrix, in exact
     // 64-bit integers; y = float(acc * 2^-s), x = float(y / d_i).  W == nullptr: the float arithmetic above (fx_bits).
     const u64 *W; const unsigned short *A16; const double *row_div; double fx_inv;
-    i32 sym;                        // dense + whole matrix: launch wv covers rows [0, (wv + 1) * cap) only (blocks J >= I); the rest is transposed
+    i32 sym;                        // dense: launch wv covers only the rows of the blocks I <= wv (blocks J >= I of S); the rest is mirrored afterwards
+    i32 sym_row0;                   // ... global index of local row 0 (a row block of a multi-GPU rank; 0 for the whole matrix)
 };
 
 struct ExLds {
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__re
                 // float arithmetic: the x of window_power_sum, bit for bit.  Integer arithmetic: y = float(S_ij), symmetric — the
                 // division by d_i is the epilogue's (k_dense_epilogue)
                 dst[t] = FX ? (float)((double)(long long)ai * P.fx_inv) : (float)((double)(long long)ai * 0x1p-52 * P.inv_scale);
-                nnzc += ai != 0 ? (P.sym && row / cap != wv ? 2 : 1) : 0;       // symmetric mode: an off-diagonal block stands for its mirror image too
+                nnzc += ai != 0 ? (P.sym && (P.sym_row0 + row) / cap != wv ? 2 : 1) : 0;       // symmetric mode: an off-diagonal block stands for its mirror image too
             }
             __syncthreads();
             continue;
@@ -1442,7 +1443,8 @@ struct CodedOperand {
     const unsigned short *a16 = nullptr;     // link counts of a's entries
     const double *a_row_sum = nullptr;       // d_i of a's rows
     int shift = 0;
-    int sym = 0;                        // dense mode, a == all rows: compute the blocks J >= I only, transpose the rest
+    int sym = 0;                        // dense mode: compute the blocks J >= I only; a == all rows: mirrored here, a row block: by the caller
+    i32 sym_row0 = 0;
 };
 
 template <int PROBE, int UX, int RX, int RW, bool FX, int T = EX_T_WIN>
@@ -1456,7 +1458,8 @@ static int launch_window_fx(const ExParams &P, const i32 *rows, i32 n_list, i32 
     }
     for (i32 wv = 0; wv < P.n_win; ++wv) {
         // symmetric mode: the rows are in identity order and launch wv takes the row blocks I <= wv (blocks J >= I of S)
-        const i32 n_w = P.sym ? (i32)std::min<i64>(n_list, (i64)(wv + 1) * cap) : n_list;
+        const i32 n_w = P.sym ? (i32)std::max<i64>(0, std::min<i64>(n_list, (i64)(wv + 1) * cap - P.sym_row0)) : n_list;
+        if (n_w == 0) continue;
         k_expand_window<PROBE, UX, RX, RW, FX, T><<<std::min<unsigned>(grid, (unsigned)std::max(n_w, 1)), T, lds, g_stream>>>(P, P.sym ? nullptr : rows, n_w, cap, wv);
     }
     return 0;
@@ -1499,7 +1502,8 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     const bool use_cls = coded.n16 != nullptr && !coded.raw && tune_get("cls", 1) != 0;
     const bool fx = use_cls && coded.W != nullptr;           // integer arithmetic of the link matrix: every row through the window class
     if (coded.W && !fx) return fail("expand: the integer arithmetic needs the class stream");
-    if (coded.sym && !(dense && fx && a->n_rows == b->n_rows)) return fail("expand: the symmetric mode needs the whole link matrix in dense integer mode");
+    if (coded.sym && !(dense && fx)) return fail("expand: the symmetric mode needs the dense integer mode");
+    const bool sym_whole = coded.sym && a->n_rows == b->n_rows;          // all rows here: the mirror image is written here too
     // link counts 1..n_classes are streamed as columns only.  Measured at n = 100k (profiles/r02_expand_probe_c3.jsonl): counts 1-3
     // move 17 % fewer bytes than count 1 alone but run 20 % longer (the count-2 / count-3 sub-segments are a few dozen entries:
     // tiles of 128 that are mostly empty), so the default is 1
@@ -1606,7 +1610,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
         P.dense = coded.dense_out; P.dense_ld = n_cols;
         P.W = fx ? coded.W : nullptr; P.A16 = coded.a16; P.row_div = coded.a_row_sum; P.fx_inv = ldexp(1.0, -coded.shift);
-        P.sym = coded.sym;
+        P.sym = coded.sym; P.sym_row0 = coded.sym_row0;
         P.Sc16 = nullptr; P.Sx = nullptr; P.rec = nullptr; P.Bjx = nullptr; P.narrow_classes = 0; P.wb = WB_MAX;
         if (hc[3]) {                                      // hash class first: it may add rows to the window / compact lists
             if (!bjx.p) {                                 // B as 8-byte (column, value) words, built once per call
@@ -1699,7 +1703,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 else HHX_TRY((launch_window<0, 1, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
             }
             HHX_LAUNCH_CHECK();
-            if (coded.sym && n_win > 1) {
+            if (sym_whole && n_win > 1) {
                 KTimer kt("dense_transpose");
                 const unsigned tiles = (unsigned)((n_cols + 63) / 64);
                 k_transpose_lower<<<dim3(tiles, tiles), 256, 0, g_stream>>>(coded.dense_out, (i64)n_cols, n_cols, cap_win);
@@ -1778,7 +1782,7 @@ int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const hhx_links_op
         c.n16 = lk->n16; c.row_sum = lk->row_sum;
         if (lk->W) {                                   // integer arithmetic: the block holds y = float(S); its epilogue divides by d_i
             c.W = lk->W; c.shift = lk->shift; c.a16 = lk->n16 + lk->a_off; c.a_row_sum = lk->row_sum + lk->a_row0;
-            c.sym = lk->sym;
+            c.sym = lk->sym; c.sym_row0 = lk->a_row0;
             if (d->row_div.alloc((size_t)a->n_rows + 1)) { delete d; return 1; }
             if (a->n_rows) HHX_HIP(hipMemcpyAsync(d->row_div.p, c.a_row_sum, sizeof(double) * (size_t)a->n_rows, hipMemcpyDeviceToDevice, g_stream));
             d->integer = true;
@@ -1863,6 +1867,15 @@ extern "C" int hhx_dense_shape(const hhx_dense *d, i32 *n_rows, i32 *n_cols, i64
     if (n_rows) *n_rows = d->n_rows;
     if (n_cols) *n_cols = d->n_cols;
     if (bytes) *bytes = (i64)sizeof(float) * (i64)d->n_rows * (i64)d->n_cols;
+    return 0;
+}
+
+// the block as device memory: n_rows x n_cols float32, row-major (multi-GPU: the ranks mirror their upper block triangles through it)
+extern "C" int hhx_dense_device(const hhx_dense *d, void **x, i32 *cap_win, i32 *n_win) {
+    if (!d || !x) return fail("null pointer");
+    *x = d->x.p;
+    if (cap_win) *cap_win = d->cap_win;
+    if (n_win) *n_win = d->n_win;
     return 0;
 }
 

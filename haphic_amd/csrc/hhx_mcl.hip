@@ -547,7 +547,8 @@ extern "C" int hhx_expand_links(const hhx_csr *links, i32 r0, i32 r1, int fx_shi
 // run_mcl_clustering :2144-2147 for rows [r0, r1) of the link matrix, kept for the whole inflation sweep: L1 normalisation, then the
 // rows of M^2 = T[r0:r1, :] * T as a dense float32 block (hhx_dense).  hhx_dense_inflate_prune then gives iteration 0 of mcl()
 // (:2037-2042) of these rows at any inflation without walking the products again.
-extern "C" int hhx_expand_links_dense(const hhx_csr *links, i32 r0, i32 r1, int fx_shift, hhx_dense **out, i64 *n_products, i64 *nnz_expanded) {
+extern "C" int hhx_expand_links_dense(const hhx_csr *links, i32 r0, i32 r1, int fx_shift, int upper_only, hhx_dense **out, i64 *n_products,
+                                      i64 *nnz_expanded) {
     if (!links || !out) return fail("null pointer");
     if (links->n_rows != links->n_cols) return fail("hhx_expand_links_dense needs the square link matrix");
     if (r0 < 0 || r1 < r0 || r1 > links->n_rows) return fail("row block [%d,%d) out of range", r0, r1);
@@ -559,10 +560,22 @@ extern "C" int hhx_expand_links_dense(const hhx_csr *links, i32 r0, i32 r1, int 
     HHX_HIP(hipMemcpyAsync(&off, links->indptr.p + r0, sizeof off, hipMemcpyDeviceToHost, g_stream));
     HHX_HIP(hipStreamSynchronize(g_stream));
     const bool whole = r0 == 0 && r1 == links->n_rows;
-    const hhx_links_operand lk = nl.operand(r0, off, whole && tune_get("links_sym", 1) != 0 ? 1 : 0);       // all rows: the symmetric half + transposition
+    if (upper_only && !nl.integer) { hhx_csr_free(a); return fail("hhx_expand_links_dense: upper_only needs the integer arithmetic (symmetric counts, row sums < 2^18)"); }
+    // all rows: the symmetric half + transposition; upper_only on a row block: the half alone, the caller mirrors (multi-GPU)
+    const hhx_links_operand lk = nl.operand(r0, off, (upper_only || (whole && tune_get("links_sym", 1) != 0)) ? 1 : 0);
     const int rc = hhx_expand_dense_impl(a, nl.norm, nl.usable ? &lk : nullptr, fx_shift, out, n_products, nnz_expanded);
     hhx_csr_free(a);
     return rc;
+}
+
+// can iteration 0 on this link matrix run in the integer arithmetic (symmetric counts, row sums below 2^18)?  *shift = s of DESIGN 4.1
+extern "C" int hhx_links_integer_ok(const hhx_csr *links, int *ok, int *shift) {
+    if (!links || !ok) return fail("null pointer");
+    NormalisedLinks nl;
+    HHX_TRY(normalise_links(links, &nl));
+    *ok = nl.integer ? 1 : 0;
+    if (shift) *shift = nl.integer ? nl.shift : -1;
+    return 0;
 }
 
 // interpret_result(), array half.  The final matrix holds ~n entries, so this is a host pass over a

@@ -90,6 +90,26 @@ class HipEngine:
     def row_products(self, a, b):
         return _lib.row_products(a, b)
 
+    # ---- iteration 0 on the symmetric half across ranks (expand_links_symmetric below)
+    def links_integer_ok(self, links):
+        return _lib.links_integer_ok(links)
+
+    def dense_upper(self, links, r0, r1):
+        """rows [r0, r1) of Y = float(S), blocks (I, J >= I) only: (handle, [n_rows, n] float32 torch view, columns per window)"""
+        d = _lib.DenseRows(links, r0, r1, upper_only=True)
+        ptr, cap, _nw = d.device()
+        y = self.view(ptr, d.n_rows * d.n_cols, '<f4', self.torch.float32).view(d.n_rows, d.n_cols) if d.n_rows else \
+            self.torch.empty((0, d.n_cols), dtype=self.torch.float32, device=self.device)
+        return d, y, cap
+
+    def dense_finish(self, d, inflation, pruning):
+        """the rows finished from the completed block: (pruned rows, products, nnz of the expanded rows)"""
+        self.torch.cuda.current_stream(self.device).synchronize()
+        p = d.inflate_prune(inflation, pruning)
+        out = (p, d.n_products, d.nnz_expanded)
+        d.free()
+        return out
+
     def convergence_stat(self, m, last):
         return _lib.convergence_stat(m, last)
 
@@ -331,6 +351,70 @@ def allgather_rows(engine, local, n_cols, dist):
     return exchange_rows(engine, local, n_cols, dist)[0]
 
 
+SYMMETRIC_HALF = True          # tests switch it off to compare the two multi-rank paths
+
+
+def symmetric_window(engine, n):
+    """columns per window of the expansion's plan for an order-n matrix (the library's own rule: the fewest windows whose 8-byte
+    accumulators fit the 160 KB of LDS; hhx_expand.hip) — only the balance of the row blocks depends on it"""
+    cap_max = ((160 * 1024 - 784) // 8) & ~63                    # 784: the window kernel's scratch slots and reduction arrays
+    n_win = -(-n // cap_max)
+    return (-(-n // n_win) + 63) & ~63
+
+
+def upper_cost(products, cap):
+    """cost of a row in the symmetric iteration 0: its products in the column windows J >= its own block — estimated as the
+    share of the columns right of the block start (the link matrix has no column structure a row block could exploit)"""
+    products = np.asarray(products, np.float64)
+    n = len(products)
+    start = (np.arange(n, dtype=np.int64) // cap) * cap
+    return np.maximum(1, products * (n - start) / max(n, 1)).astype(np.int64)
+
+
+def expand_links_symmetric(engine, links_full, bounds, inflation, pruning, dist):
+    """Iteration 0 of mcl() on the raw link matrix with the SYMMETRIC HALF shared out over the ranks: S = L D^-1 L
+    is an exactly symmetric integer matrix, so rank r fills only the blocks (I, J >= I) of ITS rows [bounds[r], bounds[r + 1]) of
+    Y = float(S) — 60 % of their products at five column windows — and the ranks hand each other the mirror image:
+      * rank s sends the rectangle Y[rows of s][columns = rows of r] to every rank r > s (ONE all-to-all(v) of float32; every
+        entry of such a rectangle lies right of its row's own block, so s has computed it); r stores its transpose;
+      * what mirrors inside a rank's own rows (block pairs I < J both cut by the row range) is transposed locally.
+    Entries that both sides computed (the diagonal blocks) are bit-identical, so overwriting them is harmless.  Then the dense
+    epilogue finishes the rows — the same bits as the one-GPU call.  Returns (pruned rows of this rank, products, nnz of M^2)."""
+    torch = engine.torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    d, y, cap = engine.dense_upper(links_full, r0, r1)
+    n_loc = r1 - r0
+    # mirror inside the own rows: for the blocks I < J that both meet [r0, r1)
+    if n_loc:
+        cuts = sorted({r0, r1} | {c for c in range((r0 // cap + 1) * cap, r1, cap)})
+        segs = list(zip(cuts[:-1], cuts[1:]))                    # the row range cut at the block boundaries
+        for a in range(len(segs)):
+            for b_ in range(a + 1, len(segs)):
+                (ia, ib), (ja, jb) = segs[a], segs[b_]
+                y[ja - r0:jb - r0, ia:ib] = y[ia - r0:ib - r0, ja:jb].t()
+    # the rectangles for the ranks above, laid out by destination
+    send_counts = [0] * world
+    pieces = []
+    for r in range(rank + 1, world):
+        c0, c1 = bounds[r], bounds[r + 1]
+        if n_loc and c1 > c0:
+            pieces.append(y[:, c0:c1].contiguous().view(-1))
+            send_counts[r] = n_loc * (c1 - c0)
+    send = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.float32, device=y.device)
+    got, recv_counts = _all_to_all_var(send, send_counts, dist, torch)
+    at = 0
+    for s_ in range(world):
+        k = recv_counts[s_]
+        if k:
+            rows_s = bounds[s_ + 1] - bounds[s_]
+            assert s_ < rank and k == rows_s * n_loc
+            y[:, bounds[s_]:bounds[s_ + 1]] = got[at:at + k].view(rows_s, n_loc).t()
+            at += k
+    del got, send, pieces
+    return engine.dense_finish(d, inflation, pruning)
+
+
 REPLICATE_NNZ = 4_000_000      # below this many entries the iterations are cheaper than their collectives: every rank runs them whole
 
 
@@ -365,7 +449,15 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
         # Every rank holds the whole raw matrix now, so the MCL row blocks need not be the build's: they are cut at
         # equal PRODUCT counts of iteration 0.  Equal row counts are not balanced: a contig's matrix
         # index is its first-seen rank in the pair stream, and heavily linked contigs are seen first.
-        b = balanced_ranges(engine.row_products(links_full, links_full), world)
+        products = engine.row_products(links_full, links_full)
+        # the symmetric half across the ranks when the engine has it and the integer arithmetic applies (every rank decides the same:
+        # the matrix is the same); the rows are then balanced by their products right of their own block
+        symmetric = world > 1 and expansion == 2 and hasattr(engine, 'dense_upper') and engine.links_integer_ok(links_full) and SYMMETRIC_HALF
+        if symmetric:
+            _lib_cap = symmetric_window(engine, n)
+            b = balanced_ranges(upper_cost(products, _lib_cap), world)
+        else:
+            b = balanced_ranges(products, world)
         r0, r1 = b[rank], b[rank + 1]
         cur_local = engine.normalize_l1(engine.row_block(links_full, r0, r1))
     else:
@@ -388,7 +480,9 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
                 engine.free(run)
             run = nxt
         if expansion > 1:
-            if links_full is not None:
+            if links_full is not None and symmetric:
+                p, f, st_c = expand_links_symmetric(engine, links_full, b, inflation, pruning, dist)   # iteration 0 on the symmetric half
+            elif links_full is not None:
                 p, f, st_c = engine.expand_links(links_full, r0, r1, inflation, pruning)       # iteration 0, class stream
             else:
                 p, f, st_c = engine.expand_inflate_prune(run, cur_full, inflation, pruning)   # :2030-2042 fused

@@ -147,8 +147,13 @@ int hhx_mcl_normalized(const hhx_csr *normalized, int expansion, double inflatio
  * mcl() (:2037-2042: power, normalise, prune, restore the maximum, normalise) of those rows at one inflation, bit for bit what
  * hhx_mcl_links computes in its first iteration; stack the blocks (hhx_csr_vstack) and continue with hhx_mcl_resume(done = 1). */
 typedef struct hhx_dense hhx_dense;
-int hhx_expand_links_dense(const hhx_csr *links, int32_t r0, int32_t r1, int fx_shift, hhx_dense **out, int64_t *n_products,
-                           int64_t *nnz_expanded);
+/* upper_only = 1 (integer arithmetic only): fill just the blocks (I, J >= I) of the rows — 60 % of their products — and leave the
+ * columns left of a row's own block to the caller, who owns the mirror image: the ranks of the multi-GPU driver exchange them
+ * (hhx_dense_device gives the block and its column-window plan).  hhx_links_integer_ok says whether the arithmetic applies. */
+int hhx_expand_links_dense(const hhx_csr *links, int32_t r0, int32_t r1, int fx_shift, int upper_only, hhx_dense **out,
+                           int64_t *n_products, int64_t *nnz_expanded);
+int hhx_links_integer_ok(const hhx_csr *links, int *ok, int *shift);
+int hhx_dense_device(const hhx_dense *d, void **x_dev, int32_t *cap_win, int32_t *n_win);
 int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, double pruning, hhx_csr **out);
 int hhx_dense_shape(const hhx_dense *d, int32_t *n_rows, int32_t *n_cols, int64_t *bytes);
 int hhx_dense_free(hhx_dense *d);

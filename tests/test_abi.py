@@ -52,7 +52,7 @@ def test_new_bindings_marshal_and_reject_null_handles():
     o, f, z = _lib.C.c_void_p(), _lib.C.c_int64(0), _lib.C.c_int64(0)
     assert L.hhx_expand_links(None, 0, 0, 52, 2.0, 1e-4, _lib.C.byref(o), _lib.C.byref(f), _lib.C.byref(z)) != 0
     d = _lib.C.c_void_p()
-    assert L.hhx_expand_links_dense(None, 0, 0, 52, _lib.C.byref(d), _lib.C.byref(f), _lib.C.byref(z)) != 0
+    assert L.hhx_expand_links_dense(None, 0, 0, 52, 0, _lib.C.byref(d), _lib.C.byref(f), _lib.C.byref(z)) != 0
     assert L.hhx_dense_inflate_prune(None, 2.0, 1e-4, _lib.C.byref(o)) != 0 and L.hhx_dense_free(None) == 0
     assert L.hhx_csr_pack_block(None, None, 0) != 0
     assert L.hhx_tune(b'cls', 1) == 0
