@@ -351,6 +351,11 @@ def allgather_rows(engine, local, n_cols, dist):
     return exchange_rows(engine, local, n_cols, dist)[0]
 
 
+# Iteration 0 on the symmetric half across ranks trades 0.4 F / N products per rank (187 / N ms at C3) for an exchange of
+# n^2 * 4 B / N^2 per peer pair (10 GB at N = 2, 2.5 GB at 4, 0.6 GB at 8: ~156 / 39 / 10 ms at ~64 GB/s per xGMI link and
+# direction, the links of a rank running side by side): by that model it pays from 8 ranks on, is a wash at 4 and loses at 2 —
+# so it is on from SYMMETRIC_MIN_WORLD ranks (to be re-set from the first measured SCALE run; tests lower it to 2).
+SYMMETRIC_MIN_WORLD = 8
 SYMMETRIC_HALF = True          # tests switch it off to compare the two multi-rank paths
 
 
@@ -452,7 +457,8 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
         products = engine.row_products(links_full, links_full)
         # the symmetric half across the ranks when the engine has it and the integer arithmetic applies (every rank decides the same:
         # the matrix is the same); the rows are then balanced by their products right of their own block
-        symmetric = world > 1 and expansion == 2 and hasattr(engine, 'dense_upper') and engine.links_integer_ok(links_full) and SYMMETRIC_HALF
+        symmetric = (world >= SYMMETRIC_MIN_WORLD and SYMMETRIC_HALF and expansion == 2 and hasattr(engine, 'dense_upper')
+                     and engine.links_integer_ok(links_full))
         if symmetric:
             _lib_cap = symmetric_window(engine, n)
             b = balanced_ranges(upper_cost(products, _lib_cap), world)

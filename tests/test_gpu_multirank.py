@@ -53,6 +53,7 @@ def _worker(rank, world, port, q):
         from haphic_amd import _lib, sharded
         gen, table, pairs = _setup()
         hd = sharded.HostStagedCollectives(dist)
+        sharded.SYMMETRIC_MIN_WORLD = 2                  # (on from 8 ranks by default: the bandwidth model of sharded.py)
         cuts = _cuts(PAIRS, world)
         lo, hi = cuts[rank], cuts[rank + 1]
         ing = _lib.Ingest(table, 500_000, bins=False, skip_intra=True)
