@@ -7,7 +7,7 @@
      same iteration count, same clusters, final matrix within 1e-6; entries kept by one and pruned by the other are counted.
   C3 (configs[2], 100k contigs / 500 M pairs): the fused iteration 0 — the kernel instantiation the roofline is quoted on
      (5 column windows, the class stream) — against the oracle on 2048 rows of the real operand stratified by product
-     count; ingest parity on a 20 M-pair prefix against the full 100k-contig table; THE WHOLE mcl(): the oracle picks the
+     count; THE WHOLE INGEST (all 500 M pairs) and dict_to_matrix bit exact against the oracle; THE WHOLE mcl(): the oracle picks the
      loop up from the device's (sample-verified) iteration-0 output and runs it to convergence — iteration count,
      convergence flag, survivors per iteration, final pattern + values and the cluster sets must be bit equal; the same
      tail in float32 accumulation (mode 0) must end in the same clusters and a final matrix within 1e-6.
@@ -175,15 +175,32 @@ def test_c3_iteration0_sampled_rows_and_ingest_prefix():
         assert np.array_equal(got[k], ref[k]), 'C3 ingest (20 M-pair prefix) differs: ' + k
     pre_ing.destroy()
     del got, ref
-    # the real operand: all 500 M pairs
+    # the real operand: all 500 M pairs — and THE WHOLE INGEST against the oracle (the scalar C port of the reference loop walks the
+    # 500 M pairs in ~90 s): every table, bit for bit, then dict_to_matrix's triple and index map
     ing = _lib.Ingest(t, 500_000, bins=False, skip_intra=True)
     ing.push_device(P, *[x.data_ptr() for x in dev])
     torch.cuda.synchronize()
     ing.finalize()
+    h = _host(dev)
     del dev
     torch.cuda.empty_cache()
+    ref = _oracle_ingest(t, h)
+    del h
+    got = ing.fetch()
+    for k in TABLES:
+        assert np.array_equal(got[k], ref[k]), 'C3 ingest (all 500 M pairs) differs: ' + k
+    del got
     m, fidx, n_linked = ing.link_matrix(np.ones(n, np.uint8))
     ing.destroy()
+    linked = np.zeros(n, bool)
+    linked[ref['flank_i']] = True
+    linked[ref['flank_j']] = True
+    rp, rj, rx, ridx, rl = orc.dict_to_matrix(ref['flank_i'], ref['flank_j'], ref['flank_cnt'].astype(np.float64), n, np.ones(n, np.uint8),
+                                             int(n - linked.sum()))
+    del ref
+    assert n_linked == rl and np.array_equal(fidx, ridx), 'C3 dict_to_matrix: index map'
+    assert all(np.array_equal(u, v) for u, v in zip(m.to_arrays(), (rp, rj, rx))), 'C3 dict_to_matrix: CSR triple'
+    del rp, rj, rx
     assert m.shape3[0] > 99_000 and m.nnz > 300_000_000
     n = m.shape3[0]
     # the whole mcl() as bench.py times it (normalisation + pre-expansion fused into iteration 0, class stream)
