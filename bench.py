@@ -527,8 +527,8 @@ def parity_leg(args, m, rows=64):
             'specification': 'integer (S = L D^-1 L exact, orc_expand_links)' if integer else 'fixed point 2^-52 (orc_spgemm mode 1)',
             'iteration1_hash_class': {'rows_checked': int(len(rows1)), 'rows_differing': int(bad1), 'bit_identical': bad1 == 0, 'products_checked': prod1},
             'oracle_threads': orc.get_threads(), 'seconds': time.perf_counter() - t0,
-            'full_size_tests': 'tests/test_gpu_scale.py: C2 whole mcl() bit equal; C3 2k stratified rows of iteration 0 + the whole tail continued by the '
-                               'oracle to convergence, bit equal; C5 (4 pushes) sampled rows + cross-push ingest prefix; C4 40k-contig containers'}
+            'full_size_tests': 'tests/test_gpu_scale.py: C2 whole ingest + mcl() bit equal; C3 whole ingest (500 M pairs) + dict_to_matrix, 2k stratified rows of '
+                               'iteration 0 + the whole tail continued by the oracle to convergence, bit equal; C5 (4 pushes) sampled rows + cross-push ingest prefix; C4 40k-contig containers'}
 
 
 def pmc_traffic(n_contigs, pairs):

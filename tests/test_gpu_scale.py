@@ -155,7 +155,7 @@ def test_c2_full_size_against_oracle():
     np.testing.assert_allclose(gx, o0[2], rtol=1e-6, atol=0)
 
 
-def test_c3_iteration0_sampled_rows_and_ingest_prefix():
+def test_c3_whole_ingest_and_whole_mcl_against_oracle():
     import torch
     from haphic_amd import _lib, synth
     gen = synth.make_genome(24, (100_000 // 24) * 30_000, 30_000, seed=12345)   # bench.py defaults
