@@ -1784,7 +1784,10 @@ int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const hhx_links_op
             c.W = lk->W; c.shift = lk->shift; c.a16 = lk->n16 + lk->a_off; c.a_row_sum = lk->row_sum + lk->a_row0;
             c.sym = lk->sym; c.sym_row0 = lk->a_row0;
             if (d->row_div.alloc((size_t)a->n_rows + 1)) { delete d; return 1; }
-            if (a->n_rows) HHX_HIP(hipMemcpyAsync(d->row_div.p, c.a_row_sum, sizeof(double) * (size_t)a->n_rows, hipMemcpyDeviceToDevice, g_stream));
+            if (a->n_rows && hipMemcpyAsync(d->row_div.p, c.a_row_sum, sizeof(double) * (size_t)a->n_rows, hipMemcpyDeviceToDevice, g_stream) != hipSuccess) {
+                delete d;
+                return fail("hhx_expand_dense_impl: copy of the row sums failed");
+            }
             d->integer = true;
         }
     }
