@@ -1775,7 +1775,7 @@ int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const hhx_links_op
     if (!a || !b || !out) return fail("null pointer");
     hhx_dense *d = new hhx_dense();
     d->n_rows = a->n_rows; d->n_cols = b->n_cols;
-    if (d->x.alloc((size_t)a->n_rows * (size_t)b->n_cols + 1)) { delete d; return 1; }
+    if (d->x.alloc((size_t)a->n_rows * (size_t)b->n_cols + 1)) { delete d; return 2; }      // 2: the block itself does not fit (callers may fall back)
     CodedOperand c;
     c.dense_out = d->x.p;
     if (lk) {

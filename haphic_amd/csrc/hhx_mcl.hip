@@ -500,10 +500,13 @@ static int expand_links_iteration0(const hhx_csr *norm, const NormalisedLinks &n
         if (need * 2.0 + 4e9 < (double)free_b + (double)pool_cached_bytes()) {       // the block + room for the operand stream and the pools
             const hhx_links_operand lk = nl.operand(0, 0, 1);
             hhx_dense *d = nullptr;
-            HHX_TRY(hhx_expand_dense_impl(norm, norm, &lk, HHX_MCL_FX_SHIFT, &d, n_products, nnz_expanded));
-            const int rc = hhx_dense_inflate_prune(d, inflation, pruning, out);
-            hhx_dense_free(d);
-            return rc;
+            const int rc_d = hhx_expand_dense_impl(norm, norm, &lk, HHX_MCL_FX_SHIFT, &d, n_products, nnz_expanded);
+            if (rc_d == 0) {
+                const int rc = hhx_dense_inflate_prune(d, inflation, pruning, out);
+                hhx_dense_free(d);
+                return rc;
+            }
+            if (rc_d != 2) return rc_d;              // 2: the dense block could not be allocated after all — every row walks all its products
         }
     }
     const hhx_links_operand lk = nl.operand();

@@ -700,6 +700,63 @@ def test_mcl_links_class_stream_iteration0():
     assert (n3, c3) == (n4, c4) and all(np.array_equal(x, y) for x, y in zip(r3.to_arrays(), r4.to_arrays()))
 
 
+def test_integer_arithmetic_applicability():
+    """hhx_mcl_links takes the integer arithmetic only where its specification applies — symmetric integer counts, row sums up to
+    2^18 — and the float arithmetic (bit-identical to hhx_normalize_l1 + hhx_mcl_normalized) everywhere else; the device's
+    decision is the oracle's (orc.links_shift)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    n = 3000
+    a = sp.random(n, n, 0.01, random_state=5, format='coo')
+    cnt = rng.geometric(0.4, size=a.nnz).astype(np.float32)
+    base = sp.coo_matrix((cnt, (a.row, a.col)), shape=(n, n)).tocsr()
+    sym = (base + base.T + sp.identity(n, dtype=np.float32, format='csr')).tocsr()
+    sym.sort_indices()
+
+    def triple(m):
+        m = m.tocsr()
+        m.sort_indices()
+        return m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32)
+
+    def links_equal_normalized(L):
+        d = _lib.DeviceCSR.from_arrays(*L)
+        r1, n1, c1 = _lib.mcl(d, 2, 2.0, 60, 1e-4, links=True)
+        nn = d.copy()
+        _lib.normalize_l1(nn)
+        r2, n2, c2 = _lib.mcl(nn, 2, 2.0, 60, 1e-4, normalized=True)
+        same = (n1, c1) == (n2, c2) and all(np.array_equal(x, y) for x, y in zip(r1.to_arrays(), r2.to_arrays()))
+        for x in (r1, r2, nn, d):
+            x.free()
+        return same
+    cases = {}
+    cases['symmetric'] = triple(sym)
+    asym = sym.tolil()
+    asym[5, 9] = asym[5, 9] + 3                                  # one count differs from its mirror image
+    cases['asymmetric'] = triple(asym.tocsr())
+    heavy = sym.tolil()
+    for k in range(1, 7):                                        # a row sum beyond 2^18 (symmetric, counts <= 65535)
+        heavy[0, k] = 60000
+        heavy[k, 0] = 60000
+    cases['heavy row'] = triple(heavy.tocsr())
+    for name, L in cases.items():
+        d = _lib.DeviceCSR.from_arrays(*L)
+        ok = _lib.links_integer_ok(d)
+        d.free()
+        assert ok == (name == 'symmetric'), name
+        if name != 'asymmetric':                                 # (the oracle's rule looks at the values only; symmetry is the caller's)
+            assert (orc.links_shift(L) > 0) == ok, name
+        if not ok:
+            assert links_equal_normalized(L), name + ': the float arithmetic must be the two-call path, bit for bit'
+    # where it applies: the oracle's integer pre-expansion, bit for bit, through the whole mcl()
+    L = cases['symmetric']
+    d = _lib.DeviceCSR.from_arrays(*L)
+    r, n_it, cv = _lib.mcl(d, 2, 2.0, 60, 1e-4, links=True)
+    o = orc.mcl(orc.expand_links(L), 2, 2.0, 60, 1e-4, spgemm_mode=1, fx_shift=52)
+    assert (n_it, cv) == (o[3], o[4]) and all(np.array_equal(x, y) for x, y in zip(r.to_arrays(), o[:3]))
+    r.free()
+    d.free()
+
+
 def test_dense_sweep_equals_fused_iteration0():
     """The inflation sweep with one expansion (hhx_expand_links_dense + hhx_dense_inflate_prune): rows of M^2 stored once as
     float32, iteration 0 of every inflation from them — bit for bit the first iteration of hhx_mcl_links at that inflation, with
