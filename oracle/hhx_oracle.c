@@ -166,7 +166,13 @@ int orc_links_shift(i32 n, const i32 *Lp, const float *Lx, double *d_out) {
     return shift - lg >= 24 ? shift : -1;
 }
 
+i64 orc_expand_links_ex(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i32 n_rows, const i32 *rows, i32 *Cp, i32 *Cj, float *Cx, int divide);
 i64 orc_expand_links(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i32 n_rows, const i32 *rows, i32 *Cp, i32 *Cj, float *Cx) {
+    return orc_expand_links_ex(n, Lp, Lj, Lx, n_rows, rows, Cp, Cj, Cx, 1);
+}
+/* divide == 0: the values are y_ij = float(S_ij), the symmetric matrix itself (what the kernels keep in their dense block and what
+ * the ranks of the multi-GPU driver hand each other), without the final division by d_i */
+i64 orc_expand_links_ex(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i32 n_rows, const i32 *rows, i32 *Cp, i32 *Cj, float *Cx, int divide) {
     double *d = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
     const int shift = orc_links_shift(n, Lp, Lx, d);
     if (shift < 0) { free(d); return -2; }
@@ -202,7 +208,7 @@ i64 orc_expand_links(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i32 n
                     for (i32 c = 0; c < cnt; ++c) {
                         const float y = (float)((double)acc[cols[c]] * inv);
                         Cj[base + c] = cols[c];
-                        Cx[base + c] = (float)((double)y / d[i]);
+                        Cx[base + c] = divide ? (float)((double)y / d[i]) : y;
                     }
                 }
                 for (i32 c = 0; c < cnt; ++c) mark[cols[c]] = -1;

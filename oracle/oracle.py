@@ -44,6 +44,8 @@ def lib():
         L.orc_spgemm.restype = C.c_int64
         L.orc_expand_links.argtypes = [C.c_int32, _i32p, _i32p, _f32p, C.c_int32, C.c_void_p, _i32p, C.c_void_p, C.c_void_p]
         L.orc_expand_links.restype = C.c_int64
+        L.orc_expand_links_ex.argtypes = L.orc_expand_links.argtypes + [C.c_int]
+        L.orc_expand_links_ex.restype = C.c_int64
         L.orc_links_shift.argtypes = [C.c_int32, _i32p, _f32p, C.c_void_p]
         L.orc_links_shift.restype = C.c_int
         L.orc_set_threads.argtypes = [C.c_int]
@@ -132,9 +134,10 @@ def links_shift(L):
     return int(lib().orc_links_shift(len(lp) - 1, lp, lx, None))
 
 
-def expand_links(L, rows=None):
+def expand_links(L, rows=None, divide=True):
     """run_mcl_clustering :2144-2147 on the RAW link matrix L (integer counts, symmetric): the rows `rows` (all if None) of
     the pre-expanded matrix M^2, M = L1-normalised L, in the kernels' integer specification (hhx_oracle.c: orc_expand_links).
+    divide=False: the values are y = float(S_ij) of the symmetric matrix S = L D^-1 L, without the final division by d_i.
     Returns the CSR triple (indptr over the selected rows, columns, values)."""
     lp, lj, lx = _csr(*L)
     n = len(lp) - 1
@@ -144,12 +147,12 @@ def expand_links(L, rows=None):
         rows = np.ascontiguousarray(rows, np.int32)
         n_rows, rp = len(rows), rows.ctypes.data
     cp = np.zeros(n_rows + 1, np.int32)
-    nnz = lib().orc_expand_links(n, lp, lj, lx, n_rows, rp, cp, None, None)
+    nnz = lib().orc_expand_links_ex(n, lp, lj, lx, n_rows, rp, cp, None, None, int(bool(divide)))
     if nnz == -2:
         raise ValueError('the integer specification does not apply to this matrix (row sums beyond 2^18, zero rows or non-integer values)')
     cj = np.zeros(max(nnz, 1), np.int32)
     cx = np.zeros(max(nnz, 1), np.float32)
-    lib().orc_expand_links(n, lp, lj, lx, n_rows, rp, cp, cj.ctypes.data, cx.ctypes.data)
+    lib().orc_expand_links_ex(n, lp, lj, lx, n_rows, rp, cp, cj.ctypes.data, cx.ctypes.data, int(bool(divide)))
     return cp, cj[:nnz], cx[:nnz]
 
 

@@ -72,6 +72,36 @@ class OracleEngine:
     def convergence_stat(self, m, last):
         return orc.convergence_stat(m, last)
 
+    # ---- the symmetric half across ranks (sharded.expand_links_symmetric): numpy stand-ins of hhx_expand_links_dense(upper_only) and
+    # hhx_dense_inflate_prune.  CAP columns per window (a small number, so that the row blocks of the test cut several windows)
+    CAP = 64
+
+    def links_integer_ok(self, links):
+        return orc.links_shift(links) > 0
+
+    def dense_upper(self, links, r0, r1):
+        self.upper_calls = getattr(self, 'upper_calls', 0) + 1
+        n = len(links[0]) - 1
+        y = orc.expand_links(links, rows=np.arange(r0, r1, dtype=np.int32), divide=False)
+        dense = np.zeros((r1 - r0, n), np.float32)
+        rows = np.repeat(np.arange(r1 - r0), np.diff(y[0]))
+        dense[rows, y[1]] = y[2]
+        for i in range(r0, r1):                                  # what upper_only leaves unwritten: the columns left of the row's own block
+            dense[i - r0, :(i // self.CAP) * self.CAP] = np.nan
+        sums = np.add.reduceat(links[2].astype(np.float64), links[0][:-1])
+        yt = torch.from_numpy(dense)
+        return {'y': yt, 'd': sums[r0:r1], 'f': int(np.diff(links[0])[links[1][links[0][r0]:links[0][r1]]].sum())}, yt, self.CAP
+
+    def dense_finish(self, h, inflation, pruning):
+        y = h['y'].numpy()
+        assert not np.isnan(y).any(), 'a part of the block was never mirrored'
+        x = (y.astype(np.float64) / h['d'][:, None]).astype(np.float32)
+        rows, cols = np.nonzero(y)
+        p = np.zeros(y.shape[0] + 1, np.int32)
+        p[1:] = np.cumsum(np.bincount(rows, minlength=y.shape[0]))
+        c = (p, cols.astype(np.int32), x[rows, cols])
+        return self.inflate_prune(c, inflation, pruning), h['f'], int(p[-1])
+
     def mcl_resume(self, m, done, expansion, inflation, iters, pruning):
         """mcl() :2026-2062 from iteration `done` on the whole matrix (hhx_mcl_resume)"""
         cur, n_iter, conv, stats = m, done, False, []
@@ -210,6 +240,22 @@ def _worker(rank, world, port, q):
         # the same from the RAW row blocks (all-gathered once, iteration 0 through expand_links): identical results
         res3, n_iter3, conv3, _st3 = sharded.mcl_sharded_engine(eng, None, 2, 2.0, 100, 1e-4, dist, local_links=block, n=shape)
         assert (n_iter3, conv3) == (n_iter2, conv2) and all(np.array_equal(x, y) for x, y in zip(res3, res2))
+        # ... and with iteration 0 on the SYMMETRIC HALF shared out over the ranks (each rank fills the upper blocks of its rows, one
+        # all-to-all(v) mirrors them): the integer specification of the pre-expansion, so the reference run is the oracle's own
+        sharded.SYMMETRIC_MIN_WORLD = 2
+        old_window = sharded.symmetric_window
+        sharded.symmetric_window = lambda engine, n_: OracleEngine.CAP
+        try:
+            eng.upper_calls = 0
+            res4, n_iter4, conv4, st4 = sharded.mcl_sharded_engine(eng, None, 2, 2.0, 100, 1e-4, dist, local_links=block, n=shape)
+            assert eng.upper_calls == 1, 'the symmetric path was not taken'
+        finally:
+            sharded.symmetric_window = old_window
+            sharded.SYMMETRIC_MIN_WORLD = 8
+        full_links = sharded.allgather_rows(eng, block, shape, dist)
+        o4 = orc.mcl(orc.expand_links(full_links), 2, 2.0, 100, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True)
+        assert (n_iter4, conv4) == (o4[3], o4[4]) and all(np.array_equal(x, y) for x, y in zip(res4, o4[:3])), 'symmetric half across ranks'
+        assert np.array_equal(np.asarray(st4)[1:, 1:], o4[5][1:, 1:]) and np.array_equal(np.asarray(st4)[0, 1:3], o4[5][0, 1:3])
         built = (block, fi, n_linked, shape, res2, n_iter2, conv2)
         sweep = sharded.inflation_sweep(lambda infl: (round(infl * 10), rank), [1.2, 1.4, 1.6, 1.8, 2.0], dist)
         q.put((rank, res, n_iter, conv, stats, merged, sweep, built))
