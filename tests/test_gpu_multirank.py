@@ -13,7 +13,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CONTIGS_PER_CHR, NCHRS, MEAN, PAIRS = 624, 16, 50_000, 50_000_000
+C2 = (624, 16, 50_000, 50_000_000)                 # BASELINE configs[1]: one column window
+WIDE = (3000, 8, 20_000, 20_000_000)               # 24k contigs: TWO column windows, the row blocks of the ranks cut them
 
 
 def _free_port():
@@ -30,20 +31,21 @@ def _cuts(n, world):
     return c
 
 
-def _setup():
+def _setup(cfg):
     import torch
     from haphic_amd import _lib, synth
     from haphic_amd.cluster import FragTable
+    per_chr, nchrs, mean, n_pairs = cfg
     torch.cuda.set_device(0)
     _lib.check(_lib.load().hhx_set_device(0))
-    gen = synth.make_genome(NCHRS, CONTIGS_PER_CHR * MEAN, MEAN, seed=12345)
+    gen = synth.make_genome(nchrs, per_chr * mean, mean, seed=12345)
     table = FragTable.for_contigs(gen.lexical_rank(), gen.length, np.ones(gen.n, np.uint8))
-    pairs = synth.sample_pairs(gen, PAIRS, seed=12345, device='cuda:0')         # the SAME stream in every process
+    pairs = synth.sample_pairs(gen, n_pairs, seed=12345, device='cuda:0')       # the SAME stream in every process
     torch.cuda.synchronize()
     return gen, table, pairs
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, cfg):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch
@@ -51,7 +53,8 @@ def _worker(rank, world, port, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from haphic_amd import _lib, sharded
-        gen, table, pairs = _setup()
+        gen, table, pairs = _setup(cfg)
+        PAIRS = cfg[3]
         hd = sharded.HostStagedCollectives(dist)
         sharded.SYMMETRIC_MIN_WORLD = 2                  # (on from 8 ranks by default: the bandwidth model of sharded.py)
         cuts = _cuts(PAIRS, world)
@@ -85,12 +88,13 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(400)
-@pytest.mark.parametrize('world', [2, 3])
-def test_hip_engine_under_several_ranks_on_one_gpu(world):
+@pytest.mark.parametrize('world,cfg', [(2, C2), (3, C2), (3, WIDE), (2, WIDE)])
+def test_hip_engine_under_several_ranks_on_one_gpu(world, cfg):
     import torch
     import torch.multiprocessing as mp
     from haphic_amd import _lib
-    gen, table, pairs = _setup()
+    gen, table, pairs = _setup(cfg)
+    PAIRS = cfg[3]
     one = _lib.Ingest(table, 500_000, bins=False, skip_intra=True)
     one.push_device(PAIRS, *[x.data_ptr() for x in pairs])
     torch.cuda.synchronize()
@@ -108,7 +112,7 @@ def test_hip_engine_under_several_ranks_on_one_gpu(world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, cfg)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
