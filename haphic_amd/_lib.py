@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, 'libhaphic_hip.so')
+SO_PATH = os.environ.get('HAPHIC_HIP_SO') or os.path.join(_HERE, 'libhaphic_hip.so')      # (the override: the sanitizer build of build.build_asan)
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)

@@ -44,5 +44,28 @@ def build(force=False, verbose=False):
     return SO
 
 
+ASAN_SO = os.path.join(HERE, 'libhaphic_hip_asan.so')
+
+
+def asan_runtime():
+    """clang's shared AddressSanitizer runtime (to LD_PRELOAD under python)"""
+    hits = glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so')
+    return hits[0] if hits else None
+
+
+def build_asan(verbose=False):
+    """The HOST side of the library under AddressSanitizer (the C-ABI layer is hand-written C++ — handle lifetimes, staging
+    buffers, host vectors of the BAM / interpret / merge code); the device code is compiled as usual.  Run with
+      LD_PRELOAD=$(python -c 'from haphic_amd import build; print(build.asan_runtime())') ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 \
+      HAPHIC_HIP_SO=haphic_amd/libhaphic_hip_asan.so python -m pytest tests -m gpu ...      (tools/gpu_pass.sh asan)"""
+    flags = [f for f in FLAGS if f != '-O3'] + ['-O1', '-g', '-fno-omit-frame-pointer', '-fsanitize=address', '-shared-libasan', '-Wno-option-ignored']
+    cmd = [HIPCC] + flags + sources() + ['-lz', '-lpthread', '-o', ASAN_SO]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return ASAN_SO
+
+
 if __name__ == '__main__':
-    print(build(force=True, verbose=True))
+    import sys
+    print(build_asan(verbose=True) if 'asan' in sys.argv[1:] else build(force=True, verbose=True))

@@ -45,6 +45,11 @@ for l in open('gpurun_out/bench_text.log'):
     rccl) timeout 600 python tools/rccl_probe.py > gpurun_out/rccl_probe.jsonl 2> gpurun_out/rccl_probe.err; echo "rccl rc=$?"; cat gpurun_out/rccl_probe.jsonl; tail -3 gpurun_out/rccl_probe.err;;
     host2) timeout 900 python bench.py --gpus 2 --transport host --contigs 10000 --pairs 50000000 --nchrs 16 --mean-len 50000 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_host2.log 2>&1; echo "host2 rc=$?"; python tools/bench_brief.py gpurun_out/bench_host2.log; tail -3 gpurun_out/bench_host2.log | cut -c1-400;;
     c5) timeout 1500 python bench.py --contigs 200000 --pairs 2000000000 --pushes 4 --steps 1 --warmup 1 --no-cpu-baseline --text-lines 0 --sweep 0 > gpurun_out/bench_c5.log 2>&1; echo "c5 rc=$?"; python tools/bench_brief.py gpurun_out/bench_c5.log; tail -2 gpurun_out/bench_c5.log | cut -c1-300;;
+    asan) # the host side of the library under AddressSanitizer (haphic_amd/build.py build_asan), a subset of the gpu tests
+        RT=$(python -c "from haphic_amd import build; print(build.asan_runtime())")
+        LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:verify_asan_link_order=0:halt_on_error=1 HAPHIC_HIP_SO=haphic_amd/libhaphic_hip_asan.so \
+          timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py tests/test_bam.py tests/test_plot.py -m gpu -q -x -p no:cacheprovider > gpurun_out/pytest_asan.log 2>&1
+        echo "asan rc=$?"; grep -E "passed|failed|ERROR: AddressSanitizer|SUMMARY" gpurun_out/pytest_asan.log | tail -5; tail -3 gpurun_out/pytest_asan.log | cut -c1-300;;
     listpmc) rocprofv3 -L > gpurun_out/pmc_list.txt 2>&1; grep -c . gpurun_out/pmc_list.txt;;
     env:*) export "${what#env:}"; echo "set ${what#env:}";;
     *) echo "unknown $what";;
