@@ -48,9 +48,11 @@ ASAN_SO = os.path.join(HERE, 'libhaphic_hip_asan.so')
 
 
 def asan_runtime():
-    """clang's shared AddressSanitizer runtime (to LD_PRELOAD under python)"""
-    hits = glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so')
-    return hits[0] if hits else None
+    """the AddressSanitizer runtime to LD_PRELOAD under python: GCC's libasan.  (ROCm clang's own runtime intercepts
+    hsa_amd_memory_pool_allocate for xnack+ device sanitizing and aborts the HIP runtime of an xnack- process at its first pool;
+    GCC 11's speaks the same instrumentation ABI, the three helpers it lacks are in csrc/asan_shim.cpp.)"""
+    out = subprocess.run(['gcc', '-print-file-name=libasan.so'], capture_output=True, text=True).stdout.strip()
+    return os.path.realpath(out) if out and os.path.exists(out) else None
 
 
 def build_asan(verbose=False):
@@ -58,8 +60,8 @@ def build_asan(verbose=False):
     buffers, host vectors of the BAM / interpret / merge code); the device code is compiled as usual.  Run with
       LD_PRELOAD=$(python -c 'from haphic_amd import build; print(build.asan_runtime())') ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 \
       HAPHIC_HIP_SO=haphic_amd/libhaphic_hip_asan.so python -m pytest tests -m gpu ...      (tools/gpu_pass.sh asan)"""
-    flags = [f for f in FLAGS if f != '-O3'] + ['-O1', '-g', '-fno-omit-frame-pointer', '-fsanitize=address', '-shared-libasan', '-Wno-option-ignored']
-    cmd = [HIPCC] + flags + sources() + ['-lz', '-lpthread', '-o', ASAN_SO]
+    flags = [f for f in FLAGS if f != '-O3'] + ['-O1', '-g', '-fno-omit-frame-pointer', '-fsanitize=address', '-Wno-option-ignored']
+    cmd = [HIPCC] + flags + sources() + [os.path.join(CSRC, 'asan_shim.cpp'), '-lz', '-lpthread', '-o', ASAN_SO]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
