@@ -88,7 +88,7 @@ def _worker(rank, world, port, q, cfg):
 
 
 @pytest.mark.timeout(400)
-@pytest.mark.parametrize('world,cfg', [(2, C2), (3, C2), (3, WIDE), (2, WIDE)])
+@pytest.mark.parametrize('world,cfg', [(2, C2), (3, C2), (3, WIDE), (2, WIDE), (8, WIDE)])      # 8: the rank count of one node
 def test_hip_engine_under_several_ranks_on_one_gpu(world, cfg):
     import torch
     import torch.multiprocessing as mp
@@ -123,7 +123,7 @@ def test_hip_engine_under_several_ranks_on_one_gpu(world, cfg):
             outs.append(q.get(timeout=2))
         except queue.Empty:
             dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
-            if dead or time.time() - t0 > 240:
+            if dead or time.time() - t0 > 360:
                 for p in procs:
                     p.kill()
                 raise AssertionError('worker exit codes %r after %.0f s' % ([p.exitcode for p in procs], time.time() - t0))
