@@ -1010,6 +1010,199 @@ __global__ __launch_bounds__(EX_T_WIN, SQUARE ? 8 : 4) void k_dense_epilogue(ExP
     if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
 }
 
+// k_dense_epilogue with the window's slots kept conflict-free and the per-slot divisions replaced — the same values, slot for slot:
+//   * a thread owns `per` CONSECUTIVE slots (the order of the row sum and of the candidates depends on it), so with an even `per`
+//     the 32 lanes of a ds_read group fall on 32 / g banks (g = the power of two in `per`: 4-way at per = 20).  Every 32-slot
+//     bank row is therefore stored with its bank index XORed by (row mod g): the g lanes that met on one bank sit in rows an odd
+//     number apart, so their keys differ, and they land on the g banks of their own aligned group (the other lanes' banks are g
+//     apart).  The fill (consecutive slots per lane) stays a permutation of a row.
+//   * float(a / d) with d fixed per row (the row sum d_i, then the running sum S) is taken as float(a * (1 / d)) unless that
+//     product lies within 8 double ulps of the midpoint of two floats (or in the float subnormal range), where the true
+//     quotient is computed: a * RN(1 / d) is within 2 ulps of a / d, RN(a / d) within half of one, so away from a midpoint
+//     both round to the same float.  One multiplication instead of the ~64-cycle fp64 division sequence, 3e10 times at C3.
+//   * the survival test of a slot is evaluated once (a bit per owned slot), not in the counting and in the writing pass.
+//     (Deciding it by two float comparisons outside a band around thr * S, and reading the slots four at a time, measured
+//     4 % slower in the same box: the pass is not bound by its instruction count.)
+// Needs per <= DE_PER (the owned slots of the emission pass live in registers): any window the window kernel can hold in LDS.
+constexpr int DE_PER = 20;
+__device__ __forceinline__ i32 de_swz(i32 t, i32 gm) { return t ^ ((t >> 5) & gm); }
+__device__ __forceinline__ float quot_fast(double a, double rd, bool *exact) {      // float(a * rd); *exact: it is float(a / d) for certain
+    const double q = a * rd;
+    const u32 lo = (u32)(u64)__double_as_longlong(q) & 0x1fffffffu;           // the 29 bits below a float32 mantissa
+    *exact = (u32)(lo - 0x0ffffff8u) > 16u && q >= 0x1p-120;
+    return (float)q;
+}
+__device__ __forceinline__ float quot_f32(double a, double d, double rd) {
+    bool exact;
+    const float q = quot_fast(a, rd, &exact);
+    return __builtin_expect(exact, 1) ? q : (float)(a / d);
+}
+// LDS: the reduction scratch of ExLds plus a second i32 row (the scan's wave totals are written while the argmax's are still read)
+__device__ __forceinline__ float de_load(const float *base, i32 idx) {        // uniform base + 32-bit byte offset (no 64-bit address arithmetic per load)
+    return *(const float *)((const char *)base + (u32)(idx << 2));
+}
+__host__ __device__ inline size_t dense_epi_sw_lds_bytes(i32 cap) { return (size_t)((cap + 31) & ~31) * 4 + (size_t)EX_WAVES_MAX * (8 + 4 + 4 + 4) + 8 + 8; }
+// PF: one workgroup per CU (128 registers a lane) that loads the window of step k + 1 into registers while step k is reduced;
+// !PF: two workgroups per CU (64 registers), each loading its window at the start of the step.
+template <bool SQUARE, bool PF>
+__global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExParams P, const float *__restrict__ X, i64 ld, i32 cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *red_d; i64 *bcast; i32 *red_i, *red_s; float *red_f, *slot;
+    {
+        unsigned char *p = smem;
+        red_d = (double *)p; p += EX_WAVES_MAX * 8;
+        bcast = (i64 *)p; p += 8;
+        red_i = (i32 *)p; p += EX_WAVES_MAX * 4;
+        red_f = (float *)p; p += EX_WAVES_MAX * 4;
+        red_s = (i32 *)p; p += EX_WAVES_MAX * 4;
+        p += 8;
+        slot = (float *)p;                                  // [cap rounded up to 32] floats
+    }
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / HHX_WAVE;
+    i64 nnzc = 0;
+    // The (row, window) steps of this workgroup in one sequence (every barrier below orders LDS only: a __syncthreads() would wait
+    // for the loads of the next window).
+    i32 row = blockIdx.x, wv = 0;
+    if (row >= P.n_rows) return;
+    float v[DE_PER];
+    double div_n = P.row_div ? P.row_div[row] : 0.0;
+    if (PF) {
+        const i32 wlen = min(P.n_cols, cap);
+        const float *src = X + (size_t)row * (size_t)ld;
+#pragma unroll
+        for (int i = 0; i < DE_PER; ++i) v[i] = de_load(src, min(tid + i * EX_T_WIN, wlen - 1));
+    }
+    double s_run = 0.0, div = 0.0, rdiv = 0.0;
+    for (;;) {
+        const i32 c0 = wv * cap, wlen = min(P.n_cols, c0 + cap) - c0;
+        const i32 per = (wlen + EX_T_WIN - 1) / EX_T_WIN, gm = min(32, per & -per) - 1;
+        i32 lt = tid;
+        asm volatile("" : "+v"(lt));                        // opaque: or the 20 offsets lt + i * 1024 are hoisted out of the loop and spilled
+        const i32 s0 = min(wlen, lt * per), s1 = min(wlen, s0 + per);
+        if (!PF) {
+            const float *src = X + (size_t)row * (size_t)ld + c0;
+#pragma unroll
+            for (int i = 0; i < DE_PER; ++i) v[i] = de_load(src, min(lt + i * EX_T_WIN, wlen - 1));      // clamped, not predicated: no branch per load
+        }
+        if (wv == 0) { div = div_n; rdiv = div != 0.0 ? 1.0 / div : 0.0; }
+#pragma unroll
+        for (int i = 0; i < DE_PER; ++i) { const i32 t = lt + i * EX_T_WIN; if (t < wlen) slot[de_swz(t, gm)] = v[i]; }
+        lds_barrier();
+        i32 row_n = row, wv_n = wv + 1;
+        if (wv_n == P.n_win) { wv_n = 0; row_n = row + (i32)gridDim.x; }
+        const bool more = row_n < P.n_rows;
+        // x -> p = x^r, the window sum and the window maximum: the owned slots in ascending order (window_power_sum<false, true, SQUARE>
+        // and the first pass of window_emit_candidates<false, 1>)
+        // A slot survives the window if float(p / S) >= thr, S = the running row sum INCLUDING this window — known only after the
+        // exchange below.  But S is at least the sum S' of the windows before, so p < thr * S' * (1 - 2^-18) already decides "pruned"
+        // (float(p / S) is monotone in p and in 1 / S): the pass over the slots notes the others (a bit per owned slot), and the
+        // exact test after the exchange visits those alone — every present slot in window 0, a handful of slots in the later ones.
+        const double ts = (double)P.thr * s_run;            // s_run: still the sum of the windows before (unused at wv == 0)
+        const float lo_p = (wv > 0 && !P.raw && ts >= 0x1p-100 && ts <= 0x1p100) ? (float)(ts * (1.0 - 0x1p-18)) : 0.0f;
+        u32 maybe = 0;
+        double s = 0.0;
+        i32 nz = 0;
+        float bq = -1.0f; i32 bs = 0x7fffffff;
+        for (i32 t0 = s0; t0 < s1; t0 += 4) {
+            u32 b[4];
+            i32 at[4];                                      // the slot's place in LDS: the same for its read and its write
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { at[u] = de_swz(min(t0 + u, s1 - 1), gm); b[u] = ((const u32 *)slot)[at[u]]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t0 + u < s1) {
+                    float p = -1.0f;
+                    if (b[u] != 0) {
+                        const float y = __uint_as_float(b[u]);
+                        const float x = div != 0.0 ? quot_f32((double)y, div, rdiv) : y;
+                        p = SQUARE ? x * x : (P.raw ? x : ex_inflate(x, P.r, P.square));
+                        s += (double)p;
+                        ++nz;
+                    }
+                    if (p > bq) { bq = p; bs = t0 + u; }
+                    if (p >= lo_p) maybe |= 1u << (t0 + u - s0);
+                    slot[at[u]] = p;
+                }
+        }
+        nnzc += nz;
+        if (more && wv_n == 0 && P.row_div) div_n = P.row_div[row_n];
+        if (PF && more) {                                   // the next step's window: 20 values in flight through the rest of this step
+            const i32 c0n = wv_n * cap, wlen_n = min(P.n_cols, c0n + cap) - c0n;
+            const float *src = X + (size_t)row_n * (size_t)ld + c0n;
+#pragma unroll
+            for (int i = 0; i < DE_PER; ++i) v[i] = de_load(src, min(lt + i * EX_T_WIN, wlen_n - 1));
+        }
+        // block_sum_f64 and block_argmax in one exchange: the same wave trees, the same order over the waves
+        s = wave_sum_f64(s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float oq = __shfl_down(bq, o, HHX_WAVE);
+            const i32 oc = __shfl_down(bs, o, HHX_WAVE);
+            if (oq > bq || (oq == bq && oc < bs)) { bq = oq; bs = oc; }
+        }
+        if (lane == 0) { red_d[wave] = s; red_f[wave] = bq; red_i[wave] = bs; }
+        lds_barrier();
+        double sw = red_d[0];
+        bq = red_f[0]; bs = red_i[0];
+#pragma unroll 3
+        for (int k = 1; k < EX_T_WIN / HHX_WAVE; ++k) {       // (a full unroll holds 16 x 4 registers at once)
+            sw += red_d[k];
+            if (red_f[k] > bq || (red_f[k] == bq && red_i[k] < bs)) { bq = red_f[k]; bs = red_i[k]; }
+        }
+        s_run = (wv == 0 ? 0.0 : s_run) + sw;
+        // survivors against the running sum: one bit per owned slot
+        const double rs = 1.0 / s_run;
+        u32 keep = (bs >= s0 && bs < s1) ? 1u << (bs - s0) : 0u;          // the window maximum stays, whatever its value
+        while (maybe) {
+            const int k = __ffs(maybe) - 1;
+            maybe &= maybe - 1;
+            if (P.raw || quot_f32((double)slot[de_swz(s0 + k, gm)], s_run, rs) >= P.thr) keep |= 1u << k;
+        }
+        // block_excl_scan_i32 of the survivor counts
+        const i32 cnt = __popc(keep);
+        i32 incl = cnt;
+#pragma unroll
+        for (int o = 1; o < HHX_WAVE; o <<= 1) {
+            const i32 t = __shfl_up(incl, o, HHX_WAVE);
+            if (lane >= o) incl += t;
+        }
+        if (lane == HHX_WAVE - 1) red_s[wave] = incl;
+        lds_barrier();
+        i32 off = 0, total = 0;
+#pragma unroll 4
+        for (int k = 0; k < EX_T_WIN / HHX_WAVE; ++k) { if (k < wave) off += red_s[k]; total += red_s[k]; }
+        off += incl - cnt;
+        if (tid == 0) {
+            i64 base = 0;
+            if (total) {
+                base = (i64)atomicAdd(&P.cursors[0], (unsigned long long)total);
+                if (base + total > P.cand_cap) { atomicExch(&P.cursors[2], 1ull); base = -1; }
+            }
+            P.g_win_off[(size_t)row * P.n_win + wv] = base;
+            P.g_win_cnt[(size_t)row * P.n_win + wv] = base < 0 ? 0 : total;
+            *bcast = base;
+        }
+        lds_barrier();
+        const i64 base = *bcast;
+        if (base >= 0 && total) {
+            i64 o = base + off;
+            while (keep) {
+                const int k = __ffs(keep) - 1;
+                keep &= keep - 1;
+                P.cand_col[o] = c0 + s0 + k;
+                P.cand_val[o] = slot[de_swz(s0 + k, gm)];
+                ++o;
+            }
+        }
+        if (wv == P.n_win - 1 && tid == 0) P.s_run[row] = s_run;
+        if (!more) break;
+        lds_barrier();                                      // the slots, the reduction rows and the broadcast word are rewritten by the next step
+        row = row_n; wv = wv_n;
+    }
+    nnzc = wave_sum_i64(nnzc);
+    if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
+}
+
 __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ExLds l = ex_carve(smem, cap, W, MAX_WIN);
@@ -1249,10 +1442,13 @@ __global__ __launch_bounds__(HASH_T, 4) void k_expand_hash(ExParams P, const i32
 // The symmetric pre-expansion computes the blocks (I, J >= I) of Y = float(S) only; block (J, I), J > I, is the transpose of (I, J)
 // bit for bit (S is an exact integer matrix).  One workgroup per 64 x 64 tile of the strictly lower block triangle: the source
 // tile is read row-wise (coalesced), turned in LDS and written row-wise.  cap is a multiple of 64, so a tile never straddles blocks.
+// grid: (cap / 64, cap / 64, block pairs J > I) — only the tiles that are copied are launched.
 __global__ __launch_bounds__(256) void k_transpose_lower(float *__restrict__ Y, i64 ld, i32 n, i32 cap) {
     __shared__ float tile[64][65];
-    const i32 r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;          // destination tile: rows r0.., columns c0..
-    if (r0 / cap <= c0 / cap) return;                               // on or above the block diagonal: computed, not copied
+    i32 bj = 1, bi = (i32)blockIdx.z;                               // pair index z = J (J - 1) / 2 + I, I < J
+    while (bi >= bj) { bi -= bj; ++bj; }
+    const i32 r0 = bj * cap + blockIdx.y * 64, c0 = bi * cap + blockIdx.x * 64;          // destination tile: rows r0.., columns c0..
+    if (r0 >= n) return;                                            // the last block of rows is short
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int k = ty; k < 64; k += 4) {                              // source tile: rows c0.., columns r0..
         const i32 sr = c0 + k, sc = r0 + tx;
@@ -1705,8 +1901,8 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             HHX_LAUNCH_CHECK();
             if (sym_whole && n_win > 1) {
                 KTimer kt("dense_transpose");
-                const unsigned tiles = (unsigned)((n_cols + 63) / 64);
-                k_transpose_lower<<<dim3(tiles, tiles), 256, 0, g_stream>>>(coded.dense_out, (i64)n_cols, n_cols, cap_win);
+                const unsigned tiles = (unsigned)(cap_win / 64), pairs = (unsigned)(n_win * (n_win - 1) / 2);
+                k_transpose_lower<<<dim3(tiles, tiles, pairs), 256, 0, g_stream>>>(coded.dense_out, (i64)n_cols, n_cols, cap_win);
                 HHX_LAUNCH_CHECK();
             }
             if (!dense) {
@@ -1816,6 +2012,9 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
     if (attr_dev != dev) {
         HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue_sw<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue_sw<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue_sw<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_dev = dev;
     }
     // a pruned row holds at most 1 / pruning entries; an early window tests against a partial row sum and admits more
@@ -1842,8 +2041,15 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
         if (n_rows) {
             {
                 KTimer kt("dense_epilogue");
-                if (P.square) k_dense_epilogue<true><<<std::min<unsigned>((unsigned)n_rows, 512), EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
-                else k_dense_epilogue<false><<<std::min<unsigned>((unsigned)n_rows, 512), EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
+                const unsigned grid = std::min<unsigned>((unsigned)n_rows, 512);
+                static const int use_sw = getenv("HHX_DENSE_EPI_SW") ? atoi(getenv("HHX_DENSE_EPI_SW")) : 1;
+                if (use_sw && (cap + EX_T_WIN - 1) / EX_T_WIN <= DE_PER) {
+                    const unsigned grid1 = std::min<unsigned>((unsigned)n_rows, 256);
+                    if (!P.square) k_dense_epilogue_sw<false, true><<<grid1, EX_T_WIN, dense_epi_sw_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
+                    else if (use_sw == 2) k_dense_epilogue_sw<true, true><<<grid1, EX_T_WIN, dense_epi_sw_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
+                    else k_dense_epilogue_sw<true, false><<<grid, EX_T_WIN, dense_epi_sw_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
+                } else if (P.square) k_dense_epilogue<true><<<grid, EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
+                else k_dense_epilogue<false><<<grid, EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
             }
             HHX_LAUNCH_CHECK();
             KTimer kt("expand_finalize");
