@@ -1086,7 +1086,8 @@ __global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExPa
         }
         if (wv == 0) { div = div_n; rdiv = div != 0.0 ? 1.0 / div : 0.0; }
 #pragma unroll
-        for (int i = 0; i < DE_PER; ++i) { const i32 t = lt + i * EX_T_WIN; if (t < wlen) slot[de_swz(t, gm)] = v[i]; }
+        for (int i = 0; i < DE_PER; ++i)                    // (t >> 5) & gm does not depend on i: one swizzled base, constant offsets
+            if (lt + i * EX_T_WIN < wlen) slot[de_swz(lt, gm) + i * EX_T_WIN] = v[i];
         lds_barrier();
         i32 row_n = row, wv_n = wv + 1;
         if (wv_n == P.n_win) { wv_n = 0; row_n = row + (i32)gridDim.x; }

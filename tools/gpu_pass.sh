@@ -20,7 +20,7 @@ for l in open('gpurun_out/bench_text.log'):
 ";;
     pcie) timeout 600 python tools/pcie_rate.py 100000000 2>&1 | tail -4;;
     full) timeout 900 python bench.py > gpurun_out/bench_full.log 2>&1; echo "rc=$?" >> gpurun_out/bench_full.log; python tools/bench_brief.py gpurun_out/bench_full.log; tail -c 600 gpurun_out/bench_full.log | grep -v "^{";;
-    prof) rm -rf gpurun_out/prof; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity --text-lines 0 > gpurun_out/prof.log 2>&1; echo "rc=$?" >> gpurun_out/prof.log; ls -R gpurun_out/prof | head; tail -2 gpurun_out/prof.log | cut -c1-400;;
+    prof) rm -rf gpurun_out/prof; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity --text-lines 0 $PMC_ARGS > gpurun_out/prof.log 2>&1; echo "rc=$?" >> gpurun_out/prof.log; ls -R gpurun_out/prof | head; tail -2 gpurun_out/prof.log | cut -c1-400;;
     pmc:*) # pmc:NAME:COUNTER1,COUNTER2  -> one rocprofv3 --pmc pass of the default bench (1 step, no warmup)
         spec="${what#pmc:}"; name="${spec%%:*}"; ctrs="${spec#*:}"; rm -rf gpurun_out/pmc_$name
         timeout 900 rocprofv3 --kernel-trace --pmc ${ctrs//,/ } --output-format csv -d gpurun_out/pmc_$name -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity --text-lines 0 $PMC_ARGS > gpurun_out/pmc_$name.log 2>&1; echo "pmc $name rc=$?"; ls gpurun_out/pmc_$name | head -5;;
