@@ -92,7 +92,7 @@ SIGNATURES = {
     'hhx_mcl_resume': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, c_vpp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
     'hhx_expand_links_dense': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_int, c_vpp, c_i64p, c_i64p]),
     'hhx_links_integer_ok': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    'hhx_dense_device': (C.c_int, [C.c_void_p, c_vpp, c_i32p, c_i32p]),
+    'hhx_dense_device': (C.c_int, [C.c_void_p, c_vpp, c_i64p, c_i32p, c_i32p]),
     'hhx_dense_inflate_prune': (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_vpp]),
     'hhx_dense_shape': (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i64p]),
     'hhx_dense_free': (C.c_int, [C.c_void_p]),
@@ -350,10 +350,10 @@ class DenseRows:
         self.n_rows, self.n_cols = int(r1) - int(r0), links.shape3[1]
 
     def device(self):
-        """(device pointer of the n_rows x n_cols float32 block, columns per window, number of windows)"""
-        x, cap, nw = C.c_void_p(), C.c_int32(0), C.c_int32(0)
-        check(load().hhx_dense_device(self.h, C.byref(x), C.byref(cap), C.byref(nw)))
-        return x.value or 0, cap.value, nw.value
+        """(device pointer of the block — n_rows rows of n_cols float32 —, row pitch in floats, columns per window, number of windows)"""
+        x, ld, cap, nw = C.c_void_p(), C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        check(load().hhx_dense_device(self.h, C.byref(x), C.byref(ld), C.byref(cap), C.byref(nw)))
+        return x.value or 0, ld.value, cap.value, nw.value
 
     def inflate_prune(self, inflation, pruning):
         """iteration 0 of mcl() (:2037-2042) of these rows at `inflation`"""

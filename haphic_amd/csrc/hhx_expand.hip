@@ -1042,8 +1042,9 @@ __device__ __forceinline__ float de_load(const float *base, i32 idx) {        //
     return *(const float *)((const char *)base + (u32)(idx << 2));
 }
 __host__ __device__ inline size_t dense_epi_sw_lds_bytes(i32 cap) { return (size_t)((cap + 31) & ~31) * 4 + (size_t)EX_WAVES_MAX * (8 + 4 + 4 + 4) + 8 + 8; }
-// PF: one workgroup per CU (128 registers a lane) that loads the window of step k + 1 into registers while step k is reduced;
-// !PF: two workgroups per CU (64 registers), each loading its window at the start of the step.
+// PF: one workgroup per CU (128 registers a lane) that loads the window of step k + 1 into registers while step k is reduced — the
+// general inflation, whose pow() needs the registers anyway; !PF: two workgroups per CU (64 registers), each loading its window at
+// the start of the step — inflation 2 (measured: 28 ms against 32.5 ms with the prefetch and one workgroup).
 template <bool SQUARE, bool PF>
 __global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExParams P, const float *__restrict__ X, i64 ld, i32 cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExPa
         slot = (float *)p;                                  // [cap rounded up to 32] floats
     }
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / HHX_WAVE;
-    i64 nnzc = 0;
+    i32 nnzc = 0;                                           // at most rows per workgroup x n_cols slots: below 2^31
     // The (row, window) steps of this workgroup in one sequence (every barrier below orders LDS only: a __syncthreads() would wait
     // for the loads of the next window).
     i32 row = blockIdx.x, wv = 0;
@@ -1072,7 +1073,7 @@ __global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExPa
 #pragma unroll
         for (int i = 0; i < DE_PER; ++i) v[i] = de_load(src, min(tid + i * EX_T_WIN, wlen - 1));
     }
-    double s_run = 0.0, div = 0.0, rdiv = 0.0;
+    double s_run = 0.0, div = 0.0;
     for (;;) {
         const i32 c0 = wv * cap, wlen = min(P.n_cols, c0 + cap) - c0;
         const i32 per = (wlen + EX_T_WIN - 1) / EX_T_WIN, gm = min(32, per & -per) - 1;
@@ -1084,7 +1085,8 @@ __global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExPa
 #pragma unroll
             for (int i = 0; i < DE_PER; ++i) v[i] = de_load(src, min(lt + i * EX_T_WIN, wlen - 1));      // clamped, not predicated: no branch per load
         }
-        if (wv == 0) { div = div_n; rdiv = div != 0.0 ? 1.0 / div : 0.0; }
+        if (wv == 0) div = div_n;
+        const double rdiv = div != 0.0 ? 1.0 / div : 0.0;          // per step, not held across it: the two registers spilled
 #pragma unroll
         for (int i = 0; i < DE_PER; ++i)                    // (t >> 5) & gm does not depend on i: one swizzled base, constant offsets
             if (lt + i * EX_T_WIN < wlen) slot[de_swz(lt, gm) + i * EX_T_WIN] = v[i];
@@ -1200,8 +1202,8 @@ __global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExPa
         lds_barrier();                                      // the slots, the reduction rows and the broadcast word are rewritten by the next step
         row = row_n; wv = wv_n;
     }
-    nnzc = wave_sum_i64(nnzc);
-    if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
+    const i64 nnz_wave = wave_sum_i64((i64)nnzc);
+    if (lane_id() == 0 && nnz_wave) atomicAdd(&P.cursors[3], (unsigned long long)nnz_wave);
 }
 
 __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 W) {
@@ -1634,6 +1636,7 @@ struct CodedOperand {
     const double *row_sum = nullptr;
     int raw = 0;                        // plain product (no inflation / pruning): hhx_spgemm's fast path
     float *dense_out = nullptr;         // dense mode: n_rows x n_cols float32 block that receives the expanded rows; no CSR result
+    i64 dense_ld = 0;                   // ... and its row pitch in floats (>= n_cols)
     i32 *plan_out = nullptr;            // dense mode: [cap_win, n_win] of the column-window plan, for k_dense_epilogue
     // integer arithmetic (ExParams::W): a = rows [a_row0, a_row0 + a->n_rows) of the link matrix whose normalised form is b
     const u64 *W = nullptr;
@@ -1805,7 +1808,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         P.cursors = cursors.p; P.row_off = row_off.p; P.row_cnt = row_cnt.p;
         P.n_win = n_win;
         P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
-        P.dense = coded.dense_out; P.dense_ld = n_cols;
+        P.dense = coded.dense_out; P.dense_ld = coded.dense_ld ? coded.dense_ld : (i64)n_cols;
         P.W = fx ? coded.W : nullptr; P.A16 = coded.a16; P.row_div = coded.a_row_sum; P.fx_inv = ldexp(1.0, -coded.shift);
         P.sym = coded.sym; P.sym_row0 = coded.sym_row0;
         P.Sc16 = nullptr; P.Sx = nullptr; P.rec = nullptr; P.Bjx = nullptr; P.narrow_classes = 0; P.wb = WB_MAX;
@@ -1903,7 +1906,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             if (sym_whole && n_win > 1) {
                 KTimer kt("dense_transpose");
                 const unsigned tiles = (unsigned)(cap_win / 64), pairs = (unsigned)(n_win * (n_win - 1) / 2);
-                k_transpose_lower<<<dim3(tiles, tiles, pairs), 256, 0, g_stream>>>(coded.dense_out, (i64)n_cols, n_cols, cap_win);
+                k_transpose_lower<<<dim3(tiles, tiles, pairs), 256, 0, g_stream>>>(coded.dense_out, coded.dense_ld ? coded.dense_ld : (i64)n_cols, n_cols, cap_win);
                 HHX_LAUNCH_CHECK();
             }
             if (!dense) {
@@ -1972,9 +1975,10 @@ int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const hhx_links_op
     if (!a || !b || !out) return fail("null pointer");
     hhx_dense *d = new hhx_dense();
     d->n_rows = a->n_rows; d->n_cols = b->n_cols;
-    if (d->x.alloc((size_t)a->n_rows * (size_t)b->n_cols + 1)) { delete d; return 2; }      // 2: the block itself does not fit (callers may fall back)
+    d->ld = ((i64)b->n_cols + 31) & ~(i64)31;
+    if (d->x.alloc((size_t)a->n_rows * (size_t)d->ld + 1)) { delete d; return 2; }      // 2: the block itself does not fit (callers may fall back)
     CodedOperand c;
-    c.dense_out = d->x.p;
+    c.dense_out = d->x.p; c.dense_ld = d->ld;
     if (lk) {
         c.n16 = lk->n16; c.row_sum = lk->row_sum;
         if (lk->W) {                                   // integer arithmetic: the block holds y = float(S); its epilogue divides by d_i
@@ -2014,7 +2018,6 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
         HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue_sw<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue_sw<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue_sw<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_dev = dev;
     }
@@ -2046,11 +2049,10 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
                 static const int use_sw = getenv("HHX_DENSE_EPI_SW") ? atoi(getenv("HHX_DENSE_EPI_SW")) : 1;
                 if (use_sw && (cap + EX_T_WIN - 1) / EX_T_WIN <= DE_PER) {
                     const unsigned grid1 = std::min<unsigned>((unsigned)n_rows, 256);
-                    if (!P.square) k_dense_epilogue_sw<false, true><<<grid1, EX_T_WIN, dense_epi_sw_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
-                    else if (use_sw == 2) k_dense_epilogue_sw<true, true><<<grid1, EX_T_WIN, dense_epi_sw_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
-                    else k_dense_epilogue_sw<true, false><<<grid, EX_T_WIN, dense_epi_sw_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
-                } else if (P.square) k_dense_epilogue<true><<<grid, EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
-                else k_dense_epilogue<false><<<grid, EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, d->x.p, (i64)n_cols, cap);
+                    if (!P.square) k_dense_epilogue_sw<false, true><<<grid1, EX_T_WIN, dense_epi_sw_lds_bytes(cap), g_stream>>>(P, d->x.p, d->ld, cap);
+                    else k_dense_epilogue_sw<true, false><<<grid, EX_T_WIN, dense_epi_sw_lds_bytes(cap), g_stream>>>(P, d->x.p, d->ld, cap);
+                } else if (P.square) k_dense_epilogue<true><<<grid, EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, d->x.p, d->ld, cap);
+                else k_dense_epilogue<false><<<grid, EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, d->x.p, d->ld, cap);
             }
             HHX_LAUNCH_CHECK();
             KTimer kt("expand_finalize");
@@ -2076,14 +2078,15 @@ extern "C" int hhx_dense_shape(const hhx_dense *d, i32 *n_rows, i32 *n_cols, i64
     if (!d) return fail("null handle");
     if (n_rows) *n_rows = d->n_rows;
     if (n_cols) *n_cols = d->n_cols;
-    if (bytes) *bytes = (i64)sizeof(float) * (i64)d->n_rows * (i64)d->n_cols;
+    if (bytes) *bytes = (i64)sizeof(float) * (i64)d->n_rows * d->ld;
     return 0;
 }
 
-// the block as device memory: n_rows x n_cols float32, row-major (multi-GPU: the ranks mirror their upper block triangles through it)
-extern "C" int hhx_dense_device(const hhx_dense *d, void **x, i32 *cap_win, i32 *n_win) {
-    if (!d || !x) return fail("null pointer");
+// the block as device memory: n_rows rows of n_cols float32, *ld floats apart (multi-GPU: the ranks mirror their upper block triangles through it)
+extern "C" int hhx_dense_device(const hhx_dense *d, void **x, i64 *ld, i32 *cap_win, i32 *n_win) {
+    if (!d || !x || !ld) return fail("null pointer");
     *x = d->x.p;
+    *ld = d->ld;
     if (cap_win) *cap_win = d->cap_win;
     if (n_win) *n_win = d->n_win;
     return 0;

@@ -97,9 +97,9 @@ class HipEngine:
     def dense_upper(self, links, r0, r1):
         """rows [r0, r1) of Y = float(S), blocks (I, J >= I) only: (handle, [n_rows, n] float32 torch view, columns per window)"""
         d = _lib.DenseRows(links, r0, r1, upper_only=True)
-        ptr, cap, _nw = d.device()
-        y = self.view(ptr, d.n_rows * d.n_cols, '<f4', self.torch.float32).view(d.n_rows, d.n_cols) if d.n_rows else \
-            self.torch.empty((0, d.n_cols), dtype=self.torch.float32, device=self.device)
+        ptr, ld, cap, _nw = d.device()
+        y = self.view(ptr, d.n_rows * ld, '<f4', self.torch.float32).view(d.n_rows, ld)[:, :d.n_cols] if d.n_rows else \
+            self.torch.empty((0, d.n_cols), dtype=self.torch.float32, device=self.device)         # rows `ld` floats apart
         return d, y, cap
 
     def dense_finish(self, d, inflation, pruning):

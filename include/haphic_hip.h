@@ -153,7 +153,7 @@ typedef struct hhx_dense hhx_dense;
 int hhx_expand_links_dense(const hhx_csr *links, int32_t r0, int32_t r1, int fx_shift, int upper_only, hhx_dense **out,
                            int64_t *n_products, int64_t *nnz_expanded);
 int hhx_links_integer_ok(const hhx_csr *links, int *ok, int *shift);
-int hhx_dense_device(const hhx_dense *d, void **x_dev, int32_t *cap_win, int32_t *n_win);
+int hhx_dense_device(const hhx_dense *d, void **x_dev, int64_t *ld, int32_t *cap_win, int32_t *n_win);   /* ld: row pitch in floats (>= n_cols) */
 int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, double pruning, hhx_csr **out);
 int hhx_dense_shape(const hhx_dense *d, int32_t *n_rows, int32_t *n_cols, int64_t *bytes);
 int hhx_dense_free(hhx_dense *d);
