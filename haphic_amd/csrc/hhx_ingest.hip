@@ -56,15 +56,31 @@ struct SrcPairs {
 // Four consecutive pairs per lane: the four streams arrive as 16-byte loads, the eight table gathers (clamped ids,
 // unconditional) are all issued before the first is consumed, and the records leave as two 16-byte stores — the
 // kernel is bound by the latency of its dependent loads, not by bytes.  VEC = false: any alignment, any tail.
+// The level-1 histogram of the group-by's radix partition is counted here too (hist: 2^bits counts of `bucket >> shift` over the
+// admitted records, or null): the pass waits on its gathers, the hash and an LDS atomic per record ride along, and the
+// partition's own COUNT pass over the 8-byte records (4 GB, 0.8 ms per 500 M pairs) is not launched.
+struct MapHist {
+    unsigned long long *hist;       // null: no histogram
+    int total_bits, shift, bins;
+};
+__device__ __forceinline__ void map_hist_add(u32 *lh, const MapHist &H, u64 w) {
+    if (w != EMPTY_KEY) atomicAdd(&lh[bucket_of(w & KEY_MASK, H.total_bits) >> H.shift], 1u);
+}
 template <bool COMBINED, bool VEC, class POS = i32>
-__global__ __launch_bounds__(256) void k_map_records(SrcPairs<COMBINED, POS> src, i64 i0, i64 n, u64 *__restrict__ rec) {
+__global__ __launch_bounds__(256) void k_map_records(SrcPairs<COMBINED, POS> src, i64 i0, i64 n, u64 *__restrict__ rec, MapHist H) {
+    __shared__ u32 lh[hhx::P_MAX_BINS];
+    if (H.hist) {
+        for (int t = threadIdx.x; t < H.bins; t += blockDim.x) lh[t] = 0;
+        __syncthreads();
+    }
     if (!VEC || sizeof(POS) != 4) {
         for (i64 idx = i0 + (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (i64)gridDim.x * blockDim.x) {
             u64 w0; u32 w1;
-            rec[idx] = src.get(idx, w0, w1) ? w0 : EMPTY_KEY;
+            const u64 w = src.get(idx, w0, w1) ? w0 : EMPTY_KEY;
+            rec[idx] = w;
+            if (H.hist) map_hist_add(lh, H, w);
         }
-        return;
-    }
+    } else {
     const i64 groups = n >> 2;
     for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (i64)gridDim.x * blockDim.x) {
         const int4 q1 = reinterpret_cast<const int4 *>(src.id1)[g], q2 = reinterpret_cast<const int4 *>(src.id2)[g];
@@ -87,15 +103,25 @@ __global__ __launch_bounds__(256) void k_map_records(SrcPairs<COMBINED, POS> src
         }
         reinterpret_cast<ulonglong2 *>(rec)[2 * g] = make_ulonglong2(w[0], w[1]);
         reinterpret_cast<ulonglong2 *>(rec)[2 * g + 1] = make_ulonglong2(w[2], w[3]);
+        if (H.hist) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) map_hist_add(lh, H, w[k]);
+        }
+    }
+    }
+    if (H.hist) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < H.bins; t += blockDim.x)
+            if (lh[t]) atomicAdd(&H.hist[t], (unsigned long long)lh[t]);
     }
 }
 template <bool COMBINED, class POS>
-void launch_map(const SrcPairs<COMBINED, POS> &src, i64 n, u64 *rec) {
+void launch_map(const SrcPairs<COMBINED, POS> &src, i64 n, u64 *rec, const MapHist &H) {
     // (64-bit positions — contigs beyond 2^31 bp, rare — take the scalar kernel: one pair per lane)
     const bool aligned = sizeof(POS) == 4 && ((((uintptr_t)src.id1) | ((uintptr_t)src.id2) | ((uintptr_t)src.pos1) | ((uintptr_t)src.pos2) | ((uintptr_t)rec)) & 15) == 0;
     const i64 bulk = aligned && src.t.n_ctg > 0 ? (n & ~(i64)3) : 0;
-    if (bulk) k_map_records<COMBINED, true, POS><<<(unsigned)std::max<i64>(1, std::min<i64>((bulk / 4 + 255) / 256, 256 * 16)), 256, 0, g_stream>>>(src, 0, bulk, rec);
-    if (bulk < n) k_map_records<COMBINED, false, POS><<<(unsigned)std::max<i64>(1, std::min<i64>((n - bulk + 255) / 256, 256 * 16)), 256, 0, g_stream>>>(src, bulk, n, rec);
+    if (bulk) k_map_records<COMBINED, true, POS><<<(unsigned)std::max<i64>(1, std::min<i64>((bulk / 4 + 255) / 256, 256 * 16)), 256, 0, g_stream>>>(src, 0, bulk, rec, H);
+    if (bulk < n) k_map_records<COMBINED, false, POS><<<(unsigned)std::max<i64>(1, std::min<i64>((n - bulk + 255) / 256, 256 * 16)), 256, 0, g_stream>>>(src, bulk, n, rec, H);
 }
 struct SrcMapped {
     typedef u32 w1_t;
@@ -330,8 +356,18 @@ struct Payload {            // MODE 1 only
     const u32 *ht = nullptr, *fl = nullptr;
 };
 
+// bucket bits of the group-by of n_items records (attempt: after an LDS overflow, more buckets) and the radix bits per level
+inline i64 ingest_per_bucket() { static const i64 v = getenv("HHX_ING_BUCKET") ? atoll(getenv("HHX_ING_BUCKET")) : 1024; return v; }
+inline int ingest_level_bits() { static const int v = getenv("HHX_ING_LBITS") ? atoi(getenv("HHX_ING_LBITS")) : 7; return v; }
+inline int ingest_total_bits(i64 n_items, int attempt) {
+    int total_bits = 0;
+    while ((n_items >> total_bits) > ingest_per_bucket() && total_bits < 24) ++total_bits;
+    return std::min(24, total_bits + 2 * attempt);
+}
+
+// hist0: the level-1 histogram of the records counted by their producer for attempt 0's bucket bits (or null)
 template <class Src, int MODE>
-int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, LinkRun **out) {
+int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, LinkRun **out, const unsigned long long *hist0 = nullptr) {
     static int attr_set = -1;           // the attribute is per device: keyed on the current ordinal
     int attr_dev = 0;
     HHX_HIP(hipGetDevice(&attr_dev));
@@ -347,14 +383,11 @@ int build_run(const Src &src, i64 n_items, const Payload &pl, u64 ord_base, Link
         // buckets of ~<= 1k records (half of the 2048-slot LDS table even if every record is a new key; larger
         // buckets are aggregated in sub-passes), radix levels of <= 7 bits: >= 32 records = 256 B per (tile, bucket)
         // run.  Measured at 500 M pairs: 3 levels of 7+6+6 bits 34 ms, 2 levels of 8+8 bits + 8 sub-passes 40 ms.
-        static const i64 per_bucket = getenv("HHX_ING_BUCKET") ? atoll(getenv("HHX_ING_BUCKET")) : 1024;
-        static const int level_bits = getenv("HHX_ING_LBITS") ? atoi(getenv("HHX_ING_LBITS")) : 7;
-        int total_bits = 0;
-        while ((n_items >> total_bits) > per_bucket && total_bits < 24) ++total_bits;
-        total_bits = std::min(24, total_bits + 2 * attempt);
+        const int level_bits = ingest_level_bits(), total_bits = ingest_total_bits(n_items, attempt);
         const DigKeyHash dig{total_bits};
         Partitioned<u32> part;
-        { int rc = partition_records(src, dig, n_items, total_bits, level_bits, &part, "part"); if (rc) { delete run; return rc; } }
+        { int rc = partition_records(src, dig, n_items, total_bits, level_bits, &part, "part", (const Src *)nullptr, attempt == 0 ? hist0 : nullptr);
+          if (rc) { delete run; return rc; } }
         const i64 n_valid = part.n_valid;
         if (n_valid == 0) { *out = run; return run->alloc(0) ? (delete run, 1) : 0; }
         if (MODE == 0 && attempt == 0) prof_count("ingest_records", n_valid);
@@ -637,16 +670,24 @@ static int ingest_push_device(hhx_ingest *h, i64 n_pairs, const i32 *id1, const 
     const u64 ord0 = h->ord_base + h->n_pushed;
     { KTimer kt("ingest");
     DevBuf<u64> mapped;
-    if (mapped.alloc((size_t)n_pairs)) return 1;
+    DevBuf<unsigned long long> hist0;
+    if (mapped.alloc((size_t)n_pairs) || hist0.alloc(P_MAX_BINS)) return 1;
+    // the level-1 histogram of the group-by comes out of the map pass (build_run's first attempt; same bits as it derives)
+    int lbits[4];
+    const int total_bits = ingest_total_bits(n_pairs, 0);
+    const int n_levels = part_levels(total_bits, std::min(ingest_level_bits(), 9), lbits);
+    const bool fuse = total_bits > 0 && n_levels >= 1 && lbits[0] > 0 && !getenv("HHX_ING_NO_FUSED_COUNT");
+    const MapHist H{fuse ? hist0.p : nullptr, total_bits, total_bits - lbits[0], 1 << lbits[0]};
     for (int stream = 0; stream < 3; ++stream) {
         if (stream == 1 && h->combined) continue;
         if (stream == 2 && !h->keep_frag_pairs) continue;
+        if (fuse) HHX_HIP(hipMemsetAsync(hist0.p, 0, sizeof(unsigned long long) * P_MAX_BINS, g_stream));
         { KTimer kt2("map");
-        if (h->combined && stream == 0) launch_map(SrcPairs<true, POS>{id1, pos1, id2, pos2, h->t, 0}, n_pairs, mapped.p);
-        else launch_map(SrcPairs<false, POS>{id1, pos1, id2, pos2, h->t, stream}, n_pairs, mapped.p); }
+        if (h->combined && stream == 0) launch_map(SrcPairs<true, POS>{id1, pos1, id2, pos2, h->t, 0}, n_pairs, mapped.p, H);
+        else launch_map(SrcPairs<false, POS>{id1, pos1, id2, pos2, h->t, stream}, n_pairs, mapped.p, H); }
         HHX_LAUNCH_CHECK();
         LinkRun *run = nullptr;
-        HHX_TRY((build_run<SrcMapped, 0>(SrcMapped{mapped.p}, n_pairs, Payload(), ord0, &run)));
+        HHX_TRY((build_run<SrcMapped, 0>(SrcMapped{mapped.p}, n_pairs, Payload(), ord0, &run, fuse ? hist0.p : nullptr)));
         h->runs[stream].push_back(run);
     } }
     if (h->keep_pairs) HHX_TRY(hhx_side_records_push<POS>(h, n_pairs, id1, pos1, id2, pos2));

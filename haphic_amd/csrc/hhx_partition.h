@@ -233,9 +233,12 @@ inline int part_levels(int total_bits, int max_bits, int *bits /* [4] */) {
 
 // count_src (optional): the source object the level-1 COUNT pass reads through instead of src — same records, but its
 // get() may carry a side effect that has to happen exactly once per record (hhx_matrix.hip: first positions).
+// hist0 (optional): the level-1 histogram already counted by whoever produced the records (hhx_ingest.hip: k_map_records) —
+// 2^bits[0] counts of the digit `bucket >> (total_bits - bits[0])` over the valid records; the level's COUNT pass is skipped.
 template <class Src, class Dig>
 int partition_records(const Src &src, const Dig &dig, i64 n_items, int total_bits, int max_bits_per_level,
-                      Partitioned<typename Src::w1_t> *out, const char *timer_prefix, const Src *count_src = nullptr) {
+                      Partitioned<typename Src::w1_t> *out, const char *timer_prefix, const Src *count_src = nullptr,
+                      const unsigned long long *hist0 = nullptr) {
     typedef typename Src::w1_t W1;
     static bool attr_set = false;
     if (!attr_set) {
@@ -269,7 +272,8 @@ int partition_records(const Src &src, const Dig &dig, i64 n_items, int total_bit
         const SrcRecs<W1> rs{cur_w0.p, cur_w1.p};
         snprintf(tname, sizeof tname, "%s_count%d", timer_prefix, l + 1);
         { KTimer kt(tname);
-        if (l == 0) k_part_count<Src, Dig><<<grid, PT, 0, g_stream>>>(count_src ? *count_src : src, dig, n_cur, L, hist.p);
+        if (l == 0 && hist0) u64_copy_async(hist0, hist.p, (i64)nbk);
+        else if (l == 0) k_part_count<Src, Dig><<<grid, PT, 0, g_stream>>>(count_src ? *count_src : src, dig, n_cur, L, hist.p);
         else k_part_count<SrcRecs<W1>, Dig><<<grid, PT, 0, g_stream>>>(rs, dig, n_cur, L, hist.p); }
         HHX_LAUNCH_CHECK();
         i64 n_valid = 0;
