@@ -64,3 +64,68 @@ def test_bench_self_launch_command(monkeypatch):
     monkeypatch.delenv('WORLD_SIZE')
     bench.self_launch(argparse.Namespace(gpus=1, master_port=0))
     assert len(calls) == 1
+
+
+# ---- the two arithmetic claims of k_dense_epilogue_sw (csrc/hhx_expand.hip), restated in numpy --------------------------------
+def test_dense_epilogue_slot_swizzle_is_bank_conflict_free():
+    """A thread owns `per` consecutive 4-byte slots; slot t is stored at t ^ ((t >> 5) & gm), gm = (power of two in per, capped
+    at 32) - 1.  ds_read_b32 serves a wave in two groups of 32 lanes over 32 banks: for every per <= DE_PER, every k and every
+    group, the 32 lanes must fall on 32 different banks; and the fill (lane t of a group writes slot base + t) must too."""
+    for per in range(1, 21):
+        gm = min(32, per & -per) - 1
+        tid = np.arange(1024)
+        for k in range(per):
+            t = tid * per + k
+            bank = (t ^ ((t >> 5) & gm)) & 31
+            groups = bank.reshape(-1, 32)
+            assert all(len(set(g.tolist())) == 32 for g in groups), (per, k)
+        for i in range(per):                                          # the fill: t = tid + i * 1024
+            t = tid + i * 1024
+            phys = t ^ ((t >> 5) & gm)
+            assert np.array_equal(phys, (tid ^ ((tid >> 5) & gm)) + i * 1024)          # one swizzled base, constant offsets
+            assert all(len(set((g & 31).tolist())) == 32 for g in phys.reshape(-1, 32)), (per, i)
+        # and the map is a permutation of the slots of a window (rounded up to a 32-slot row)
+        n = per * 1024
+        t = np.arange(n)
+        assert np.array_equal(np.sort(t ^ ((t >> 5) & gm)), t)
+
+
+def test_quotient_by_reciprocal_matches_true_quotient_outside_the_midpoint_window():
+    """float32(a / d) == float32(a * (1 / d)) whenever the double product a * RN(1 / d) is more than 8 ulps away from the midpoint
+    of two float32 values and not below 2^-120 (quot_f32 takes the true quotient otherwise).  Random operands shaped like the
+    kernel's: a = a float32 (y of the integer arithmetic, or p = x^2), d = an integer row sum or a running sum of float32s."""
+    rng = np.random.default_rng(20260926)
+    checked = 0
+    for scale in (1.0, 1e-6, 1e-12, 1e6):
+        a = (rng.random(2_000_000, dtype=np.float32) * np.float32(scale)).astype(np.float32).astype(np.float64)
+        for d in (rng.integers(1, 1 << 34, 2_000_000).astype(np.float64), rng.random(2_000_000) * 1e3 + 1e-3):
+            q = a * (1.0 / d)
+            lo = q.view(np.uint64) & np.uint64(0x1fffffff)
+            exact = ((lo - np.uint64(0x0ffffff8)) & np.uint64(0xffffffff)) > np.uint64(16)
+            exact &= q >= 2.0 ** -120
+            true = (a / d).astype(np.float32)
+            fast = q.astype(np.float32)
+            assert np.array_equal(true[exact], fast[exact])
+            checked += int(exact.sum())
+    assert checked > 15_000_000
+    # and the window does catch what it is for: products placed exactly on a midpoint are sent to the true quotient
+    mid = (np.float32(1.5).astype(np.float64) + np.float32(1.5000001).astype(np.float64)) / 2
+    lo = np.array([mid]).view(np.uint64) & np.uint64(0x1fffffff)
+    assert int(lo[0]) == 0x10000000
+
+
+def test_early_pruning_bound_of_the_dense_epilogue():
+    """k_dense_epilogue_sw decides "pruned" before the running row sum S of a window is known: S is at least the sum S' of the
+    windows before, and p < float32(thr * S' * (1 - 2^-18)) must imply float32(p / S) < thr for every S >= S' (the exact test
+    visits only the other slots)."""
+    rng = np.random.default_rng(7)
+    thr = np.float32(1e-4)
+    n = 4_000_000
+    s_prev = rng.random(n) * 10.0 ** rng.integers(-6, 3, n) + 1e-9
+    s = s_prev * (1.0 + rng.random(n) * rng.integers(0, 2, n))                      # S == S' half of the time: the tight case
+    lo = (np.float64(thr) * s_prev * (1.0 - 2.0 ** -18)).astype(np.float32)
+    # p just below the bound (the hardest case), and anywhere below it
+    for p in (np.nextafter(lo, np.float32(0)), (lo * rng.random(n, dtype=np.float32)).astype(np.float32)):
+        below = p < lo
+        q = (p.astype(np.float64) / s).astype(np.float32)
+        assert not (q[below] >= thr).any()
