@@ -171,8 +171,8 @@ def device_count():
 
 
 def tune(name, value):
-    """measurement / experiment switch of the kernels (hhx_tune)"""
-    check(load().hhx_tune(name.encode(), int(value)))
+    """which kernel class / arithmetic / layout the calls take (hhx_tune; same results under every setting); None: back to the default"""
+    check(load().hhx_tune(name.encode(), -2 ** 63 if value is None else int(value)))
 
 
 def profile_enable(on=True):
@@ -699,9 +699,13 @@ class Ingest:
         check(load().hhx_ingest_create(C.byref(cfg), C.byref(self.h)))
         self.n_full = self.n_flank = None
 
-    def push(self, id1, pos1, id2, pos2):
-        """host arrays; positions of dtype int64 go through hhx_ingest_push64 (contigs of 2^31 bp and more, :116-147)"""
-        if np.asarray(pos1).dtype == np.int64 or np.asarray(pos2).dtype == np.int64:
+    def push(self, id1, pos1, id2, pos2, wide=None):
+        """host arrays.  wide=True: 64-bit positions through hhx_ingest_push64 (contigs of 2^31 bp and more, :116-147).  wide=None:
+        decided by the VALUES, not the dtype — default-int64 numpy arrays whose positions fit 32 bits take the packed 32-bit path
+        (half the host-to-device bytes, four pairs per lane in the map kernel)."""
+        if wide is None:
+            wide = any(a.dtype.itemsize > 4 and a.size and int(a.max()) > np.iinfo(np.int32).max for a in (np.asarray(pos1), np.asarray(pos2)))
+        if wide:
             ids = [np.ascontiguousarray(a, np.int32) for a in (id1, id2)]
             pos = [np.ascontiguousarray(a, np.int64) for a in (pos1, pos2)]
             check(load().hhx_ingest_push64(self.h, ids[0].size, ptr(ids[0]), ptr(pos[0]), ptr(ids[1]), ptr(pos[1]), 0))

@@ -888,6 +888,27 @@ def bam_generator(bam, threads, format_options):
 
 
 # ------------------------------------------------------------------ S5: ingest
+class IdArrays:
+    """Alignments that are already integer arrays — contig ids in fa_dict order (-1: a name that is not in the FASTA) and 0-based
+    positions — accepted wherever the S5 mirrors take the reference's (ref, mref, pos, mpos) iterator (:1539-1593); iterating
+    yields those tuples.  The arrays go to the device ingest as they are, without a pass through Python objects."""
+
+    def __init__(self, names, id1, pos1, id2, pos2):
+        self.names = list(names)
+        self.id1, self.id2 = np.ascontiguousarray(id1, np.int32), np.ascontiguousarray(id2, np.int32)
+        self.pos1, self.pos2 = np.ascontiguousarray(pos1), np.ascontiguousarray(pos2)
+        if not (len(self.id1) == len(self.id2) == len(self.pos1) == len(self.pos2)):
+            raise ValueError('IdArrays: arrays of different lengths')
+
+    def __len__(self):
+        return len(self.id1)
+
+    def __iter__(self):
+        nm = self.names
+        for a, x, b, y in zip(self.id1.tolist(), self.pos1.tolist(), self.id2.tolist(), self.pos2.tolist()):
+            yield (nm[a] if a >= 0 else None, nm[b] if b >= 0 else None, x, y)
+
+
 def _ids_from_alignments(alignments, cid, chunk, wide=False):
     """(ref, mref, pos, mpos) iterator -> id (int32) and position (int32; int64 when wide) arrays, `chunk` pairs at a time"""
     pos_t = np.int64 if wide else np.int32
@@ -930,10 +951,20 @@ def ingest_links(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False
         elif bam:                            # f4: BGZF inflate on host threads, record decode on the device
             for _reader, k, ptrs in alignments.batches(table.ctg_names):
                 ing.push_device(k, *ptrs)
+        elif isinstance(alignments, IdArrays):
+            if alignments.names != list(table.ctg_names):
+                raise ValueError('IdArrays: the ids do not refer to the contigs of fa_dict, in its order')
+            pos_t = np.int64 if table.wide else np.int32
+            if len(alignments) and max(int(alignments.pos1.max()), int(alignments.pos2.max())) >= np.iinfo(pos_t).max:
+                raise RuntimeError('a position does not fit the {} coordinates of the MI355X ingest'.format(pos_t.__name__))
+            for lo in range(0, len(alignments), chunk):
+                hi = min(len(alignments), lo + chunk)
+                ing.push(alignments.id1[lo:hi], alignments.pos1[lo:hi].astype(pos_t, copy=False), alignments.id2[lo:hi],
+                         alignments.pos2[lo:hi].astype(pos_t, copy=False), wide=table.wide)
         else:
             cid = {n: i for i, n in enumerate(table.ctg_names)}
             for b1, p1, b2, p2, k in _ids_from_alignments(alignments, cid, chunk, wide=table.wide):
-                ing.push(b1, p1, b2, p2)     # unknown names (-1) and intra-contig pairs are filtered on the device
+                ing.push(b1, p1, b2, p2, wide=table.wide)     # unknown names (-1) and intra-contig pairs are filtered on the device
         ing.finalize()
         out = ing.fetch()
         if want_pairs:
@@ -1112,12 +1143,15 @@ def recommend_inflation(result_stat, nchrs, len_ratio):
 
 def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, expansion, min_inflation,
                        max_inflation, inflation_step, max_iter, pruning, fa_dict, nchrs, dense_matrix=False,
-                       outdir_root='.', dist=None, _block_rows=None):
+                       outdir_root='.', dist=None, _block_rows=None, _engine=None):
     """run_mcl_clustering() :2132-2242.  link_matrix: scipy CSC or a DeviceCSR.  The normalised,
     pre-expanded matrix is built once and stays in HBM for the whole inflation sweep (_block_rows: rows per float32 block of
     the dense sweep — tests force the blocked path at small orders with it).  With a torch.distributed
-    group (`dist`, one process per GPU, every rank holding the link matrix) the inflations are dealt round-robin
-    to the ranks (sharded.inflation_sweep); every rank gets all results, rank 0 writes the files."""
+    group (`dist`, one process per GPU, every rank holding the link matrix) the sweep is shared out over the ranks
+    (sharded.sweep_sharded: one expansion across the ranks, the heavy iterations of the low inflations row-sharded, the light
+    remainders dealt by predicted cost; expansion != 2: whole inflations dealt round-robin, sharded.inflation_sweep); every rank
+    gets all results, rank 0 writes the files.  _engine: the arithmetic behind sharded.py (default: the HIP library on the
+    current device; CPU tests pass an oracle-backed one)."""
     if dense_matrix:
         raise ValueError('dense_matrix mode is not on the MI355X path; use the reference function')
     logger.info('Performing Markov clustering...')
@@ -1135,7 +1169,12 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
     inflations = _inflation_values(min_inflation, max_inflation, inflation_step)
     pre = None
     sweep = None
-    if expansion == 2 and not materialise and len(inflations) > 1 and max_iter >= 1:
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    across = world > 1 and expansion == 2 and max_iter >= 1          # the sweep shared out over the ranks (sharded.sweep_sharded)
+    if across:
+        pass
+    elif expansion == 2 and not materialise and len(inflations) > 1 and max_iter >= 1:
         sweep = DenseSweep(m, pruning, block_rows=_block_rows)
     elif materialise:
         _lib.normalize_l1(m)                                         # :2144
@@ -1150,9 +1189,7 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
         pre = m
     result_clusters_list = []
     mcl_nrounds = 0
-    world = dist.get_world_size() if dist is not None else 1
-    rank = dist.get_rank() if dist is not None else 0
-    # with several ranks the inflations are dealt round-robin; a rank forms iteration 0 only of its own inflations
+    # expansion != 2 with several ranks: the inflations are dealt round-robin; a rank forms iteration 0 only of its own inflations
     mine = [infl for k, infl in enumerate(inflations) if k % world == rank] if world > 1 else inflations
     firsts = sweep.first_iterations(mine) if sweep is not None else None
 
@@ -1168,10 +1205,21 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
         finally:
             res.free()
 
-    if dist is not None and dist.get_world_size() > 1:
+    if across:
+        from . import sharded
+        if _engine is None:
+            import torch
+            _engine = sharded.HipEngine('cuda:%d' % torch.cuda.current_device())
+        attractor_arrays = []
+        for inflation, (att, att_ptr, members, shape, n_iter, converged) in zip(
+                inflations, sharded.sweep_sharded(_engine, m, inflations, max_iter, pruning, dist)):
+            _log_mcl(n_iter, converged, expansion, float(inflation), max_iter, pruning)      # in the order of the sweep, like the reference
+            attractor_arrays.append((att, att_ptr, members, shape))
+        write_files = rank == 0
+    elif world > 1:
         from . import sharded
         attractor_arrays = sharded.inflation_sweep(run_one, inflations, dist)
-        write_files = dist.get_rank() == 0
+        write_files = rank == 0
     else:
         attractor_arrays = None
         write_files = True

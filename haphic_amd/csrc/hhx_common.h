@@ -125,6 +125,8 @@ struct hhx_dense {
     i32 cap_win = 0, n_win = 0;         // the column-window plan of the expansion that filled it (summation order of the epilogue)
     mutable i64 last_cand = 0, last_out = 0;    // pool demand of the previous hhx_dense_inflate_prune (sizes the next call's pools)
     bool integer = false;               // x holds y = float(S_ij) of the integer arithmetic; the entry of M^2 is float(y / row_div[i])
+    bool tri = false;                   // all rows, symmetric: x holds the upper block triangle alone (hhx_expand.hip: tri_row_off), ldn = n_win * cap_win
+    i64 ldn = 0;
     hhx::DevBuf<float> x;
     hhx::DevBuf<double> row_div;
 };

@@ -25,6 +25,7 @@
 using namespace hhx;
 
 int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
+namespace hhx { i64 pool_cached_bytes(); }
 
 namespace {
 
@@ -69,6 +70,10 @@ struct ExParams {
     // dense mode (the inflation sweep, run_mcl_clustering :2155-2158): the window kernel stores x = float(acc) of every column
     // into row `row` of this n_rows x dense_ld float32 block instead of inflating / pruning (0 = no entry)
     float *dense; i64 dense_ld;
+    // dense, all rows, symmetric mode: `dense` holds the UPPER BLOCK TRIANGLE alone (tri != 0) — block row I (rows [I cap, (I + 1) cap))
+    // starts at tri_row_off(I) and keeps only its windows J >= I, rows tri_ldn - I cap floats apart (tri_ldn = n_win * cap):
+    // cap^2 n_win (n_win + 1) / 2 floats instead of n^2 (88 GB instead of 160 GB at n = 200k)
+    i32 tri; i64 tri_ldn;
     // INTEGER arithmetic of iteration 0 on the raw link matrix (specification: DESIGN.md 4.1, "integer arithmetic").  A = rows of L, B = L, integer link counts c:
     // the addend of product (i, k, j) is c_ik * W_k * c_kj with W_k = rint(2^s / d_k) — S = L D^-1 L, a symmetric matrix, in exact
     // 64-bit integers; y = float(acc * 2^-s), x = float(y / d_i).  W == nullptr: the float arithmetic above (fx_bits).
@@ -703,6 +708,22 @@ __device__ __forceinline__ void finalize_row(const ExParams &P, const ExLds &l, 
     }
 }
 
+// ---- the dense block of the expanded rows: square (every row n floats, `ld` apart) or upper block triangle ----------------------
+__host__ __device__ inline i64 tri_row_off(i32 I, i32 cap, i64 ldn) { return (i64)cap * ((i64)I * ldn - (i64)cap * I * (I - 1) / 2); }
+__host__ __device__ inline i64 tri_floats(i32 n_win, i32 cap) { return (i64)cap * cap * n_win * (n_win + 1) / 2; }
+// where the epilogue finds (row, window): windows >= up_win0 in `up` (rows up_ld apart, its first window is up_win0), the windows
+// before in `lo` (rows lo_ld apart) — the square block is up_win0 = 0; a block row I of the triangle is up_win0 = I with `lo` the
+// transposed blocks (J < I, I) laid side by side.  Rows [row0, row1); row `row0` is row 0 of both.
+struct DenseSrc {
+    const float *up; i64 up_ld; i32 up_win0;
+    const float *lo; i64 lo_ld;
+    i32 row0, row1;
+    __device__ __forceinline__ const float *at(i32 row, i32 wv, i32 cap) const {
+        return wv >= up_win0 ? up + (size_t)(row - row0) * (size_t)up_ld + (size_t)(wv - up_win0) * cap
+                             : lo + (size_t)(row - row0) * (size_t)lo_ld + (size_t)wv * cap;
+    }
+};
+
 // ---- the kernels ----------------------------------------------------------------------------------
 // Window class.  The loop nest is WINDOW-OUTER: one launch per column window, every launch sweeping all
 // the rows.  While window w is being processed the only part of B that is read is its column slice
@@ -752,7 +773,11 @@ __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__re
         }
         __syncthreads();
         if (P.dense) {                              // the sweep: the expanded row leaves as float32, inflation-independent
-            float *dst = P.dense + (size_t)row * (size_t)P.dense_ld + c0;
+            float *dst;
+            if (P.tri) {                            // upper block triangle: this launch (window wv) only sees rows of the blocks I <= wv
+                const i32 I = row / cap;
+                dst = P.dense + tri_row_off(I, cap, P.tri_ldn) + (size_t)(row - I * cap) * (size_t)(P.tri_ldn - (i64)I * cap) + (size_t)(wv - I) * cap;
+            } else dst = P.dense + (size_t)row * (size_t)P.dense_ld + c0;
             for (i32 t = tid; t < wlen; t += EX_T) {
                 const u64 ai = l.acc[t];
                 // float arithmetic: the x of window_power_sum, bit for bit.  Integer arithmetic: y = float(S_ij), symmetric — the
@@ -972,7 +997,7 @@ __global__ __launch_bounds__(EX_T_CMP) void k_expand_window_finalize(ExParams P,
 // single-inflation iteration gives.  k_expand_window_finalize then finishes the rows.
 __host__ __device__ inline size_t dense_epi_lds_bytes(i32 cap) { return (size_t)cap * 4 + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + 8; }
 template <bool SQUARE>
-__global__ __launch_bounds__(EX_T_WIN, SQUARE ? 8 : 4) void k_dense_epilogue(ExParams P, const float *__restrict__ X, i64 ld, i32 cap) {
+__global__ __launch_bounds__(EX_T_WIN, SQUARE ? 8 : 4) void k_dense_epilogue(ExParams P, const DenseSrc S, i32 cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // 4-byte slots (the expanded row is float32 already): two workgroups share a CU, one loading its window while the other reduces
     ExLds l;
@@ -989,12 +1014,12 @@ __global__ __launch_bounds__(EX_T_WIN, SQUARE ? 8 : 4) void k_dense_epilogue(ExP
     float *slot = (float *)l.acc;
     const int tid = threadIdx.x;
     i64 nnzc = 0;
-    for (i32 row = blockIdx.x; row < P.n_rows; row += gridDim.x) {
+    for (i32 row = S.row0 + blockIdx.x; row < S.row1; row += gridDim.x) {
         double s_run = 0.0;
         const double div = P.row_div ? P.row_div[row] : 0.0;
         for (i32 wv = 0; wv < P.n_win; ++wv) {
             const i32 c0 = wv * cap, wlen = min(P.n_cols, c0 + cap) - c0;
-            const float *src = X + (size_t)row * (size_t)ld + c0;
+            const float *src = S.at(row, wv, cap);
             for (i32 t = tid; t < wlen; t += EX_T) slot[t] = src[t];
             __syncthreads();
             i32 nz;
@@ -1046,7 +1071,7 @@ __host__ __device__ inline size_t dense_epi_sw_lds_bytes(i32 cap) { return (size
 // general inflation, whose pow() needs the registers anyway; !PF: two workgroups per CU (64 registers), each loading its window at
 // the start of the step — inflation 2 (measured: 28 ms against 32.5 ms with the prefetch and one workgroup).
 template <bool SQUARE, bool PF>
-__global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExParams P, const float *__restrict__ X, i64 ld, i32 cap) {
+__global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExParams P, const DenseSrc S, i32 cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *red_d; i64 *bcast; i32 *red_i, *red_s; float *red_f, *slot;
     {
@@ -1063,13 +1088,13 @@ __global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExPa
     i32 nnzc = 0;                                           // at most rows per workgroup x n_cols slots: below 2^31
     // The (row, window) steps of this workgroup in one sequence (every barrier below orders LDS only: a __syncthreads() would wait
     // for the loads of the next window).
-    i32 row = blockIdx.x, wv = 0;
-    if (row >= P.n_rows) return;
+    i32 row = S.row0 + (i32)blockIdx.x, wv = 0;
+    if (row >= S.row1) return;
     float v[DE_PER];
     double div_n = P.row_div ? P.row_div[row] : 0.0;
     if (PF) {
         const i32 wlen = min(P.n_cols, cap);
-        const float *src = X + (size_t)row * (size_t)ld;
+        const float *src = S.at(row, 0, cap);
 #pragma unroll
         for (int i = 0; i < DE_PER; ++i) v[i] = de_load(src, min(tid + i * EX_T_WIN, wlen - 1));
     }
@@ -1081,7 +1106,7 @@ __global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExPa
         asm volatile("" : "+v"(lt));                        // opaque: or the 20 offsets lt + i * 1024 are hoisted out of the loop and spilled
         const i32 s0 = min(wlen, lt * per), s1 = min(wlen, s0 + per);
         if (!PF) {
-            const float *src = X + (size_t)row * (size_t)ld + c0;
+            const float *src = S.at(row, wv, cap);
 #pragma unroll
             for (int i = 0; i < DE_PER; ++i) v[i] = de_load(src, min(lt + i * EX_T_WIN, wlen - 1));      // clamped, not predicated: no branch per load
         }
@@ -1093,7 +1118,7 @@ __global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExPa
         lds_barrier();
         i32 row_n = row, wv_n = wv + 1;
         if (wv_n == P.n_win) { wv_n = 0; row_n = row + (i32)gridDim.x; }
-        const bool more = row_n < P.n_rows;
+        const bool more = row_n < S.row1;
         // x -> p = x^r, the window sum and the window maximum: the owned slots in ascending order (window_power_sum<false, true, SQUARE>
         // and the first pass of window_emit_candidates<false, 1>)
         // A slot survives the window if float(p / S) >= thr, S = the running row sum INCLUDING this window — known only after the
@@ -1131,7 +1156,7 @@ __global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExPa
         if (more && wv_n == 0 && P.row_div) div_n = P.row_div[row_n];
         if (PF && more) {                                   // the next step's window: 20 values in flight through the rest of this step
             const i32 c0n = wv_n * cap, wlen_n = min(P.n_cols, c0n + cap) - c0n;
-            const float *src = X + (size_t)row_n * (size_t)ld + c0n;
+            const float *src = S.at(row_n, wv_n, cap);
 #pragma unroll
             for (int i = 0; i < DE_PER; ++i) v[i] = de_load(src, min(lt + i * EX_T_WIN, wlen_n - 1));
         }
@@ -1464,6 +1489,25 @@ __global__ __launch_bounds__(256) void k_transpose_lower(float *__restrict__ Y, 
     }
 }
 
+// Upper-block-triangle storage: before the rows of block row I are finished, the blocks (J, I), J < I — held as rows of block row J —
+// are turned into rows of block row I, side by side in a scratch block (cap rows x I cap floats): dst[r][J cap + c] = src_J[c][r].
+// grid: (cap / 64 tiles of destination columns, tiles of destination rows, J).  src block (J, I) starts at
+// tri + tri_row_off(J) + (I - J) cap with pitch ldn - J cap; rows_I = rows of block row I (the last one may be short).
+__global__ __launch_bounds__(256) void k_transpose_tri(const float *__restrict__ tri, float *__restrict__ dst, i64 dst_ld, i32 I, i32 rows_I, i32 cap, i64 ldn) {
+    __shared__ float tile[64][65];
+    const i32 J = (i32)blockIdx.z;
+    const float *src = tri + tri_row_off(J, cap, ldn) + (size_t)(I - J) * cap;
+    const i64 src_ld = ldn - (i64)J * cap;
+    const i32 r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;             // destination tile: rows r0.. (of block row I), columns J cap + c0..
+    if (r0 >= rows_I) return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4)                                  // source tile: rows c0 + k of block row J, columns r0 + tx of window I
+        tile[k][tx] = (r0 + tx < rows_I) ? src[(size_t)(c0 + k) * (size_t)src_ld + r0 + tx] : 0.0f;
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4)
+        if (r0 + k < rows_I) dst[(size_t)(r0 + k) * (size_t)dst_ld + (size_t)J * cap + c0 + tx] = tile[tx][k];
+}
+
 // ---- classification: product count per row, three row lists -----------------------------------------
 // A block takes 64 consecutive rows at a time: its waves count the products of one row each (coalesced),
 // then the first wave sorts the 64 rows into the class lists with ONE atomic per class and chunk (a
@@ -1645,7 +1689,25 @@ struct CodedOperand {
     int shift = 0;
     int sym = 0;                        // dense mode: compute the blocks J >= I only; a == all rows: mirrored here, a row block: by the caller
     i32 sym_row0 = 0;
+    int tri = 0;                        // sym over all rows, dense_out = the upper block triangle alone (tri_floats(n_win, cap_win) floats): nothing is mirrored
 };
+
+// the column-window plan of the window class for an operand of n_cols columns / nnz_b entries: the fewest, widest windows whose
+// 8-byte accumulators fit LDS (hhx_expand_impl; hhx_expand_dense_impl sizes the triangle with it before the expansion runs)
+static void window_plan(i32 n_cols, i64 nnz_b, i32 *cap_win_out, i32 *n_win_out) {
+    const size_t fixed_win = win_fixed_bytes();
+    const i64 slice_mb = tune_get("cache_slice_mb", 0);
+    const i64 slice_bytes = slice_mb > 0 ? slice_mb << 20 : (i64)1 << 60;
+    const i32 cap_max = (i32)((160 * 1024 - fixed_win) / 8) & ~63;
+    i64 n_win64 = ((i64)n_cols + cap_max - 1) / cap_max;
+    const i64 by_cache = (nnz_b * 8 + slice_bytes - 1) / slice_bytes;
+    const i64 widest = std::max<i64>(1, (i64)n_cols / 2048);           // never narrower than 2048 columns
+    n_win64 = std::max(n_win64, std::min(by_cache, widest));
+    i32 cap_win = (i32)((((i64)n_cols + n_win64 - 1) / n_win64 + 63) & ~63);
+    if (cap_win > cap_max) cap_win = cap_max;
+    *cap_win_out = cap_win;
+    *n_win_out = (n_cols + cap_win - 1) / cap_win;
+}
 
 template <int PROBE, int UX, int RX, int RW, bool FX, int T = EX_T_WIN>
 static int launch_window_fx(const ExParams &P, const i32 *rows, i32 n_list, i32 cap, size_t lds, unsigned grid) {
@@ -1713,16 +1775,9 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     // entries): the fewest, widest windows win — 6 windows 1.41 s, 13 windows 1.54 s, 27 windows 2.24 s —
     // because the per-segment cost grows faster than the Infinity Cache hit rate of a narrower column slice
     // B[:, w].  tune "cache_slice_mb" (MB of B per slice) forces more windows for experiments.
-    const i64 slice_mb = tune_get("cache_slice_mb", 0);
-    const i64 slice_bytes = slice_mb > 0 ? slice_mb << 20 : (i64)1 << 60;
-    const i32 cap_max = (i32)((160 * 1024 - fixed_win) / 8) & ~63;
-    i64 n_win64 = ((i64)n_cols + cap_max - 1) / cap_max;
-    const i64 by_cache = (b->nnz * 8 + slice_bytes - 1) / slice_bytes;
-    const i64 widest = std::max<i64>(1, (i64)n_cols / 2048);           // never narrower than 2048 columns
-    n_win64 = std::max(n_win64, std::min(by_cache, widest));
-    i32 cap_win = (i32)((((i64)n_cols + n_win64 - 1) / n_win64 + 63) & ~63);
-    if (cap_win > cap_max) cap_win = cap_max;
-    const i32 n_win = (n_cols + cap_win - 1) / cap_win;
+    i32 cap_win = 0, n_win = 0;
+    window_plan(n_cols, b->nnz, &cap_win, &n_win);
+    if (coded.tri && !(coded.sym && a->n_rows == b->n_rows && coded.sym_row0 == 0)) return fail("expand: the triangle storage needs the symmetric mode over all rows");
     size_t budget_cmp = 64 * 1024;
     if (fixed_cmp + 2048 * 8 > budget_cmp) budget_cmp = 160 * 1024;
     if (fixed_cmp + 1024 * 8 > budget_cmp) return fail("expand: %d columns exceed the LDS bitmap capacity", n_cols);
@@ -1749,7 +1804,12 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     const size_t lds_hash = hash_lds_bytes(W);
     // off when B's rows are longer than the table can hold distinct columns anyway (iteration 0: the link matrix itself)
     const bool hash_fits = lds_hash <= 160 * 1024 && b->n_rows > 0 && b->nnz / b->n_rows <= HASH_LIMIT / 2;
-    const i64 hash_max = all_window ? -1 : (hash_fits ? std::max<i64>(0, tune_get("hash_max", 4000000)) : 0);
+    // ... and only for rows the window class would not serve faster.  Measured on the tails of the low inflations at n = 100k
+    // (profiles/r04_tail_probe.jsonl): the hash kernel walks 3.4-5.3e11 products/s whatever the row, the window kernel 1.1e12 /s plus
+    // ~0.6 us per row of sweeping its n accumulators — the hash class wins below ~4.5 n products per row, not up to 4 M
+    // (at inflation 1.3, iterations 3-6: 312 ms through the hash class for 1.1e11 products that the window class walks in ~160)
+    const i64 hash_dflt = std::min<i64>(4000000, std::max<i64>(65536, (i64)(4.5 * (double)n_cols)));
+    const i64 hash_max = all_window ? -1 : (hash_fits ? std::max<i64>(0, tune_get("hash_max", hash_dflt)) : 0);
     DevBuf<int2> bjx;
     DevBuf<double> s_run;
     DevBuf<unsigned int> counts;
@@ -1811,6 +1871,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         P.dense = coded.dense_out; P.dense_ld = coded.dense_ld ? coded.dense_ld : (i64)n_cols;
         P.W = fx ? coded.W : nullptr; P.A16 = coded.a16; P.row_div = coded.a_row_sum; P.fx_inv = ldexp(1.0, -coded.shift);
         P.sym = coded.sym; P.sym_row0 = coded.sym_row0;
+        P.tri = coded.tri; P.tri_ldn = (i64)n_win * cap_win;
         P.Sc16 = nullptr; P.Sx = nullptr; P.rec = nullptr; P.Bjx = nullptr; P.narrow_classes = 0; P.wb = WB_MAX;
         if (hc[3]) {                                      // hash class first: it may add rows to the window / compact lists
             if (!bjx.p) {                                 // B as 8-byte (column, value) words, built once per call
@@ -1903,7 +1964,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 else HHX_TRY((launch_window<0, 1, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
             }
             HHX_LAUNCH_CHECK();
-            if (sym_whole && n_win > 1) {
+            if (sym_whole && n_win > 1 && !coded.tri) {
                 KTimer kt("dense_transpose");
                 const unsigned tiles = (unsigned)(cap_win / 64), pairs = (unsigned)(n_win * (n_win - 1) / 2);
                 k_transpose_lower<<<dim3(tiles, tiles, pairs), 256, 0, g_stream>>>(coded.dense_out, coded.dense_ld ? coded.dense_ld : (i64)n_cols, n_cols, cap_win);
@@ -1970,15 +2031,45 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
 // (nearly) dense — n^2 entries at n = 100k — so here a ROW BLOCK of it is stored as plain float32 (4 B per entry instead of the 8 of a
 // CSR entry, no index traffic) by the window kernel's dense mode, and iteration 0 of every inflation is the epilogue alone over that
 // block (k_dense_epilogue + k_expand_window_finalize): the 1.15e12 products of the expansion are walked once for the whole sweep.
+// How the dense block of ALL rows of an order-n link matrix in the symmetric integer mode is stored — 1: the square (n rows of n floats:
+// the upper block triangle is computed, the rest mirrored by k_transpose_lower), 2: the upper block triangle alone (+ a scratch block row
+// while the rows are finished), 0: neither fits next to the operand stream and the pools (the caller walks all products into the
+// fused epilogue instead).  tune "dense_tri": 1 forces the triangle, 0 forbids it.
+int hhx_dense_layout(i32 n_rows, i32 n_cols, i64 nnz_b) {
+    i32 cap = 0, n_win = 0;
+    window_plan(n_cols, nnz_b, &cap, &n_win);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    const double avail = (double)free_b + (double)pool_cached_bytes();
+    const double square = 4.0 * (double)n_rows * (double)(((i64)n_cols + 31) & ~(i64)31);
+    const double tri = 4.0 * (double)tri_floats(n_win, cap) + 4.0 * (double)cap * (double)(n_win - 1) * cap;
+    const double rest = 12.0 * (double)nnz_b + 8e9;             // operand stream (records, 16-bit columns, values: padded), candidate pools, the result
+    const i64 mode = tune_get("dense_tri", -1);
+    if (mode == 1 && n_win > 1) return tri + rest <= avail ? 2 : 0;
+    if (square * 1.25 + rest <= avail) return 1;
+    if (mode != 0 && n_win > 1 && tri + rest <= avail) return 2;
+    return 0;
+}
+
 int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const hhx_links_operand *lk, int fx_shift, hhx_dense **out, i64 *n_products,
                           i64 *nnz_expanded) {
     if (!a || !b || !out) return fail("null pointer");
     hhx_dense *d = new hhx_dense();
     d->n_rows = a->n_rows; d->n_cols = b->n_cols;
     d->ld = ((i64)b->n_cols + 31) & ~(i64)31;
-    if (d->x.alloc((size_t)a->n_rows * (size_t)d->ld + 1)) { delete d; return 2; }      // 2: the block itself does not fit (callers may fall back)
+    // Layout.  All rows in the symmetric integer mode: the upper block triangle alone when the square does not fit next to the
+    // operand stream and the pools (n = 200k: 160 GB against 88) — the lower blocks are then never stored, the epilogue turns them
+    // one block row at a time (hhx_dense_inflate_prune).  tune "dense_tri": 1 forces the triangle, 0 forbids it.
+    const bool tri_ok = lk && lk->W && lk->sym && a->n_rows == b->n_rows && lk->a_row0 == 0;
+    i32 plan_cap = 0, plan_win = 0;
+    window_plan(b->n_cols, b->nnz, &plan_cap, &plan_win);
+    const bool tri = tri_ok && hhx_dense_layout(a->n_rows, b->n_cols, b->nnz) == 2;
+    d->tri = tri;
+    d->ldn = (i64)plan_win * plan_cap;
+    const size_t floats = tri ? (size_t)tri_floats(plan_win, plan_cap) : (size_t)a->n_rows * (size_t)d->ld;
+    if (d->x.alloc(floats + 1)) { delete d; return 2; }      // 2: the block itself does not fit (callers may fall back)
     CodedOperand c;
-    c.dense_out = d->x.p; c.dense_ld = d->ld;
+    c.dense_out = d->x.p; c.dense_ld = d->ld; c.tri = tri ? 1 : 0;
     if (lk) {
         c.n16 = lk->n16; c.row_sum = lk->row_sum;
         if (lk->W) {                                   // integer arithmetic: the block holds y = float(S); its epilogue divides by d_i
@@ -1997,6 +2088,7 @@ int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const hhx_links_op
     const int rc = hhx_expand_impl(a, b, c, fx_shift, 2.0, 0.0, nullptr, n_products, nnz_expanded);
     if (rc) { delete d; return rc; }
     d->cap_win = plan[0]; d->n_win = plan[1];
+    if (tri && (plan[0] != plan_cap || plan[1] != plan_win)) { delete d; return fail("hhx_expand_dense_impl: the window plan changed under the triangle"); }
     *out = d;
     return 0;
 }
@@ -2043,18 +2135,37 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
         P.n_win = n_win; P.s_run = s_run.p; P.g_win_off = g_win_off.p; P.g_win_cnt = g_win_cnt.p;
         P.row_div = d->integer ? d->row_div.p : nullptr;
         if (n_rows) {
-            {
+            // square block: one launch over all rows.  Upper block triangle: block row by block row — the blocks (J < I, I) are turned
+            // into rows of block row I in a scratch block first (k_transpose_tri), then the rows of block row I are finished
+            DevBuf<float> lower;
+            const i64 lo_ld = (i64)(n_win - 1) * cap;
+            if (d->tri && n_win > 1 && lower.alloc((size_t)cap * (size_t)lo_ld + 1)) return 1;
+            static const int use_sw = getenv("HHX_DENSE_EPI_SW") ? atoi(getenv("HHX_DENSE_EPI_SW")) : 1;
+            for (i32 I = 0; I < (d->tri ? n_win : 1); ++I) {
+                DenseSrc S;
+                if (d->tri) {
+                    S.row0 = I * cap; S.row1 = std::min<i32>(n_rows, (I + 1) * cap);
+                    S.up = d->x.p + tri_row_off(I, cap, d->ldn); S.up_ld = d->ldn - (i64)I * cap; S.up_win0 = I;
+                    S.lo = lower.p; S.lo_ld = lo_ld;
+                    if (I > 0) {
+                        KTimer kt("dense_transpose");
+                        const unsigned tiles = (unsigned)(cap / 64);
+                        k_transpose_tri<<<dim3(tiles, (unsigned)((S.row1 - S.row0 + 63) / 64), (unsigned)I), 256, 0, g_stream>>>(d->x.p, lower.p, lo_ld, I, S.row1 - S.row0, cap, d->ldn);
+                    }
+                } else { S.row0 = 0; S.row1 = n_rows; S.up = d->x.p; S.up_ld = d->ld; S.up_win0 = 0; S.lo = nullptr; S.lo_ld = 0; }
+                const i32 rows_here = S.row1 - S.row0;
+                if (rows_here <= 0) continue;
                 KTimer kt("dense_epilogue");
-                const unsigned grid = std::min<unsigned>((unsigned)n_rows, 512);
-                static const int use_sw = getenv("HHX_DENSE_EPI_SW") ? atoi(getenv("HHX_DENSE_EPI_SW")) : 1;
+                const unsigned grid = std::min<unsigned>((unsigned)rows_here, 512);
                 if (use_sw && (cap + EX_T_WIN - 1) / EX_T_WIN <= DE_PER) {
-                    const unsigned grid1 = std::min<unsigned>((unsigned)n_rows, 256);
-                    if (!P.square) k_dense_epilogue_sw<false, true><<<grid1, EX_T_WIN, dense_epi_sw_lds_bytes(cap), g_stream>>>(P, d->x.p, d->ld, cap);
-                    else k_dense_epilogue_sw<true, false><<<grid, EX_T_WIN, dense_epi_sw_lds_bytes(cap), g_stream>>>(P, d->x.p, d->ld, cap);
-                } else if (P.square) k_dense_epilogue<true><<<grid, EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, d->x.p, d->ld, cap);
-                else k_dense_epilogue<false><<<grid, EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, d->x.p, d->ld, cap);
+                    const unsigned grid1 = std::min<unsigned>((unsigned)rows_here, 256);
+                    if (!P.square) k_dense_epilogue_sw<false, true><<<grid1, EX_T_WIN, dense_epi_sw_lds_bytes(cap), g_stream>>>(P, S, cap);
+                    else k_dense_epilogue_sw<true, false><<<grid, EX_T_WIN, dense_epi_sw_lds_bytes(cap), g_stream>>>(P, S, cap);
+                } else if (P.square) k_dense_epilogue<true><<<grid, EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, S, cap);
+                else k_dense_epilogue<false><<<grid, EX_T_WIN, dense_epi_lds_bytes(cap), g_stream>>>(P, S, cap);
             }
             HHX_LAUNCH_CHECK();
+            if (lower.p) HHX_HIP(hipStreamSynchronize(g_stream));          // the scratch block dies with this scope
             KTimer kt("expand_finalize");
             k_expand_window_finalize<<<std::min<unsigned>((unsigned)n_rows, 256 * 8), EX_T_CMP, ex_fixed_bytes(0, 0), g_stream>>>(P, nullptr, n_rows);
         }
@@ -2078,13 +2189,14 @@ extern "C" int hhx_dense_shape(const hhx_dense *d, i32 *n_rows, i32 *n_cols, i64
     if (!d) return fail("null handle");
     if (n_rows) *n_rows = d->n_rows;
     if (n_cols) *n_cols = d->n_cols;
-    if (bytes) *bytes = (i64)sizeof(float) * (i64)d->n_rows * d->ld;
+    if (bytes) *bytes = (i64)sizeof(float) * (d->tri ? tri_floats(d->n_win, d->cap_win) : (i64)d->n_rows * d->ld);
     return 0;
 }
 
 // the block as device memory: n_rows rows of n_cols float32, *ld floats apart (multi-GPU: the ranks mirror their upper block triangles through it)
 extern "C" int hhx_dense_device(const hhx_dense *d, void **x, i64 *ld, i32 *cap_win, i32 *n_win) {
     if (!d || !x || !ld) return fail("null pointer");
+    if (d->tri) return fail("hhx_dense_device: this block is stored as its upper block triangle, not as rows");
     *x = d->x.p;
     *ld = d->ld;
     if (cap_win) *cap_win = d->cap_win;

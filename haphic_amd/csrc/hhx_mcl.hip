@@ -14,6 +14,7 @@ int hhx_expand_class_stream(const hhx_csr *a, const hhx_csr *b, const hhx_links_
                      double inflation, double pruning, hhx_csr **out, i64 *n_products, i64 *nnz_expanded);
 int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const hhx_links_operand *lk, int fx_shift, hhx_dense **out, i64 *n_products,
                           i64 *nnz_expanded);
+int hhx_dense_layout(i32 n_rows, i32 n_cols, i64 nnz_b);
 namespace hhx { i64 pool_cached_bytes(); }
 
 namespace {
@@ -494,10 +495,7 @@ static int expand_links_iteration0(const hhx_csr *norm, const NormalisedLinks &n
                                    i64 *nnz_expanded) {
     if (!nl.usable) return hhx_expand_inflate_prune(norm, norm, HHX_MCL_FX_SHIFT, inflation, pruning, out, n_products, nnz_expanded);
     if (nl.integer && tune_get("links_sym", 1) != 0) {
-        size_t free_b = 0, total_b = 0;
-        HHX_HIP(hipMemGetInfo(&free_b, &total_b));
-        const double need = 4.0 * (double)norm->n_rows * (double)norm->n_cols;
-        if (need * 2.0 + 4e9 < (double)free_b + (double)pool_cached_bytes()) {       // the block + room for the operand stream and the pools
+        if (hhx_dense_layout(norm->n_rows, norm->n_cols, norm->nnz) != 0) {          // the square block or its upper block triangle fits (+ operand stream, pools)
             const hhx_links_operand lk = nl.operand(0, 0, 1);
             hhx_dense *d = nullptr;
             const int rc_d = hhx_expand_dense_impl(norm, norm, &lk, HHX_MCL_FX_SHIFT, &d, n_products, nnz_expanded);
@@ -532,14 +530,14 @@ extern "C" int hhx_expand_links(const hhx_csr *links, i32 r0, i32 r1, int fx_shi
     if (r0 < 0 || r1 < r0 || r1 > links->n_rows) return fail("row block [%d,%d) out of range", r0, r1);
     NormalisedLinks nl;
     HHX_TRY(normalise_links(links, &nl));
+    i32 off = 0;                                  // before the row block exists: an error here must not leak it
+    HHX_HIP(hipMemcpyAsync(&off, links->indptr.p + r0, sizeof off, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
     hhx_csr *a = nullptr;
     HHX_TRY(hhx_csr_row_block(nl.norm, r0, r1, &a));
     int rc;
     if (!nl.usable) rc = hhx_expand_inflate_prune(a, nl.norm, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
     else {
-        i32 off = 0;
-        HHX_HIP(hipMemcpyAsync(&off, links->indptr.p + r0, sizeof off, hipMemcpyDeviceToHost, g_stream));
-        HHX_HIP(hipStreamSynchronize(g_stream));
         const hhx_links_operand lk = nl.operand(r0, off);
         rc = hhx_expand_class_stream(a, nl.norm, &lk, fx_shift, inflation, pruning, out, n_products, nnz_expanded);
     }
@@ -557,11 +555,11 @@ extern "C" int hhx_expand_links_dense(const hhx_csr *links, i32 r0, i32 r1, int 
     if (r0 < 0 || r1 < r0 || r1 > links->n_rows) return fail("row block [%d,%d) out of range", r0, r1);
     NormalisedLinks nl;
     HHX_TRY(normalise_links(links, &nl));
-    hhx_csr *a = nullptr;
-    HHX_TRY(hhx_csr_row_block(nl.norm, r0, r1, &a));
-    i32 off = 0;
+    i32 off = 0;                                  // before the row block exists: an error here must not leak it
     HHX_HIP(hipMemcpyAsync(&off, links->indptr.p + r0, sizeof off, hipMemcpyDeviceToHost, g_stream));
     HHX_HIP(hipStreamSynchronize(g_stream));
+    hhx_csr *a = nullptr;
+    HHX_TRY(hhx_csr_row_block(nl.norm, r0, r1, &a));
     const bool whole = r0 == 0 && r1 == links->n_rows;
     if (upper_only && !nl.integer) { hhx_csr_free(a); return fail("hhx_expand_links_dense: upper_only needs the integer arithmetic (symmetric counts, row sums < 2^18)"); }
     // all rows: the symmetric half + transposition; upper_only on a row block: the half alone, the caller mirrors (multi-GPU)

@@ -240,11 +240,13 @@ int partition_records(const Src &src, const Dig &dig, i64 n_items, int total_bit
                       Partitioned<typename Src::w1_t> *out, const char *timer_prefix, const Src *count_src = nullptr,
                       const unsigned long long *hist0 = nullptr) {
     typedef typename Src::w1_t W1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_dev = -1;           // the attribute is per device: keyed on the current ordinal (one static per instantiation)
+    int dev = 0;
+    HHX_HIP(hipGetDevice(&dev));
+    if (attr_dev != dev) {
         HHX_HIP(hipFuncSetAttribute((const void *)k_part_scatter<Src, Dig>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_scatter_lds<W1>()));
         HHX_HIP(hipFuncSetAttribute((const void *)k_part_scatter<SrcRecs<W1>, Dig>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_scatter_lds<W1>()));
-        attr_set = true;
+        attr_dev = dev;
     }
     if (max_bits_per_level > 9) max_bits_per_level = 9;          // P_MAX_BINS
     int bits[4];

@@ -298,10 +298,18 @@ extern "C" int hhx_pool_trim(void) {
     pool_trim();
     return 0;
 }
+// The knobs the kernels read (tune_get): which kernel class / arithmetic / layout a call takes.  Every setting of every knob gives
+// the same results (the verification tests switch classes with them and compare bits); an unknown name is refused.
+static const char *const k_tune_names[] = {"cls", "cls_nc", "cls_balance", "links_integer", "links_sym", "hash_max", "tile_u", "win_batch",
+                                           "cache_slice_mb", "dense_tri", "probe", nullptr};
 extern "C" int hhx_tune(const char *name, int64_t value) {
     if (!name) return fail("null name");
+    bool known = false;
+    for (const char *const *k = k_tune_names; *k; ++k) known |= strcmp(*k, name) == 0;
+    if (!known) return fail("hhx_tune: unknown knob '%s'", name);
     std::lock_guard<std::mutex> lk(g_tune_mu);
-    g_tune[name] = value;
+    if (value == INT64_MIN) g_tune.erase(name);              // back to the default (or HHX_<NAME> of the environment)
+    else g_tune[name] = value;
     return 0;
 }
 extern "C" int hhx_profile_enable(int on) {

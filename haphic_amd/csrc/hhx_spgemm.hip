@@ -305,11 +305,13 @@ extern "C" int hhx_spgemm_ex(const hhx_csr *a, const hhx_csr *b, int fx_shift, h
     i32 cap = (i32)((budget - fixed) / 8);
     cap &= ~63;
     size_t lds = (size_t)cap * 8 + fixed;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_dev = -1;           // the attribute is per device: keyed on the current ordinal
+    int dev = 0;
+    HHX_HIP(hipGetDevice(&dev));
+    if (attr_dev != dev) {
         HHX_HIP(hipFuncSetAttribute((const void *)k_spgemm_symbolic, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HHX_HIP(hipFuncSetAttribute((const void *)k_spgemm_numeric, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_dev = dev;
     }
     DevBuf<i32> row_nnz;
     DevBuf<u64> prods;

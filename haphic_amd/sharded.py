@@ -17,6 +17,8 @@ SURVEY §8e:
 The collective logic is written against a small `engine` interface so that tests/ can drive it on
 CPU (gloo, world_size 2) with an oracle-backed engine; the product engine is HipEngine (no fallback).
 """
+import os
+
 import numpy as np
 
 from . import _lib
@@ -102,6 +104,9 @@ class HipEngine:
             self.torch.empty((0, d.n_cols), dtype=self.torch.float32, device=self.device)         # rows `ld` floats apart
         return d, y, cap
 
+    def dense_drop(self, d):
+        d.free()
+
     def dense_finish(self, d, inflation, pruning):
         """the rows finished from the completed block: (pruned rows, products, nnz of the expanded rows)"""
         self.torch.cuda.current_stream(self.device).synchronize()
@@ -109,6 +114,22 @@ class HipEngine:
         out = (p, d.n_products, d.nnz_expanded)
         d.free()
         return out
+
+    # ---- the inflation sweep shared out over the ranks (sweep_sharded below): this rank's rows of M^2, kept for every inflation
+    def dense_rows(self, links, r0, r1):
+        """rows [r0, r1) of the pre-expanded matrix as a float32 block (hhx_expand_links_dense): (handle, products, nnz of the rows)"""
+        d = _lib.DenseRows(links, r0, r1)
+        return d, d.n_products, d.nnz_expanded
+
+    def dense_first(self, d, inflation, pruning):
+        """iteration 0 of mcl() of the block's rows at `inflation` (hhx_dense_inflate_prune); the block stays"""
+        return d.inflate_prune(inflation, pruning)
+
+    def dense_free(self, d):
+        d.free()
+
+    def interpret(self, m):
+        return _lib.interpret(m)
 
     def convergence_stat(self, m, last):
         return _lib.convergence_stat(m, last)
@@ -225,8 +246,9 @@ class HostStagedCollectives:
 
 
 # ------------------------------------------------------------------ collectives on variable-size blocks
-MAX_MESSAGE_BYTES = 1 << 30     # one collective call never moves more than this per peer: a 2.6 GB all-to-all was
-                                # observed to come back truncated (32-bit byte counts somewhere below torch.distributed)
+MAX_MESSAGE_BYTES = 1 << 30     # one collective call never moves more than this per peer: all_to_all_single of this stack (RCCL 2.26.6 /
+                                # torch 2.10) silently delivers only the first half of any per-peer message above 2^30 bytes
+                                # (tools/rccl_probe.py -> profiles/r03_rccl_probe.jsonl; all-gather and all-reduce are intact to 8.7 GB)
 
 
 def _all_gather_var(t, dist, torch):
@@ -354,8 +376,9 @@ def allgather_rows(engine, local, n_cols, dist):
 # Iteration 0 on the symmetric half across ranks trades 0.4 F / N products per rank (187 / N ms at C3) for an exchange of
 # n^2 * 4 B / N^2 per peer pair (10 GB at N = 2, 2.5 GB at 4, 0.6 GB at 8: ~156 / 39 / 10 ms at ~64 GB/s per xGMI link and
 # direction, the links of a rank running side by side): by that model it pays from 8 ranks on, is a wash at 4 and loses at 2 —
-# so it is on from SYMMETRIC_MIN_WORLD ranks (to be re-set from the first measured SCALE run; tests lower it to 2).
-SYMMETRIC_MIN_WORLD = 8
+# so it would be on from 8 ranks.  No run on more than one physical GPU exists yet, so it is OPT-IN until one does:
+# SYMMETRIC_MIN_WORLD = None (off) unless HAPHIC_SYMMETRIC_MIN_WORLD names a world size; tests set it to 2.
+SYMMETRIC_MIN_WORLD = int(os.environ['HAPHIC_SYMMETRIC_MIN_WORLD']) if os.environ.get('HAPHIC_SYMMETRIC_MIN_WORLD') else None
 SYMMETRIC_HALF = True          # tests switch it off to compare the two multi-rank paths
 
 
@@ -388,7 +411,14 @@ def expand_links_symmetric(engine, links_full, bounds, inflation, pruning, dist)
     torch = engine.torch
     world, rank = dist.get_world_size(), dist.get_rank()
     r0, r1 = bounds[rank], bounds[rank + 1]
-    d, y, cap = engine.dense_upper(links_full, r0, r1)
+    try:
+        d, y, cap = engine.dense_upper(links_full, r0, r1)
+    except RuntimeError:                          # e.g. the block does not fit this rank's memory
+        d = None
+    if not _agree(d is not None, engine, dist):   # all or none: a rank alone in the all-to-all below would hang the others
+        if d is not None:
+            engine.dense_drop(d)
+        return None, 0, 0
     n_loc = r1 - r0
     # mirror inside the own rows: for the blocks I < J that both meet [r0, r1)
     if n_loc:
@@ -423,6 +453,48 @@ def expand_links_symmetric(engine, links_full, bounds, inflation, pruning, dist)
 REPLICATE_NNZ = 4_000_000      # below this many entries the iterations are cheaper than their collectives: every rank runs them whole
 
 
+def _agree(ok, engine, dist):
+    """True only if every rank says so: one all-reduce(min) — a rank that cannot take a path (e.g. its dense block does not fit)
+    must not leave the others waiting in that path's collective"""
+    t = engine.torch.tensor([1 if ok else 0], dtype=engine.torch.int32, device=engine.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def sharded_iteration(engine, cur_full, it, expansion, inflation, pruning, dist):
+    """Iteration `it` >= 1 of mcl() (:2030-2050) with T sharded by row block: the blocks are cut anew at equal PRODUCT counts of
+    THIS iteration (every rank holds cur_full, so re-cutting costs no communication — a row's weight changes from one iteration to
+    the next as clusters form), every rank expands / inflates / prunes its rows against the whole matrix, then the two-collective
+    exchange.  Returns (the new full matrix, largest convergence statistic over the ranks, [nnz_A, nnz_C, survivors, products])."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = engine.shape(cur_full)[0]
+    b = balanced_ranges(engine.row_products(cur_full, cur_full), world)
+    a = engine.row_block(cur_full, b[rank], b[rank + 1])
+    st_f = 0
+    run = a
+    for _ in range(2, expansion):                 # T^(e-1) rows, :2017-2023
+        nxt, f = engine.spgemm(run, cur_full)
+        st_f += f
+        if run is not a:
+            engine.free(run)
+        run = nxt
+    if expansion > 1:
+        p, f, st_c = engine.expand_inflate_prune(run, cur_full, inflation, pruning)   # :2030-2042 fused
+        st_f += f
+    else:
+        c = engine.copy(run)
+        st_c = engine.shape(c)[2]
+        p = engine.inflate_prune(c, inflation, pruning)
+        engine.free(c)
+    if run is not a:
+        engine.free(run)
+    stat = engine.convergence_stat(p, a) if it > 1 else 0.0
+    engine.free(a)
+    full, heads = exchange_rows(engine, p, n, dist, stat=stat, counts=(st_c, engine.shape(p)[2], st_f))
+    engine.free(p)
+    return full, np.float32(heads[:, 2].max()), [engine.shape(cur_full)[2]] + [int(v) for v in heads[:, 3:].sum(axis=0)]
+
+
 def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, dist, local_block=None, n=None, local_links=None,
                        replicate_nnz=None):
     """run_mcl_clustering's pre-expansion (:2146-2147) + mcl() (:2026-2062) with T sharded by row block.
@@ -438,97 +510,147 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
     Returns (full result, n_iter, converged, stats)."""
     if replicate_nnz is None:
         replicate_nnz = REPLICATE_NNZ
-    torch = engine.torch
     world, rank = dist.get_world_size(), dist.get_rank()
-    own_full = False
     links_full = None
+    own_full = False
     if local_links is not None:
         links_full = allgather_rows(engine, local_links, n, dist)       # exchange: the raw link matrix, once
-        full_norm = links_full                                           # shape / nnz bookkeeping of iteration 0
+        if expansion != 2:
+            # mkl_matrix_power :2017-2023 recurses for any e: T^(e-1) rows need the normalised matrix as a plain operand, so the
+            # raw blocks are normalised (:2144, row-local) and the general path below runs
+            full_norm = engine.normalize_l1(links_full)
+            links_full = None
+            own_full = True
     elif full_norm is None:
         full_norm = allgather_rows(engine, local_block, n, dist)         # n: order of the matrix
         own_full = True
-    n = engine.shape(full_norm)[0]
     stats = []
-    if local_links is not None:
+    converged = False
+    n_iter = 0
+    if links_full is not None:
+        n = engine.shape(links_full)[0]
+        if iters < 1:
+            return engine.normalize_l1(links_full), 0, False, np.zeros((0, 4), np.int64)
         # Every rank holds the whole raw matrix now, so the MCL row blocks need not be the build's: they are cut at
         # equal PRODUCT counts of iteration 0 (SURVEY §8e).  Equal row counts are not balanced: a contig's matrix
         # index is its first-seen rank in the pair stream, and heavily linked contigs are seen first.
         products = engine.row_products(links_full, links_full)
-        # the symmetric half across the ranks when the engine has it and the integer arithmetic applies (every rank decides the same:
-        # the matrix is the same); the rows are then balanced by their products right of their own block
-        symmetric = (world >= SYMMETRIC_MIN_WORLD and SYMMETRIC_HALF and expansion == 2 and hasattr(engine, 'dense_upper')
+        # the symmetric half across the ranks: opt-in (SYMMETRIC_MIN_WORLD), when the engine has it and the integer arithmetic
+        # applies; the rows are then balanced by their products right of their own block.  Every rank must agree before any
+        # of them enters its all-to-all
+        symmetric = (SYMMETRIC_MIN_WORLD is not None and world >= SYMMETRIC_MIN_WORLD and SYMMETRIC_HALF and hasattr(engine, 'dense_upper')
                      and engine.links_integer_ok(links_full))
+        p = None
         if symmetric:
-            _lib_cap = symmetric_window(engine, n)
-            b = balanced_ranges(upper_cost(products, _lib_cap), world)
-        else:
+            b = balanced_ranges(upper_cost(products, symmetric_window(engine, n)), world)
+            p, f, st_c = expand_links_symmetric(engine, links_full, b, inflation, pruning, dist)   # None: some rank could not hold its block
+        if p is None:
             b = balanced_ranges(products, world)
-        r0, r1 = b[rank], b[rank + 1]
-        cur_local = engine.normalize_l1(engine.row_block(links_full, r0, r1))
-    else:
-        b = row_ranges(n, world)
-        r0, r1 = b[rank], b[rank + 1]
-        cur_local = engine.row_block(full_norm, r0, r1) if local_block is None else engine.copy(local_block)
-    cur_full = full_norm                              # all rows: right operand of the expansion
-    converged = False
-    n_iter = 0
-    for it in range(iters):
-        st_a = engine.shape(cur_full)[2]
-        st_f = 0
-        run = cur_local
-        for _ in range(2, expansion):                 # T^(e-1) rows, :2017-2023
-            if links_full is not None:
-                raise NotImplementedError('expansion > 2 from raw link blocks: normalise and pass local_block')
-            nxt, f = engine.spgemm(run, cur_full)
-            st_f += f
-            if run is not cur_local:
-                engine.free(run)
-            run = nxt
-        if expansion > 1:
-            if links_full is not None and symmetric:
-                p, f, st_c = expand_links_symmetric(engine, links_full, b, inflation, pruning, dist)   # iteration 0 on the symmetric half
-            elif links_full is not None:
-                p, f, st_c = engine.expand_links(links_full, r0, r1, inflation, pruning)       # iteration 0, class stream
-            else:
-                p, f, st_c = engine.expand_inflate_prune(run, cur_full, inflation, pruning)   # :2030-2042 fused
-            st_f += f
-        else:
-            c = engine.copy(run)
-            st_c = engine.shape(c)[2]
-            p = engine.inflate_prune(c, inflation, pruning)
-            engine.free(c)
-        if run is not cur_local:
-            engine.free(run)
-        n_iter = it + 1
-        stat = engine.convergence_stat(p, cur_local) if it > 1 else 0.0
-        # the per-iteration exchange: header all-gather (sizes + convergence max + counts) and one packed all-gather(v)
-        full, heads = exchange_rows(engine, p, n, dist, stat=stat, counts=(st_c, engine.shape(p)[2], st_f))
-        mx = np.float32(heads[:, 2].max())
+            p, f, st_c = engine.expand_links(links_full, b[rank], b[rank + 1], inflation, pruning)       # iteration 0, class stream
+        st_a = engine.shape(links_full)[2]
+        engine.free(links_full)
+        cur_full, heads = exchange_rows(engine, p, n, dist, counts=(st_c, engine.shape(p)[2], f))
+        engine.free(p)
         stats.append([st_a] + [int(v) for v in heads[:, 3:].sum(axis=0)])
-        engine.free(cur_local)
-        if links_full is not None:
-            engine.free(links_full)
-            links_full = None
-        elif own_full:
+        own_full = True
+        n_iter = 1
+    else:
+        cur_full = full_norm                          # all rows: right operand of the expansion
+        n = engine.shape(cur_full)[0]
+    for it in range(n_iter, iters):
+        if world > 1 and it >= 1 and engine.shape(cur_full)[2] <= replicate_nnz and hasattr(engine, 'mcl_resume'):
+            res, n_iter, converged, tail = engine.mcl_resume(cur_full, it, expansion, inflation, iters, pruning)
+            stats.extend(np.asarray(tail, np.int64).tolist())
+            if own_full:
+                engine.free(cur_full)
+            cur_full, own_full = res, True
+            break
+        full, mx, st = sharded_iteration(engine, cur_full, it, expansion, inflation, pruning, dist)
+        stats.append(st)
+        if own_full:
             engine.free(cur_full)
-        cur_local, cur_full, own_full = p, full, True
+        cur_full, own_full = full, True
+        n_iter = it + 1
         if it > 1 and mx <= np.float32(1e-8):
             converged = True
             break
-        if world > 1 and it + 1 < iters and engine.shape(cur_full)[2] <= replicate_nnz and hasattr(engine, 'mcl_resume'):
-            res, n_iter, converged, tail = engine.mcl_resume(cur_full, it + 1, expansion, inflation, iters, pruning)
-            stats.extend(np.asarray(tail, np.int64).tolist())
-            engine.free(cur_full)
-            cur_full = res
-            break
-    engine.free(cur_local)
-    if links_full is not None:                         # iters == 0
-        engine.free(links_full)
-        cur_full = engine.normalize_l1(allgather_rows(engine, local_links, n, dist))
-    elif not own_full:
+    if not own_full:
         cur_full = engine.copy(cur_full)
-    return cur_full, n_iter, converged, np.asarray(stats, np.int64)
+    return cur_full, n_iter, converged, np.asarray(stats, np.int64).reshape(-1, 4)
+
+
+# ------------------------------------------------------------------ the inflation sweep of run_mcl_clustering across the ranks
+SWEEP_SHARD_PRODUCTS = 4e9     # an iteration of at least this many products (~2 ms of kernel on one GPU) is shared out over the ranks
+
+
+def sweep_sharded(engine, links_full, inflations, iters, pruning, dist, shard_products=None):
+    """run_mcl_clustering :2144-2165 (expansion 2) over N ranks that all hold the raw link matrix.  Every inflation restarts mcl()
+    from the same pre-expanded matrix; on one GPU that is one expansion + an epilogue and a tail per inflation, and the tails of
+    the LOW inflations are nearly all of the time (14 of 18.5 s at 100k contigs: inflations 1.1-1.3 run ~100 iterations on matrices
+    of 10^8 entries) — dealing whole inflations to the ranks would end when the rank holding 1.1 ends.  Here:
+      1. ONE expansion, shared: rank r holds only ITS rows of M^2 (products-balanced row block) as the dense float32 block;
+      2. iteration 0 of every inflation = the dense epilogue over the rank's rows + the two-collective exchange: every rank
+         gets T1(inflation) whole;
+      3. while the next iteration of an inflation is HEAVY (nnz^2 / n >= shard_products) it is run row-sharded by all ranks
+         together (sharded_iteration: blocks re-cut at equal products every iteration);
+      4. what is left of every inflation — a matrix + the number of iterations done — is a LIGHT task: given to the least-loaded
+         rank by predicted cost (nnz^2 / n: the products of its next iteration), run there without collectives (hhx_mcl_resume);
+      5. ONE all_gather_object of the attractor arrays.
+    Same kernels on the same values: the results are bit-identical to the one-GPU sweep for every rank count.
+    Returns, on every rank, a list over `inflations` of (att, att_ptr, members, shape, n_iter, converged)."""
+    if shard_products is None:
+        shard_products = SWEEP_SHARD_PRODUCTS
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = engine.shape(links_full)[0]
+    b = balanced_ranges(engine.row_products(links_full, links_full), world)
+    d, f_local, c_local = engine.dense_rows(links_full, b[rank], b[rank + 1])
+    load = [0.0] * world
+    mine = []                                             # (index of the inflation, matrix, iterations done)
+    done = {}                                             # inflations that converged / ran out of iterations inside the sharded phase
+    try:
+        for k, infl in enumerate(inflations):
+            infl = float(infl)
+            p = engine.dense_first(d, infl, pruning)
+            cur, _heads = exchange_rows(engine, p, n, dist, counts=(c_local, engine.shape(p)[2], f_local))
+            engine.free(p)
+            it, converged, finished = 1, False, iters <= 1
+            while not finished and world > 1 and float(engine.shape(cur)[2]) ** 2 / max(n, 1) >= shard_products:
+                full, mx, _st = sharded_iteration(engine, cur, it, 2, infl, pruning, dist)
+                engine.free(cur)
+                cur = full
+                it += 1
+                if it > 2 and mx <= np.float32(1e-8):
+                    converged = finished = True
+                elif it >= iters:
+                    finished = True
+            if finished:
+                done[k] = (cur, it, converged)
+                continue
+            owner = min(range(world), key=lambda r: (load[r], r))          # the same on every rank
+            load[owner] += float(engine.shape(cur)[2]) ** 2 / max(n, 1) + float(engine.shape(cur)[2])
+            if owner == rank:
+                mine.append((k, cur, it))
+            else:
+                engine.free(cur)
+    finally:
+        engine.dense_free(d)
+    results = []
+    for k, (cur, it, converged) in done.items():          # every rank holds these: rank k % world reads them out
+        if k % world == rank:
+            results.append((k,) + tuple(engine.interpret(cur)) + (n, it, converged))
+        engine.free(cur)
+    for k, cur, it in mine:
+        res, n_iter, converged, _tail = engine.mcl_resume(cur, it, 2, float(inflations[k]), iters, pruning)
+        engine.free(cur)
+        results.append((k,) + tuple(engine.interpret(res)) + (n, n_iter, converged))
+        engine.free(res)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, results)
+    out = [None] * len(inflations)
+    for part in gathered:
+        for r in part:
+            out[r[0]] = r[1:]
+    return out
 
 
 # ------------------------------------------------------------------ product entry points (HIP engine)

@@ -28,7 +28,12 @@ typedef int64_t i64;
  * reference call sites :2014 :2038 :2144; arithmetic = sklearn utils/sparsefuncs_fast.pyx
  * _inplace_csr_row_normalize_l1: double accumulator, sequential storage order, x = float(x / sum).
  * ---------------------------------------------------------------------------------------------- */
+static int g_threads;                            /* 0: OpenMP default (all cores); orc_set_threads */
+int orc_get_threads(void);
+/* rows are independent: the row loops below are spread over the host threads (a row's arithmetic is the serial loop's, so every
+ * result bit is too); a call from inside a parallel region (orc_links_iteration0) runs its rows on the calling thread */
 void orc_normalize_l1(i32 n, const i32 *indptr, float *data) {
+#pragma omp parallel for schedule(static, 256) num_threads(orc_get_threads()) if (n > 4096)
     for (i32 r = 0; r < n; ++r) {
         double s = 0.0;
         for (i32 p = indptr[r]; p < indptr[r + 1]; ++p) s += fabs((double)data[p]);
@@ -44,9 +49,11 @@ void orc_normalize_l1(i32 n, const i32 *indptr, float *data) {
  * ---------------------------------------------------------------------------------------------- */
 void orc_power(i64 nnz, float *data, double r) {
     if (r == 2.0) {
+#pragma omp parallel for schedule(static) num_threads(orc_get_threads()) if (nnz > 1000000)
         for (i64 p = 0; p < nnz; ++p) data[p] = data[p] * data[p];
     } else {
         float rf = (float)r;
+#pragma omp parallel for schedule(static) num_threads(orc_get_threads()) if (nnz > 100000)
         for (i64 p = 0; p < nnz; ++p) data[p] = powf(data[p], rf);
     }
 }
@@ -73,7 +80,6 @@ static int cmp_i32(const void *a, const void *b) {
 /* Rows are independent, so the sweep is spread over host threads (OpenMP, static per-thread scratch); the
  * arithmetic inside a row — and therefore every result bit, mode 0's sequential float32 sums included — is
  * what the serial loop produces.  orc_set_threads(1) (bench.py's cpu_baseline leg) gives the scalar port. */
-static int g_threads = 0;                        /* 0: OpenMP default (all cores) */
 void orc_set_threads(int n) { g_threads = n; }
 int orc_get_threads(void) { return g_threads > 0 ? g_threads : omp_get_max_threads(); }
 
@@ -225,6 +231,70 @@ i64 orc_expand_links_ex(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i3
     return nnz;
 }
 
+i64 orc_prune(i32 n, const i32 *indptr, const i32 *indices, const float *data, double pruning,
+              i32 *out_indptr, i32 *out_indices, float *out_data);
+/* Iteration 0 of mcl() (:2037-2042) for the rows `rows` of the pre-expanded matrix of the RAW link matrix L, in ONE pass over
+ * the products: per row, the accumulators of orc_expand_links_ex (same integers, same two roundings), then orc_power,
+ * orc_normalize_l1 and orc_prune applied to that single row — the composition tests/ use on sampled rows, here without ever
+ * holding a row of M^2 longer than its own turn, so that ALL rows of a 100k-contig matrix (1.2e12 products, 1e10 entries of M^2)
+ * can be checked.  Out: row t occupies [t * cap_row, t * cap_row + Ocnt[t]); returns the total, -2 if the integer specification
+ * does not apply, -1 if a pruned row exceeds cap_row. */
+i64 orc_links_iteration0(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i32 n_rows, const i32 *rows, double inflation,
+                         double pruning, i32 cap_row, i32 *Ocnt, i32 *Oj, float *Ox, i64 *n_expanded) {
+    double *d = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+    const int shift = orc_links_shift(n, Lp, Lx, d);
+    if (shift < 0) { free(d); return -2; }
+    uint64_t *W = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n ? n : 1));
+    for (i32 k = 0; k < n; ++k) W[k] = (uint64_t)rint(ldexp(1.0, shift) / d[k]);
+    const double inv = ldexp(1.0, -shift);
+    const int nt = orc_get_threads();
+    i64 total = 0, expanded = 0;
+    int overflow = 0;
+#pragma omp parallel num_threads(nt) reduction(+ : total, expanded) reduction(| : overflow)
+    {
+        struct slot { uint64_t acc; i64 mark; } *sl = (struct slot *)malloc(sizeof(struct slot) * (size_t)n);     /* one cache line per product, not two */
+        i32 *cols = (i32 *)malloc(sizeof(i32) * (size_t)n);
+        float *val = (float *)malloc(sizeof(float) * (size_t)n);
+        i32 *pj = (i32 *)malloc(sizeof(i32) * (size_t)n);
+        float *px = (float *)malloc(sizeof(float) * (size_t)n);
+        for (i32 c = 0; c < n; ++c) { sl[c].acc = 0; sl[c].mark = -1; }
+#pragma omp for schedule(dynamic, 8)
+        for (i32 t = 0; t < n_rows; ++t) {
+            const i32 i = rows ? rows[t] : t;
+            i32 cnt = 0;
+            for (i32 p = Lp[i]; p < Lp[i + 1]; ++p) {
+                const i32 k = Lj[p];
+                const uint64_t g = (uint64_t)Lx[p] * W[k];
+                for (i32 q = Lp[k]; q < Lp[k + 1]; ++q) {
+                    struct slot *s_ = &sl[Lj[q]];
+                    if (s_->mark != t) { s_->mark = t; cols[cnt++] = Lj[q]; s_->acc = 0; }
+                    s_->acc += g * (uint64_t)Lx[q];
+                }
+            }
+            qsort(cols, (size_t)cnt, sizeof(i32), cmp_i32);
+            for (i32 c = 0; c < cnt; ++c) {
+                const float y = (float)((double)sl[cols[c]].acc * inv);
+                val[c] = (float)((double)y / d[i]);
+                sl[cols[c]].mark = -1;
+            }
+            expanded += cnt;
+            i32 one[2] = {0, cnt}, op[2];
+            orc_power(cnt, val, inflation);
+            orc_normalize_l1(1, one, val);
+            const i64 kept = orc_prune(1, one, cols, val, pruning, op, pj, px);
+            if (kept > cap_row) { overflow = 1; Ocnt[t] = 0; continue; }
+            Ocnt[t] = (i32)kept;
+            memcpy(Oj + (size_t)t * cap_row, pj, sizeof(i32) * (size_t)kept);
+            memcpy(Ox + (size_t)t * cap_row, px, sizeof(float) * (size_t)kept);
+            total += kept;
+        }
+        free(sl); free(cols); free(val); free(pj); free(px);
+    }
+    free(W); free(d);
+    if (n_expanded) *n_expanded = expanded;
+    return overflow ? -1 : total;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * prune(), :1987-2014.  Input = inflated+normalised matrix (sorted rows).  Keep entries >= the
  * float32-rounded threshold (:1994 sparse branch / :2005 dense branch compare float32 data against
@@ -235,25 +305,37 @@ i64 orc_expand_links_ex(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i3
 i64 orc_prune(i32 n, const i32 *indptr, const i32 *indices, const float *data, double pruning,
               i32 *out_indptr, i32 *out_indices, float *out_data) {
     const float thr = (float)pruning;
-    i64 nnz = 0;
+    const int nt = orc_get_threads();
+    /* pass 1: the first maximum and the number of survivors of every row; pass 2 (after the prefix sum): the ordered copy */
+    i32 *amax = (i32 *)malloc(sizeof(i32) * (size_t)(n ? n : 1));
     out_indptr[0] = 0;
+#pragma omp parallel for schedule(static, 256) num_threads(nt) if (n > 4096)
     for (i32 r = 0; r < n; ++r) {
         i32 b = indptr[r], e = indptr[r + 1];
-        i32 am = -1;
+        i32 am = -1, keep = 0;
         float m = 0.0f;
         for (i32 p = b; p < e; ++p)
             if (am < 0 || data[p] > m) { am = p; m = data[p]; }
-        for (i32 p = b; p < e; ++p) {
+        for (i32 p = b; p < e; ++p) keep += (data[p] >= thr || p == am);
+        amax[r] = am;
+        out_indptr[r + 1] = keep;
+    }
+    for (i32 r = 0; r < n; ++r) out_indptr[r + 1] += out_indptr[r];
+#pragma omp parallel for schedule(static, 256) num_threads(nt) if (n > 4096)
+    for (i32 r = 0; r < n; ++r) {
+        i64 o = out_indptr[r];
+        const i32 am = amax[r];
+        for (i32 p = indptr[r]; p < indptr[r + 1]; ++p) {
             if (data[p] >= thr || p == am) {
-                out_indices[nnz] = indices[p];
-                out_data[nnz] = data[p];
-                ++nnz;
+                out_indices[o] = indices[p];
+                out_data[o] = data[p];
+                ++o;
             }
         }
-        out_indptr[r + 1] = (i32)nnz;
     }
+    free(amax);
     orc_normalize_l1(n, out_indptr, out_data);
-    return nnz;
+    return out_indptr[n];
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -266,6 +348,7 @@ float orc_convergence_stat(i32 n, const i32 *ap, const i32 *aj, const float *ax,
                            const i32 *bj, const float *bx) {
     float best = 0.0f;
     const float rtol = (float)1e-5;
+#pragma omp parallel for schedule(static, 256) reduction(max : best) num_threads(orc_get_threads()) if (n > 4096)
     for (i32 r = 0; r < n; ++r) {
         i32 p = ap[r], pe = ap[r + 1], q = bp[r], qe = bp[r + 1];
         while (p < pe || q < qe) {
@@ -287,6 +370,7 @@ float orc_convergence_stat(i32 n, const i32 *ap, const i32 *aj, const float *ax,
  * ---------------------------------------------------------------------------------------------- */
 static i64 count_products(i32 n, const i32 *Ap, const i32 *Aj, const i32 *Bp) {
     i64 f = 0;
+#pragma omp parallel for schedule(static, 256) reduction(+ : f) num_threads(orc_get_threads()) if (n > 4096)
     for (i32 i = 0; i < n; ++i)
         for (i32 p = Ap[i]; p < Ap[i + 1]; ++p) f += Bp[Aj[p] + 1] - Bp[Aj[p]];
     return f;

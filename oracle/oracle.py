@@ -46,6 +46,9 @@ def lib():
         L.orc_expand_links.restype = C.c_int64
         L.orc_expand_links_ex.argtypes = L.orc_expand_links.argtypes + [C.c_int]
         L.orc_expand_links_ex.restype = C.c_int64
+        L.orc_links_iteration0.argtypes = [C.c_int32, _i32p, _i32p, _f32p, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_int32,
+                                           _i32p, _i32p, _f32p, C.POINTER(C.c_int64)]
+        L.orc_links_iteration0.restype = C.c_int64
         L.orc_links_shift.argtypes = [C.c_int32, _i32p, _f32p, C.c_void_p]
         L.orc_links_shift.restype = C.c_int
         L.orc_set_threads.argtypes = [C.c_int]
@@ -154,6 +157,31 @@ def expand_links(L, rows=None, divide=True):
     cx = np.zeros(max(nnz, 1), np.float32)
     lib().orc_expand_links_ex(n, lp, lj, lx, n_rows, rp, cp, cj.ctypes.data, cx.ctypes.data, int(bool(divide)))
     return cp, cj[:nnz], cx[:nnz]
+
+
+def links_iteration0(L, rows, inflation, pruning):
+    """iteration 0 of mcl() (:2037-2042: power, normalize, prune) on the rows `rows` of the pre-expanded raw link matrix L, one
+    pass over the products (hhx_oracle.c: orc_links_iteration0) — bit for bit prune(normalize_l1(power(expand_links(L, rows)))).
+    Returns (indptr over the selected rows, columns, values, entries of M^2 in those rows)."""
+    lp, lj, lx = _csr(*L)
+    n = len(lp) - 1
+    rows = np.ascontiguousarray(rows, np.int32)
+    cap_row = n if pruning <= 0 else min(n, int(1.0 / pruning) + 2)
+    cnt = np.zeros(len(rows), np.int32)
+    oj = np.zeros(max(len(rows) * cap_row, 1), np.int32)           # lazily paged: only what the rows keep is touched
+    ox = np.zeros(max(len(rows) * cap_row, 1), np.float32)
+    nc = C.c_int64(0)
+    total = lib().orc_links_iteration0(n, lp, lj, lx, len(rows), rows.ctypes.data, float(inflation), float(pruning), cap_row, cnt, oj, ox,
+                                       C.byref(nc))
+    if total == -2:
+        raise ValueError('the integer specification does not apply to this matrix')
+    if total < 0:
+        raise RuntimeError('oracle: a pruned row holds more than 1 / pruning + 1 entries')
+    ptr = np.zeros(len(rows) + 1, np.int32)
+    ptr[1:] = np.cumsum(cnt)
+    take = (np.arange(total, dtype=np.int64) - np.repeat(ptr[:-1].astype(np.int64), cnt)
+            + np.repeat(np.arange(len(rows), dtype=np.int64) * cap_row, cnt))
+    return ptr, oj[take], ox[take], nc.value
 
 
 def prune(A, pruning):

@@ -225,7 +225,7 @@ class Ingest:
     def keep_frag_pairs(self, on=True):
         self.frag = bool(on)
 
-    def push(self, id1, pos1, id2, pos2):
+    def push(self, id1, pos1, id2, pos2, wide=None):
         self.parts.append([np.array(a, np.int64) for a in (id1, pos1, id2, pos2)])
 
     def push_device(self, n, id1, pos1, id2, pos2, wide=False):

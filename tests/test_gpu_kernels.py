@@ -173,7 +173,7 @@ def test_mcl_whole(golden_mcl):
         pre = _lib.DeviceCSR.from_arrays(*tri(g, tag + '_m2'))
         res, n_iter, conv, stats = _lib.mcl(pre, 2, infl, 200, 1e-4, want_stats=True)
         assert conv and n_iter == niter
-        assert_close_csr(res.to_arrays(), tri(g, '%s_it%d' % (tag, niter - 1)), 1e-5, str(tag) + ' final')
+        assert_close_csr(res.to_arrays(), tri(g, '%s_it%d' % (tag, niter - 1)), 1e-6, str(tag) + ' final')     # north_star: 1e-6 relative
         want = {tuple(g[tag + '_clusters'][g[tag + '_clusters_ptr'][a]:g[tag + '_clusters_ptr'][a + 1]].tolist())
                 for a in range(len(g[tag + '_clusters_ptr']) - 1)}
         assert clusters_of(*_lib.interpret(res)) == want
@@ -565,7 +565,7 @@ def test_fused_expand_inflate_prune(n, block, deg_in, deg_out, infl, hash_max):
         p3, _, _ = _lib.expand_inflate_prune(d, d, infl, 1e-4)
         assert all(np.array_equal(x, y) for x, y in zip(p3.to_arrays(), got))
     finally:
-        _lib.tune('hash_max', 4_000_000)
+        _lib.tune('hash_max', None)
 
 
 def test_mcl_normalized_fuses_pre_expansion(golden_mcl):
@@ -576,7 +576,7 @@ def test_mcl_normalized_fuses_pre_expansion(golden_mcl):
         norm = _lib.DeviceCSR.from_arrays(*tri(g, tag + '_norm'))
         res, n_iter, conv, stats = _lib.mcl(norm, 2, infl, 200, 1e-4, want_stats=True, normalized=True)
         assert conv and n_iter == niter
-        assert_close_csr(res.to_arrays(), tri(g, '%s_it%d' % (tag, niter - 1)), 1e-5, str(tag) + ' final')
+        assert_close_csr(res.to_arrays(), tri(g, '%s_it%d' % (tag, niter - 1)), 1e-6, str(tag) + ' final')     # north_star: 1e-6 relative
         want = {tuple(g[tag + '_clusters'][g[tag + '_clusters_ptr'][a]:g[tag + '_clusters_ptr'][a + 1]].tolist())
                 for a in range(len(g[tag + '_clusters_ptr']) - 1)}
         assert clusters_of(*_lib.interpret(res)) == want

@@ -5,17 +5,22 @@
      runs the kernels' own specification, mode 1: exact fixed-point sums) and within 1e-6 of it by construction.
      The knife-edge audit (was tools/flip_count.py): the reference-like float32 accumulation (oracle mode 0) run beside it —
      same iteration count, same clusters, final matrix within 1e-6; entries kept by one and pruned by the other are counted.
-  C3 (configs[2], 100k contigs / 500 M pairs): the fused iteration 0 — the kernel instantiation the roofline is quoted on
-     (5 column windows, the class stream) — against the oracle on 2048 rows of the real operand stratified by product
-     count; THE WHOLE INGEST (all 500 M pairs) and dict_to_matrix bit exact against the oracle; THE WHOLE mcl(): the oracle picks the
-     loop up from the device's (sample-verified) iteration-0 output and runs it to convergence — iteration count,
-     convergence flag, survivors per iteration, final pattern + values and the cluster sets must be bit equal; the same
-     tail in float32 accumulation (mode 0) must end in the same clusters and a final matrix within 1e-6.
-  C5 (configs[4], 200k contigs / 2 G pairs in four pushes, one GPU): iteration 0 under the n_win = 10 instantiation on sampled
-     rows; ingest parity of a prefix pushed in two ragged batches (the merge of pushed runs) against the full 200k-contig table;
-     size-independent invariants of the full four-push table.
+  C3 (configs[2], 100k contigs / 500 M pairs): THE WHOLE INGEST (all 500 M pairs) and dict_to_matrix bit exact against the
+     oracle; the fused iteration 0 — the kernel instantiation the roofline is quoted on (5 column windows, the class stream,
+     symmetric half + transposition + dense epilogue) — against the oracle on EVERY ROW (all 1.15e12 products walked by the
+     oracle, row-parallel); THE WHOLE mcl(): the oracle picks the loop up from that iteration-0 output and runs it to
+     convergence — iteration count, convergence flag, per-iteration statistics, final pattern + values and the cluster sets
+     must be bit equal; the same tail in float32 accumulation (mode 0) must end in the same clusters and a final matrix
+     within 1e-6.  THE INFLATION SWEEP through the one-expansion path: iteration 0 at 1.1 / 1.4 / 3.0 on stratified rows, the
+     whole tails at 1.4 and 3.0 continued by the oracle, iteration 1 at 1.1 incl. rows beyond the hash class.
+  C5 (configs[4], 200k contigs / 2 G pairs in four pushes, one GPU): iteration 0 on 1024 stratified rows, THE WHOLE TAIL
+     continued by the oracle to convergence (iteration count, statistics, final matrix, clusters); ingest parity of a prefix
+     pushed in two ragged batches (the merge of pushed runs) against the full 200k-contig table; size-independent invariants of
+     the full four-push table.
   C4 (configs[3] at 40k contigs): the device ingest with --remove_allelic_links containers (coordinate lists, CLM
-     distances, HT counts) against the oracle, entry for entry.
+     distances, HT counts) against the oracle, entry for entry; and THE CLUSTER CHECK AT THAT SIZE against the reference's own
+     run (tests/golden/pipeline_c4_40k.npz: the reference's remove_allelic_HiC_links verdict, index map and the SHA-256 of
+     every file run_mcl_clustering wrote at four inflations).
 
 The oracle's SpGEMM is row-parallel over the host cores (results do not depend on the thread count)."""
 import numpy as np
@@ -155,14 +160,57 @@ def test_c2_full_size_against_oracle():
     np.testing.assert_allclose(gx, o0[2], rtol=1e-6, atol=0)
 
 
-def test_c3_whole_ingest_and_whole_mcl_against_oracle():
+class _C3:
+    """configs[2]: the 100k-contig / 500 M-pair job of bench.py's default run, ingested once for the tests below"""
+    pass
+
+
+@pytest.fixture(scope='module')
+def c3():
     import torch
     from haphic_amd import _lib, synth
-    gen = synth.make_genome(24, (100_000 // 24) * 30_000, 30_000, seed=12345)   # bench.py defaults
-    n = gen.n
-    t = _table(gen)
-    P = 500_000_000
-    dev = synth.sample_pairs(gen, P, seed=12345, device='cuda:0')
+    c = _C3()
+    c.gen = synth.make_genome(24, (100_000 // 24) * 30_000, 30_000, seed=12345)   # bench.py defaults
+    c.table = _table(c.gen)
+    c.P = 500_000_000
+    c.dev = synth.sample_pairs(c.gen, c.P, seed=12345, device='cuda:0')
+    c.ing = _lib.Ingest(c.table, 500_000, bins=False, skip_intra=True)
+    c.ing.push_device(c.P, *[x.data_ptr() for x in c.dev])
+    torch.cuda.synchronize()
+    c.ing.finalize()
+    c.m, c.fidx, c.n_linked = c.ing.link_matrix(np.ones(c.gen.n, np.uint8))
+    c.host = None
+    yield c
+    c.m.free()
+    if c.ing is not None:
+        c.ing.destroy()
+    c.dev = None
+    torch.cuda.empty_cache()
+
+
+def _c3_host_matrix(c):
+    if c.host is None:
+        c.host = c.m.to_arrays()
+    return c.host
+
+
+def _assert_rows_equal(got, want, rows, what, rtol=0.0):
+    gp, gj, gx = got
+    for k, r in enumerate(rows):
+        lo, hi = gp[r], gp[r + 1]
+        wl, wh = want[0][k], want[0][k + 1]
+        assert np.array_equal(gj[lo:hi], want[1][wl:wh]), '%s: pattern of row %d' % (what, r)
+        if rtol:
+            np.testing.assert_allclose(gx[lo:hi], want[2][wl:wh], rtol=rtol, atol=0, err_msg='%s: values of row %d' % (what, r))
+        else:
+            assert np.array_equal(gx[lo:hi], want[2][wl:wh]), '%s: values of row %d' % (what, r)
+
+
+def test_c3_whole_ingest_against_oracle(c3):
+    import torch
+    from haphic_amd import _lib
+    c = c3
+    n, t, dev = c.gen.n, c.table, c.dev
     # ingest parity: the first 20 M pairs against the full 100k-contig table
     S = 20_000_000
     pre_ing = _lib.Ingest(t, 500_000, bins=False, skip_intra=True)
@@ -175,33 +223,34 @@ def test_c3_whole_ingest_and_whole_mcl_against_oracle():
         assert np.array_equal(got[k], ref[k]), 'C3 ingest (20 M-pair prefix) differs: ' + k
     pre_ing.destroy()
     del got, ref
-    # the real operand: all 500 M pairs — and THE WHOLE INGEST against the oracle (the scalar C port of the reference loop walks the
-    # 500 M pairs in ~90 s): every table, bit for bit, then dict_to_matrix's triple and index map
-    ing = _lib.Ingest(t, 500_000, bins=False, skip_intra=True)
-    ing.push_device(P, *[x.data_ptr() for x in dev])
-    torch.cuda.synchronize()
-    ing.finalize()
+    # THE WHOLE INGEST against the oracle (the scalar C port of the reference loop walks the 500 M pairs in ~90 s): every table,
+    # bit for bit, then dict_to_matrix's triple and index map
     h = _host(dev)
+    c.dev = None
     del dev
     torch.cuda.empty_cache()
     ref = _oracle_ingest(t, h)
     del h
-    got = ing.fetch()
+    got = c.ing.fetch()
     for k in TABLES:
         assert np.array_equal(got[k], ref[k]), 'C3 ingest (all 500 M pairs) differs: ' + k
     del got
-    m, fidx, n_linked = ing.link_matrix(np.ones(n, np.uint8))
-    ing.destroy()
+    c.ing.destroy()
+    c.ing = None
     linked = np.zeros(n, bool)
     linked[ref['flank_i']] = True
     linked[ref['flank_j']] = True
     rp, rj, rx, ridx, rl = orc.dict_to_matrix(ref['flank_i'], ref['flank_j'], ref['flank_cnt'].astype(np.float64), n, np.ones(n, np.uint8),
                                              int(n - linked.sum()))
     del ref
-    assert n_linked == rl and np.array_equal(fidx, ridx), 'C3 dict_to_matrix: index map'
-    assert all(np.array_equal(u, v) for u, v in zip(m.to_arrays(), (rp, rj, rx))), 'C3 dict_to_matrix: CSR triple'
-    del rp, rj, rx
-    assert m.shape3[0] > 99_000 and m.nnz > 300_000_000
+    assert c.n_linked == rl and np.array_equal(c.fidx, ridx), 'C3 dict_to_matrix: index map'
+    assert all(np.array_equal(u, v) for u, v in zip(_c3_host_matrix(c), (rp, rj, rx))), 'C3 dict_to_matrix: CSR triple'
+    assert c.m.shape3[0] > 99_000 and c.m.nnz > 300_000_000
+
+
+def test_c3_whole_mcl_against_oracle(c3):
+    from haphic_amd import _lib
+    m = c3.m
     n = m.shape3[0]
     # the whole mcl() as bench.py times it (normalisation + pre-expansion fused into iteration 0, class stream)
     res, n_iter_full, conv_full, stats_full = _lib.mcl(m, 2, 2.0, 200, 1e-4, want_stats=True, links=True)
@@ -212,19 +261,21 @@ def test_c3_whole_ingest_and_whole_mcl_against_oracle():
     assert n_iter == 1 and stats[0, 3] > 10 ** 12
     assert np.array_equal(stats[0], stats_full[0])
     gp, gj, gx = one.to_arrays()
-    mp, mj, mx = m.to_arrays()
+    mp, mj, mx = _c3_host_matrix(c3)
     assert (mx == np.rint(mx)).all() and mx.max() < 65536                # integer link counts: the class stream was taken
     assert orc.links_shift((mp, mj, mx)) > 0                             # ... in the integer arithmetic
-    # iteration 0: 2048 rows spread over the product-count distribution (+ the lightest, the heaviest, 64 random ones)
+    # ITERATION 0, EVERY ROW: the oracle walks all 1.15e12 products of the pre-expansion, row-parallel on the host
+    # cores, one pass (orc.links_iteration0), and every pruned row of the device — upper block triangle, transposition, dense
+    # epilogue, finalize — must equal it in pattern and bits
+    expanded = 0
+    for r0 in range(0, n, 8192):
+        rows = np.arange(r0, min(n, r0 + 8192), dtype=np.int32)
+        want = orc.links_iteration0((mp, mj, mx), rows, 2.0, 1e-4)
+        expanded += want[3]
+        _assert_rows_equal((gp, gj, gx), want, rows, 'C3 iteration 0')
+    assert expanded == stats[0, 1], 'C3 iteration 0: entries of M^2'
+    # a stratified sample in the reference's float32 accumulation: how far apart the two specifications are after one iteration
     rows = _stratified_rows(_lib.row_products(m, m), 2048, seed=5)
-    assert len(rows) >= 2048
-    want = _sample_rows_oracle((mp, mj, mx), rows)
-    for k, r in enumerate(rows):
-        lo, hi = gp[r], gp[r + 1]
-        wl, wh = want[0][k], want[0][k + 1]
-        assert np.array_equal(gj[lo:hi], want[1][wl:wh]), 'C3 iteration 0: pattern of row %d' % r
-        assert np.array_equal(gx[lo:hi], want[2][wl:wh]), 'C3 iteration 0: values of row %d' % r
-    # the same rows in the reference's float32 accumulation: how far apart the two specifications are after one iteration
     rows0 = rows[:: max(1, len(rows) // 256)]
     want0 = _sample_rows_oracle((mp, mj, mx), rows0, mode=0)
     got0_p = np.zeros(len(rows0) + 1, np.int32)
@@ -233,8 +284,8 @@ def test_c3_whole_ingest_and_whole_mcl_against_oracle():
     only_f32, only_exact, rel0 = _flips(want0, (got0_p, gj[take0], gx[take0]), n)
     assert only_f32 + only_exact <= 8 and rel0 < 2e-3, 'C3 iteration 0 (%d rows): %d + %d entries decided differently, rel %g' % (
         len(rows0), only_f32, only_exact, rel0)
-    # THE TAIL: the oracle continues mcl() :2026-2062 from the device's iteration-0 output (iteration 1 = 1.6e10 products,
-    # row-parallel on the host cores) to convergence; the device's own full run must agree bit for bit
+    # THE TAIL: the oracle continues mcl() :2026-2062 from the (now fully verified) iteration-0 output (iteration 1 = 1.6e10
+    # products, row-parallel on the host cores) to convergence; the device's own full run must agree bit for bit
     o = orc.mcl((gp, gj, gx), 2, 2.0, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
     assert (n_iter_full, conv_full) == (o[3], o[4]), 'C3 mcl: iteration count / convergence flag'
     assert np.array_equal(stats_full[1:], o[5]), 'C3 mcl: nnz_A, nnz_C, survivors, products of every iteration'
@@ -270,22 +321,83 @@ def test_c3_whole_ingest_and_whole_mcl_against_oracle():
         _lib.tune('links_sym', 1)
     # iteration 1 — T1 x T1, the hash class (rows of ~1000 distinct columns reached by ~160k products) — on 128 sampled rows
     # of the real T1 against the oracle, and the same rows through the window / compact classes
-    m.free()
     n1 = one.shape3[0]
     rows1 = np.sort(np.random.default_rng(6).choice(n1, 128, replace=False))
-    sub_p = np.zeros(len(rows1) + 1, np.int32)
-    sub_p[1:] = np.cumsum(gp[rows1 + 1] - gp[rows1])
-    take = np.concatenate([np.arange(gp[r], gp[r + 1]) for r in rows1])
+    _check_iteration_rows(one, (gp, gj, gx), rows1, 2.0, 'C3 iteration 1', hash_max=(4_000_000, 0))
+    one.free()
+
+
+def _check_iteration_rows(T, T_host, rows, inflation, what, hash_max=(4_000_000,), rtol=0.0):
+    """one fused iteration (expand, inflate, prune) of the rows `rows` of the device matrix T against the oracle (mode 1: the kernels'
+    specification); rtol for inflations other than 2 (powf of the oracle vs float(exp2(r log2 x)) of the device)"""
+    from haphic_amd import _lib
+    gp, gj, gx = T_host
+    n1 = T.shape3[0]
+    sub_p = np.zeros(len(rows) + 1, np.int32)
+    sub_p[1:] = np.cumsum(gp[rows + 1] - gp[rows])
+    take = np.concatenate([np.arange(gp[r], gp[r + 1]) for r in rows])
     c = orc.spgemm((sub_p, gj[take], gx[take]), (gp, gj, gx), n_cols=n1, mode=1, fx_shift=52)
-    want = orc.prune((c[0], c[1], orc.normalize_l1(c[0], orc.power(c[2], 2.0))), 1e-4)
+    want = orc.prune((c[0], c[1], orc.normalize_l1(c[0], orc.power(c[2], inflation))), 1e-4)
     sub = _lib.DeviceCSR.from_arrays(sub_p, gj[take], gx[take], n_cols=n1)
-    for hash_max in (4_000_000, 0):
-        _lib.tune('hash_max', hash_max)
+    for hm in hash_max:
+        _lib.tune('hash_max', hm)
         try:
-            got1 = _lib.expand_inflate_prune(sub, one, 2.0, 1e-4)[0].to_arrays()
+            got1 = _lib.expand_inflate_prune(sub, T, inflation, 1e-4)[0].to_arrays()
         finally:
-            _lib.tune('hash_max', 4_000_000)
-        assert all(np.array_equal(u, v) for u, v in zip(got1, want)), 'C3 iteration 1, hash_max %d' % hash_max
+            _lib.tune('hash_max', None)
+        assert np.array_equal(got1[0], want[0]) and np.array_equal(got1[1], want[1]), '%s, hash_max %d: pattern' % (what, hm)
+        if rtol:
+            np.testing.assert_allclose(got1[2], want[2], rtol=rtol, atol=0, err_msg=what)
+        else:
+            assert np.array_equal(got1[2], want[2]), '%s, hash_max %d: values' % (what, hm)
+    sub.free()
+    return np.diff(c[0])                     # distinct output columns of the expanded rows
+
+
+POW_RTOL = 1e-6      # inflations other than 2: the oracle's powf against the device's float(exp2(r log2 x)), north_star's 1e-6
+
+
+def test_c3_inflation_sweep_against_oracle(c3):
+    """run_mcl_clustering's sweep :2155-2158 at C3 through the one-expansion path (cluster.DenseSweep: hhx_expand_links_dense +
+    hhx_dense_inflate_prune + hhx_mcl_resume) against the oracle: iteration 0 at inflations 1.1 / 1.4 / 3.0 on
+    stratified rows (pattern equal, values within 1e-6: x^r is powf in the oracle); the WHOLE tails at 3.0 and 1.4 continued by
+    the oracle from the device's iteration-0 output — iteration count, flag, final pattern, values within 1e-6, clusters; at 1.1
+    iteration 1 on sampled rows of the real T1, among them rows with more than 3072 distinct output columns (the rows that leave
+    the hash class for the generic-stream window class)."""
+    from haphic_amd import _lib, cluster
+    m = c3.m
+    n = m.shape3[0]
+    L = _c3_host_matrix(c3)
+    rows = _stratified_rows(_lib.row_products(m, m), 512, seed=11)
+    inflations = (1.1, 1.4, 3.0)
+    sweep = cluster.DenseSweep(m, 1e-4)
+    assert len(sweep.bounds) == 2, 'C3: the whole of M^2 is one resident block'
+    for r, first in zip(inflations, sweep.first_iterations(inflations)):
+        f_host = first.to_arrays()
+        want = orc.links_iteration0(L, rows, r, 1e-4)
+        _assert_rows_equal(f_host, want, rows, 'C3 sweep, iteration 0 at inflation %r' % r, rtol=POW_RTOL)
+        if r == 1.1:
+            # iteration 1 at 1.1 on rows of the real T1: the heaviest rows (most distinct output columns) + a random sample
+            T1p = f_host[0]
+            prod = _lib.row_products(first, first)
+            heavy = np.argsort(prod, kind='stable')[-48:]
+            pick = np.unique(np.concatenate([heavy, np.random.default_rng(12).choice(n, 48, replace=False)]))
+            width = _check_iteration_rows(first, f_host, pick, r, 'C3 sweep, iteration 1 at inflation 1.1', rtol=POW_RTOL)
+            assert width.max() > 3072, 'no sampled row beyond the hash class (widest: %d columns)' % width.max()
+            first.free()
+            continue
+        res, n_iter, conv, stats = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4, want_stats=True)
+        first.free()
+        o = orc.mcl(f_host, 2, r, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
+        assert (n_iter, conv) == (o[3], o[4]), 'C3 sweep, inflation %r: iteration count / convergence flag' % r
+        got = res.to_arrays()
+        assert np.array_equal(got[0], o[0]) and np.array_equal(got[1], o[1]), 'C3 sweep, inflation %r: final pattern' % r
+        np.testing.assert_allclose(got[2], o[2], rtol=POW_RTOL, atol=0)
+        assert _clusters(*_lib.interpret(res)) == _clusters(*orc.interpret(o[:3])), 'C3 sweep, inflation %r: clusters' % r
+        # survivors per iteration: equal up to the handful of entries a 1-ulp difference of x^r moves across the pruning threshold
+        assert np.abs(stats[:, 2] - o[5][:, 2]).max() <= 8, 'C3 sweep, inflation %r: survivors per iteration' % r
+        res.free()
+    sweep.close()
 
 
 def test_c5_200k_contigs_four_pushes():
@@ -339,19 +451,27 @@ def test_c5_200k_contigs_four_pushes():
     m, fidx, n_linked = ing.link_matrix(np.ones(n, np.uint8))
     ing.destroy()
     assert m.shape3[0] == n and m.nnz == 2 * n_flank + n
-    one, n_iter, conv, stats = _lib.mcl(m, 2, 2.0, 1, 1e-4, want_stats=True, links=True)        # iteration 0, n_win = 10
+    res, n_iter_full, conv_full, stats_full = _lib.mcl(m, 2, 2.0, 200, 1e-4, want_stats=True, links=True)   # the whole mcl(), n_win = 10
+    fp, fj, fx = res.to_arrays()
+    dev_clusters = _clusters(*_lib.interpret(res))
+    res.free()
+    one, n_iter, conv, stats = _lib.mcl(m, 2, 2.0, 1, 1e-4, want_stats=True, links=True)        # iteration 0 alone
+    assert np.array_equal(stats[0], stats_full[0])
     gp, gj, gx = one.to_arrays()
     one.free()
     mp, mj, mx = m.to_arrays()
-    rows = _stratified_rows(_lib.row_products(m, m), 192, seed=7)
+    rows = _stratified_rows(_lib.row_products(m, m), 1024, seed=7)
     m.free()
     assert orc.links_shift((mp, mj, mx)) > 0
-    want = _sample_rows_oracle((mp, mj, mx), rows)
-    for k, r in enumerate(rows):
-        lo, hi = gp[r], gp[r + 1]
-        wl, wh = want[0][k], want[0][k + 1]
-        assert np.array_equal(gj[lo:hi], want[1][wl:wh]), 'C5 iteration 0: pattern of row %d' % r
-        assert np.array_equal(gx[lo:hi], want[2][wl:wh]), 'C5 iteration 0: values of row %d' % r
+    want = orc.links_iteration0((mp, mj, mx), rows, 2.0, 1e-4)
+    _assert_rows_equal((gp, gj, gx), want, rows, 'C5 iteration 0')
+    del mp, mj, mx
+    # THE TAIL: the oracle continues mcl() from the device's iteration-0 output to convergence
+    o = orc.mcl((gp, gj, gx), 2, 2.0, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
+    assert (n_iter_full, conv_full) == (o[3], o[4]), 'C5 mcl: iteration count / convergence flag'
+    assert np.array_equal(stats_full[1:], o[5]), 'C5 mcl: nnz_A, nnz_C, survivors, products of every iteration'
+    assert np.array_equal(fp, o[0]) and np.array_equal(fj, o[1]) and np.array_equal(fx, o[2]), 'C5 mcl: final matrix'
+    assert dev_clusters == _clusters(*orc.interpret(o[:3])), 'C5 mcl: clusters'
 
 
 def test_c4_40k_contigs_allele_aware_containers():
@@ -385,3 +505,86 @@ def test_c4_40k_contigs_allele_aware_containers():
     # the allelic contacts are there: pairs of the same contig on two haplotypes hold far more links than their neighbours
     same = (got['full_i'] % base.n) == (got['full_j'] % base.n)
     assert same.sum() > 10_000 and got['full_cnt'][same].mean() > 5 * got['full_cnt'][~same].mean()
+
+
+def test_c4_40k_cluster_files_against_the_reference(tmp_path):
+    """configs[3] AT ITS STATED SIZE, cluster check against the reference itself.  tests/golden/pipeline_c4_40k.npz
+    was frozen from one run of the reference in the dev container on the same 40k-contig autotetraploid (make_golden.py c4_40k):
+    parse_alignments_for_ctgs :1596 -> remove_allelic_HiC_links :474-689 -> dict_to_matrix :310 -> run_mcl_clustering :2132 at
+    inflations 1.5 / 2.0 / 2.5 / 3.0.  Here: the S5 mirror on the device hands over the same containers (digests of ctg_coord_dict
+    as the filter receives it: key order, collapsed entries, concordance ratios, raw coordinate lists); the reference's verdict
+    (networkx cliques + Hungarian matching: its own Python, absent on this box) is applied to OUR dicts; dict_to_matrix must give
+    the reference's index map and matrix; run_mcl_clustering must write byte-identical files (SHA-256 of every cluster / group
+    file) — the integer contig -> group map of north_star — and log the same convergence and recommendation lines."""
+    import hashlib
+    import logging
+    import os
+    from haphic_amd import cluster
+    from tests import c4_40k
+    from tests.conftest import load_golden
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'pipeline_c4_40k.npz')
+    if not os.path.exists(path):
+        pytest.skip('tests/golden/pipeline_c4_40k.npz has not been generated (make_golden.py c4_40k)')
+    g = load_golden('pipeline_c4_40k.npz')
+    cfg = c4_40k.CFG
+    gen, base, id1, p1, id2, p2 = c4_40k.inputs()
+    if c4_40k.checksum(id1, p1, id2, p2) != int(g['pairs_checksum']):
+        pytest.skip('torch CPU generator differs from the one that made the fixture')
+    names = list(gen.names)
+    assert len(names) == int(g['n_contigs']) and 39_000 < len(names) < 41_000
+    cid = {n_: i for i, n_ in enumerate(names)}
+    fa_dict = {n_: [None, int(l), int(r)] for n_, l, r in zip(names, gen.length, gen.re_sites)}
+    frag_len_dict = {n_: fa_dict[n_][1] for n_ in names}
+
+    class A:
+        flank = cfg['flank']
+        remove_allelic_links = cfg['ploidy']
+        remove_concentrated_links = False
+        max_read_pairs = cfg['max_read_pairs']
+        min_read_pairs = cfg['min_read_pairs']
+        concordance_ratio_cutoff = cfg['concordance_ratio_cutoff']
+        nwindows = cfg['nwindows']
+    full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(cluster.IdArrays(names, id1, p1, id2, p2), fa_dict, A(),
+                                                                             frag_len_dict, set(names), 'int32', 'int32')
+    del HT, clm, id1, p1, id2, p2
+    assert (len(full), len(flank), sum(full.values())) == (int(g['n_full']), int(g['n_flank']), int(g['full_total']))
+    for k, v in c4_40k.coord_digest(coord, cid).items():
+        assert str(v) == str(g[k]), 'ctg_coord_dict differs from the reference\'s: ' + k
+    del coord
+    # the reference's remove_allelic_HiC_links verdict, applied to OUR dicts (in dict order)
+    for d, mask in ((full, g['full_removed']), (flank, g['flank_removed'])):
+        gone = np.unpackbits(mask)[:len(d)].astype(bool)
+        for k in [k for k, x in zip(d, gone) if x]:
+            del d[k]
+    remaining = {n_ for n_, r in zip(names, g['remaining']) if r}
+    mat, fidx = cluster.dict_to_matrix(flank, remaining, dense_matrix=False, add_self_loops=True, _device=True)
+    del full, flank
+    assert np.array_equal(np.array([fidx.get(n_, -1) for n_ in names], np.int32), g['frag_index']), 'index map'
+    assert mat.nnz == int(g['matrix_nnz'])
+    assert hashlib.sha256(b''.join(np.ascontiguousarray(a).tobytes() for a in mat.to_arrays())).hexdigest() == str(g['matrix_sha']), 'link matrix'
+    records = []
+    handler = logging.Handler()
+    handler.emit = lambda rec: records.append(rec.getMessage())
+    cluster.logger.addHandler(handler)
+    cluster.logger.setLevel('INFO')
+    lo, hi, step = cfg['inflations']
+    try:
+        cluster.run_mcl_clustering(mat, set(), frag_len_dict, fidx, 2, lo, hi, step, 200, 1e-4, fa_dict, int(g['nchrs']), False,
+                                   outdir_root=str(tmp_path))
+    finally:
+        cluster.logger.removeHandler(handler)
+    assert [str(x) for x in g['inflations']] == sorted(d.split('_', 1)[1] for d in os.listdir(tmp_path) if d.startswith('inflation_'))
+    for tag in (str(x) for x in g['inflations']):
+        d = os.path.join(str(tmp_path), 'inflation_' + tag)
+        txt = open(os.path.join(d, 'mcl_inflation_{}.clusters.txt'.format(tag))).read()
+        got_map = c4_40k.group_map(txt, cid)
+        assert np.array_equal(got_map, g['group_map_' + tag]), 'contig -> group map at inflation %s: %d contigs differ' % (
+            tag, int((got_map != g['group_map_' + tag]).sum()))
+        assert hashlib.sha256(txt.encode()).hexdigest() == str(g['clusters_sha_' + tag]), 'cluster file at inflation ' + tag
+        groups = sorted(f for f in os.listdir(d) if f.startswith('group'))
+        assert groups == [str(x) for x in g['group_files_' + tag]]
+        assert [c4_40k.file_digest(os.path.join(d, f)) for f in groups] == [str(x) for x in g['group_sha_' + tag]], 'group files at inflation ' + tag
+    assert [m for m in records if 'rounds of iterations' in m] == [str(x) for x in g['log_mcl']], 'convergence log lines'
+    want = str(g['log_recommend'][0])
+    if want:
+        assert want in records

@@ -68,6 +68,13 @@ def test_integer_pre_expansion_against_the_reference(golden_mcl):
         sub = orc.expand_links(L, rows=rows)
         for t, r in enumerate(rows):
             assert np.array_equal(sub[2][sub[0][t]:sub[0][t + 1]], C[2][C[0][r]:C[0][r + 1]])
+        # the one-pass form the whole-matrix checks at C3 use (orc.links_iteration0) == the composition, bit for bit
+        for r in (infl, 1.3):
+            rows7 = np.arange(len(L[0]) - 1, dtype=np.int32)[::-1][::3].copy()
+            sub7 = orc.expand_links(L, rows=rows7)
+            want = orc.prune((sub7[0], sub7[1], orc.normalize_l1(sub7[0], orc.power(sub7[2], r))), 1e-4)
+            got = orc.links_iteration0(L, rows7, r, 1e-4)
+            assert got[3] == len(sub7[1]) and all(np.array_equal(u, v) for u, v in zip(got[:3], want))
     assert done >= 1, 'no golden case holds a symmetric integer link matrix'
 
 

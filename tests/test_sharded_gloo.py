@@ -44,6 +44,7 @@ class OracleEngine:
         return indptr, np.concatenate(ix).astype(np.int32), np.concatenate(dx).astype(np.float32)
 
     def shape(self, m):
+        m = getattr(m, 'a', m)                   # (the link matrix of cluster.run_mcl_clustering under tests.oracle_lib)
         return len(m[0]) - 1, None, int(m[0][-1])
 
     def row_block(self, m, r0, r1):
@@ -63,6 +64,7 @@ class OracleEngine:
         return self.inflate_prune(c, inflation, pruning), f, int(c[0][-1])
 
     def row_products(self, a, b):
+        a, b = getattr(a, 'a', a), getattr(b, 'a', b)
         return np.add.reduceat(np.concatenate([np.diff(b[0])[a[1]].astype(np.int64), [0]]), np.minimum(a[0][:-1], len(a[1]))) * (np.diff(a[0]) > 0)
 
     def expand_links(self, links, r0, r1, inflation, pruning):
@@ -101,6 +103,27 @@ class OracleEngine:
         p[1:] = np.cumsum(np.bincount(rows, minlength=y.shape[0]))
         c = (p, cols.astype(np.int32), x[rows, cols])
         return self.inflate_prune(c, inflation, pruning), h['f'], int(p[-1])
+
+    def dense_drop(self, h):
+        pass
+
+    # ---- the sweep shared out over the ranks (sharded.sweep_sharded): stand-ins of hhx_expand_links_dense on a row block,
+    # hhx_dense_inflate_prune, hhx_interpret
+    def dense_rows(self, links, r0, r1):
+        links = getattr(links, 'a', links)
+        self.dense_calls = getattr(self, 'dense_calls', 0) + 1
+        norm = self.normalize_l1(links)
+        c, f = self.spgemm(self.row_block(norm, r0, r1), norm)
+        return c, f, int(c[0][-1])
+
+    def dense_first(self, c, inflation, pruning):
+        return self.inflate_prune(c, inflation, pruning)
+
+    def dense_free(self, c):
+        pass
+
+    def interpret(self, m):
+        return orc.interpret(m)
 
     def mcl_resume(self, m, done, expansion, inflation, iters, pruning):
         """mcl() :2026-2062 from iteration `done` on the whole matrix (hhx_mcl_resume)"""
@@ -240,6 +263,14 @@ def _worker(rank, world, port, q):
         # the same from the RAW row blocks (all-gathered once, iteration 0 through expand_links): identical results
         res3, n_iter3, conv3, _st3 = sharded.mcl_sharded_engine(eng, None, 2, 2.0, 100, 1e-4, dist, local_links=block, n=shape)
         assert (n_iter3, conv3) == (n_iter2, conv2) and all(np.array_equal(x, y) for x, y in zip(res3, res2))
+        # --expansion 3 from the raw blocks (mkl_matrix_power :2017-2023 recurses for any e): the blocks are normalised and the
+        # general path runs — equal to the single-process oracle on the stacked matrix
+        res5, n_iter5, conv5, _st5 = sharded.mcl_sharded_engine(eng, None, 3, 2.0, 100, 1e-4, dist, local_links=block, n=shape)
+        fl = sharded.allgather_rows(eng, block, shape, dist)
+        T5 = eng.normalize_l1(fl)
+        pre5 = orc.spgemm(orc.spgemm(T5, T5, mode=1, fx_shift=52), T5, mode=1, fx_shift=52)
+        o5 = orc.mcl(pre5, 3, 2.0, 100, 1e-4, spgemm_mode=1, fx_shift=52)
+        assert (n_iter5, conv5) == (o5[3], o5[4]) and all(np.array_equal(x, y) for x, y in zip(res5, o5[:3])), 'expansion 3 from raw row blocks'
         # ... and with iteration 0 on the SYMMETRIC HALF shared out over the ranks (each rank fills the upper blocks of its rows, one
         # all-to-all(v) mirrors them): the integer specification of the pre-expansion, so the reference run is the oracle's own
         sharded.SYMMETRIC_MIN_WORLD = 2
@@ -251,7 +282,7 @@ def _worker(rank, world, port, q):
             assert eng.upper_calls == 1, 'the symmetric path was not taken'
         finally:
             sharded.symmetric_window = old_window
-            sharded.SYMMETRIC_MIN_WORLD = 8
+            sharded.SYMMETRIC_MIN_WORLD = None
         full_links = sharded.allgather_rows(eng, block, shape, dist)
         o4 = orc.mcl(orc.expand_links(full_links), 2, 2.0, 100, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True)
         assert (n_iter4, conv4) == (o4[3], o4[4]) and all(np.array_equal(x, y) for x, y in zip(res4, o4[:3])), 'symmetric half across ranks'
@@ -263,8 +294,9 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _sweep_worker(rank, world, port, outdir, q):
-    """run_mcl_clustering(dist=...) : the inflations dealt to the ranks, rank 0 writes the files"""
+def _sweep_worker(rank, world, port, outdir, q, shard_products=None, expansion=2):
+    """run_mcl_clustering(dist=...): the sweep shared out over the ranks (sharded.sweep_sharded; expansion 3: whole inflations dealt
+    round-robin), rank 0 writes the files"""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -287,28 +319,51 @@ def _sweep_worker(rank, world, port, outdir, q):
         frag_len_dict = {n_: fa_dict[n_][1] for n_ in names}
         full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(aln, fa_dict, A(), frag_len_dict, set(names), 'int32', 'int32')
         mat, fidx = cluster.dict_to_matrix(flank, set(names), dense_matrix=False, add_self_loops=True, _device=True)
-        res, nrounds = cluster.run_mcl_clustering(mat, set(), frag_len_dict, fidx, 2, 1.2, 2.0, 0.4, 200, 1e-4, fa_dict, int(g['nchrs']), False,
-                                                  outdir_root=outdir, dist=dist)
-        q.put((rank, nrounds, [(str(i), [(list(c), l) for c, l in r]) for i, r in res]))
+        eng = OracleEngine()
+        if shard_products is not None:
+            sharded.SWEEP_SHARD_PRODUCTS = shard_products
+        records = []
+        import logging
+        handler = logging.Handler()
+        handler.emit = lambda rec: records.append(rec.getMessage())
+        cluster.logger.addHandler(handler)
+        cluster.logger.setLevel('INFO')
+        shared = []
+        orig = sharded.sharded_iteration
+        sharded.sharded_iteration = lambda *a, **k: (shared.append(1), orig(*a, **k))[1]
+        res, nrounds = cluster.run_mcl_clustering(mat, set(), frag_len_dict, fidx, expansion, 1.2, 2.0, 0.4, 200, 1e-4, fa_dict, int(g['nchrs']), False,
+                                                  outdir_root=outdir, dist=dist, _engine=eng)
+        q.put((rank, nrounds, [(str(i), [(list(c), l) for c, l in r]) for i, r in res], [m_ for m_ in records if 'rounds of iterations' in m_],
+               len(shared), getattr(eng, 'dense_calls', 0)))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_inflation_sweep_across_ranks_writes_the_reference_files(tmp_path):
+@pytest.mark.parametrize('world,shard_products', [(2, None), (3, 2000.0), (2, 0.0)])
+def test_inflation_sweep_across_ranks_writes_the_reference_files(tmp_path, world, shard_products):
+    """sharded.sweep_sharded through run_mcl_clustering: ONE expansion shared by the ranks (every rank expands only its rows), the
+    heavy iterations row-sharded, the light remainders dealt to the ranks; shard_products = None: the product threshold (every
+    tail of this toy is light: replicas from iteration 1 on), 2000: the first iterations of every inflation are shared, 0: every
+    iteration of every inflation is (the tasks finish inside the sharded phase).  The files must be the reference's in every mode."""
     from tests.conftest import load_golden
-    world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sweep_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    procs = [ctx.Process(target=_sweep_worker, args=(r, world, port, str(tmp_path), q, shard_products)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda o: o[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert outs[0][1:] == outs[1][1:] and outs[0][1] == 3            # every rank returns the whole sweep
+    assert all(o[1:4] == outs[0][1:4] for o in outs) and outs[0][1] == 3            # every rank returns the whole sweep, logs the same lines
+    assert len(outs[0][3]) == 3 and all('converged after' in l for l in outs[0][3])
+    assert all(o[5] == 1 for o in outs), 'one expansion per rank, of its own rows'
+    if shard_products is None:
+        assert all(o[4] == 0 for o in outs)
+    else:
+        assert all(o[4] == outs[0][4] and o[4] >= 3 for o in outs), 'every rank takes part in every shared iteration'
     g = load_golden('pipeline_toy.npz')
     for infl in g['inflations']:
         infl = str(infl)
