@@ -413,17 +413,23 @@ def sweep_leg(args, m, one_mcl_s):
         _lib.profile_reset()
         _lib.profile_enable(True)
         ep = {}
-        for infl in inflations:                                      # ascending: the pools sized by the previous (larger) demand fit
+        G = cluster.DenseSweep.GROUP                                 # inflations per pass over the block (hhx_dense_inflate_prune_multi), as run_mcl_clustering takes them
+        for lo in range(0, len(inflations), G):                      # ascending: the pools sized by the previous (larger) demand fit
+            grp = inflations[lo:lo + G]
             te = time.perf_counter()
             try:
-                firsts.append(blk.inflate_prune(float(infl), 1e-4))
+                firsts.extend(blk.inflate_prune_multi([float(x) for x in grp], 1e-4))
             except RuntimeError as e:                                # e.g. a first iteration of more than 2^31 entries at inflation 1.1
-                firsts.append(None)
-                errors[str(infl)] = str(e)[:200]
+                for infl in grp:                                     # one by one: only the inflation that fails is lost
+                    try:
+                        firsts.append(blk.inflate_prune(float(infl), 1e-4))
+                    except RuntimeError as e1:
+                        firsts.append(None)
+                        errors[str(infl)] = str(e1)[:200]
             sync()
-            ep[str(infl)] = (time.perf_counter() - te) * 1e3
+            ep[' '.join(str(x) for x in grp)] = (time.perf_counter() - te) * 1e3
         firsts = firsts[::-1]
-        out['epilogue_ms'] = ep
+        out['epilogue_group_ms'] = ep
         sync()
         tc = time.perf_counter()
         _lib.profile_enable(False)
@@ -483,6 +489,7 @@ def parity_leg(args, m, rows=64):
     from oracle import oracle as orc
     orc.set_threads(0)                                   # all host cores: this is the checker, not the timed baseline
     t0 = time.perf_counter()
+    integer_dev, layout = _lib.links_plan(m)             # what iteration 0 does with this matrix on this device (label below)
     one = _lib.mcl(m, 2, args.inflation, 1, 1e-4, links=True)[0]
     gp, gj, gx = one.to_arrays()
     # iteration 1 (T1 x T1, the hash class) on sampled rows of the real T1
@@ -521,14 +528,19 @@ def parity_leg(args, m, rows=64):
         lo, hi, wl, wh = gp[r], gp[r + 1], want[0][k], want[0][k + 1]
         if not (np.array_equal(gj[lo:hi], want[1][wl:wh]) and np.array_equal(gx[lo:hi], want[2][wl:wh])):
             bad += 1
-    return {'what': 'iteration 0 (pre-expansion: integer arithmetic, upper block triangle + transposition; inflate + prune from the dense rows) vs oracle, sampled rows of the real operand',
+    path = ('integer arithmetic, ' if integer_dev else 'float arithmetic, ') + {
+        0: 'every row walks all its products into the fused epilogue',
+        1: 'symmetric half into the square dense block + transposition; inflate + prune from the dense rows',
+        2: 'symmetric half into the upper block triangle alone; inflate + prune block row by block row'}[layout]
+    return {'what': 'iteration 0 (pre-expansion: %s) vs oracle, sampled rows of the real operand' % path,
             'rows_checked': int(len(pick_rows)), 'rows_differing': int(bad), 'bit_identical': bad == 0,
             'products_checked': int(sum(int(np.diff(mp)[mj[mp[r]:mp[r + 1]]].sum()) for r in pick_rows)),
             'specification': 'integer (S = L D^-1 L exact, orc_expand_links)' if integer else 'fixed point 2^-52 (orc_spgemm mode 1)',
             'iteration1_hash_class': {'rows_checked': int(len(rows1)), 'rows_differing': int(bad1), 'bit_identical': bad1 == 0, 'products_checked': prod1},
             'oracle_threads': orc.get_threads(), 'seconds': time.perf_counter() - t0,
-            'full_size_tests': 'tests/test_gpu_scale.py: C2 whole ingest + mcl() bit equal; C3 whole ingest (500 M pairs) + dict_to_matrix, 2k stratified rows of '
-                               'iteration 0 + the whole tail continued by the oracle to convergence, bit equal; C5 (4 pushes) sampled rows + cross-push ingest prefix; C4 40k-contig containers'}
+            'full_size_tests': 'tests/test_gpu_scale.py: C2 whole ingest + mcl() bit equal; C3 whole ingest (500 M pairs) + dict_to_matrix, EVERY row of '
+                               'iteration 0 + the whole tail continued by the oracle to convergence, bit equal, sweep inflations 1.1 / 1.4 / 3.0; C5 (4 pushes) 1k rows + whole tail + '
+                               'cross-push ingest prefix; C4 at 40k contigs: containers vs oracle, cluster files vs the reference run'}
 
 
 def pmc_traffic(n_contigs, pairs):

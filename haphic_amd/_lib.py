@@ -92,8 +92,10 @@ SIGNATURES = {
     'hhx_mcl_resume': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, c_vpp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
     'hhx_expand_links_dense': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_int, c_vpp, c_i64p, c_i64p]),
     'hhx_links_integer_ok': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'hhx_links_plan': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'hhx_dense_device': (C.c_int, [C.c_void_p, c_vpp, c_i64p, c_i32p, c_i32p]),
     'hhx_dense_inflate_prune': (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_vpp]),
+    'hhx_dense_inflate_prune_multi': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, c_vpp]),
     'hhx_dense_shape': (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i64p]),
     'hhx_dense_free': (C.c_int, [C.c_void_p]),
     'hhx_shard_create': (C.c_int, [C.c_void_p, C.c_void_p, c_vpp]),
@@ -361,6 +363,21 @@ class DenseRows:
         check(load().hhx_dense_inflate_prune(self.h, float(inflation), float(pruning), C.byref(out)))
         return DeviceCSR(out)
 
+    MULTI = 8       # inflations per pass of inflate_prune_multi (hhx_expand.hip: MULTI_MAX)
+
+    def inflate_prune_multi(self, inflations, pruning):
+        """iteration 0 at several inflations in one pass over the block per group of MULTI (hhx_dense_inflate_prune_multi): the
+        matrices inflate_prune would return, in the order of `inflations`"""
+        res = []
+        inflations = [float(x) for x in inflations]
+        for lo in range(0, len(inflations), self.MULTI):
+            grp = inflations[lo:lo + self.MULTI]
+            arr = (C.c_double * len(grp))(*grp)
+            outs = (C.c_void_p * len(grp))()
+            check(load().hhx_dense_inflate_prune_multi(self.h, len(grp), arr, float(pruning), outs))
+            res.extend(DeviceCSR(o) for o in outs)
+        return res
+
     def free(self):
         if self.h is not None and self.h.value:
             load().hhx_dense_free(self.h)
@@ -378,6 +395,13 @@ def links_integer_ok(links):
     ok, shift = C.c_int(0), C.c_int(0)
     check(load().hhx_links_integer_ok(links.h, C.byref(ok), C.byref(shift)))
     return bool(ok.value)
+
+
+def links_plan(links):
+    """(integer arithmetic?, layout of iteration 0: 0 all products into the fused epilogue / 1 square dense block / 2 upper block triangle)"""
+    a, b = C.c_int(0), C.c_int(0)
+    check(load().hhx_links_plan(links.h, C.byref(a), C.byref(b)))
+    return bool(a.value), b.value
 
 
 def mcl_resume(m, done, expansion, inflation, max_iter, pruning, want_stats=False):

@@ -531,6 +531,8 @@ class DenseSweep:
     produced and consumed one after the other: the first inflations of every block are formed while it is resident and the
     pieces of every inflation wait (pruned: small) until the last block is done."""
 
+    GROUP = 5       # inflations per pass over the dense block (their candidate pools live side by side: ~2-4 GB each at the low inflations of C3)
+
     def __init__(self, links, pruning, block_rows=None, budget_bytes=None):
         self.links, self.pruning = links, pruning
         n = links.shape3[0]
@@ -545,24 +547,38 @@ class DenseSweep:
         self.bounds = list(range(0, n, int(block_rows))) + [n]
         self.resident = None                                 # the only block when the whole M^2 fits: kept for the whole sweep
         self.n_products = 0
+        self._gen = None
 
     def first_iterations(self, inflations):
-        """iteration 0 of mcl() at every inflation -> one matrix per inflation (generator when M^2 is one resident block:
-        an inflation's matrix is formed when asked for, so that at most one of them exists at a time)"""
+        """iteration 0 of mcl() at every inflation -> one matrix per inflation, as a generator"""
+        self._gen = self._first_iterations(inflations)
+        return self._gen
+
+    def _first_iterations(self, inflations):
+        inflations = [float(x) for x in inflations]
         if len(self.bounds) == 2:
             if self.resident is None:
                 self.resident = _lib.DenseRows(self.links, 0, self.n)
                 self.n_products = self.resident.n_products
-            for infl in inflations:
-                yield self.resident.inflate_prune(float(infl), self.pruning)
+            # GROUP inflations at a time in one pass over the block (hhx_dense_inflate_prune_multi: the division and the log2 of
+            # x^r = exp2(r log2 x) once per entry, the 4 n^2 bytes read once per group); the matrices of a group wait their turn
+            for lo in range(0, len(inflations), self.GROUP):
+                ready = self.resident.inflate_prune_multi(inflations[lo:lo + self.GROUP], self.pruning)
+                try:
+                    while ready:
+                        yield ready.pop(0)
+                finally:
+                    for m in ready:                           # the consumer stopped early
+                        m.free()
             return
         pieces = [[] for _ in inflations]
         for r0, r1 in zip(self.bounds[:-1], self.bounds[1:]):
             blk = _lib.DenseRows(self.links, r0, r1)
             self.n_products += blk.n_products
             try:
-                for k, infl in enumerate(inflations):
-                    pieces[k].append(blk.inflate_prune(float(infl), self.pruning))
+                for lo in range(0, len(inflations), self.GROUP):
+                    for k, piece in enumerate(blk.inflate_prune_multi(inflations[lo:lo + self.GROUP], self.pruning)):
+                        pieces[lo + k].append(piece)
             finally:
                 blk.free()
         for k in range(len(inflations)):
@@ -573,6 +589,9 @@ class DenseSweep:
                     p.free()
 
     def close(self):
+        if self._gen is not None:                            # a suspended generator holds the matrices of its group: release them now
+            self._gen.close()
+            self._gen = None
         if self.resident is not None:
             self.resident.free()
             self.resident = None

@@ -1231,6 +1231,181 @@ __global__ __launch_bounds__(EX_T_WIN, PF ? 4 : 8) void k_dense_epilogue_sw(ExPa
     if (lane_id() == 0 && nnz_wave) atomicAdd(&P.cursors[3], (unsigned long long)nnz_wave);
 }
 
+// ---- the dense epilogue for SEVERAL inflations in one pass (run_mcl_clustering :2155-2158: every inflation restarts from the same
+// pre-expanded matrix).  Per entry of M^2 the work of iteration 0 at inflation r is x = float(y / d_i), p = x^r =
+// float(exp2(r * log2(double(x)))) (hhx_powr), the row sum, the survivors.  x and log2(x) do not depend on r: they are formed ONCE
+// per (row, window) step and kept in registers (20 owned slots a thread: 20 floats + 20 doubles), then the rest of
+// k_dense_epilogue_sw's step runs once per inflation — exp2, block sum + argmax, survivors against the running sum, scan, emission
+// into that inflation's own candidate pool.  The same operations on the same operands in the same order as the one-inflation
+// kernel: the same bits.  The log2 is more than half of hhx_powr and the 40 GB block is read once per group instead of once per
+// inflation.
+constexpr int MULTI_MAX = 8;
+struct MultiOut {                       // one inflation of the group: its parameters and where its results go
+    double r; int square, pad;
+    i32 *cand_col; float *cand_val; i64 cand_cap;
+    unsigned long long *cursors;        // [0] candidate cursor [2] overflow flag
+    i64 *g_win_off; i32 *g_win_cnt;     // [n_rows][n_win]
+    double *s_run;                      // [n_rows]
+};
+constexpr int MULTI_LREG = 11;          // of a thread's DE_PER logarithms, this many stay in registers; the others wait in LDS (conflict-free: slot tid + i * 1024)
+__host__ __device__ inline size_t dense_epi_multi_lds_bytes(i32 cap) {
+    return ((dense_epi_sw_lds_bytes(cap) + MULTI_MAX * 8 + 15) & ~(size_t)15) + (size_t)(DE_PER - MULTI_LREG) * EX_T_WIN * 8;
+}
+__global__ __launch_bounds__(EX_T_WIN, 4) void k_dense_epilogue_multi(ExParams P, const DenseSrc S, i32 cap, i32 K, const MultiOut *__restrict__ mo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *red_d, *s_run_sh; i64 *bcast; i32 *red_i, *red_s; float *red_f, *slot;
+    {
+        unsigned char *p = smem;
+        red_d = (double *)p; p += EX_WAVES_MAX * 8;
+        s_run_sh = (double *)p; p += MULTI_MAX * 8;
+        bcast = (i64 *)p; p += 8;
+        red_i = (i32 *)p; p += EX_WAVES_MAX * 4;
+        red_f = (float *)p; p += EX_WAVES_MAX * 4;
+        red_s = (i32 *)p; p += EX_WAVES_MAX * 4;
+        p += 8;
+        slot = (float *)p;                                  // [cap rounded up to 32] floats
+    }
+    double *l_sh = (double *)(smem + ((dense_epi_sw_lds_bytes(cap) + MULTI_MAX * 8 + 15) & ~(size_t)15));      // [DE_PER - MULTI_LREG][EX_T_WIN]
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / HHX_WAVE;
+    i32 nnzc = 0;
+    i32 row = S.row0 + (i32)blockIdx.x, wv = 0;
+    if (row >= S.row1) return;
+    double div = 0.0;
+    for (;;) {
+        const i32 c0 = wv * cap, wlen = min(P.n_cols, c0 + cap) - c0;
+        const i32 per = (wlen + EX_T_WIN - 1) / EX_T_WIN, gm = min(32, per & -per) - 1;
+        i32 lt = tid;
+        asm volatile("" : "+v"(lt));
+        const i32 s0 = min(wlen, lt * per), s1 = min(wlen, s0 + per);
+        {
+            float v[DE_PER];
+            const float *src = S.at(row, wv, cap);
+#pragma unroll
+            for (int i = 0; i < DE_PER; ++i) v[i] = de_load(src, min(lt + i * EX_T_WIN, wlen - 1));
+#pragma unroll
+            for (int i = 0; i < DE_PER; ++i)
+                if (lt + i * EX_T_WIN < wlen) slot[de_swz(lt, gm) + i * EX_T_WIN] = v[i];
+        }
+        if (wv == 0) div = P.row_div ? P.row_div[row] : 0.0;
+        const double rdiv = div != 0.0 ? 1.0 / div : 0.0;
+        lds_barrier();
+        // the owned slots, once for all inflations: log2 of x = float(y / d_i); NaN: no entry; x = 0 gives -inf, whose exp2(r * .)
+        // is the 0 hhx_powr returns for it
+        double Ls[MULTI_LREG];
+        i32 nz = 0;
+#pragma unroll
+        for (int u = 0; u < DE_PER; ++u) {
+            double L = __longlong_as_double(0x7ff8000000000000ll);
+            if (s0 + u < s1) {
+                const u32 b = ((const u32 *)slot)[de_swz(s0 + u, gm)];
+                if (b != 0) {
+                    const float y = __uint_as_float(b);
+                    const float x = div != 0.0 ? quot_f32((double)y, div, rdiv) : y;
+                    L = log2((double)x);
+                    ++nz;
+                }
+            }
+            if (u < MULTI_LREG) Ls[u] = L; else l_sh[(u - MULTI_LREG) * EX_T_WIN + tid] = L;      // (a thread reads back only what it wrote: no barrier)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        nnzc += nz;
+        i32 row_n = row, wv_n = wv + 1;
+        if (wv_n == P.n_win) { wv_n = 0; row_n = row + (i32)gridDim.x; }
+        const bool more = row_n < S.row1;
+        for (i32 k = 0; k < K; ++k) {
+            const double r = mo[k].r;
+            const double s_prev = wv == 0 ? 0.0 : s_run_sh[k];
+            const double ts = (double)P.thr * s_prev;
+            const float lo_p = (wv > 0 && ts >= 0x1p-100 && ts <= 0x1p100) ? (float)(ts * (1.0 - 0x1p-18)) : 0.0f;
+            u32 maybe = 0;
+            double s = 0.0;
+            float bq = -1.0f; i32 bs = 0x7fffffff;
+#pragma unroll
+            for (int u = 0; u < DE_PER; ++u)
+                if (s0 + u < s1) {
+                    float p = -1.0f;
+                    const double L = u < MULTI_LREG ? Ls[u < MULTI_LREG ? u : 0] : l_sh[(u - MULTI_LREG) * EX_T_WIN + tid];
+                    if (L == L) {
+                        p = (float)exp2(r * L);                     // hhx_powr with its log2 hoisted
+                        s += (double)p;
+                    }
+                    if (p > bq) { bq = p; bs = s0 + u; }
+                    if (p >= lo_p) maybe |= 1u << u;
+                    slot[de_swz(s0 + u, gm)] = p;
+                    __builtin_amdgcn_sched_barrier(0);          // one exp2 at a time: twenty interleaved ones do not fit the 128 registers next to Ls
+                }
+            s = wave_sum_f64(s);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float oq = __shfl_down(bq, o, HHX_WAVE);
+                const i32 oc = __shfl_down(bs, o, HHX_WAVE);
+                if (oq > bq || (oq == bq && oc < bs)) { bq = oq; bs = oc; }
+            }
+            if (lane == 0) { red_d[wave] = s; red_f[wave] = bq; red_i[wave] = bs; }
+            lds_barrier();
+            double sw = red_d[0];
+            bq = red_f[0]; bs = red_i[0];
+#pragma unroll 3
+            for (int j = 1; j < EX_T_WIN / HHX_WAVE; ++j) {
+                sw += red_d[j];
+                if (red_f[j] > bq || (red_f[j] == bq && red_i[j] < bs)) { bq = red_f[j]; bs = red_i[j]; }
+            }
+            const double s_run = s_prev + sw;
+            const double rs = 1.0 / s_run;
+            u32 keep = (bs >= s0 && bs < s1) ? 1u << (bs - s0) : 0u;
+            while (maybe) {
+                const int j = __ffs(maybe) - 1;
+                maybe &= maybe - 1;
+                if (quot_f32((double)slot[de_swz(s0 + j, gm)], s_run, rs) >= P.thr) keep |= 1u << j;
+            }
+            const i32 cnt = __popc(keep);
+            i32 incl = cnt;
+#pragma unroll
+            for (int o = 1; o < HHX_WAVE; o <<= 1) {
+                const i32 t = __shfl_up(incl, o, HHX_WAVE);
+                if (lane >= o) incl += t;
+            }
+            if (lane == HHX_WAVE - 1) red_s[wave] = incl;
+            lds_barrier();
+            i32 off = 0, total = 0;
+#pragma unroll 4
+            for (int j = 0; j < EX_T_WIN / HHX_WAVE; ++j) { if (j < wave) off += red_s[j]; total += red_s[j]; }
+            off += incl - cnt;
+            if (tid == 0) {
+                i64 base = 0;
+                if (total) {
+                    base = (i64)atomicAdd(&mo[k].cursors[0], (unsigned long long)total);
+                    if (base + total > mo[k].cand_cap) { atomicExch(&mo[k].cursors[2], 1ull); base = -1; }
+                }
+                mo[k].g_win_off[(size_t)row * P.n_win + wv] = base;
+                mo[k].g_win_cnt[(size_t)row * P.n_win + wv] = base < 0 ? 0 : total;
+                *bcast = base;
+                s_run_sh[k] = s_run;                            // read again at the next window (every lane read s_prev before the first barrier above)
+                if (wv == P.n_win - 1) mo[k].s_run[row] = s_run;
+            }
+            lds_barrier();
+            const i64 base = *bcast;
+            if (base >= 0 && total) {
+                i32 *cc = mo[k].cand_col;
+                float *cv = mo[k].cand_val;
+                i64 o = base + off;
+                while (keep) {
+                    const int j = __ffs(keep) - 1;
+                    keep &= keep - 1;
+                    cc[o] = c0 + s0 + j;
+                    cv[o] = slot[de_swz(s0 + j, gm)];
+                    ++o;
+                }
+            }
+            lds_barrier();                                      // the slots, the reduction rows and the broadcast word are rewritten by the next inflation / step
+        }
+        if (!more) break;
+        row = row_n; wv = wv_n;
+    }
+    const i64 nnz_wave = wave_sum_i64((i64)nnzc);
+    if (lane_id() == 0 && nnz_wave) atomicAdd(&P.cursors[3], (unsigned long long)nnz_wave);
+}
+
 __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ExLds l = ex_carve(smem, cap, W, MAX_WIN);
@@ -2046,8 +2221,12 @@ int hhx_dense_layout(i32 n_rows, i32 n_cols, i64 nnz_b) {
     const double rest = 12.0 * (double)nnz_b + 8e9;             // operand stream (records, 16-bit columns, values: padded), candidate pools, the result
     const i64 mode = tune_get("dense_tri", -1);
     if (mode == 1 && n_win > 1) return tri + rest <= avail ? 2 : 0;
-    if (square * 1.25 + rest <= avail) return 1;
-    if (mode != 0 && n_win > 1 && tri + rest <= avail) return 2;
+    // the square while it is a modest share of the device (n = 100k: 40 GB of 288); beyond that the triangle, even where the square
+    // would still fit: a block of that size, cached between calls, starves everything else (n = 200k: 160 GB next to the resident
+    // pairs made the ingest of the next step trim the pool and re-allocate — 5 s — and hipMalloc itself costs ~30 ms per GB)
+    const bool square_fits = square * 1.25 + rest <= avail, tri_fits = mode != 0 && n_win > 1 && tri + rest <= avail;
+    if (square_fits && (square <= 0.25 * (double)total_b || !tri_fits)) return 1;
+    if (tri_fits) return 2;
     return 0;
 }
 
@@ -2183,6 +2362,147 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
         return pack_rows_to_csr(n_rows, n_cols, row_cnt.p, indptr.p, row_off.p, out_col.p, out_val.p, out);
     }
     return fail("dense inflate / prune: survivor pool kept overflowing");
+}
+
+// iteration 0 of mcl() (:2037-2042) of the block's rows at K inflations in ONE pass over the block (k_dense_epilogue_multi): outs[k] is
+// bit for bit what hhx_dense_inflate_prune(d, inflations[k]) returns
+extern "C" int hhx_dense_inflate_prune_multi(const hhx_dense *d, int K, const double *inflations, double pruning, hhx_csr **outs) {
+    if (!d || !inflations || !outs) return fail("null pointer");
+    if (K < 1 || K > MULTI_MAX) return fail("hhx_dense_inflate_prune_multi: 1 to %d inflations per pass", MULTI_MAX);
+    for (int k = 0; k < K; ++k) { if (!(inflations[k] > 0)) return fail("inflation must be positive"); outs[k] = nullptr; }
+    const i32 n_rows = d->n_rows, n_cols = d->n_cols, n_win = d->n_win, cap = d->cap_win;
+    // inflation 2 is x * x, not exp2(2 log2 x) (numpy's `** 2`, hhx_powr's callers): it goes through the one-inflation kernel;
+    // so does everything when the window is wider than the owned-slot registers of the fused kernel
+    bool single = (cap + EX_T_WIN - 1) / EX_T_WIN > DE_PER || K == 1;
+    for (int k = 0; k < K; ++k) single = single || inflations[k] == 2.0;
+    if (single) {
+        int rc1 = 0;
+        std::vector<double> rest;
+        std::vector<int> at;
+        for (int k = 0; k < K && !rc1; ++k) {
+            if (inflations[k] == 2.0 || K == 1 || (cap + EX_T_WIN - 1) / EX_T_WIN > DE_PER) rc1 = hhx_dense_inflate_prune(d, inflations[k], pruning, &outs[k]);
+            else { rest.push_back(inflations[k]); at.push_back(k); }
+        }
+        if (!rc1 && !rest.empty()) {
+            std::vector<hhx_csr *> o2(rest.size(), nullptr);
+            rc1 = hhx_dense_inflate_prune_multi(d, (int)rest.size(), rest.data(), pruning, o2.data());
+            for (size_t t = 0; t < at.size(); ++t) outs[at[t]] = o2[t];
+        }
+        if (rc1) for (int k = 0; k < K; ++k) if (outs[k]) { hhx_csr_free(outs[k]); outs[k] = nullptr; }
+        return rc1;
+    }
+    static int attr_dev = -1;
+    int dev = 0;
+    HHX_HIP(hipGetDevice(&dev));
+    if (attr_dev != dev) {
+        HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue_multi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_dev = dev;
+    }
+    struct PerK {
+        DevBuf<i32> row_cnt, indptr, g_win_cnt, cand_col, out_col;
+        DevBuf<i64> row_off, g_win_off;
+        DevBuf<float> cand_val, out_val;
+        DevBuf<double> s_run;
+        DevBuf<unsigned long long> cursors;
+        i64 pool_cap = 0, cand_cap = 0;
+        bool done = false;
+    };
+    std::vector<PerK> pk((size_t)K);
+    for (int k = 0; k < K; ++k) {
+        PerK &q = pk[(size_t)k];
+        if (q.row_cnt.alloc((size_t)n_rows + 1) || q.indptr.alloc((size_t)n_rows + 1) || q.row_off.alloc((size_t)n_rows + 1) || q.cursors.alloc(12) ||
+            q.s_run.alloc((size_t)n_rows + 1) || q.g_win_off.alloc((size_t)n_rows * n_win + 1) || q.g_win_cnt.alloc((size_t)n_rows * n_win + 1)) return 1;
+        q.pool_cap = std::max<i64>((i64)n_rows * 512, (i64)1 << 22);
+        if (d->last_out) q.pool_cap = d->last_out + d->last_out / 2 + n_rows;           // the demand of the call before (a neighbouring inflation)
+        q.cand_cap = d->last_out ? d->last_cand + d->last_cand / 2 + n_rows : 2 * q.pool_cap;
+    }
+    DevBuf<MultiOut> mo_dev;
+    DevBuf<unsigned long long> cursors0;                    // P.cursors of the kernel: only [3] (entries of the block) is written
+    if (mo_dev.alloc((size_t)MULTI_MAX) || cursors0.alloc(12)) return 1;
+    int rc = 0;
+    for (int attempt = 0; attempt < 4 && !rc; ++attempt) {
+        // the inflations still to do (first attempt: all; then those whose pools overflowed, with the pools at their demand)
+        std::vector<int> todo;
+        for (int k = 0; k < K; ++k) if (!pk[(size_t)k].done) todo.push_back(k);
+        if (todo.empty()) break;
+        MultiOut mo[MULTI_MAX];
+        memset(mo, 0, sizeof mo);
+        for (size_t t = 0; t < todo.size(); ++t) {
+            PerK &q = pk[(size_t)todo[t]];
+            if (q.cand_col.alloc((size_t)q.cand_cap) || q.cand_val.alloc((size_t)q.cand_cap) || q.out_col.alloc((size_t)q.pool_cap) || q.out_val.alloc((size_t)q.pool_cap)) return 1;
+            HHX_HIP(hipMemsetAsync(q.cursors.p, 0, 12 * sizeof(unsigned long long), g_stream));
+            mo[t].r = (double)(float)inflations[todo[t]]; mo[t].square = inflations[todo[t]] == 2.0;
+            mo[t].cand_col = q.cand_col.p; mo[t].cand_val = q.cand_val.p; mo[t].cand_cap = q.cand_cap;
+            mo[t].cursors = q.cursors.p; mo[t].g_win_off = q.g_win_off.p; mo[t].g_win_cnt = q.g_win_cnt.p; mo[t].s_run = q.s_run.p;
+        }
+        HHX_HIP(hipMemcpyAsync(mo_dev.p, mo, sizeof mo, hipMemcpyHostToDevice, g_stream));
+        HHX_HIP(hipMemsetAsync(cursors0.p, 0, 12 * sizeof(unsigned long long), g_stream));
+        ExParams P;
+        memset(&P, 0, sizeof P);
+        P.n_rows = n_rows; P.n_cols = n_cols;
+        P.scale = 1.0; P.inv_scale = 1.0;
+        P.thr = (float)pruning;
+        P.n_win = n_win;
+        P.cursors = cursors0.p;
+        P.row_div = d->integer ? d->row_div.p : nullptr;
+        if (n_rows) {
+            DevBuf<float> lower;
+            const i64 lo_ld = (i64)(n_win - 1) * cap;
+            if (d->tri && n_win > 1 && lower.alloc((size_t)cap * (size_t)lo_ld + 1)) return 1;
+            for (i32 I = 0; I < (d->tri ? n_win : 1); ++I) {
+                DenseSrc S;
+                if (d->tri) {
+                    S.row0 = I * cap; S.row1 = std::min<i32>(n_rows, (I + 1) * cap);
+                    S.up = d->x.p + tri_row_off(I, cap, d->ldn); S.up_ld = d->ldn - (i64)I * cap; S.up_win0 = I;
+                    S.lo = lower.p; S.lo_ld = lo_ld;
+                    if (I > 0) {
+                        KTimer kt("dense_transpose");
+                        k_transpose_tri<<<dim3((unsigned)(cap / 64), (unsigned)((S.row1 - S.row0 + 63) / 64), (unsigned)I), 256, 0, g_stream>>>(d->x.p, lower.p, lo_ld, I, S.row1 - S.row0, cap, d->ldn);
+                    }
+                } else { S.row0 = 0; S.row1 = n_rows; S.up = d->x.p; S.up_ld = d->ld; S.up_win0 = 0; S.lo = nullptr; S.lo_ld = 0; }
+                if (S.row1 <= S.row0) continue;
+                KTimer kt("dense_epilogue");
+                k_dense_epilogue_multi<<<std::min<unsigned>((unsigned)(S.row1 - S.row0), 256), EX_T_WIN, dense_epi_multi_lds_bytes(cap), g_stream>>>(P, S, cap, (i32)todo.size(), mo_dev.p);
+            }
+            HHX_LAUNCH_CHECK();
+            for (size_t t = 0; t < todo.size(); ++t) {         // the rows of every inflation finished from its own candidate segments
+                PerK &q = pk[(size_t)todo[t]];
+                ExParams Q = P;
+                Q.r = mo[t].r; Q.square = mo[t].square;
+                Q.cand_col = q.cand_col.p; Q.cand_val = q.cand_val.p; Q.cand_cap = q.cand_cap;
+                Q.out_col = q.out_col.p; Q.out_val = q.out_val.p; Q.out_cap = q.pool_cap;
+                Q.cursors = q.cursors.p; Q.row_off = q.row_off.p; Q.row_cnt = q.row_cnt.p;
+                Q.s_run = q.s_run.p; Q.g_win_off = q.g_win_off.p; Q.g_win_cnt = q.g_win_cnt.p;
+                KTimer kt("expand_finalize");
+                k_expand_window_finalize<<<std::min<unsigned>((unsigned)n_rows, 256 * 8), EX_T_CMP, ex_fixed_bytes(0, 0), g_stream>>>(Q, nullptr, n_rows);
+            }
+            HHX_LAUNCH_CHECK();
+            HHX_HIP(hipStreamSynchronize(g_stream));             // (the scratch block row of the triangle dies with this scope)
+        }
+        for (size_t t = 0; t < todo.size() && !rc; ++t) {
+            PerK &q = pk[(size_t)todo[t]];
+            unsigned long long cur[4];
+            HHX_HIP(hipMemcpyAsync(cur, q.cursors.p, sizeof cur, hipMemcpyDeviceToHost, g_stream));
+            HHX_HIP(hipStreamSynchronize(g_stream));
+            if (cur[2]) {                                      // a pool overflowed: the cursors hold the demand
+                if ((i64)cur[0] > q.cand_cap) q.cand_cap = (i64)cur[0] + (i64)n_rows;
+                if ((i64)cur[1] > q.pool_cap) q.pool_cap = std::max<i64>(q.pool_cap * 2, (i64)cur[1] + (i64)n_rows);
+                continue;
+            }
+            d->last_cand = (i64)cur[0];
+            d->last_out = (i64)cur[1];
+            rc = pack_rows_to_csr(n_rows, n_cols, q.row_cnt.p, q.indptr.p, q.row_off.p, q.out_col.p, q.out_val.p, &outs[todo[t]]);
+            q.done = true;
+            q.cand_col.release(); q.cand_val.release(); q.out_col.release(); q.out_val.release();
+        }
+    }
+    bool all = true;
+    for (int k = 0; k < K; ++k) all = all && pk[(size_t)k].done;
+    if (rc || !all) {
+        for (int k = 0; k < K; ++k) if (outs[k]) { hhx_csr_free(outs[k]); outs[k] = nullptr; }
+        return rc ? rc : fail("dense inflate / prune (multi): survivor pool kept overflowing");
+    }
+    return 0;
 }
 
 extern "C" int hhx_dense_shape(const hhx_dense *d, i32 *n_rows, i32 *n_cols, i64 *bytes) {

@@ -579,6 +579,18 @@ extern "C" int hhx_links_integer_ok(const hhx_csr *links, int *ok, int *shift) {
     return 0;
 }
 
+// what hhx_mcl_links' iteration 0 will do with this matrix on this device right now: *integer = 1 the integer arithmetic (symmetric
+// counts, row sums below 2^18); *layout = 1 the symmetric half into the square dense block (+ transposition), 2 into the upper
+// block triangle alone, 0 every row walks all its products into the fused epilogue (no symmetry, or neither block fits)
+extern "C" int hhx_links_plan(const hhx_csr *links, int *integer, int *layout) {
+    if (!links || !integer || !layout) return fail("null pointer");
+    NormalisedLinks nl;
+    HHX_TRY(normalise_links(links, &nl));
+    *integer = nl.integer ? 1 : 0;
+    *layout = (nl.usable && nl.integer && tune_get("links_sym", 1) != 0) ? hhx_dense_layout(links->n_rows, links->n_cols, links->nnz) : 0;
+    return 0;
+}
+
 // interpret_result(), array half.  The final matrix holds ~n entries, so this is a host pass over a
 // D2H copy; the per-iteration work never leaves the device.
 extern "C" int hhx_interpret(const hhx_csr *m, i32 *att, i32 *att_ptr, i32 *members, i32 *n_att) {

@@ -30,8 +30,10 @@ void *pool_alloc(size_t bytes) {
         // best fit: the smallest cached block that is large enough and wastes at most 3/4 of itself.
         // hipMalloc costs ~30 ms per GB on this platform (0.48 s for a 17 GB table), so re-using a
         // somewhat larger block beats a fresh allocation by orders of magnitude.
+        // (multi-GB blocks: at most 1/4 wasted — a cached 88 GB dense block must not be handed to a 25 GB request while the rest
+        // of the device fills up behind it)
         auto it = g_free.lower_bound(c);
-        if (it != g_free.end() && it->first <= 4 * c) {
+        if (it != g_free.end() && (it->first <= 4 * c && (it->first < (size_t(16) << 30) || it->first <= c + c / 4))) {
             void *p = it->second;
             g_live[p] = it->first;
             g_free.erase(it);
@@ -301,7 +303,11 @@ extern "C" int hhx_pool_trim(void) {
 // The knobs the kernels read (tune_get): which kernel class / arithmetic / layout a call takes.  Every setting of every knob gives
 // the same results (the verification tests switch classes with them and compare bits); an unknown name is refused.
 static const char *const k_tune_names[] = {"cls", "cls_nc", "cls_balance", "links_integer", "links_sym", "hash_max", "tile_u", "win_batch",
-                                           "cache_slice_mb", "dense_tri", "probe", nullptr};
+                                           "cache_slice_mb", "dense_tri",
+#ifdef HHX_PROBE_BUILD
+                                           "probe",          // measurement build only: the LDS atomics switched off, results are garbage
+#endif
+                                           nullptr};
 extern "C" int hhx_tune(const char *name, int64_t value) {
     if (!name) return fail("null name");
     bool known = false;

@@ -46,10 +46,15 @@ int hhx_pool_trim(void);                       /* release cached device memory *
  * "spgemm_symbolic", "spgemm_numeric", "expand_window", "expand_window_short", "expand_hash", "expand_compact",
  * "expand_tiny", "inflate_stats", "prune_write", "convergence", "class_layout", "d2m_*" (the stages of the link-matrix
  * build), "bin_contacts" */
-/* measurement / experiment switches of the kernels (tools/ and bench.py only; no reference counterpart): e.g.
- * "cls" 0 = stream iteration 0 as (column, value) pairs instead of the class stream, "probe" 1 = no LDS atomics (garbage
- * results), "hash_max" = largest product count of a row that tries the LDS hash table first (0: window / compact classes
- * only).  Unset knobs fall back to the environment variable HHX_<NAME>. */
+/* Which kernel class / arithmetic / layout the calls take (no reference counterpart).  EVERY setting of every knob gives the same
+ * results — the verification tests switch classes with them and compare bits; bench.py / tools time the variants.  Known names
+ * (anything else is refused): "cls" 0 = stream iteration 0 as (column, value) pairs instead of the class stream; "cls_nc",
+ * "cls_balance" (layout of the class stream); "links_integer" 0 = float arithmetic for iteration 0 (results within float32
+ * round-off, not the same bits: the other specification of DESIGN.md 2); "links_sym" 0 = every row walks all its products;
+ * "dense_tri" 1 / 0 = force / forbid the upper-block-triangle storage of the dense block; "hash_max" = largest product count of a
+ * row that tries the LDS hash table first (0: window / compact classes only); "tile_u", "win_batch", "cache_slice_mb" (tile
+ * shapes and window count of the window kernel).  value INT64_MIN: back to the default.  Unset knobs fall back to the
+ * environment variable HHX_<NAME>. */
 int hhx_tune(const char *name, int64_t value);
 int hhx_profile_enable(int on);
 int hhx_profile_reset(void);
@@ -143,7 +148,8 @@ int hhx_mcl_normalized(const hhx_csr *normalized, int expansion, double inflatio
                        hhx_csr **out, int *n_iter, int *converged, int64_t *stats);
 /* The inflation sweep of run_mcl_clustering :2155-2158 (every inflation restarts from the matrix pre-expanded at :2146-2147) with ONE
  * expansion.  hhx_expand_links_dense: rows [r0, r1) of M^2 — M the L1-normalised (:2144) raw link matrix of dict_to_matrix — as a
- * dense float32 row block in HBM (4 B x (r1 - r0) x n; hhx_dense_shape reports the bytes).  hhx_dense_inflate_prune: iteration 0 of
+ * dense float32 row block in HBM (4 B x (r1 - r0) x n; all rows of a symmetric integer matrix whose square does not fit: the upper block
+ * triangle alone, 0.55 x 4 B x n^2; hhx_dense_shape reports the bytes).  hhx_dense_inflate_prune: iteration 0 of
  * mcl() (:2037-2042: power, normalise, prune, restore the maximum, normalise) of those rows at one inflation, bit for bit what
  * hhx_mcl_links computes in its first iteration; stack the blocks (hhx_csr_vstack) and continue with hhx_mcl_resume(done = 1). */
 typedef struct hhx_dense hhx_dense;
@@ -153,8 +159,15 @@ typedef struct hhx_dense hhx_dense;
 int hhx_expand_links_dense(const hhx_csr *links, int32_t r0, int32_t r1, int fx_shift, int upper_only, hhx_dense **out,
                            int64_t *n_products, int64_t *nnz_expanded);
 int hhx_links_integer_ok(const hhx_csr *links, int *ok, int *shift);
+/* what iteration 0 of hhx_mcl_links will do with this matrix on this device: *integer (the arithmetic above applies); *layout = 1 the
+ * symmetric half into the square float32 block of all rows (+ transposition), 2 into its upper block triangle alone (the square
+ * would take too large a share of the device), 0 every row walks all its products into the fused epilogue */
+int hhx_links_plan(const hhx_csr *links, int *integer, int *layout);
 int hhx_dense_device(const hhx_dense *d, void **x_dev, int64_t *ld, int32_t *cap_win, int32_t *n_win);   /* ld: row pitch in floats (>= n_cols) */
 int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, double pruning, hhx_csr **out);
+/* the same for k <= 8 inflations in ONE pass over the block (x = y / d_i and log2(x) are formed once per entry, the 4 B x n^2 block
+ * is read once): outs[i] is bit for bit what hhx_dense_inflate_prune(d, inflations[i], ...) returns */
+int hhx_dense_inflate_prune_multi(const hhx_dense *d, int k, const double *inflations, double pruning, hhx_csr **outs);
 int hhx_dense_shape(const hhx_dense *d, int32_t *n_rows, int32_t *n_cols, int64_t *bytes);
 int hhx_dense_free(hhx_dense *d);
 

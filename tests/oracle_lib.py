@@ -110,6 +110,9 @@ class DenseRows:
     def inflate_prune(self, inflation, pruning):
         return inflate_prune_keep(self.c, inflation, pruning)
 
+    def inflate_prune_multi(self, inflations, pruning):
+        return [self.inflate_prune(r, pruning) for r in inflations]
+
     def free(self):
         pass
 

@@ -783,6 +783,37 @@ def test_dense_sweep_equals_fused_iteration0():
         assert all(np.array_equal(x, y) for x, y in zip(got.to_arrays(), want[r][0].to_arrays())), 'dense sweep, one block, inflation %r' % r
         got.free()
     whole.free()
+    # several inflations in ONE pass over the block (hhx_dense_inflate_prune_multi: x and log2 x once per entry): the same bits, in
+    # every grouping — 2.0 (x * x) is routed through the one-inflation kernel
+    whole = _lib.DenseRows(links, 0, n)
+    extra = {r: whole.inflate_prune(r, 1e-4) for r in (1.1, 1.7)}
+    for group in ((1.4, 3.0), (3.0, 2.0, 1.1, 1.4, 1.7), (2.0,), (1.7,)):
+        got = whole.inflate_prune_multi(group, 1e-4)
+        for r, g_ in zip(group, got):
+            ref = want[r][0] if r in want else extra[r]
+            assert all(np.array_equal(x, y) for x, y in zip(g_.to_arrays(), ref.to_arrays())), 'multi-inflation epilogue, group %r, inflation %r' % (group, r)
+            g_.free()
+    whole.free()
+    # the block stored as its UPPER BLOCK TRIANGLE alone (what an order the square does not fit for takes: n = 200k on one GPU) —
+    # the lower blocks are never written, the epilogue turns them one block row at a time: the same bits
+    _lib.tune('dense_tri', 1)
+    try:
+        tri = _lib.DenseRows(links, 0, n)
+        assert tri.n_products == want[2.0][3][0, 3] and tri.nnz_expanded == want[2.0][3][0, 1]
+        for r in inflations:
+            got = tri.inflate_prune(r, 1e-4)
+            assert all(np.array_equal(x, y) for x, y in zip(got.to_arrays(), want[r][0].to_arrays())), 'dense sweep, upper block triangle, inflation %r' % r
+            got.free()
+        for r, got in zip((1.4, 3.0, 1.7), tri.inflate_prune_multi((1.4, 3.0, 1.7), 1e-4)):
+            ref = want[r][0] if r in want else extra[r]
+            assert all(np.array_equal(x, y) for x, y in zip(got.to_arrays(), ref.to_arrays())), 'multi-inflation epilogue over the triangle, inflation %r' % r
+            got.free()
+        tri.free()
+        fused = _lib.mcl(links, 2, 2.0, 1, 1e-4, want_stats=True, links=True)
+        assert all(np.array_equal(x, y) for x, y in zip(fused[0].to_arrays(), want[2.0][0].to_arrays())) and np.array_equal(fused[3], want[2.0][3])
+        fused[0].free()
+    finally:
+        _lib.tune('dense_tri', None)
     # ragged row blocks through the host driver (cluster.DenseSweep), the pieces stacked
     sweep = cluster.DenseSweep(links, 1e-4, block_rows=7001)
     assert len(sweep.bounds) == 5

@@ -305,6 +305,12 @@ def test_c3_whole_mcl_against_oracle(c3):
         two = _lib.mcl(m, 2, 2.0, 1, 1e-4, links=True)[0]
         assert all(np.array_equal(u, v) for u, v in zip(two.to_arrays(), (gp, gj, gx))), 'C3 iteration 0: symmetric half + transposition vs all products'
         two.free()
+        _lib.tune('links_sym', 1)
+        _lib.tune('dense_tri', 1)                        # the symmetric half stored as the upper block triangle alone (5 block rows, the last one short)
+        tri = _lib.mcl(m, 2, 2.0, 1, 1e-4, links=True)[0]
+        assert all(np.array_equal(u, v) for u, v in zip(tri.to_arrays(), (gp, gj, gx))), 'C3 iteration 0: upper-block-triangle storage vs the square block'
+        tri.free()
+        _lib.tune('dense_tri', None)
         _lib.tune('links_integer', 0)
         flt = _lib.mcl(m, 2, 2.0, 1, 1e-4, links=True)[0]
         fa = flt.to_arrays()
@@ -316,9 +322,10 @@ def test_c3_whole_mcl_against_oracle(c3):
         assert all(np.array_equal(u, v) for u, v in zip(gen_.to_arrays(), fa)), 'C3 iteration 0: class stream vs generic stream (float arithmetic)'
         gen_.free()
     finally:
-        _lib.tune('cls', 1)
-        _lib.tune('links_integer', 1)
-        _lib.tune('links_sym', 1)
+        _lib.tune('cls', None)
+        _lib.tune('links_integer', None)
+        _lib.tune('links_sym', None)
+        _lib.tune('dense_tri', None)
     # iteration 1 — T1 x T1, the hash class (rows of ~1000 distinct columns reached by ~160k products) — on 128 sampled rows
     # of the real T1 against the oracle, and the same rows through the window / compact classes
     n1 = one.shape3[0]
@@ -459,6 +466,16 @@ def test_c5_200k_contigs_four_pushes():
     assert np.array_equal(stats[0], stats_full[0])
     gp, gj, gx = one.to_arrays()
     one.free()
+    # the symmetric half at this order (10 block rows): with the 160 GB square block when it fits, with the upper block triangle
+    # alone (88 GB) when it does not — forced here — and without the symmetry (every row walks all its products): the same bits
+    for knob, val in (('dense_tri', 1), ('links_sym', 0)):
+        _lib.tune(knob, val)
+        try:
+            alt, _n, _c, st_alt = _lib.mcl(m, 2, 2.0, 1, 1e-4, want_stats=True, links=True)
+        finally:
+            _lib.tune(knob, None)
+        assert all(np.array_equal(u, v) for u, v in zip(alt.to_arrays(), (gp, gj, gx))) and np.array_equal(st_alt[0, :3], stats[0, :3]), 'C5 iteration 0 with %s = %d' % (knob, val)
+        alt.free()
     mp, mj, mx = m.to_arrays()
     rows = _stratified_rows(_lib.row_products(m, m), 1024, seed=7)
     m.free()
