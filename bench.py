@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--mean-len', type=int, default=30_000)
     ap.add_argument('--inflation', type=float, default=2.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-reference-python', action='store_true', help='cpu_baseline: do not time the reference checkout even if it is present (carry the stored measurement)')
     ap.add_argument('--pushes', type=int, default=1, help='hand the pairs over in this many batches (streaming ingest: one aggregated run per batch, merged at finalize)')
     ap.add_argument('--force-sharded', action='store_true', help='take the multi-GPU code path on one rank (1-rank nccl group)')
     ap.add_argument('--cpu-sample-pairs', type=int, default=20_000_000)
@@ -54,7 +55,7 @@ def parse():
     ap.add_argument('--sweep-tail-seconds', type=float, default=20.0, help='sweep leg: wall-time budget for the mcl() tails (run from the highest inflation down)')
     ap.add_argument('--transport', choices=('rccl', 'host'), default='rccl',
                     help='rccl: one rank per GPU over RCCL / xGMI (the product path).  host: the same ranks and the same exchanges, every collective '
-                         'staged through host memory over gloo (sharded.HostStagedCollectives) — runs N ranks on ONE GPU, a functional proof of '
+                         'staged through host memory over gloo (haphic_amd.host_transport) — runs N ranks on ONE GPU, a functional proof of '
                          'the multi-rank path on a box without xGMI; its timings say nothing about scaling')
     ap.add_argument('--master-port', type=int, default=0, help='rendezvous port of the self-launch (0: pick a free one)')
     return ap.parse_args()
@@ -104,9 +105,9 @@ def main():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29533')
         if args.transport == 'host':
-            from haphic_amd import sharded as _sh
+            from haphic_amd import host_transport as _ht
             dist.init_process_group('gloo', rank=rank, world_size=world)
-            raw_dist, dist = dist, _sh.HostStagedCollectives(dist)
+            raw_dist, dist = dist, _ht.HostStagedCollectives(dist)
             dist.destroy_process_group = raw_dist.destroy_process_group
         elif world == 1:
             dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(dev))
@@ -173,6 +174,8 @@ def main():
         res.free()
         if state.get('keep_matrix'):
             state['matrix'] = m                      # the parity leg (after the timed region) re-uses the last link matrix
+        elif state.get('keep_block'):
+            state['block'], state['shape'] = m, shape        # the N-rank sweep leg re-uses this rank's row block of the link matrix
         else:
             m.free()
 
@@ -192,6 +195,7 @@ def main():
     iters = 0
     for k_step in range(args.steps):
         state['keep_matrix'] = (k_step == args.steps - 1) and world == 1 and not sharded_path and not (args.no_parity and args.sweep <= 1)
+        state['keep_block'] = (k_step == args.steps - 1) and sharded_path and world > 1 and args.sweep > 1
         step()
         t_ing += state['t_ingest']; t_mcl += state['t_mcl']; t_pre += state['t_pre']; iters += state['n_iter']
     barrier()
@@ -201,6 +205,28 @@ def main():
     if sharded_path:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     elapsed, t_ing, t_mcl, t_pre = tm.tolist()
+
+    # ---- outside the timed region, every rank: run_mcl_clustering's inflation sweep (:2155-2158) shared out over the ranks
+    # (sharded.sweep_sharded: ONE expansion across the ranks, the heavy iterations of the low inflations row-sharded, the light
+    # remainders dealt by predicted cost) — the N-rank counterpart of the one-GPU `sweep` leg
+    sweep_sh = None
+    if state.get('block') is not None:
+        from decimal import Decimal
+        eng = sharded.HipEngine(dev)
+        infl = [float(Decimal('1.1') + Decimal('0.1') * k) for k in range(args.sweep)]
+        try:
+            full = sharded.allgather_rows(eng, state.pop('block'), state['shape'], dist)
+            barrier()
+            ts = time.perf_counter()
+            res_sw = sharded.sweep_sharded(eng, full, infl, 200, 1e-4, dist)
+            barrier()
+            sweep_sh = {'seconds': time.perf_counter() - ts, 'inflations': infl, 'iterations': [r[4] for r in res_sw], 'converged': [bool(r[5]) for r in res_sw],
+                        'clusters': [int(len(r[0])) for r in res_sw], 'ranks': world,
+                        'what': 'sharded.sweep_sharded: one expansion shared by the ranks (each holds its rows of M^2), dense epilogue + exchange per '
+                                'inflation, heavy iterations row-sharded (>= %.0e products), light remainders dealt by predicted cost' % sharded.SWEEP_SHARD_PRODUCTS}
+            full.free()
+        except RuntimeError as e:
+            sweep_sh = {'error': str(e)[:300]}
 
     if rank == 0:
         K = args.steps
@@ -293,6 +319,8 @@ def main():
             out['ingest']['text'] = text_leg(args, gen, id1, p1, id2, p2, dev)
         if sharded_path:
             out['ingest']['sharded_build_ms_last_step'] = state.get('shard_ms')
+        if sweep_sh is not None:
+            out['sweep_sharded'] = sweep_sh
         if state.get('matrix') is not None and args.sweep > 1:
             try:
                 out['sweep'] = sweep_leg(args, state['matrix'], t_mcl / K)
@@ -596,6 +624,15 @@ def cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state):
     t1 = time.perf_counter()
     res = orc.mcl(pre, 2, args.inflation, 200, 1e-4)
     dm = time.perf_counter() - t1
+    # the same mcl() with the expansion and every row-local step spread over ALL host cores (OpenMP; the reference's own SpGEMM —
+    # sparse_dot_mkl — is multithreaded too, its Python prune() is not): same result, bit for bit
+    orc.set_threads(0)
+    all_threads = orc.get_threads()
+    t1 = time.perf_counter()
+    res_all = orc.mcl(pre, 2, args.inflation, 200, 1e-4)
+    dm_all = time.perf_counter() - t1
+    orc.set_threads(1)
+    assert res_all[3] == res[3] and np.array_equal(res_all[2], res[2])
     # a1 beside it: the reference's tokeniser loop (pairs_generator :1539-1559, restated in oracle.parse_pairs_text) on
     # 300 k lines of this workload's .pairs text
     names = list(gen.names)
@@ -605,18 +642,34 @@ def cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state):
     t2 = time.perf_counter()
     orc.parse_pairs_text(text, names)
     dtok = time.perf_counter() - t2
+    # the reference's OWN Python: measured in this run when its checkout is here (the dev container), otherwise the stored
+    # measurement of tools/reference_cpu_baseline.py is carried along and labelled as such
     ref_py = None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_reference_python_baseline.json')) as f:
-            ref_py = json.load(f)
-        ref_py['measured_where'] = 'dev container (the reference checkout does not exist on the GPU box): tools/reference_cpu_baseline.py'
-    except (OSError, ValueError):
-        pass
+    if os.path.exists('/root/reference/scripts/HapHiC_cluster.py') and not args.no_reference_python:
+        import subprocess
+        try:
+            r_ = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'reference_cpu_baseline.py'), '3000', '2000000'], capture_output=True,
+                                text=True, timeout=900, env=dict(os.environ, PYTHONHASHSEED='0'))
+            ref_py = json.loads([l for l in r_.stdout.splitlines() if l.startswith('{')][-1])
+            ref_py['measured_where'] = 'THIS run, this host (the reference checkout is present)'
+            ref_py['stored'] = False
+        except Exception as e:                           # noqa: BLE001 — a baseline leg must not take the bench line down
+            ref_py = {'error': str(e)[:200]}
+    if ref_py is None or 'error' in ref_py:
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r02_reference_python_baseline.json')) as f:
+                ref_py = json.load(f)
+            ref_py['measured_where'] = 'STORED: dev container, round 2 (the reference checkout does not exist on the GPU box): tools/reference_cpu_baseline.py'
+            ref_py['stored'] = True
+        except (OSError, ValueError):
+            pass
     return {'value': S / dt, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port', 'reference_python': ref_py,
             'sample': 'ingest: first %d pairs of the rank-0 shard through the C oracle (hash-map port of '
                       'parse_alignments_for_ctgs); mcl: oracle mcl() on the %d-contig sub-assembly (first quarter '
                       'of the chromosomes) built from those pairs' % (S, nq),
             'ingest_seconds': dt, 'mcl_iters_per_s': res[3] / dm, 'mcl_n': int(nq), 'mcl_iterations': int(res[3]),
+            'mcl_all_cores': {'iters_per_s': res_all[3] / dm_all, 'threads': all_threads, 'what': 'the same oracle mcl(), expansion and row-local steps '
+                              'row-parallel over all host cores (OpenMP), bit-identical result'},
             'text_tokeniser_pairs_per_s': nt / dtok, 'text_tokeniser_lines': nt, 'host_cpus': os.cpu_count()}
 
 

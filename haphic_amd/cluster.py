@@ -531,6 +531,7 @@ class DenseSweep:
     produced and consumed one after the other: the first inflations of every block are formed while it is resident and the
     pieces of every inflation wait (pruned: small) until the last block is done."""
 
+    MAX_BLOCKS = 4  # run_mcl_clustering falls back to one fused expansion per inflation beyond this many row blocks
     GROUP = 5       # inflations per pass over the dense block (their candidate pools live side by side: ~2-4 GB each at the low inflations of C3)
 
     def __init__(self, links, pruning, block_rows=None, budget_bytes=None):
@@ -544,6 +545,8 @@ class DenseSweep:
                 free_bytes, _total = _lib.mem_info()
                 budget_bytes = 0.45 * (free_bytes + _lib.pool_cached_bytes())
             block_rows = max(1, min(n, int(budget_bytes // (4 * max(n, 1)))))
+            if block_rows < n and _lib.links_plan(links)[1] != 0:
+                block_rows = n                               # all rows in one block after all: the library stores it as the upper block triangle
         self.bounds = list(range(0, n, int(block_rows))) + [n]
         self.resident = None                                 # the only block when the whole M^2 fits: kept for the whole sweep
         self.n_products = 0
@@ -1195,6 +1198,10 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
         pass
     elif expansion == 2 and not materialise and len(inflations) > 1 and max_iter >= 1:
         sweep = DenseSweep(m, pruning, block_rows=_block_rows)
+        if _block_rows is None and len(sweep.bounds) - 1 > DenseSweep.MAX_BLOCKS:
+            # under memory pressure the blocks get small and every block pays the normalisation and the operand layout again,
+            # without the symmetric half: beyond a handful of blocks one fused expansion per inflation is the cheaper sweep
+            sweep = None
     elif materialise:
         _lib.normalize_l1(m)                                         # :2144
         pre = m

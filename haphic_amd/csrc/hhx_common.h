@@ -123,7 +123,8 @@ struct hhx_dense {
     i32 n_rows = 0, n_cols = 0;
     i64 ld = 0;                         // row pitch in floats: n_cols rounded up to a 128-byte line (rows and 64-column tiles start on line boundaries)
     i32 cap_win = 0, n_win = 0;         // the column-window plan of the expansion that filled it (summation order of the epilogue)
-    mutable i64 last_cand = 0, last_out = 0;    // pool demand of the previous hhx_dense_inflate_prune (sizes the next call's pools)
+    mutable i64 last_cand = 0, last_out = 0;    // pool demand of the previous hhx_dense_inflate_prune (sizes the next call's pools) ...
+    mutable double last_inflation = 0.0;        // ... and the inflation it was measured at
     bool integer = false;               // x holds y = float(S_ij) of the integer arithmetic; the entry of M^2 is float(y / row_div[i])
     bool tri = false;                   // all rows, symmetric: x holds the upper block triangle alone (hhx_expand.hip: tri_row_off), ldn = n_win * cap_win
     i64 ldn = 0;

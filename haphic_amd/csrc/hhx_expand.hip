@@ -2295,8 +2295,9 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
     // a pruned row holds at most 1 / pruning entries; an early window tests against a partial row sum and admits more
     i64 pool_cap = std::max<i64>((i64)n_rows * 512, (i64)1 << 22), cand_cap = 2 * pool_cap;
     if (d->last_out) {                                 // a sweep: the demand of the previous inflation, with room for a neighbouring one
-        pool_cap = d->last_out + d->last_out / 2 + n_rows;
-        cand_cap = d->last_cand + d->last_cand / 2 + n_rows;
+        const bool above = inflation >= d->last_inflation;     // (demands shrink as the inflation grows)
+        pool_cap = d->last_out + (above ? d->last_out / 10 : d->last_out / 2) + n_rows;
+        cand_cap = d->last_cand + (above ? d->last_cand / 10 : d->last_cand / 2) + n_rows;
     }
     for (int attempt = 0; attempt < 4; ++attempt) {
         DevBuf<i32> cand_col, out_col;
@@ -2359,6 +2360,7 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
         }
         d->last_cand = (i64)cur[0];
         d->last_out = (i64)cur[1];
+        d->last_inflation = inflation;
         return pack_rows_to_csr(n_rows, n_cols, row_cnt.p, indptr.p, row_off.p, out_col.p, out_val.p, out);
     }
     return fail("dense inflate / prune: survivor pool kept overflowing");
@@ -2391,6 +2393,33 @@ extern "C" int hhx_dense_inflate_prune_multi(const hhx_dense *d, int K, const do
         if (rc1) for (int k = 0; k < K; ++k) if (outs[k]) { hhx_csr_free(outs[k]); outs[k] = nullptr; }
         return rc1;
     }
+    // No hint yet (first call on this block): the lowest inflation goes alone through the one-inflation kernel — its demand bounds
+    // everybody else's, so the pools of the pass over the others are sized right at once (a retry of a K-inflation pass, or K pools
+    // at a guess, cost more: device allocations run at ~30 ms per GB).  With a hint: as many inflations per pass as fit ~6 GB of pools.
+    {
+        int lowest = 0;
+        for (int k = 1; k < K; ++k) if (inflations[k] < inflations[lowest]) lowest = k;
+        i64 per_infl = d->last_out ? 8 * ((d->last_out + d->last_cand) + (d->last_out + d->last_cand) / 10) : 0;
+        if (d->last_out && inflations[lowest] < d->last_inflation) per_infl *= 2;
+        const int fit = !d->last_out ? 0 : (int)std::max<i64>(1, std::min<i64>(MULTI_MAX, ((i64)6 << 30) / std::max<i64>(per_infl, 1)));
+        if (!d->last_out || fit < K) {
+            // split: [lowest alone | the rest] without a hint; [the first `fit` | the rest] with one — recursion ends at K == 1 or fit >= K
+            std::vector<int> first, rest;
+            if (!d->last_out) { for (int k = 0; k < K; ++k) (k == lowest ? first : rest).push_back(k); }
+            else { for (int k = 0; k < K; ++k) (k < fit ? first : rest).push_back(k); }
+            int rc2 = 0;
+            for (const std::vector<int> *part : {&first, &rest}) {
+                if (rc2 || part->empty()) continue;
+                std::vector<double> r2;
+                for (int k : *part) r2.push_back(inflations[k]);
+                std::vector<hhx_csr *> o2(part->size(), nullptr);
+                rc2 = hhx_dense_inflate_prune_multi(d, (int)r2.size(), r2.data(), pruning, o2.data());
+                for (size_t t = 0; t < part->size(); ++t) outs[(*part)[t]] = o2[t];
+            }
+            if (rc2) for (int k = 0; k < K; ++k) if (outs[k]) { hhx_csr_free(outs[k]); outs[k] = nullptr; }
+            return rc2;
+        }
+    }
     static int attr_dev = -1;
     int dev = 0;
     HHX_HIP(hipGetDevice(&dev));
@@ -2398,6 +2427,8 @@ extern "C" int hhx_dense_inflate_prune_multi(const hhx_dense *d, int K, const do
         HHX_HIP(hipFuncSetAttribute((const void *)k_dense_epilogue_multi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_dev = dev;
     }
+    int hint_k = 0;
+    for (int k = 1; k < K; ++k) if (inflations[k] < inflations[hint_k]) hint_k = k;
     struct PerK {
         DevBuf<i32> row_cnt, indptr, g_win_cnt, cand_col, out_col;
         DevBuf<i64> row_off, g_win_off;
@@ -2413,8 +2444,14 @@ extern "C" int hhx_dense_inflate_prune_multi(const hhx_dense *d, int K, const do
         if (q.row_cnt.alloc((size_t)n_rows + 1) || q.indptr.alloc((size_t)n_rows + 1) || q.row_off.alloc((size_t)n_rows + 1) || q.cursors.alloc(12) ||
             q.s_run.alloc((size_t)n_rows + 1) || q.g_win_off.alloc((size_t)n_rows * n_win + 1) || q.g_win_cnt.alloc((size_t)n_rows * n_win + 1)) return 1;
         q.pool_cap = std::max<i64>((i64)n_rows * 512, (i64)1 << 22);
-        if (d->last_out) q.pool_cap = d->last_out + d->last_out / 2 + n_rows;           // the demand of the call before (a neighbouring inflation)
-        q.cand_cap = d->last_out ? d->last_cand + d->last_cand / 2 + n_rows : 2 * q.pool_cap;
+        q.cand_cap = 2 * q.pool_cap;
+        if (d->last_out) {
+            // the demand of the call before.  Survivors and candidates shrink as the inflation grows: an inflation at or above the
+            // one that left the hint needs no more than it did (+ 10 %: the candidate test runs against partial row sums)
+            const bool above = inflations[k] >= d->last_inflation;
+            q.pool_cap = d->last_out + (above ? d->last_out / 10 : d->last_out) + n_rows;
+            q.cand_cap = d->last_cand + (above ? d->last_cand / 10 : d->last_cand) + n_rows;
+        }
     }
     DevBuf<MultiOut> mo_dev;
     DevBuf<unsigned long long> cursors0;                    // P.cursors of the kernel: only [3] (entries of the block) is written
@@ -2489,8 +2526,9 @@ extern "C" int hhx_dense_inflate_prune_multi(const hhx_dense *d, int K, const do
                 if ((i64)cur[1] > q.pool_cap) q.pool_cap = std::max<i64>(q.pool_cap * 2, (i64)cur[1] + (i64)n_rows);
                 continue;
             }
-            d->last_cand = (i64)cur[0];
-            d->last_out = (i64)cur[1];
+            if (todo[t] == hint_k) {                           // the hint for the next call: the demand of THIS call's lowest inflation (its largest)
+                d->last_cand = std::max<i64>((i64)cur[0], 1); d->last_out = std::max<i64>((i64)cur[1], 1); d->last_inflation = inflations[todo[t]];
+            }
             rc = pack_rows_to_csr(n_rows, n_cols, q.row_cnt.p, q.indptr.p, q.row_off.p, q.out_col.p, q.out_val.p, &outs[todo[t]]);
             q.done = true;
             q.cand_col.release(); q.cand_val.release(); q.out_col.release(); q.out_val.release();

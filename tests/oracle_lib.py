@@ -69,6 +69,10 @@ def ptr(a):
     return a
 
 
+def links_plan(links):
+    return False, 0
+
+
 def mem_info():
     return 1 << 40, 1 << 40
 

@@ -3,7 +3,7 @@ box and run the multi-GPU driver unchanged (haphic_amd/sharded.py: chunked inges
 + all-to-all(v) row-owner build of the link matrix, all-gather(v) of the raw row blocks, iteration 0 on the SYMMETRIC HALF shared
 out over the ranks (each rank fills the upper blocks of its rows, one all-to-all(v) mirrors them) and, for comparison, per row
 block over all products, the two-collective exchange per iteration); the collectives travel through host memory over gloo
-(sharded.HostStagedCollectives) because RCCL refuses two ranks on one device.  BASELINE configs[1] size; everything
+(haphic_amd.host_transport.HostStagedCollectives) because RCCL refuses two ranks on one device.  BASELINE configs[1] size; everything
 must be bit-identical to the one-rank result."""
 import os
 import socket
@@ -52,10 +52,10 @@ def _worker(rank, world, port, q, cfg):
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from haphic_amd import _lib, sharded
+        from haphic_amd import _lib, host_transport, sharded
         gen, table, pairs = _setup(cfg)
         PAIRS = cfg[3]
-        hd = sharded.HostStagedCollectives(dist)
+        hd = host_transport.HostStagedCollectives(dist)
         sharded.SYMMETRIC_MIN_WORLD = 2                  # (on from 8 ranks by default: the bandwidth model of sharded.py)
         cuts = _cuts(PAIRS, world)
         lo, hi = cuts[rank], cuts[rank + 1]
@@ -184,9 +184,9 @@ def _sweep_worker(rank, world, port, q, cfg, outdir):
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from haphic_amd import cluster, sharded
+        from haphic_amd import cluster, host_transport, sharded
         gen, m, fa_dict, frag_len_dict, frag_index = _sweep_setup(cfg)
-        hd = sharded.HostStagedCollectives(dist)
+        hd = host_transport.HostStagedCollectives(dist)
         sharded.SWEEP_SHARD_PRODUCTS = 2e8             # at 24k contigs: the first two or three iterations of every inflation are shared
         shared = []
         orig = sharded.sharded_iteration

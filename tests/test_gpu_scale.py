@@ -29,6 +29,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import oracle as orc
+from tests.conftest import late, tick
 
 TABLES = ('full_i', 'full_j', 'full_cnt', 'ht_cnt', 'flank_i', 'flank_j', 'flank_cnt', 'frag_links')
 
@@ -229,7 +230,8 @@ def test_c3_whole_ingest_against_oracle(c3):
     c.dev = None
     del dev
     torch.cuda.empty_cache()
-    ref = _oracle_ingest(t, h)
+    with tick('c3 oracle ingest, 500 M pairs'):
+        ref = _oracle_ingest(t, h)
     del h
     got = c.ing.fetch()
     for k in TABLES:
@@ -268,11 +270,12 @@ def test_c3_whole_mcl_against_oracle(c3):
     # cores, one pass (orc.links_iteration0), and every pruned row of the device — upper block triangle, transposition, dense
     # epilogue, finalize — must equal it in pattern and bits
     expanded = 0
-    for r0 in range(0, n, 8192):
-        rows = np.arange(r0, min(n, r0 + 8192), dtype=np.int32)
-        want = orc.links_iteration0((mp, mj, mx), rows, 2.0, 1e-4)
-        expanded += want[3]
-        _assert_rows_equal((gp, gj, gx), want, rows, 'C3 iteration 0')
+    with tick('c3 iteration 0, every row (oracle: 1.15e12 products)'):
+        for r0 in range(0, n, 8192):
+            rows = np.arange(r0, min(n, r0 + 8192), dtype=np.int32)
+            want = orc.links_iteration0((mp, mj, mx), rows, 2.0, 1e-4)
+            expanded += want[3]
+            _assert_rows_equal((gp, gj, gx), want, rows, 'C3 iteration 0')
     assert expanded == stats[0, 1], 'C3 iteration 0: entries of M^2'
     # a stratified sample in the reference's float32 accumulation: how far apart the two specifications are after one iteration
     rows = _stratified_rows(_lib.row_products(m, m), 2048, seed=5)
@@ -286,14 +289,16 @@ def test_c3_whole_mcl_against_oracle(c3):
         len(rows0), only_f32, only_exact, rel0)
     # THE TAIL: the oracle continues mcl() :2026-2062 from the (now fully verified) iteration-0 output (iteration 1 = 1.6e10
     # products, row-parallel on the host cores) to convergence; the device's own full run must agree bit for bit
-    o = orc.mcl((gp, gj, gx), 2, 2.0, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
+    with tick('c3 oracle tail at 2.0, mode 1'):
+        o = orc.mcl((gp, gj, gx), 2, 2.0, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
     assert (n_iter_full, conv_full) == (o[3], o[4]), 'C3 mcl: iteration count / convergence flag'
     assert np.array_equal(stats_full[1:], o[5]), 'C3 mcl: nnz_A, nnz_C, survivors, products of every iteration'
     assert np.array_equal(fp, o[0]) and np.array_equal(fj, o[1]), 'C3 mcl: final pattern'
     assert np.array_equal(fx, o[2]), 'C3 mcl: final values'
     assert dev_clusters == _clusters(*orc.interpret(o[:3])), 'C3 mcl: clusters'
     # the same tail in float32 accumulation: the outcome north_star asks for — identical clusters, final matrix within 1e-6
-    o0 = orc.mcl((gp, gj, gx), 2, 2.0, 200, 1e-4, spgemm_mode=0, first_it=1)
+    with tick('c3 oracle tail at 2.0, mode 0'):
+        o0 = orc.mcl((gp, gj, gx), 2, 2.0, 200, 1e-4, spgemm_mode=0, first_it=1)
     assert dev_clusters == _clusters(*orc.interpret(o0[:3])), 'C3 float32 tail: clusters'
     assert o0[3] == n_iter_full, 'C3 float32 tail: iteration count'
     assert np.array_equal(fp, o0[0]) and np.array_equal(fj, o0[1]), 'C3 float32 tail: final pattern'
@@ -393,9 +398,16 @@ def test_c3_inflation_sweep_against_oracle(c3):
             assert width.max() > 3072, 'no sampled row beyond the hash class (widest: %d columns)' % width.max()
             first.free()
             continue
+        if r == 1.4 and late(margin=200):
+            # the tail at 1.4 costs the oracle ~10^12 products; the driver's limit for the whole gpu run must not be overrun
+            first.free()
+            import warnings
+            warnings.warn('C3 sweep: the oracle tail at inflation 1.4 was SKIPPED (the session is late); run this test alone for it')
+            continue
         res, n_iter, conv, stats = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4, want_stats=True)
         first.free()
-        o = orc.mcl(f_host, 2, r, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
+        with tick('c3 sweep oracle tail at %r' % r):
+            o = orc.mcl(f_host, 2, r, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
         assert (n_iter, conv) == (o[3], o[4]), 'C3 sweep, inflation %r: iteration count / convergence flag' % r
         got = res.to_arrays()
         assert np.array_equal(got[0], o[0]) and np.array_equal(got[1], o[1]), 'C3 sweep, inflation %r: final pattern' % r
@@ -484,7 +496,8 @@ def test_c5_200k_contigs_four_pushes():
     _assert_rows_equal((gp, gj, gx), want, rows, 'C5 iteration 0')
     del mp, mj, mx
     # THE TAIL: the oracle continues mcl() from the device's iteration-0 output to convergence
-    o = orc.mcl((gp, gj, gx), 2, 2.0, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
+    with tick('c5 oracle tail'):
+        o = orc.mcl((gp, gj, gx), 2, 2.0, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
     assert (n_iter_full, conv_full) == (o[3], o[4]), 'C5 mcl: iteration count / convergence flag'
     assert np.array_equal(stats_full[1:], o[5]), 'C5 mcl: nnz_A, nnz_C, survivors, products of every iteration'
     assert np.array_equal(fp, o[0]) and np.array_equal(fj, o[1]) and np.array_equal(fx, o[2]), 'C5 mcl: final matrix'
@@ -561,8 +574,9 @@ def test_c4_40k_cluster_files_against_the_reference(tmp_path):
         min_read_pairs = cfg['min_read_pairs']
         concordance_ratio_cutoff = cfg['concordance_ratio_cutoff']
         nwindows = cfg['nwindows']
-    full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(cluster.IdArrays(names, id1, p1, id2, p2), fa_dict, A(),
-                                                                             frag_len_dict, set(names), 'int32', 'int32')
+    with tick('c4 40k: parse_alignments_for_ctgs mirror (device ingest + the six Python containers)'):
+        full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(cluster.IdArrays(names, id1, p1, id2, p2), fa_dict, A(),
+                                                                                 frag_len_dict, set(names), 'int32', 'int32')
     del HT, clm, id1, p1, id2, p2
     assert (len(full), len(flank), sum(full.values())) == (int(g['n_full']), int(g['n_flank']), int(g['full_total']))
     for k, v in c4_40k.coord_digest(coord, cid).items():
@@ -586,8 +600,9 @@ def test_c4_40k_cluster_files_against_the_reference(tmp_path):
     cluster.logger.setLevel('INFO')
     lo, hi, step = cfg['inflations']
     try:
-        cluster.run_mcl_clustering(mat, set(), frag_len_dict, fidx, 2, lo, hi, step, 200, 1e-4, fa_dict, int(g['nchrs']), False,
-                                   outdir_root=str(tmp_path))
+        with tick('c4 40k: run_mcl_clustering, 4 inflations'):
+            cluster.run_mcl_clustering(mat, set(), frag_len_dict, fidx, 2, lo, hi, step, 200, 1e-4, fa_dict, int(g['nchrs']), False,
+                                       outdir_root=str(tmp_path))
     finally:
         cluster.logger.removeHandler(handler)
     assert [str(x) for x in g['inflations']] == sorted(d.split('_', 1)[1] for d in os.listdir(tmp_path) if d.startswith('inflation_'))

@@ -44,6 +44,11 @@ for l in open('gpurun_out/bench_text.log'):
     k:*) timeout 900 python -m pytest tests -m gpu -x -q -k "${what#k:}" > gpurun_out/pytest_sel.log 2>&1; echo "sel rc=$?"; grep -E "passed|failed|Error|^E " gpurun_out/pytest_sel.log | tail -12;;
     rccl) timeout 600 python tools/rccl_probe.py > gpurun_out/rccl_probe.jsonl 2> gpurun_out/rccl_probe.err; echo "rccl rc=$?"; cat gpurun_out/rccl_probe.jsonl; tail -3 gpurun_out/rccl_probe.err;;
     host2) timeout 900 python bench.py --gpus 2 --transport host --contigs 10000 --pairs 50000000 --nchrs 16 --mean-len 50000 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_host2.log 2>&1; echo "host2 rc=$?"; python tools/bench_brief.py gpurun_out/bench_host2.log; tail -3 gpurun_out/bench_host2.log | cut -c1-400;;
+    host8) timeout 1200 python bench.py --gpus 8 --transport host --contigs 10000 --pairs 50000000 --nchrs 16 --mean-len 50000 --steps 1 --warmup 0 --no-cpu-baseline --sweep 8 > gpurun_out/bench_host8.log 2>&1; echo "host8 rc=$?"; python tools/bench_brief.py gpurun_out/bench_host8.log | head -3; python -c "
+import json
+for l in open('gpurun_out/bench_host8.log'):
+    if l.startswith('{'): print(json.dumps(json.loads(l).get('sweep_sharded'))[:900])
+";;
     c5) timeout 1500 python bench.py --contigs 200000 --pairs 2000000000 --pushes 4 --steps 1 --warmup 1 --no-cpu-baseline --text-lines 0 --sweep 0 > gpurun_out/bench_c5.log 2>&1; echo "c5 rc=$?"; python tools/bench_brief.py gpurun_out/bench_c5.log; tail -2 gpurun_out/bench_c5.log | cut -c1-300;;
     asan) # the host side of the library under AddressSanitizer (haphic_amd/build.py build_asan), a subset of the gpu tests
         RT=$(python -c "from haphic_amd import build; print(build.asan_runtime())")
