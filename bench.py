@@ -670,7 +670,8 @@ def cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state):
             'ingest_seconds': dt, 'mcl_iters_per_s': res[3] / dm, 'mcl_n': int(nq), 'mcl_iterations': int(res[3]),
             'mcl_all_cores': {'iters_per_s': res_all[3] / dm_all, 'threads': all_threads, 'what': 'the same oracle mcl(), expansion and row-local steps '
                               'row-parallel over all host cores (OpenMP), bit-identical result'},
-            'text_tokeniser_pairs_per_s': nt / dtok, 'text_tokeniser_lines': nt, 'host_cpus': os.cpu_count()}
+            'text_tokeniser_pairs_per_s': nt / dtok, 'text_tokeniser_lines': nt, 'host_cpus': os.cpu_count(),
+            'cpus_usable': orc.effective_cpus()}      # (affinity mask capped by the cgroup CPU quota: what "all cores" means for this process)
 
 
 if __name__ == '__main__':

@@ -91,11 +91,13 @@ i64 orc_spgemm(i32 n_rows, i32 n_cols, const i32 *Ap, const i32 *Aj, const float
     for (int pass = 0; pass < (Cj ? 2 : 1); ++pass) {
 #pragma omp parallel num_threads(nt)
         {
-            i32 *mark = (i32 *)malloc(sizeof(i32) * (size_t)n_cols);
-            float *accf = (float *)calloc((size_t)n_cols, sizeof(float));
-            i64 *acci = (i64 *)calloc((size_t)n_cols, sizeof(i64));
-            i32 *cols = (i32 *)malloc(sizeof(i32) * (size_t)n_cols);
-            for (i32 c = 0; c < n_cols; ++c) mark[c] = -1;
+            /* the "touched" marks are a bitmap (n / 8 bytes: L1-resident) and only the accumulator of the mode in use exists, so that
+             * a row's working set — 4 or 8 bytes per column — stays in the core's L2 at n = 100k (the tails of a 100k-contig mcl()
+             * walk 10^11-10^12 products on the host: with an int32 mark + two accumulators per column every product missed) */
+            uint64_t *mark = (uint64_t *)calloc(((size_t)n_cols + 63) / 64 + 1, sizeof(uint64_t));
+            float *accf = mode == 0 ? (float *)calloc((size_t)n_cols + 1, sizeof(float)) : NULL;
+            i64 *acci = mode != 0 ? (i64 *)calloc((size_t)n_cols + 1, sizeof(i64)) : NULL;
+            i32 *cols = (i32 *)malloc(sizeof(i32) * ((size_t)n_cols + 1));
 #pragma omp for schedule(dynamic, 16)
             for (i32 i = 0; i < n_rows; ++i) {
                 i32 cnt = 0;
@@ -104,11 +106,11 @@ i64 orc_spgemm(i32 n_rows, i32 n_cols, const i32 *Ap, const i32 *Aj, const float
                     float a = Ax[p];
                     for (i32 q = Bp[k]; q < Bp[k + 1]; ++q) {
                         i32 j = Bj[q];
-                        if (mark[j] != i) {
-                            mark[j] = i;
+                        const uint64_t bit = (uint64_t)1 << (j & 63);
+                        if (!(mark[j >> 6] & bit)) {
+                            mark[j >> 6] |= bit;
                             cols[cnt++] = j;
-                            accf[j] = 0.0f;
-                            acci[j] = 0;
+                            if (mode == 0) accf[j] = 0.0f; else acci[j] = 0;
                         }
                         if (pass == 1) {
                             if (mode == 0) accf[j] += a * Bx[q];
@@ -125,7 +127,7 @@ i64 orc_spgemm(i32 n_rows, i32 n_cols, const i32 *Ap, const i32 *Aj, const float
                         Cx[base + c] = mode == 0 ? accf[cols[c]] : (float)((double)acci[cols[c]] * inv_scale);
                     }
                 }
-                for (i32 c = 0; c < cnt; ++c) mark[cols[c]] = -1;       /* the row id is reused by the second pass */
+                for (i32 c = 0; c < cnt; ++c) mark[cols[c] >> 6] = 0;
             }
             free(mark); free(accf); free(acci); free(cols);
         }
@@ -190,10 +192,9 @@ i64 orc_expand_links_ex(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i3
     for (int pass = 0; pass < (Cj ? 2 : 1); ++pass) {
 #pragma omp parallel num_threads(nt)
         {
-            i32 *mark = (i32 *)malloc(sizeof(i32) * (size_t)n);
-            uint64_t *acc = (uint64_t *)calloc((size_t)n, sizeof(uint64_t));
-            i32 *cols = (i32 *)malloc(sizeof(i32) * (size_t)n);
-            for (i32 c = 0; c < n; ++c) mark[c] = -1;
+            uint64_t *mark = (uint64_t *)calloc(((size_t)n + 63) / 64 + 1, sizeof(uint64_t));      /* bitmap: see orc_spgemm */
+            uint64_t *acc = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+            i32 *cols = (i32 *)malloc(sizeof(i32) * ((size_t)n + 1));
 #pragma omp for schedule(dynamic, 16)
             for (i32 t = 0; t < n_rows; ++t) {
                 const i32 i = rows ? rows[t] : t;
@@ -203,7 +204,8 @@ i64 orc_expand_links_ex(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i3
                     const uint64_t g = (uint64_t)Lx[p] * W[k];
                     for (i32 q = Lp[k]; q < Lp[k + 1]; ++q) {
                         const i32 j = Lj[q];
-                        if (mark[j] != t) { mark[j] = t; cols[cnt++] = j; acc[j] = 0; }
+                        const uint64_t bit = (uint64_t)1 << (j & 63);
+                        if (!(mark[j >> 6] & bit)) { mark[j >> 6] |= bit; cols[cnt++] = j; acc[j] = 0; }
                         if (pass == 1) acc[j] += g * (uint64_t)Lx[q];
                     }
                 }
@@ -217,7 +219,7 @@ i64 orc_expand_links_ex(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i3
                         Cx[base + c] = divide ? (float)((double)y / d[i]) : y;
                     }
                 }
-                for (i32 c = 0; c < cnt; ++c) mark[cols[c]] = -1;
+                for (i32 c = 0; c < cnt; ++c) mark[cols[c] >> 6] = 0;
             }
             free(mark); free(acc); free(cols);
         }
@@ -252,12 +254,12 @@ i64 orc_links_iteration0(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i
     int overflow = 0;
 #pragma omp parallel num_threads(nt) reduction(+ : total, expanded) reduction(| : overflow)
     {
-        struct slot { uint64_t acc; i64 mark; } *sl = (struct slot *)malloc(sizeof(struct slot) * (size_t)n);     /* one cache line per product, not two */
+        uint64_t *mark = (uint64_t *)calloc(((size_t)n + 63) / 64 + 1, sizeof(uint64_t));      /* bitmap marks + 8-byte sums: a row's working set stays in L2 */
+        uint64_t *acc = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
         i32 *cols = (i32 *)malloc(sizeof(i32) * (size_t)n);
         float *val = (float *)malloc(sizeof(float) * (size_t)n);
         i32 *pj = (i32 *)malloc(sizeof(i32) * (size_t)n);
         float *px = (float *)malloc(sizeof(float) * (size_t)n);
-        for (i32 c = 0; c < n; ++c) { sl[c].acc = 0; sl[c].mark = -1; }
 #pragma omp for schedule(dynamic, 8)
         for (i32 t = 0; t < n_rows; ++t) {
             const i32 i = rows ? rows[t] : t;
@@ -266,16 +268,17 @@ i64 orc_links_iteration0(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i
                 const i32 k = Lj[p];
                 const uint64_t g = (uint64_t)Lx[p] * W[k];
                 for (i32 q = Lp[k]; q < Lp[k + 1]; ++q) {
-                    struct slot *s_ = &sl[Lj[q]];
-                    if (s_->mark != t) { s_->mark = t; cols[cnt++] = Lj[q]; s_->acc = 0; }
-                    s_->acc += g * (uint64_t)Lx[q];
+                    const i32 j = Lj[q];
+                    const uint64_t bit = (uint64_t)1 << (j & 63);
+                    if (!(mark[j >> 6] & bit)) { mark[j >> 6] |= bit; cols[cnt++] = j; acc[j] = 0; }
+                    acc[j] += g * (uint64_t)Lx[q];
                 }
             }
             qsort(cols, (size_t)cnt, sizeof(i32), cmp_i32);
             for (i32 c = 0; c < cnt; ++c) {
-                const float y = (float)((double)sl[cols[c]].acc * inv);
+                const float y = (float)((double)acc[cols[c]] * inv);
                 val[c] = (float)((double)y / d[i]);
-                sl[cols[c]].mark = -1;
+                mark[cols[c] >> 6] = 0;
             }
             expanded += cnt;
             i32 one[2] = {0, cnt}, op[2];
@@ -288,7 +291,7 @@ i64 orc_links_iteration0(i32 n, const i32 *Lp, const i32 *Lj, const float *Lx, i
             memcpy(Ox + (size_t)t * cap_row, px, sizeof(float) * (size_t)kept);
             total += kept;
         }
-        free(sl); free(cols); free(val); free(pj); free(px);
+        free(mark); free(acc); free(cols); free(val); free(pj); free(px);
     }
     free(W); free(d);
     if (n_expanded) *n_expanded = expanded;

@@ -87,12 +87,34 @@ def lib():
         L.orc_count_re_sites.argtypes = [_u8p, C.c_int64, _i64p, _i64p, C.c_int32, _u8p, _i32p, _i64p]
         L.orc_count_re_sites.restype = None
         _lib = L
+        L.orc_set_threads(effective_cpus())           # the default: not OpenMP's (every hardware thread of the host, quota or not)
     return _lib
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a container on a 256-thread host with
+    cpu.max = "1600000 100000" gets 16 CPUs' worth of time: 128 OpenMP threads there run at HALF the rate of 16 — measured,
+    tools/oracle_scaling.py)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p_ = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0 and p_ > 0:
+                n = min(n, max(1, -(-q // p_)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def set_threads(n):
-    """host threads of the row-parallel SpGEMM (0 = all cores); results do not depend on it"""
-    lib().orc_set_threads(int(n))
+    """host threads of the row-parallel loops (0 = every CPU this process may use, effective_cpus()); results do not depend on it"""
+    n = int(n)
+    lib().orc_set_threads(n if n > 0 else effective_cpus())
 
 
 def get_threads():

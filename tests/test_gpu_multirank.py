@@ -176,6 +176,7 @@ def _sweep_setup(cfg):
 
 
 SWEEP = (1.2, 3.0, 0.6)                            # inflations 1.2, 1.8, 2.4, 3.0
+SWEEP_CFG = (3000, 8, 20_000, 8_000_000)           # 24k contigs (two column windows), fewer pairs than WIDE: eight processes ingest it side by side
 
 
 def _sweep_worker(rank, world, port, q, cfg, outdir):
@@ -187,7 +188,7 @@ def _sweep_worker(rank, world, port, q, cfg, outdir):
         from haphic_amd import cluster, host_transport, sharded
         gen, m, fa_dict, frag_len_dict, frag_index = _sweep_setup(cfg)
         hd = host_transport.HostStagedCollectives(dist)
-        sharded.SWEEP_SHARD_PRODUCTS = 2e8             # at 24k contigs: the first two or three iterations of every inflation are shared
+        sharded.SWEEP_SHARD_PRODUCTS = 5e7             # at 24k contigs / 8 M pairs: the first two or three iterations of every inflation are shared
         shared = []
         orig = sharded.sharded_iteration
         sharded.sharded_iteration = lambda *a, **k: (shared.append(1), orig(*a, **k))[1]
@@ -210,7 +211,7 @@ def test_inflation_sweep_shared_out_over_the_ranks(world, tmp_path):
     import torch
     import torch.multiprocessing as mp
     from haphic_amd import _lib, cluster
-    cfg = WIDE
+    cfg = SWEEP_CFG
     gen, m, fa_dict, frag_len_dict, frag_index = _sweep_setup(cfg)
     one_dir, many_dir = tmp_path / 'one', tmp_path / 'many'
     # the one-GPU sweep through the same arithmetic (DenseSweep: the integer pre-expansion as float32 rows; _block_rows forces it at this order)

@@ -56,6 +56,7 @@ for l in open('gpurun_out/bench_host8.log'):
           timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py tests/test_bam.py tests/test_plot.py -m gpu -q -p no:cacheprovider > gpurun_out/pytest_asan.log 2>&1
         echo "asan rc=$?"; grep -E "passed|failed|ERROR: AddressSanitizer|SUMMARY" gpurun_out/pytest_asan.log | tail -5; tail -3 gpurun_out/pytest_asan.log | cut -c1-300;;
     tails) rm -rf gpurun_out/prof_tails; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_tails -o t -- python tools/tail_probe.py $TAIL_ARGS > gpurun_out/tail_probe.jsonl 2> gpurun_out/tail_probe.err; echo "tails rc=$?"; cut -c1-400 gpurun_out/tail_probe.jsonl; tail -3 gpurun_out/tail_probe.err; find gpurun_out/prof_tails -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | cut -c1-200;;
+    oscale) timeout 600 python tools/oracle_scaling.py > gpurun_out/oracle_scaling.jsonl 2> gpurun_out/oracle_scaling.err; echo "oscale rc=$?"; cat gpurun_out/oracle_scaling.jsonl; tail -2 gpurun_out/oracle_scaling.err;;
     listpmc) rocprofv3 -L > gpurun_out/pmc_list.txt 2>&1; grep -c . gpurun_out/pmc_list.txt;;
     env:*) export "${what#env:}"; echo "set ${what#env:}";;
     *) echo "unknown $what";;
