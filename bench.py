@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--nchrs', type=int, default=24)
     ap.add_argument('--mean-len', type=int, default=30_000)
     ap.add_argument('--inflation', type=float, default=2.0)
+    ap.add_argument('--sharded-sweep-timeout', type=int, default=240, help='N > 1: seconds the sharded inflation sweep (after the timed region) may take before the line is printed without it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-reference-python', action='store_true', help='cpu_baseline: do not time the reference checkout even if it is present (carry the stored measurement)')
     ap.add_argument('--pushes', type=int, default=1, help='hand the pairs over in this many batches (streaming ingest: one aggregated run per batch, merged at finalize)')
@@ -206,28 +207,7 @@ def main():
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     elapsed, t_ing, t_mcl, t_pre = tm.tolist()
 
-    # ---- outside the timed region, every rank: run_mcl_clustering's inflation sweep (:2155-2158) shared out over the ranks
-    # (sharded.sweep_sharded: ONE expansion across the ranks, the heavy iterations of the low inflations row-sharded, the light
-    # remainders dealt by predicted cost) — the N-rank counterpart of the one-GPU `sweep` leg
-    sweep_sh = None
-    if state.get('block') is not None:
-        from decimal import Decimal
-        eng = sharded.HipEngine(dev)
-        infl = [float(Decimal('1.1') + Decimal('0.1') * k) for k in range(args.sweep)]
-        try:
-            full = sharded.allgather_rows(eng, state.pop('block'), state['shape'], dist)
-            barrier()
-            ts = time.perf_counter()
-            res_sw = sharded.sweep_sharded(eng, full, infl, 200, 1e-4, dist)
-            barrier()
-            sweep_sh = {'seconds': time.perf_counter() - ts, 'inflations': infl, 'iterations': [r[4] for r in res_sw], 'converged': [bool(r[5]) for r in res_sw],
-                        'clusters': [int(len(r[0])) for r in res_sw], 'ranks': world,
-                        'what': 'sharded.sweep_sharded: one expansion shared by the ranks (each holds its rows of M^2), dense epilogue + exchange per '
-                                'inflation, heavy iterations row-sharded (>= %.0e products), light remainders dealt by predicted cost' % sharded.SWEEP_SHARD_PRODUCTS}
-            full.free()
-        except RuntimeError as e:
-            sweep_sh = {'error': str(e)[:300]}
-
+    final_out = None
     if rank == 0:
         K = args.steps
         pairs_total = local_pairs * world * K
@@ -319,8 +299,6 @@ def main():
             out['ingest']['text'] = text_leg(args, gen, id1, p1, id2, p2, dev)
         if sharded_path:
             out['ingest']['sharded_build_ms_last_step'] = state.get('shard_ms')
-        if sweep_sh is not None:
-            out['sweep_sharded'] = sweep_sh
         if state.get('matrix') is not None and args.sweep > 1:
             try:
                 out['sweep'] = sweep_leg(args, state['matrix'], t_mcl / K)
@@ -332,7 +310,46 @@ def main():
             state.pop('matrix').free()
         if not args.no_cpu_baseline and world == 1:          # a reported baseline of the N = 1 line only
             out['cpu_baseline'] = cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state)
-        print(json.dumps(out))
+        final_out = out
+    # ---- outside the timed region, every rank: run_mcl_clustering's inflation sweep (:2155-2158) shared out over the ranks
+    # (sharded.sweep_sharded: ONE expansion across the ranks, the heavy iterations of the low inflations row-sharded, the light
+    # remainders dealt by predicted cost) — the N-rank counterpart of the one-GPU `sweep` leg
+    # The line of the timed region is complete at this point.  The leg below runs collectives that no multi-GPU node has carried yet:
+    # a watchdog prints the line without it and ends the process if it does not come back (every rank runs the same timer).
+    sweep_sh = None
+    if state.get('block') is not None:
+        import threading
+
+        def give_up():
+            if final_out is not None:
+                final_out['sweep_sharded'] = {'error': 'no result within %d s' % args.sharded_sweep_timeout}
+                print(json.dumps(final_out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.sharded_sweep_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        from decimal import Decimal
+        eng = sharded.HipEngine(dev)
+        infl = [float(Decimal('1.1') + Decimal('0.1') * k) for k in range(args.sweep)]
+        try:
+            full = sharded.allgather_rows(eng, state.pop('block'), state['shape'], dist)
+            barrier()
+            ts = time.perf_counter()
+            res_sw = sharded.sweep_sharded(eng, full, infl, 200, 1e-4, dist)
+            barrier()
+            sweep_sh = {'seconds': time.perf_counter() - ts, 'inflations': infl, 'iterations': [r[4] for r in res_sw], 'converged': [bool(r[5]) for r in res_sw],
+                        'clusters': [int(len(r[0])) for r in res_sw], 'ranks': world,
+                        'what': 'sharded.sweep_sharded: one expansion shared by the ranks (each holds its rows of M^2), dense epilogue + exchange per '
+                                'inflation, heavy iterations row-sharded (>= %.0e products), light remainders dealt by predicted cost' % sharded.SWEEP_SHARD_PRODUCTS}
+            full.free()
+        except Exception as e:                           # noqa: BLE001 — this leg must never take the line of the timed region down
+            sweep_sh = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+        watchdog.cancel()
+
+    if rank == 0:
+        if sweep_sh is not None:
+            final_out['sweep_sharded'] = sweep_sh
+        print(json.dumps(final_out))
     if sharded_path:
         dist.barrier()
         dist.destroy_process_group()

@@ -56,6 +56,35 @@ for l in open('gpurun_out/bench_host8.log'):
           timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py tests/test_bam.py tests/test_plot.py -m gpu -q -p no:cacheprovider > gpurun_out/pytest_asan.log 2>&1
         echo "asan rc=$?"; grep -E "passed|failed|ERROR: AddressSanitizer|SUMMARY" gpurun_out/pytest_asan.log | tail -5; tail -3 gpurun_out/pytest_asan.log | cut -c1-300;;
     tails) rm -rf gpurun_out/prof_tails; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_tails -o t -- python tools/tail_probe.py $TAIL_ARGS > gpurun_out/tail_probe.jsonl 2> gpurun_out/tail_probe.err; echo "tails rc=$?"; cut -c1-400 gpurun_out/tail_probe.jsonl; tail -3 gpurun_out/tail_probe.err; find gpurun_out/prof_tails -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | cut -c1-200;;
+    tailpmc) # fabric bytes of the tail kernels at inflation 1.2 (generic-stream window class, hash class): two PMC passes of the first iterations
+        for spec in "rd:FETCH_SIZE" "wr:WRITE_SIZE"; do
+            name="${spec%%:*}"; ctr="${spec#*:}"; rm -rf gpurun_out/tailpmc_$name
+            timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/tailpmc_$name -o p -- python tools/tail_probe.py --inflations 1.2 --max-iter 12 > gpurun_out/tailpmc_$name.jsonl 2> gpurun_out/tailpmc_$name.err; echo "tailpmc $name rc=$?"
+        done
+        python - <<'PY'
+import collections, csv, json
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for name in ('rd', 'wr'):
+    try:
+        for r in csv.DictReader(open('gpurun_out/tailpmc_%s/p_counter_collection.csv' % name)):
+            k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
+            agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+    except OSError as e:
+        print(e)
+out = {}
+for k, cs in agg.items():
+    if 'k_expand' in k or 'k_dense' in k:
+        rd = sum(cs.get('FETCH_SIZE', [])) * 1024 * 2
+        wr = sum(cs.get('WRITE_SIZE', [])) * 1024
+        out[k] = {'launches': max(len(v) for v in cs.values()), 'read_bytes': rd, 'write_bytes': wr}
+probe = [json.loads(l) for l in open('gpurun_out/tailpmc_rd.jsonl') if l.startswith('{')]
+res = {'what': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE x 1024 x 2 on gfx950) of tools/tail_probe.py --inflations 1.2 --max-iter 12',
+       'kernels': out, 'probe': probe}
+json.dump(res, open('gpurun_out/tail_pmc_summary.json', 'w'), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]['read_bytes'])[:8]:
+    print(k, v)
+PY
+        ;;
     oscale) timeout 600 python tools/oracle_scaling.py > gpurun_out/oracle_scaling.jsonl 2> gpurun_out/oracle_scaling.err; echo "oscale rc=$?"; cat gpurun_out/oracle_scaling.jsonl; tail -2 gpurun_out/oracle_scaling.err;;
     listpmc) rocprofv3 -L > gpurun_out/pmc_list.txt 2>&1; grep -c . gpurun_out/pmc_list.txt;;
     env:*) export "${what#env:}"; echo "set ${what#env:}";;
