@@ -129,3 +129,47 @@ def test_early_pruning_bound_of_the_dense_epilogue():
         below = p < lo
         q = (p.astype(np.float64) / s).astype(np.float32)
         assert not (q[below] >= thr).any()
+
+
+def test_triangle_storage_addresses():
+    """hhx_expand.hip: the upper block triangle of the dense block — block row I starts at cap (I ldn - cap I (I - 1) / 2) floats and
+    keeps its windows J >= I with a pitch of ldn - I cap.  Every (row, window J >= block of the row, slot) must get its own float, the
+    whole must be exactly cap^2 n_win (n_win + 1) / 2 floats, and every row segment must start on a 128-byte line (cap % 64 == 0)."""
+    for cap, n_win in ((64, 1), (64, 3), (128, 5), (192, 10)):
+        ldn = n_win * cap
+        off = lambda I: cap * (I * ldn - cap * I * (I - 1) // 2)
+        seen = np.zeros(cap * cap * n_win * (n_win + 1) // 2, np.int8)
+        for I in range(n_win):
+            pitch = ldn - I * cap
+            for r in range(cap):
+                for J in range(I, n_win):
+                    a = off(I) + r * pitch + (J - I) * cap
+                    assert a % 32 == 0
+                    assert not seen[a:a + cap].any()
+                    seen[a:a + cap] = 1
+        assert seen.all()
+
+
+def test_id_arrays_alignments():
+    """cluster.IdArrays: alignments handed over as id arrays iterate to the reference generators' tuples (:1539-1593)"""
+    from haphic_amd import cluster
+    names = ['ctgB', 'ctgA', 'ctgC']
+    a = cluster.IdArrays(names, [0, 2, -1], [5, 6, 7], [1, 1, 2], [50, 60, 70])
+    assert len(a) == 3
+    assert list(a) == [('ctgB', 'ctgA', 5, 50), ('ctgC', 'ctgA', 6, 60), (None, 'ctgC', 7, 70)]
+    with pytest.raises(ValueError):
+        cluster.IdArrays(names, [0], [1, 2], [0], [1])
+
+
+def test_oracle_threads_respect_the_cpu_quota():
+    """the oracle's default thread count is the CPUs this process may use (affinity capped by the cgroup quota), not every
+    hardware thread of the host: on the GPU box (256 threads, quota 16) 128 threads walked products at half the rate of 16"""
+    import os
+    from oracle import oracle as orc
+    e = orc.effective_cpus()
+    assert 1 <= e <= (os.cpu_count() or 1)
+    orc.set_threads(0)
+    assert orc.get_threads() == e
+    orc.set_threads(1)
+    assert orc.get_threads() == 1
+    orc.set_threads(0)
