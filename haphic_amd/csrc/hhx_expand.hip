@@ -2295,9 +2295,9 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
     // a pruned row holds at most 1 / pruning entries; an early window tests against a partial row sum and admits more
     i64 pool_cap = std::max<i64>((i64)n_rows * 512, (i64)1 << 22), cand_cap = 2 * pool_cap;
     if (d->last_out) {                                 // a sweep: the demand of the previous inflation, with room for a neighbouring one
-        const bool above = inflation >= d->last_inflation;     // (demands shrink as the inflation grows)
-        pool_cap = d->last_out + (above ? d->last_out / 10 : d->last_out / 2) + n_rows;
-        cand_cap = d->last_cand + (above ? d->last_cand / 10 : d->last_cand / 2) + n_rows;
+        const bool above = inflation >= d->last_inflation;     // (demands shrink as the inflation grows: the same size re-uses the cached block)
+        pool_cap = d->last_out + (above ? 0 : d->last_out / 2) + n_rows;
+        cand_cap = d->last_cand + (above ? 0 : d->last_cand / 2) + n_rows;
     }
     for (int attempt = 0; attempt < 4; ++attempt) {
         DevBuf<i32> cand_col, out_col;
@@ -2399,7 +2399,7 @@ extern "C" int hhx_dense_inflate_prune_multi(const hhx_dense *d, int K, const do
     {
         int lowest = 0;
         for (int k = 1; k < K; ++k) if (inflations[k] < inflations[lowest]) lowest = k;
-        i64 per_infl = d->last_out ? 8 * ((d->last_out + d->last_cand) + (d->last_out + d->last_cand) / 10) : 0;
+        i64 per_infl = d->last_out ? 8 * (d->last_out + d->last_cand) : 0;
         if (d->last_out && inflations[lowest] < d->last_inflation) per_infl *= 2;
         const int fit = !d->last_out ? 0 : (int)std::max<i64>(1, std::min<i64>(MULTI_MAX, ((i64)6 << 30) / std::max<i64>(per_infl, 1)));
         if (!d->last_out || fit < K) {
@@ -2448,9 +2448,11 @@ extern "C" int hhx_dense_inflate_prune_multi(const hhx_dense *d, int K, const do
         if (d->last_out) {
             // the demand of the call before.  Survivors and candidates shrink as the inflation grows: an inflation at or above the
             // one that left the hint needs no more than it did (+ 10 %: the candidate test runs against partial row sums)
+            // (exactly the hint's size when above it — the block the previous call left in the pool is then re-used as it is; a
+            // larger request would be a fresh device allocation at ~30 ms per GB, and an overflow only costs a retry of this pass)
             const bool above = inflations[k] >= d->last_inflation;
-            q.pool_cap = d->last_out + (above ? d->last_out / 10 : d->last_out) + n_rows;
-            q.cand_cap = d->last_cand + (above ? d->last_cand / 10 : d->last_cand) + n_rows;
+            q.pool_cap = d->last_out + (above ? 0 : d->last_out) + n_rows;
+            q.cand_cap = d->last_cand + (above ? 0 : d->last_cand) + n_rows;
         }
     }
     DevBuf<MultiOut> mo_dev;
