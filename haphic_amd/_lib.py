@@ -95,6 +95,8 @@ SIGNATURES = {
     'hhx_links_plan': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'hhx_dense_device': (C.c_int, [C.c_void_p, c_vpp, c_i64p, c_i32p, c_i32p]),
     'hhx_dense_inflate_prune': (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_vpp]),
+    'hhx_copy_rect_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
+    'hhx_transpose_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
     'hhx_dense_inflate_prune_multi': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, c_vpp]),
     'hhx_dense_shape': (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i64p]),
     'hhx_dense_free': (C.c_int, [C.c_void_p]),

@@ -2569,6 +2569,44 @@ extern "C" int hhx_dense_free(hhx_dense *d) {
     return 0;
 }
 
+// ---- rectangles of the dense block on their way between the ranks (sharded.expand_links_symmetric): rank s hands rank r > s the
+// rectangle Y[rows of s][columns = rows of r]; r stores its transpose; what mirrors inside a rank's own rows is turned in place.
+// dst[c][r] = src[r][c], 64 x 64 tiles through LDS (both sides coalesced); rows / cols / pitches in floats, any alignment.
+namespace {
+__global__ __launch_bounds__(256) void k_transpose_rect(const float *__restrict__ src, i64 src_ld, float *__restrict__ dst, i64 dst_ld, i64 rows, i64 cols) {
+    __shared__ float tile[64][65];
+    const i64 r0 = (i64)blockIdx.y * 64, c0 = (i64)blockIdx.x * 64;       // source tile: rows r0.., columns c0..
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4)
+        tile[k][tx] = (r0 + k < rows && c0 + tx < cols) ? src[(size_t)(r0 + k) * (size_t)src_ld + c0 + tx] : 0.0f;
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4)
+        if (c0 + k < cols && r0 + tx < rows) dst[(size_t)(c0 + k) * (size_t)dst_ld + r0 + tx] = tile[tx][k];
+}
+}  // namespace
+// dst (cols x rows, rows dst_ld floats apart) = transpose of src (rows x cols, rows src_ld floats apart); device pointers; the two
+// must not overlap
+extern "C" int hhx_transpose_f32(const void *src, i64 src_ld, void *dst, i64 dst_ld, i64 rows, i64 cols) {
+    if (rows < 0 || cols < 0 || src_ld < cols || dst_ld < rows) return fail("hhx_transpose_f32: bad shape");
+    if (rows == 0 || cols == 0) return 0;
+    if (!src || !dst) return fail("null pointer");
+    const i64 gx = (cols + 63) / 64, gy = (rows + 63) / 64;
+    if (gy > 65535) return fail("hhx_transpose_f32: more than 4 M rows");
+    KTimer kt("dense_transpose");
+    k_transpose_rect<<<dim3((unsigned)gx, (unsigned)gy), 256, 0, g_stream>>>((const float *)src, src_ld, (float *)dst, dst_ld, rows, cols);
+    HHX_LAUNCH_CHECK();
+    return 0;
+}
+// dst (rows x cols, packed or with its own pitch) = the rectangle src (rows x cols, rows src_ld floats apart): one strided device copy
+extern "C" int hhx_copy_rect_f32(const void *src, i64 src_ld, void *dst, i64 dst_ld, i64 rows, i64 cols) {
+    if (rows < 0 || cols < 0 || src_ld < cols || dst_ld < cols) return fail("hhx_copy_rect_f32: bad shape");
+    if (rows == 0 || cols == 0) return 0;
+    if (!src || !dst) return fail("null pointer");
+    HHX_HIP(hipMemcpy2DAsync(dst, sizeof(float) * (size_t)dst_ld, src, sizeof(float) * (size_t)src_ld, sizeof(float) * (size_t)cols, (size_t)rows,
+                             hipMemcpyDeviceToDevice, g_stream));
+    return 0;
+}
+
 extern "C" int hhx_row_products(const hhx_csr *a, const hhx_csr *b, i64 *products_host) {
     if (!a || !b || !products_host) return fail("null pointer");
     if (a->n_cols != b->n_rows) return fail("row_products shape mismatch");

@@ -107,6 +107,24 @@ class HipEngine:
     def dense_drop(self, d):
         d.free()
 
+    # rectangles of the dense block between the ranks: hand-written tile transposes / one strided copy on the library's stream
+    # (y: the [rows, n] view of dense_upper, rows y.stride(0) floats apart)
+    def _at(self, y, r, c):
+        return _lib.C.c_void_p(y.data_ptr() + 4 * (int(r) * int(y.stride(0)) + int(c)))
+
+    def mirror_block(self, y, r_src, c_src, rows, cols, r_dst, c_dst):
+        """y[r_dst : r_dst + cols, c_dst : c_dst + rows] = y[r_src : r_src + rows, c_src : c_src + cols] transposed (disjoint regions)"""
+        _lib.check(_lib.load().hhx_transpose_f32(self._at(y, r_src, c_src), int(y.stride(0)), self._at(y, r_dst, c_dst), int(y.stride(0)), int(rows), int(cols)))
+
+    def pack_columns(self, y, c0, c1, out):
+        """out (1-D, y.shape[0] * (c1 - c0) floats) = the rectangle y[:, c0:c1], row-major"""
+        _lib.check(_lib.load().hhx_copy_rect_f32(self._at(y, 0, c0), int(y.stride(0)), _lib.C.c_void_p(out.data_ptr()), int(c1 - c0), int(y.shape[0]), int(c1 - c0)))
+
+    def unpack_transposed(self, y, c0, buf, rows_s):
+        """y[:, c0 : c0 + rows_s] = buf viewed as [rows_s, y.shape[0]] (another rank's rows), transposed"""
+        self.torch.cuda.current_stream(self.device).synchronize()           # the collective that filled buf ran on torch's stream
+        _lib.check(_lib.load().hhx_transpose_f32(_lib.C.c_void_p(buf.data_ptr()), int(y.shape[0]), self._at(y, 0, c0), int(y.stride(0)), int(rows_s), int(y.shape[0])))
+
     def dense_finish(self, d, inflation, pruning):
         """the rows finished from the completed block: (pruned rows, products, nnz of the expanded rows)"""
         self.torch.cuda.current_stream(self.device).synchronize()
@@ -380,23 +398,27 @@ def expand_links_symmetric(engine, links_full, bounds, inflation, pruning, dist)
             engine.dense_drop(d)
         return None, 0, 0
     n_loc = r1 - r0
-    # mirror inside the own rows: for the blocks I < J that both meet [r0, r1)
+    # mirror inside the own rows: for the blocks I < J that both meet [r0, r1) (engine.mirror_block: tile transposes)
     if n_loc:
         cuts = sorted({r0, r1} | {c for c in range((r0 // cap + 1) * cap, r1, cap)})
         segs = list(zip(cuts[:-1], cuts[1:]))                    # the row range cut at the block boundaries
         for a in range(len(segs)):
             for b_ in range(a + 1, len(segs)):
                 (ia, ib), (ja, jb) = segs[a], segs[b_]
-                y[ja - r0:jb - r0, ia:ib] = y[ia - r0:ib - r0, ja:jb].t()
-    # the rectangles for the ranks above, laid out by destination
+                engine.mirror_block(y, ia - r0, ja, ib - ia, jb - ja, ja - r0, ia)      # y[rows of J, columns of I] = y[rows of I, columns of J]^T
+    # the rectangles for the ranks above, packed side by side in ONE send buffer laid out by destination (engine.pack_columns: one
+    # strided device copy each, straight into its place — no intermediate tensors, no concatenation)
     send_counts = [0] * world
-    pieces = []
     for r in range(rank + 1, world):
-        c0, c1 = bounds[r], bounds[r + 1]
-        if n_loc and c1 > c0:
-            pieces.append(y[:, c0:c1].contiguous().view(-1))
-            send_counts[r] = n_loc * (c1 - c0)
-    send = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.float32, device=y.device)
+        if n_loc and bounds[r + 1] > bounds[r]:
+            send_counts[r] = n_loc * (bounds[r + 1] - bounds[r])
+    send = torch.empty(int(sum(send_counts)), dtype=torch.float32, device=y.device)
+    at = 0
+    for r in range(rank + 1, world):
+        if send_counts[r]:
+            engine.pack_columns(y, bounds[r], bounds[r + 1], send[at:at + send_counts[r]])
+            at += send_counts[r]
+    engine.sync()                                               # the packing ran on the engine's stream; the collective runs on torch's
     got, recv_counts = _all_to_all_var(send, send_counts, dist, torch)
     at = 0
     for s_ in range(world):
@@ -404,9 +426,10 @@ def expand_links_symmetric(engine, links_full, bounds, inflation, pruning, dist)
         if k:
             rows_s = bounds[s_ + 1] - bounds[s_]
             assert s_ < rank and k == rows_s * n_loc
-            y[:, bounds[s_]:bounds[s_ + 1]] = got[at:at + k].view(rows_s, n_loc).t()
+            engine.unpack_transposed(y, bounds[s_], got[at:at + k], rows_s)      # rank s_'s rows, stored as this rank's columns
             at += k
-    del got, send, pieces
+    engine.sync()
+    del got, send
     return engine.dense_finish(d, inflation, pruning)
 
 

@@ -164,6 +164,11 @@ int hhx_links_integer_ok(const hhx_csr *links, int *ok, int *shift);
  * would take too large a share of the device), 0 every row walks all its products into the fused epilogue */
 int hhx_links_plan(const hhx_csr *links, int *integer, int *layout);
 int hhx_dense_device(const hhx_dense *d, void **x_dev, int64_t *ld, int32_t *cap_win, int32_t *n_win);   /* ld: row pitch in floats (>= n_cols) */
+/* rectangles of such a block on their way between ranks (device pointers, sizes and pitches in floats): hhx_copy_rect_f32 packs /
+ * places a rows x cols rectangle, hhx_transpose_f32 writes its transpose (dst is cols x rows) — the mirror image of the symmetric
+ * pre-expansion, which a rank receives as another rank's rows */
+int hhx_copy_rect_f32(const void *src, int64_t src_ld, void *dst, int64_t dst_ld, int64_t rows, int64_t cols);
+int hhx_transpose_f32(const void *src, int64_t src_ld, void *dst, int64_t dst_ld, int64_t rows, int64_t cols);
 int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, double pruning, hhx_csr **out);
 /* the same for k <= 8 inflations in ONE pass over the block (x = y / d_i and log2(x) are formed once per entry, the 4 B x n^2 block
  * is read once): outs[i] is bit for bit what hhx_dense_inflate_prune(d, inflations[i], ...) returns */

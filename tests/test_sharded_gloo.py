@@ -107,6 +107,15 @@ class OracleEngine:
     def dense_drop(self, h):
         pass
 
+    def mirror_block(self, y, r_src, c_src, rows, cols, r_dst, c_dst):
+        y[r_dst:r_dst + cols, c_dst:c_dst + rows] = y[r_src:r_src + rows, c_src:c_src + cols].t()
+
+    def pack_columns(self, y, c0, c1, out):
+        out.copy_(y[:, c0:c1].contiguous().view(-1))
+
+    def unpack_transposed(self, y, c0, buf, rows_s):
+        y[:, c0:c0 + rows_s] = buf.view(rows_s, y.shape[0]).t()
+
     # ---- the sweep shared out over the ranks (sharded.sweep_sharded): stand-ins of hhx_expand_links_dense on a row block,
     # hhx_dense_inflate_prune, hhx_interpret
     def dense_rows(self, links, r0, r1):
