@@ -476,3 +476,60 @@ def test_row_ranges():
     assert b[0] == 0 and b[-1] == 1000 and all(x <= y for x, y in zip(b, b[1:]))
     per = [int(np.arange(1000)[b[k]:b[k + 1]].sum()) for k in range(4)]
     assert max(per) - min(per) <= 2 * 999
+
+
+def _sweep_edge_worker(rank, world, port, q):
+    """sharded.sweep_sharded against the same engine on one rank: iteration limits 1 / 2 / 3 / 200 (a limit that ends an inflation
+    inside the shared phase, at its hand-over, and in the light remainder), more ranks than inflations, a threshold of zero"""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        eng = OracleEngine()
+        # a symmetric integer link matrix with unit self loops (what dict_to_matrix builds), three planted groups
+        rng = np.random.default_rng(3)
+        n = 150
+        grp = rng.integers(0, 3, n)
+        iu, ju = np.triu_indices(n, 1)
+        keep = rng.random(iu.size) < np.where(grp[iu] == grp[ju], 0.5, 0.03)
+        iu, ju = iu[keep], ju[keep]
+        cnt = rng.integers(1, 9, iu.size).astype(np.float32)
+        import scipy.sparse as sp
+        m = sp.coo_matrix((np.concatenate([cnt, cnt, np.ones(n, np.float32)]), (np.concatenate([iu, ju, np.arange(n)]), np.concatenate([ju, iu, np.arange(n)]))),
+                          shape=(n, n)).tocsr()
+        m.sort_indices()
+        links = (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32))
+        out = []
+        for inflations, iters, thr in (((1.4, 2.0), 200, None), ((1.4, 2.0), 1, 0.0), ((1.4, 2.0), 2, 0.0), ((1.4, 2.0), 3, 0.0), ((1.4, 2.0, 3.0), 3, 1e9),
+                                       ((2.0,), 200, 0.0), ((1.2, 1.6, 2.0, 2.4, 2.8), 200, 200.0)):
+            got = sharded.sweep_sharded(eng, links, list(inflations), iters, 1e-4, dist, shard_products=thr)
+            d, _f, _c = eng.dense_rows(links, 0, n)
+            for infl, g_ in zip(inflations, got):
+                first = eng.dense_first(d, infl, 1e-4)
+                if iters <= 1:
+                    want_m, want_it, want_conv = first, 1, False
+                else:
+                    want_m, want_it, want_conv, _st = eng.mcl_resume(first, 1, 2, infl, iters, 1e-4)
+                wa, wp, wm = eng.interpret(want_m)
+                assert (g_[4], bool(g_[5])) == (want_it, bool(want_conv)), (inflations, iters, thr, infl, g_[4], g_[5], want_it, want_conv)
+                assert g_[3] == n and np.array_equal(g_[0], wa) and np.array_equal(g_[1], wp) and np.array_equal(g_[2], wm), (inflations, iters, thr, infl)
+            out.append(len(got))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('world', [2, 4])
+def test_sweep_sharded_edge_cases(world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sweep_edge_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda o: o[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(o[1] == [2, 2, 2, 2, 3, 1, 5] for o in outs)
