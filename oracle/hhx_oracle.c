@@ -141,6 +141,82 @@ i64 orc_spgemm(i32 n_rows, i32 n_cols, const i32 *Ap, const i32 *Aj, const float
     return nnz;
 }
 
+/* The same product in ONE pass over the products, for orc_mcl_from (whose expansions at 100k contigs walk 10^10-10^12 products): every
+ * thread appends its finished rows to its own growing buffer, a second (parallel) step copies them to their place.  Row for row the
+ * arithmetic of orc_spgemm above — same visiting order of k and q, same accumulators, same rounding: the same bits.  The three
+ * output arrays are malloc'ed here; returns nnz. */
+static i64 spgemm_onepass(i32 n_rows, i32 n_cols, const i32 *Ap, const i32 *Aj, const float *Ax, const i32 *Bp, const i32 *Bj, const float *Bx,
+                          int mode, int fx_shift, i32 **Cp_out, i32 **Cj_out, float **Cx_out) {
+    const double scale = ldexp(1.0, fx_shift), inv_scale = ldexp(1.0, -fx_shift);
+    const int nt = orc_get_threads();
+    i32 *Cp = (i32 *)calloc((size_t)n_rows + 1, sizeof(i32));
+    i64 *row_at = (i64 *)malloc(sizeof(i64) * ((size_t)n_rows + 1));       /* offset of the row inside its thread's buffer */
+    i32 *row_th = (i32 *)malloc(sizeof(i32) * ((size_t)n_rows + 1));
+    i32 **bj = (i32 **)calloc((size_t)nt, sizeof(i32 *));
+    float **bx = (float **)calloc((size_t)nt, sizeof(float *));
+#pragma omp parallel num_threads(nt)
+    {
+        const int th = omp_get_thread_num();
+        uint64_t *mark = (uint64_t *)calloc(((size_t)n_cols + 63) / 64 + 1, sizeof(uint64_t));
+        float *accf = mode == 0 ? (float *)calloc((size_t)n_cols + 1, sizeof(float)) : NULL;
+        i64 *acci = mode != 0 ? (i64 *)calloc((size_t)n_cols + 1, sizeof(i64)) : NULL;
+        i32 *cols = (i32 *)malloc(sizeof(i32) * ((size_t)n_cols + 1));
+        size_t cap = (size_t)1 << 16, used = 0;
+        i32 *oj = (i32 *)malloc(sizeof(i32) * cap);
+        float *ox = (float *)malloc(sizeof(float) * cap);
+#pragma omp for schedule(dynamic, 16)
+        for (i32 i = 0; i < n_rows; ++i) {
+            i32 cnt = 0;
+            for (i32 p = Ap[i]; p < Ap[i + 1]; ++p) {
+                const i32 k = Aj[p];
+                const float a = Ax[p];
+                for (i32 q = Bp[k]; q < Bp[k + 1]; ++q) {
+                    const i32 j = Bj[q];
+                    const uint64_t bit = (uint64_t)1 << (j & 63);
+                    if (!(mark[j >> 6] & bit)) {
+                        mark[j >> 6] |= bit;
+                        cols[cnt++] = j;
+                        if (mode == 0) accf[j] = 0.0f; else acci[j] = 0;
+                    }
+                    if (mode == 0) accf[j] += a * Bx[q];
+                    else acci[j] += (i64)llrint((double)a * (double)Bx[q] * scale);
+                }
+            }
+            qsort(cols, (size_t)cnt, sizeof(i32), cmp_i32);
+            if (used + (size_t)cnt > cap) {
+                while (used + (size_t)cnt > cap) cap *= 2;
+                oj = (i32 *)realloc(oj, sizeof(i32) * cap);
+                ox = (float *)realloc(ox, sizeof(float) * cap);
+            }
+            for (i32 c = 0; c < cnt; ++c) {
+                oj[used + c] = cols[c];
+                ox[used + c] = mode == 0 ? accf[cols[c]] : (float)((double)acci[cols[c]] * inv_scale);
+                mark[cols[c] >> 6] = 0;
+            }
+            Cp[i + 1] = cnt;
+            row_at[i] = (i64)used;
+            row_th[i] = th;
+            used += (size_t)cnt;
+        }
+        bj[th] = oj; bx[th] = ox;
+        free(mark); free(accf); free(acci); free(cols);
+    }
+    i64 nnz = 0;
+    for (i32 i = 0; i < n_rows; ++i) { nnz += Cp[i + 1]; if (nnz > 2147483647LL) nnz = 2147483647LL; Cp[i + 1] = (i32)nnz; }
+    i32 *Cj = (i32 *)malloc(sizeof(i32) * (size_t)(nnz ? nnz : 1));
+    float *Cx = (float *)malloc(sizeof(float) * (size_t)(nnz ? nnz : 1));
+#pragma omp parallel for schedule(static, 256) num_threads(nt)
+    for (i32 i = 0; i < n_rows; ++i) {
+        const i32 len = Cp[i + 1] - Cp[i];
+        memcpy(Cj + Cp[i], bj[row_th[i]] + row_at[i], sizeof(i32) * (size_t)len);
+        memcpy(Cx + Cp[i], bx[row_th[i]] + row_at[i], sizeof(float) * (size_t)len);
+    }
+    for (int t = 0; t < nt; ++t) { free(bj[t]); free(bx[t]); }
+    free(bj); free(bx); free(row_at); free(row_th);
+    *Cp_out = Cp; *Cj_out = Cj; *Cx_out = Cx;
+    return nnz;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Pre-expansion of the link matrix, run_mcl_clustering :2144-2147, in the INTEGER specification of the HIP kernels (mode 2).
  * L is the raw symmetric link matrix of dict_to_matrix (integer counts c, :362-368), d_i its L1 row sums (:2144), and
@@ -409,12 +485,10 @@ i64 orc_mcl_from(i32 n, const i32 *indptr, const i32 *indices, const float *data
             i32 *bp = cp, *bj = cj; float *bx = cx;     /* the operand T */
             i32 *rp = cp, *rj = cj; float *rx = cx;     /* running power */
             for (int e = 2; e <= expansion; ++e) {
-                i32 *np_ = (i32 *)malloc(sizeof(i32) * ((size_t)n + 1));
+                i32 *np_ = NULL, *nj = NULL;
+                float *nx = NULL;
                 st_f += count_products(n, rp, rj, bp);
-                i64 nn = orc_spgemm(n, n, rp, rj, rx, bp, bj, bx, np_, NULL, NULL, spgemm_mode, fx_shift);
-                i32 *nj = (i32 *)malloc(sizeof(i32) * (size_t)(nn ? nn : 1));
-                float *nx = (float *)malloc(sizeof(float) * (size_t)(nn ? nn : 1));
-                orc_spgemm(n, n, rp, rj, rx, bp, bj, bx, np_, nj, nx, spgemm_mode, fx_shift);
+                spgemm_onepass(n, n, rp, rj, rx, bp, bj, bx, spgemm_mode, fx_shift, &np_, &nj, &nx);
                 if (rp != bp) { free(rp); free(rj); free(rx); }
                 rp = np_; rj = nj; rx = nx;
             }
