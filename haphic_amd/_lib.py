@@ -134,6 +134,9 @@ SIGNATURES = {
     'hhx_ingest_link_matrix': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, c_i32p, c_vpp]),
     'hhx_ingest_table_device': (C.c_int, [C.c_void_p, C.c_int, c_i64p, c_vpp, c_vpp, c_vpp, c_vpp, c_vpp]),
     'hhx_ingest_push_table': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'hhx_ingest_fetch_flank_values': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'hhx_ingest_write_clm': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, c_i64p, c_i64p]),
+    'hhx_write_link_pickle': (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, c_i64p]),
 }
 
 _lib = None
@@ -456,6 +459,29 @@ def link_weights(frag_i, frag_j, value, mode, n_frag, per_frag=None, tag=None, p
     return nz.value
 
 
+def names_blob(names):
+    """names -> (uint8 array of the UTF-8 bytes back to back, int64 offsets [len(names) + 1])"""
+    enc = [n.encode() for n in names]
+    off = np.zeros(len(enc) + 1, np.int64)
+    if enc:
+        np.cumsum(np.fromiter(map(len, enc), np.int64, len(enc)), out=off[1:])
+    blob = np.frombuffer(b''.join(enc) or b'\0', np.uint8)
+    return blob, off
+
+
+def write_link_pickle(path, i, j, count, names):
+    """full_links.pkl / HT_links.pkl (output_pickle :710-715) straight from the link arrays: a protocol-4 pickle of
+    `defaultdict(int)` {(names[i[k]], names[j[k]]): count[k]} in array order, written by the library's host code
+    (hhx_write_link_pickle) without a Python object per key.  Returns the bytes written."""
+    fi, fj = np.ascontiguousarray(i, np.int32), np.ascontiguousarray(j, np.int32)
+    cnt = np.ascontiguousarray(count, np.int64)
+    blob, off = names_blob(names)
+    n_bytes = C.c_int64(0)
+    check(load().hhx_write_link_pickle(os.fsencode(path), fi.size, ptr(fi), ptr(fj), ptr(cnt), len(names), ptr(blob), ptr(off),
+                                       C.byref(n_bytes)))
+    return n_bytes.value
+
+
 def group_link_sums(frag_i, frag_j, links, group, n_groups):
     """hhx_group_link_sums: (sums, first) int64 [n_ctg, n_groups]; first == -1 where a cell got no contribution"""
     fi, fj = np.ascontiguousarray(frag_i, np.int32), np.ascontiguousarray(frag_j, np.int32)
@@ -750,17 +776,32 @@ class Ingest:
         self.n_full, self.n_flank = a.value, b.value
         return self.n_full, self.n_flank
 
-    def fetch(self):
+    _FETCH = ('full_i', 'full_j', 'full_cnt', 'ht_cnt', 'flank_i', 'flank_j', 'flank_cnt', 'frag_links')
+
+    def fetch(self, want=None):
+        """host copies in dict insertion order (hhx_ingest_fetch); want: the subset of _FETCH to copy (default: all)"""
         if self.n_full is None:
             self.finalize()
         nf, nk = self.n_full, self.n_flank
-        out = dict(full_i=np.empty(nf, np.int32), full_j=np.empty(nf, np.int32), full_cnt=np.empty(nf, np.int64),
-                   ht_cnt=np.empty((nf, 4), np.int64), flank_i=np.empty(nk, np.int32), flank_j=np.empty(nk, np.int32),
-                   flank_cnt=np.empty(nk, np.int64), frag_links=np.empty(self.n_frag, np.int64))
-        check(load().hhx_ingest_fetch(self.h, ptr(out['full_i']), ptr(out['full_j']), ptr(out['full_cnt']),
-                                      ptr(out['ht_cnt']), ptr(out['flank_i']), ptr(out['flank_j']),
-                                      ptr(out['flank_cnt']), ptr(out['frag_links'])))
+        shape = dict(full_i=(nf, np.int32), full_j=(nf, np.int32), full_cnt=(nf, np.int64), ht_cnt=((nf, 4), np.int64),
+                     flank_i=(nk, np.int32), flank_j=(nk, np.int32), flank_cnt=(nk, np.int64), frag_links=(self.n_frag, np.int64))
+        want = self._FETCH if want is None else tuple(want)
+        out = {k: np.empty(*shape[k]) for k in want}
+        check(load().hhx_ingest_fetch(self.h, *[ptr(out[k]) if k in out else None for k in self._FETCH]))
         return out
+
+    def fetch_flank_values(self):
+        """the float64 values of the flank table in dict order (counts, or the weights hhx_link_weights left there)"""
+        out = np.empty(self.n_flank, np.float64)
+        check(load().hhx_ingest_fetch_flank_values(self.h, ptr(out)))
+        return out
+
+    def weigh_flank(self, mode, per_frag=None, tag=None, param=0.0):
+        """hhx_link_weights on the device-resident flank table (normalize_by_nlinks :718-724 and friends): the weights never
+        leave HBM on their way into link_matrix(weighted=True)"""
+        pi, pj, pv = self.flank_device()
+        return link_weights(None, None, None, mode, self.n_frag, per_frag=per_frag, tag=tag, param=param,
+                            device_ptrs=(self.n_flank, pi, pj, pv))
 
     def flank_device(self):
         a, b, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -810,17 +851,30 @@ class Ingest:
         """global stream ordinal of this handle's first pair (multi-GPU chunk offset); before the first push"""
         check(load().hhx_ingest_set_ordinal_base(self.h, int(base)))
 
-    def link_matrix(self, in_set, n_rest=-1, add_self_loops=True):
-        """dict_to_matrix fused onto the device-resident flank table: (DeviceCSR, frag_index, n_linked)"""
+    def link_matrix(self, in_set, n_rest=-1, add_self_loops=True, weighted=False):
+        """dict_to_matrix fused onto the device-resident flank table: (DeviceCSR, frag_index, n_linked).  weighted: the values
+        are the float64 weights of weigh_flank (hhx_dict_to_matrix over the ordered device arrays) instead of the counts."""
         if self.n_full is None:
             self.finalize()
         in_set = np.ascontiguousarray(in_set, np.uint8)
+        if weighted:
+            pi, pj, pv = self.flank_device()
+            return dict_to_matrix(pi, pj, pv, self.n_frag, in_set, n_rest, add_self_loops=add_self_loops, on_device=True,
+                                  n_keys=self.n_flank)
         frag_index = np.empty(max(self.n_frag, 1), np.int32)
         n_linked = C.c_int32(0)
         out = C.c_void_p()
         check(load().hhx_ingest_link_matrix(self.h, ptr(in_set), int(n_rest), int(add_self_loops), ptr(frag_index),
                                             C.byref(n_linked), C.byref(out)))
         return DeviceCSR(out), frag_index[:self.n_frag], n_linked.value
+
+    def write_clm(self, path, ctg_names):
+        """paired_links.clm (output_clm :376-392) from the kept read pairs: grouped, sorted and formatted on the device.
+        Returns (lines, bytes) written."""
+        blob, off = names_blob(ctg_names)
+        n_lines, n_bytes = C.c_int64(0), C.c_int64(0)
+        check(load().hhx_ingest_write_clm(self.h, os.fsencode(path), ptr(blob), ptr(off), C.byref(n_lines), C.byref(n_bytes)))
+        return n_lines.value, n_bytes.value
 
     def table_device(self, which=0):
         """aggregated table (unordered): (n_rows, key_ptr, ord_full_ptr, ord_flank_ptr, ht_ptr, flank_ptr)"""

@@ -17,6 +17,7 @@ reference's observable ordering depends on CPython for: the set-of-tuples in int
 """
 import logging
 import os
+from array import array
 from collections import defaultdict
 from decimal import Decimal
 from math import ceil
@@ -353,27 +354,53 @@ def filter_fragments(Nx_frag_set, RE_site_dict, RE_site_cutoff, frag_link_dict, 
 
 
 # ------------------------------------------------------------------ a6: link weights (in-place dict rewrites)
+def _frozen(container, kind=None):
+    """the container is an array-backed table of containers.py that nobody has touched yet (and of that kind)"""
+    return getattr(container, 'frozen', False) is True and (kind is None or container._kind == kind)
+
+
 def _dict_arrays(link_dict, names):
-    """(frag_i, frag_j, value) arrays of a link dict in dict order; names: fragment -> id, extended on the fly"""
-    fi = np.empty(len(link_dict), np.int32)
-    fj = np.empty(len(link_dict), np.int32)
-    val = np.empty(len(link_dict), np.float64)
-    for k, ((a, b), v) in enumerate(link_dict.items()):
-        fi[k] = names.setdefault(a, len(names))
-        fj[k] = names.setdefault(b, len(names))
-        val[k] = v
-    return fi, fj, val
+    """(frag_i, frag_j, value) arrays of a link dict in dict order; names: fragment -> id, extended on the fly in first-seen order
+    (i before j, key by key).  No Python statement per key: the keys are flattened, numbered and gathered by C-level iterators."""
+    from itertools import chain
+    if _frozen(link_dict):                                 # array-backed (containers.LinkTable): ids of the table -> ids of `names`
+        i, j, v, id_names = link_dict.arrays()
+        both = np.stack([i, j], axis=1).ravel()
+        seen, first = np.unique(both, return_index=True)
+        remap = np.zeros(len(id_names), np.int32)
+        for t in seen[np.argsort(first, kind='stable')].tolist():
+            remap[t] = names.setdefault(id_names[t], len(names))
+        return remap[i], remap[j], np.asarray(v, np.float64)
+    n = len(link_dict)
+    flat = list(chain.from_iterable(link_dict))            # a0, b0, a1, b1, ...
+    if len(flat) != 2 * n:
+        raise ValueError('link dict keys must be pairs of fragment names')
+    for name in dict.fromkeys(flat):                       # distinct names in first-seen order
+        names.setdefault(name, len(names))
+    ids = np.fromiter(map(names.__getitem__, flat), np.int32, 2 * n).reshape(n, 2)
+    val = np.fromiter(link_dict.values(), np.float64, n)
+    return np.ascontiguousarray(ids[:, 0]), np.ascontiguousarray(ids[:, 1]), val
+
+
+def _store_values(link_dict, val):
+    """dict[key] = float for every key, in order, without a Python statement per key"""
+    dict.update(link_dict, zip(link_dict, val.tolist()))
 
 
 def normalize_by_nlinks(flank_link_dict, frag_link_dict):
     """normalize_by_nlinks() :718-724 — every value divided by the geometric mean of its fragments' link totals"""
     logger.info('Normalizing flank_link_dict by the number of links to other contigs...')
+    if _frozen(flank_link_dict, 'flank'):                  # the table is still in HBM: weigh it there
+        session = flank_link_dict._session
+        get = frag_link_dict.get
+        totals = np.fromiter((get(f, 0) for f in session.table.frag_names), np.int64, session.table.n_frag)
+        session.weigh_flank(0, per_frag=totals)
+        return
     names = {}
     fi, fj, val = _dict_arrays(flank_link_dict, names)
     totals = np.fromiter((frag_link_dict[f] for f in names), np.int64, len(names))
     _lib.link_weights(fi, fj, val, 0, len(names), per_frag=totals)
-    for key, v in zip(flank_link_dict, val.tolist()):
-        flank_link_dict[key] = v
+    _store_values(flank_link_dict, val)
 
 
 def normalize_by_length(flank_link_dict, frag_len_dict, flank):
@@ -383,8 +410,7 @@ def normalize_by_length(flank_link_dict, frag_len_dict, flank):
     fi, fj, val = _dict_arrays(flank_link_dict, names)
     lengths = np.fromiter((frag_len_dict[f] for f in names), np.int64, len(names))
     _lib.link_weights(fi, fj, val, 1, len(names), per_frag=lengths, param=flank * 2000)
-    for key, v in zip(flank_link_dict, val.tolist()):
-        flank_link_dict[key] = v
+    _store_values(flank_link_dict, val)
 
 
 def reduce_inter_hap_HiC_links(link_dict, read_depth_dict, phasing_weight, target='flank_link_dict'):
@@ -661,17 +687,74 @@ def interpret_result(result_matrix, dense_matrix=False):
 
 
 # ------------------------------------------------------------------ S4: dict_to_matrix
+class ResidentMatrix:
+    """What dict_to_matrix returns for a link table that never left the device: the CSR(T) handle (== the reference's CSC(M)
+    triple) for run_mcl_clustering, which takes it over without a host round trip.  Anything else that is asked of it is
+    answered by the scipy CSC matrix the reference would have got (:368), downloaded on first use."""
+
+    def __init__(self, dev):
+        self._dev = dev
+        self._csc = None
+
+    def take_device(self):
+        dev, self._dev = self._dev, None
+        if dev is None:
+            raise RuntimeError('the device matrix has already been handed over')
+        return dev
+
+    def _scipy(self):
+        if self._csc is None:
+            if self._dev is None:
+                raise RuntimeError('the device matrix has already been handed over')
+            self._csc = self._dev.to_scipy_csc()
+        return self._csc
+
+    def __getattr__(self, name):
+        if name.startswith('__') and name.endswith('__'):
+            raise AttributeError(name)
+        return getattr(self._scipy(), name)
+
+    def __del__(self):
+        try:
+            if self._dev is not None:
+                self._dev.free()
+        except Exception:
+            pass
+
+
+def _index_dict(id_names, fidx, n_linked, rest):
+    """frag_index_dict: linked fragments in index order (== insertion order :337-349), then the link-less ones (:357-359)"""
+    linked = np.flatnonzero(fidx >= 0)
+    linked = linked[np.argsort(fidx[linked], kind='stable')]
+    frag_index_dict = dict(zip(map(id_names.__getitem__, linked.tolist()), fidx[linked].tolist()))
+    frag_index_dict.update(zip(rest, range(n_linked, n_linked + len(rest))))
+    return frag_index_dict
+
+
 def dict_to_matrix(link_dict, frag_set, dense_matrix=True, add_self_loops=False, _device=False):
-    """dict_to_matrix() :310-373.  Returns (matrix, frag_index_dict); the matrix is scipy CSC unless
-    _device=True (then a DeviceCSR that run_mcl_clustering_device consumes without a host round trip)."""
+    """dict_to_matrix() :310-373.  Returns (matrix, frag_index_dict); the matrix is scipy CSC (an ndarray with dense_matrix)
+    unless _device=True (then a DeviceCSR).  A flank table that is still frozen (containers.LinkTable: run() has only passed it
+    through the seams) is turned into the matrix where it lies, in HBM (hhx_ingest_link_matrix), and comes back as a
+    ResidentMatrix."""
+    if _frozen(link_dict, 'flank'):
+        session = link_dict._session
+        id_names = session.table.frag_names
+        in_set = np.fromiter(map(frag_set.__contains__, id_names), np.uint8, len(id_names))
+        if int(in_set.sum()) == len(frag_set):               # every member is a fragment of the table (else: the generic path)
+            m, fidx, n_linked = session.link_matrix(in_set, -1, add_self_loops)
+            frags_in_dict = set(map(id_names.__getitem__, np.flatnonzero(fidx >= 0).tolist()))
+            rest = frag_set - frags_in_dict                  # :357 — CPython set order, kept in Python
+            frag_index_dict = _index_dict(id_names, fidx, n_linked, rest)
+            if _device:
+                return m, frag_index_dict
+            if dense_matrix:
+                try:
+                    return m.to_scipy_csc().toarray(), frag_index_dict
+                finally:
+                    m.free()
+            return ResidentMatrix(m), frag_index_dict
     names = {}
-    ids_i = np.empty(len(link_dict), np.int32)
-    ids_j = np.empty(len(link_dict), np.int32)
-    vals = np.empty(len(link_dict), np.float64)
-    for k, ((fi, fj), v) in enumerate(link_dict.items()):
-        ids_i[k] = names.setdefault(fi, len(names))
-        ids_j[k] = names.setdefault(fj, len(names))
-        vals[k] = v
+    ids_i, ids_j, vals = _dict_arrays(link_dict, names)
     # The device builder writes ONE slot per (row, column).  The reference's own parsers only ever produce sorted, unique
     # name pairs, but the seam is public: a dict holding both (a, b) and (b, a) is folded into the first of the two
     # (coo_matrix(...).tocsc() :368 sums duplicates — same matrix, same first-seen index order); a key (f, f) would land on
@@ -690,23 +773,17 @@ def dict_to_matrix(link_dict, frag_set, dense_matrix=True, add_self_loops=False,
     for f in frag_set:
         names.setdefault(f, len(names))
     id_names = list(names)
-    in_set = np.fromiter((f in frag_set for f in id_names), np.uint8, len(id_names))
+    in_set = np.fromiter(map(frag_set.__contains__, id_names), np.uint8, len(id_names))
     ok = in_set[ids_i].astype(bool) & in_set[ids_j].astype(bool)
     linked = np.zeros(len(id_names), bool)
     linked[ids_i[ok]] = True
     linked[ids_j[ok]] = True
-    frags_in_dict = {id_names[i] for i in np.flatnonzero(linked)}
+    frags_in_dict = set(map(id_names.__getitem__, np.flatnonzero(linked).tolist()))
     rest = frag_set - frags_in_dict                      # :357 — CPython set order, kept in Python
     m, fidx, n_linked = _lib.dict_to_matrix(ids_i, ids_j, vals, max(len(id_names), 1), in_set if len(in_set) else
                                             np.zeros(1, np.uint8), len(rest), add_self_loops=add_self_loops)
-    frag_index_dict = {}
-    order = np.argsort(fidx[linked], kind='stable')
-    for i in np.flatnonzero(linked)[order]:              # insertion order == index order (:337-349)
-        frag_index_dict[id_names[i]] = int(fidx[i])
-    index = n_linked
-    for frag in rest:
-        frag_index_dict[frag] = index
-        index += 1
+    fidx = np.where(linked, fidx[:len(id_names)], -1) if len(id_names) else fidx[:0]
+    frag_index_dict = _index_dict(id_names, fidx, n_linked, rest)
     if _device:
         return m, frag_index_dict
     try:
@@ -714,6 +791,43 @@ def dict_to_matrix(link_dict, frag_set, dense_matrix=True, add_self_loops=False,
     finally:
         m.free()
     return (csc.toarray() if dense_matrix else csc), frag_index_dict
+
+
+# ------------------------------------------------------------------ f3 / f2: the files run() writes from the containers
+def output_pickle(dict_, from_, to, _original=None):
+    """output_pickle() :710-715.  A link table that is still frozen (full_links.pkl, HT_links.pkl) is serialised from its arrays
+    by the library's host code — the same `defaultdict(int)` pickle (protocol 4, keys in dict order, int values) without a Python
+    object per key; any other object is pickled as the reference does."""
+    import pickle
+    logger.info('Writing {} to {}...'.format(from_, to))
+    if _frozen(dict_) and dict_._kind in ('full', 'HT', 'flank'):
+        i, j, v, names = dict_.arrays()
+        if v.dtype.kind in 'iu':
+            _lib.write_link_pickle(to, i, j, v, names)
+            return
+    with open(to, 'wb') as fpkl:
+        pickle.dump(dict_, fpkl)
+
+
+def output_clm(clm_dict, _original=None):
+    """output_clm() :376-392 — paired_links.clm.  The frozen clm_dict of the S5 mirrors is written from the read pairs kept
+    in HBM (grouping, the per-orientation sorts and the text on the device: hhx_ingest_write_clm); a real dict takes the
+    reference's loop."""
+    if _frozen(clm_dict, 'clm'):
+        logger.info('Writing clm_dict to paired_links.clm...')
+        clm_dict._session.write_clm('paired_links.clm')
+        return
+    if _original is not None:
+        return _original(clm_dict)
+    logger.info('Writing clm_dict to paired_links.clm...')
+    signs = ('++', '+-', '-+', '--')
+    with open('paired_links.clm', 'w') as fout:
+        for (ctg_i, ctg_j), dists in clm_dict.items():
+            if len(dists) < 8:                               # fewer than two read pairs (:385)
+                continue
+            for n, (si, sj) in enumerate(signs):
+                ordered = sorted(dists[n::4])
+                fout.write('{}{} {}{}\t{}\t{}\n'.format(ctg_i, si, ctg_j, sj, 2 * len(ordered), ' '.join('{0} {0}'.format(d) for d in ordered)))
 
 
 # ------------------------------------------------------------------ a1: .pairs text
@@ -954,10 +1068,9 @@ def _ids_from_alignments(alignments, cid, chunk, wide=False):
         yield b1[:k], p1[:k], b2[:k], p2[:k], k
 
 
-def ingest_links(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False, max_read_pairs=0, want_frag_pairs=False):
-    """Feed an alignment iterator (name tuples, as the reference's generators :1539-1593 yield them)
-    through the device ingest; returns the insertion-ordered tables as numpy arrays (+ the CLM distances and
-    the first coordinates of every contig pair when want_pairs)."""
+def _ingest_handle(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False, want_frag_pairs=False):
+    """Feed an alignment iterator (name tuples, as the reference's generators :1539-1593 yield them, or the device-side front
+    ends of this package) through the device ingest; returns the finalized handle (_lib.Ingest), tables resident in HBM."""
     text = isinstance(alignments, PairsText)
     bam = isinstance(alignments, BamRecords)
     ing = _lib.Ingest(table, flank, bins=bins, skip_intra=(text or bam) and alignments.inter_only)      # :1582 / refid != mrefid
@@ -988,6 +1101,17 @@ def ingest_links(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False
             for b1, p1, b2, p2, k in _ids_from_alignments(alignments, cid, chunk, wide=table.wide):
                 ing.push(b1, p1, b2, p2, wide=table.wide)     # unknown names (-1) and intra-contig pairs are filtered on the device
         ing.finalize()
+        return ing
+    except BaseException:
+        ing.destroy()
+        raise
+
+
+def ingest_links(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False, max_read_pairs=0, want_frag_pairs=False):
+    """The same, fetched: the insertion-ordered tables as numpy arrays (+ the CLM distances and the first coordinates of every
+    contig pair when want_pairs); the handle is gone when this returns."""
+    ing = _ingest_handle(alignments, table, flank, bins, chunk, want_pairs, want_frag_pairs)
+    try:
         out = ing.fetch()
         if want_pairs:
             out['clm_ptr'], out['clm'], out['crd_ptr'], out['crd'] = ing.fetch_pairs(max_read_pairs, out['full_cnt'])
@@ -1024,83 +1148,143 @@ def cal_concentration_adj_ratio(coord_list, bin_width=10000):
     return keep
 
 
-def _link_dicts(out, table):
-    cn, fn = table.ctg_names, table.frag_names
-    full = defaultdict(int)
-    HT = defaultdict(int)
-    flank = defaultdict(int)
-    frag_link = defaultdict(int)
-    suffix = ('_H', '_T')
-    fi, fj, ht_cnt = out['full_i'].tolist(), out['full_j'].tolist(), out['ht_cnt']
-    for i, j, c in zip(fi, fj, out['full_cnt'].tolist()):
-        full[(cn[i], cn[j])] = c
-    if 'ht_first' in out:
-        # HT_link_dict in the reference's insertion order: the (pair, quadrant) entries by the stream position of their
-        # first read pair (:404-416)
+class IngestSession:
+    """The device-resident result of one S5 call (parse_alignments* :1596-1752): the ingest handle with its link tables (and,
+    for the CLM / coordinate side products, the kept read pairs) in HBM, the fragment table that names its ids, and host copies
+    of the tables in dict order that are fetched only when a container asks for them.  The containers the mirrors return
+    (containers.LinkTable / PairLists) all point here; the handle is destroyed when the last of them lets go."""
+
+    def __init__(self, ing, table, fa_dict, args, pos_int_type, dist_int_type):
+        self.ing, self.table = ing, table
+        self.record = bool(args.remove_allelic_links or args.remove_concentrated_links)
+        self.max_read_pairs = int(args.max_read_pairs) if self.record else 0
+        self.allelic, self.concentrated = bool(args.remove_allelic_links), bool(args.remove_concentrated_links)
+        self.nwindows = getattr(args, 'nwindows', 50)
+        self.dist = ('i', np.int32) if dist_int_type == 'int32' else ('l', np.int64)
+        self.pos = ('i', np.int32) if pos_int_type == 'int32' else ('l', np.int64)
+        self.weighted = False                   # flank values are float64 weights (normalize_by_nlinks) instead of counts
+        self._host = {}
+        self._pairs = None
+        self._ht_names = None
+
+    # ---- host copies, on demand
+    def _fetch(self, *keys):
+        missing = [k for k in keys if k not in self._host]
+        if missing:
+            self._host.update(self.ing.fetch(want=missing))
+        return [self._host[k] for k in keys]
+
+    def frag_links(self):
+        return self._fetch('frag_links')[0]
+
+    def n_keys(self, kind):
+        if kind == 'HT':
+            return int(np.count_nonzero(self._fetch('ht_cnt')[0]))
+        return self.ing.n_full if kind == 'full' else self.ing.n_flank
+
+    def link_arrays(self, kind):
+        if kind == 'full':
+            return (*self._fetch('full_i', 'full_j', 'full_cnt'), self.table.ctg_names)
+        if kind == 'flank':
+            fi, fj = self._fetch('flank_i', 'flank_j')
+            if self.weighted:
+                if 'flank_val' not in self._host:
+                    self._host['flank_val'] = self.ing.fetch_flank_values()
+                return fi, fj, self._host['flank_val'], self.table.frag_names
+            return fi, fj, self._fetch('flank_cnt')[0], self.table.frag_names
+        # HT_link_dict: the (contig pair, quadrant) entries in the order of the stream position of their first read pair
+        # (update_HT_link_dict :404-416); names carry the '_H' / '_T' suffix of the quadrant's two ends
+        fi, fj, ht_cnt = self._fetch('full_i', 'full_j', 'ht_cnt')
         k, q = np.nonzero(ht_cnt)
-        order = np.argsort(out['ht_first'][k, q], kind='stable')
-        for kk, qq in zip(k[order].tolist(), q[order].tolist()):
-            HT[(cn[fi[kk]] + suffix[qq >> 1], cn[fj[kk]] + suffix[qq & 1])] = int(ht_cnt[kk, qq])
-    else:
-        for i, j, ht in zip(fi, fj, ht_cnt.tolist()):
-            for q, v in enumerate(ht):
-                if v:
-                    HT[(cn[i] + suffix[q >> 1], cn[j] + suffix[q & 1])] = v
-    for i, j, c in zip(out['flank_i'].tolist(), out['flank_j'].tolist(), out['flank_cnt'].tolist()):
-        flank[(fn[i], fn[j])] = c
-    for f, c in enumerate(out['frag_links'].tolist()):
-        if c:
-            frag_link[fn[f]] = c
-    return full, flank, HT, frag_link
+        order = np.argsort(self.ht_first()[k, q], kind='stable')
+        k, q = k[order], q[order]
+        if self._ht_names is None:
+            self._ht_names = [n + s for n in self.table.ctg_names for s in ('_H', '_T')]
+        return 2 * fi[k] + (q >> 1).astype(np.int32), 2 * fj[k] + (q & 1).astype(np.int32), ht_cnt[k, q], self._ht_names
+
+    def ht_first(self):
+        if 'ht_first' not in self._host:
+            self._host['ht_first'] = self.ing.fetch_ht_order()
+        return self._host['ht_first']
+
+    def pairs(self):
+        """(clm_ptr, clm, crd_ptr, crd): hhx_ingest_fetch_pairs, lists in full_link_dict order"""
+        if self._pairs is None:
+            self._pairs = self.ing.fetch_pairs(self.max_read_pairs, self._fetch('full_cnt')[0])
+        return self._pairs
+
+    def pair_items(self, kind):
+        """(key, array) items of clm_dict (update_clm_dict :395-401) / ctg_coord_dict (record_coord_pairs :454-471)"""
+        from .containers import slices_as_arrays
+        cn = self.table.ctg_names
+        fi, fj = self._fetch('full_i', 'full_j')
+        keys = list(zip(map(cn.__getitem__, fi.tolist()), map(cn.__getitem__, fj.tolist())))
+        clm_ptr, clm, crd_ptr, crd = self.pairs()
+        if kind == 'clm':
+            return zip(keys, slices_as_arrays(self.dist[0], clm.astype(self.dist[1], copy=False), clm_ptr, 4))
+        values = list(slices_as_arrays(self.pos[0], crd.astype(self.pos[1], copy=False), crd_ptr, 2))
+        # a contig pair that reached max_read_pairs was replaced by its [concordance ratio, concentration factor] (:460-471)
+        ctg_len = self.table.ctg_len
+        for k in np.flatnonzero(np.diff(crd_ptr) >= self.max_read_pairs).tolist():
+            c = values[k]
+            if self.allelic:
+                shorter_len = int(min(ctg_len[fi[k]], ctg_len[fj[k]]))
+                values[k] = [cal_concordance_ratio(c, shorter_len, self.nwindows), 1]
+            if self.concentrated:
+                # as the reference (:466): evaluated on the dict entry AFTER the replacement above, i.e. on the
+                # two-element [ratio, 1] when both options are on (which always gives 1.0)
+                adj_ratio = cal_concentration_adj_ratio(values[k])
+                if self.allelic:
+                    values[k][1] = adj_ratio
+                else:
+                    values[k] = [0, adj_ratio]
+        return zip(keys, values)
+
+    def note_thawed(self):
+        pass
+
+    # ---- device-side steps on the resident flank table
+    def weigh_flank(self, mode, per_frag=None, tag=None, param=0.0):
+        """hhx_link_weights over the flank table in HBM (a6); the values become float64"""
+        self.ing.weigh_flank(mode, per_frag=per_frag, tag=tag, param=param)
+        self.weighted = True
+        self._host.pop('flank_val', None)
+
+    def link_matrix(self, in_set, n_rest, add_self_loops):
+        return self.ing.link_matrix(in_set, n_rest, add_self_loops=add_self_loops, weighted=self.weighted)
+
+    def write_clm(self, path):
+        return self.ing.write_clm(path, self.table.ctg_names)
 
 
-def _pair_dicts(out, table, fa_dict, args, pos_int_type, dist_int_type):
-    """clm_dict (update_clm_dict :395-401) and ctg_coord_dict (record_coord_pairs :454-471) from the device lists"""
-    from array import array
-    cn = table.ctg_names
-    dist_code, dist_np = ('i', np.int32) if dist_int_type == 'int32' else ('l', np.int64)
-    pos_code, pos_np = ('i', np.int32) if pos_int_type == 'int32' else ('l', np.int64)
-    clm_dict = defaultdict(lambda: array(dist_code))
-    ctg_coord_dict = defaultdict(lambda: array(pos_code))
-    record = bool(args.remove_allelic_links or args.remove_concentrated_links)
-    clm = out['clm'].astype(dist_np)
-    crd = out['crd'].astype(pos_np)
-    cp, kp = out['clm_ptr'].tolist(), out['crd_ptr'].tolist()
-    for k, (i, j) in enumerate(zip(out['full_i'].tolist(), out['full_j'].tolist())):
-        pair = (cn[i], cn[j])
-        a = array(dist_code)
-        a.frombytes(clm[4 * cp[k]:4 * cp[k + 1]].tobytes())
-        clm_dict[pair] = a
-        if record:
-            c = array(pos_code)
-            c.frombytes(crd[2 * kp[k]:2 * kp[k + 1]].tobytes())
-            ctg_coord_dict[pair] = c
-            if len(c) >= args.max_read_pairs * 2:                                     # :460-471
-                if args.remove_allelic_links:
-                    shorter_len = min(fa_dict[pair[0]][1], fa_dict[pair[1]][1])
-                    ctg_coord_dict[pair] = [cal_concordance_ratio(c, shorter_len, args.nwindows), 1]
-                if args.remove_concentrated_links:
-                    # as the reference (:466): evaluated on the dict entry AFTER the replacement above, i.e. on the
-                    # two-element [ratio, 1] when both options are on (which always gives 1.0)
-                    adj_ratio = cal_concentration_adj_ratio(ctg_coord_dict[pair])
-                    if args.remove_allelic_links:
-                        ctg_coord_dict[pair][1] = adj_ratio
-                    else:
-                        ctg_coord_dict[pair] = [0, adj_ratio]
-    return clm_dict, ctg_coord_dict
+def ingest_session(alignments, table, fa_dict, args, bins, pos_int_type, dist_int_type, chunk=1 << 22, want_frag_pairs=False):
+    """Alignments (the reference's generators :1539-1593, or this package's PairsText / BamRecords / IdArrays) through the device
+    ingest; the handle stays alive inside the returned IngestSession."""
+    ing = _ingest_handle(alignments, table, int(args.flank * 1000), bins, chunk, want_pairs=True, want_frag_pairs=want_frag_pairs)
+    return IngestSession(ing, table, fa_dict, args, pos_int_type, dist_int_type)
+
+
+def _s5_containers(session):
+    from .containers import LinkTable, PairLists
+    full, flank, HT = LinkTable(session, 'full'), LinkTable(session, 'flank'), LinkTable(session, 'HT')
+    frag_link = defaultdict(int)
+    fn = session.table.frag_names
+    links = session.frag_links()
+    for f in np.flatnonzero(links).tolist():
+        frag_link[fn[f]] = int(links[f])
+    clm_dict = PairLists(session, 'clm', session.dist[0])
+    ctg_coord_dict = PairLists(session, 'crd', session.pos[0]) if session.record else defaultdict(lambda c=session.pos[0]: array(c))
+    return full, flank, HT, clm_dict, frag_link, ctg_coord_dict
 
 
 def parse_alignments_for_ctgs(alignments, fa_dict, args, ctg_len_dict, Nx_ctg_set, pos_int_type, dist_int_type):
     """parse_alignments_for_ctgs() :1596-1655 — all six containers from the device: link tables, HT counts, the
-    CLM distance lists and the first coordinates of every contig pair."""
+    CLM distance lists and the first coordinates of every contig pair.  The big ones come back FROZEN (containers.py): their
+    entries stay in HBM / numpy arrays until something other than the next seams of run() touches them."""
     logger.info('Parsing input alignments...')
     table = FragTable.from_reference(fa_dict, ctg_len_dict, Nx_ctg_set)
-    record = bool(args.remove_allelic_links or args.remove_concentrated_links)
-    out = ingest_links(alignments, table, int(args.flank * 1000), bins=False, want_pairs=True,
-                       max_read_pairs=int(args.max_read_pairs) if record else 0)
-    full, flank, HT, frag_link = _link_dicts(out, table)
-    clm_dict, ctg_coord_dict = _pair_dicts(out, table, fa_dict, args, pos_int_type, dist_int_type)
-    return full, flank, HT, clm_dict, frag_link, ctg_coord_dict
+    session = ingest_session(alignments, table, fa_dict, args, False, pos_int_type, dist_int_type)
+    return _s5_containers(session)
 
 
 def parse_alignments(alignments, fa_dict, args, bin_size, frag_len_dict, Nx_frag_set, split_ctg_set, pos_int_type,
@@ -1108,20 +1292,18 @@ def parse_alignments(alignments, fa_dict, args, bin_size, frag_len_dict, Nx_frag
     """parse_alignments() :1658-1752 (some contigs split into bins): all seven containers from the device."""
     logger.info('Parsing input alignments...')
     table = FragTable.from_reference(fa_dict, frag_len_dict, Nx_frag_set, split_ctg_set, bin_size)
-    record = bool(args.remove_allelic_links or args.remove_concentrated_links)
-    out = ingest_links(alignments, table, int(args.flank * 1000), bins=True, want_pairs=True,
-                       max_read_pairs=int(args.max_read_pairs) if record else 0, want_frag_pairs=bool(args.remove_allelic_links))
-    full, flank, HT, frag_link = _link_dicts(out, table)
-    clm_dict, ctg_coord_dict = _pair_dicts(out, table, fa_dict, args, pos_int_type, dist_int_type)
+    session = ingest_session(alignments, table, fa_dict, args, True, pos_int_type, dist_int_type,
+                             want_frag_pairs=bool(args.remove_allelic_links))
     ctg_pair_to_frag = defaultdict(set)                         # :1731-1733
     if args.remove_allelic_links:
         fn, cn = table.frag_names, table.ctg_names
-        ci = np.searchsorted(table.ctg_frag0, out['fp_i'], side='right') - 1     # fragment id -> its contig
-        cj = np.searchsorted(table.ctg_frag0, out['fp_j'], side='right') - 1
-        for fi, fj, a, b in zip(out['fp_i'].tolist(), out['fp_j'].tolist(), ci.tolist(), cj.tolist()):
+        fp_i, fp_j = session.ing.fetch_frag_pairs()
+        ci = np.searchsorted(table.ctg_frag0, fp_i, side='right') - 1     # fragment id -> its contig
+        cj = np.searchsorted(table.ctg_frag0, fp_j, side='right') - 1
+        for fi, fj, a, b in zip(fp_i.tolist(), fp_j.tolist(), ci.tolist(), cj.tolist()):
             ca, cb = cn[a], cn[b]
             ctg_pair_to_frag[(ca, cb) if ca <= cb else (cb, ca)].add((fn[fi], fn[fj]))
-    return full, flank, HT, clm_dict, frag_link, ctg_coord_dict, ctg_pair_to_frag
+    return _s5_containers(session) + (ctg_pair_to_frag,)
 
 
 # ------------------------------------------------------------------ S6: run_mcl_clustering
@@ -1178,8 +1360,12 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
         raise ValueError('dense_matrix mode is not on the MI355X path; use the reference function')
     logger.info('Performing Markov clustering...')
     index_frag = {i: f for f, i in frag_index_dict.items()}
-    own = not isinstance(link_matrix, _lib.DeviceCSR)
-    m = _to_device(link_matrix) if own else link_matrix.copy()
+    if isinstance(link_matrix, ResidentMatrix):                      # straight from dict_to_matrix, still in HBM
+        m = link_matrix.take_device()
+    elif isinstance(link_matrix, _lib.DeviceCSR):
+        m = link_matrix.copy()
+    else:
+        m = _to_device(link_matrix)
     n = m.shape3[0]
     # The reference pre-expands once (:2146-2147) and restarts every inflation from that matrix.  M^e is nearly dense: as a
     # CSR matrix it is materialised only while it is guaranteed to fit scipy's int32 index range (n^2 < 2^31).  Beyond that

@@ -156,6 +156,7 @@ struct hhx_ingest {
     bool keep_pairs = false;
     std::vector<hhx::DevBuf<u64>> side_key, side_xy;     // one pair of arrays per push: key, (xi << 32 | xj)
     i64 n_side = 0;
+    i64 max_ctg_len = 0;                   // longest contig (bounds the CLM distances: hhx_ingest_write_clm)
     hhx::DevBuf<i32> stage[4];             // staging for host-side inputs
     hhx::DevBuf<i64> stage64[2];           // ... of 64-bit positions (hhx_ingest_push64)
     ~hhx_ingest() {

@@ -606,6 +606,7 @@ extern "C" int hhx_ingest_create(const hhx_ingest_config *cfg, hhx_ingest **out)
         ci[c].lenf = cfg->ctg_len[c] | (cfg->ctg_split[c] ? SPLIT_BIT : 0) | (identity && cfg->frag_nx[c] ? NX_BIT : 0);
     }
     hhx_ingest *h = new hhx_ingest();
+    for (i32 c = 0; c < cfg->n_ctg; ++c) h->max_ctg_len = std::max<i64>(h->max_ctg_len, cfg->ctg_len[c]);
     int rc = upload(h->ctg_info, ci.data(), ci.size()) || upload(h->frag_info, fi.data(), fi.size());
     if (rc) { delete h; return 1; }
     hipError_t e = hipStreamSynchronize(g_stream);               // the host vectors die at return

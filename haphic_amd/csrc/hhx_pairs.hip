@@ -6,6 +6,7 @@
 // time; at fetch time one STABLE radix sort by key (hhx_sort.h: hand-written LSD passes, ballot-ranked so that equal
 // keys keep their stream order) groups them, the insertion-ordered key table is sorted the same way to pair every
 // group with its dict position, and one wavefront per contig pair writes its distances.
+#include <algorithm>
 #include <cstring>
 
 #include "hhx_ingest.h"
@@ -193,20 +194,24 @@ template int hhx_side_records_push<i64>(hhx_ingest *, i64, const i32 *, const i6
 
 int hhx_ingest_ordered_full_device(hhx_ingest *h, const i32 **fi, const i32 **fj);   // hhx_ingest.hip
 
-extern "C" int hhx_ingest_fetch_pairs(hhx_ingest *h, i64 max_read_pairs, i64 *clm_ptr, i64 *clm, i64 *crd_ptr, i64 *crd) {
-    if (!h || !h->finalized) return fail("ingest handle not finalized");
-    if (!h->keep_pairs) return fail("hhx_ingest_fetch_pairs: the handle was not created with hhx_ingest_keep_pairs");
-    if (max_read_pairs < 0) max_read_pairs = 0;
+// The kept read pairs grouped by contig pair: sorted (key, xy) records (stream order inside a group), the boundaries of the groups,
+// and for the g-th smallest key the position r = srank[g] of that contig pair in full_link_dict (dict insertion order).
+struct PairGroups {
+    i64 K = 0, N = 0;
+    DevBuf<u64> skey, sxy, stk, srank;
+    DevBuf<i64> gstart;                    // [K + 1]
+};
+
+static int group_pairs(hhx_ingest *h, PairGroups &G, const char *who) {
     const i32 *fi = nullptr, *fj = nullptr;
     HHX_TRY(hhx_ingest_ordered_full_device(h, &fi, &fj));
     const i64 K = h->n_full, N = h->n_side;
-    if (clm_ptr) clm_ptr[0] = 0;
-    if (crd_ptr) crd_ptr[0] = 0;
+    G.K = K; G.N = N;
     if (K == 0) return 0;
     // concatenate the pushes (stream order), stable sort by key
-    DevBuf<u64> key, xy, skey, sxy, tkey, trnk, stk, srank;
-    if (key.alloc((size_t)N) || xy.alloc((size_t)N) || skey.alloc((size_t)N) || sxy.alloc((size_t)N) || tkey.alloc((size_t)K) || trnk.alloc((size_t)K) ||
-        stk.alloc((size_t)K) || srank.alloc((size_t)K)) return 1;
+    DevBuf<u64> key, xy, tkey, trnk;
+    if (key.alloc((size_t)N) || xy.alloc((size_t)N) || G.skey.alloc((size_t)N) || G.sxy.alloc((size_t)N) || tkey.alloc((size_t)K) || trnk.alloc((size_t)K) ||
+        G.stk.alloc((size_t)K) || G.srank.alloc((size_t)K)) return 1;
     i64 o = 0;
     for (size_t b = 0; b < h->side_key.size(); ++b) {
         const i64 nb = (i64)h->side_key[b].n;
@@ -216,24 +221,40 @@ extern "C" int hhx_ingest_fetch_pairs(hhx_ingest *h, i64 max_read_pairs, i64 *cl
         }
         o += nb;
     }
-    HHX_TRY(sort_pairs_u64(key.p, skey.p, xy.p, sxy.p, N));
+    HHX_TRY(sort_pairs_u64(key.p, G.skey.p, xy.p, G.sxy.p, N));
+    key.release(); xy.release();
     k_table_keys<<<grid_for((u64)K), 256, 0, g_stream>>>(K, fi, fj, tkey.p, trnk.p);
     HHX_LAUNCH_CHECK();
-    HHX_TRY(sort_pairs_u64(tkey.p, stk.p, trnk.p, srank.p, K));
+    HHX_TRY(sort_pairs_u64(tkey.p, G.stk.p, trnk.p, G.srank.p, K));
     // groups of the sorted records <-> sorted table keys
-    DevBuf<i64> flag, gidx, gstart, cnt_r, cap_r, clm_off, crd_off;
-    DevBuf<unsigned int> mismatch;
-    if (flag.alloc((size_t)N + 1) || gidx.alloc((size_t)N + 2) || gstart.alloc((size_t)K + 2) || cnt_r.alloc((size_t)K + 1) || cap_r.alloc((size_t)K + 1) ||
-        clm_off.alloc((size_t)K + 2) || crd_off.alloc((size_t)K + 2) || mismatch.alloc(1)) return 1;
-    HHX_HIP(hipMemsetAsync(mismatch.p, 0, sizeof(unsigned int), g_stream));
-    k_boundary_flags<<<grid_for((u64)N), 256, 0, g_stream>>>(N, skey.p, flag.p);
+    DevBuf<i64> flag, gidx;
+    if (flag.alloc((size_t)N + 1) || gidx.alloc((size_t)N + 2) || G.gstart.alloc((size_t)K + 2)) return 1;
+    k_boundary_flags<<<grid_for((u64)N), 256, 0, g_stream>>>(N, G.skey.p, flag.p);
     HHX_LAUNCH_CHECK();
     i64 n_groups = 0;
     HHX_TRY(exclusive_scan_i64(flag.p, gidx.p, N, &n_groups));
-    if (n_groups != K) return fail("hhx_ingest_fetch_pairs: %lld contig pairs in the records, %lld in the table", (long long)n_groups, (long long)K);
-    k_group_starts<<<grid_for((u64)N), 256, 0, g_stream>>>(N, skey.p, gidx.p, gstart.p);
-    HHX_HIP(hipMemcpyAsync(gstart.p + K, &N, sizeof(i64), hipMemcpyHostToDevice, g_stream));
-    k_group_counts<<<grid_for((u64)K), 256, 0, g_stream>>>(K, stk.p, skey.p, gstart.p, srank.p, max_read_pairs, cnt_r.p, cap_r.p, mismatch.p);
+    if (n_groups != K) return fail("%s: %lld contig pairs in the records, %lld in the table", who, (long long)n_groups, (long long)K);
+    k_group_starts<<<grid_for((u64)N), 256, 0, g_stream>>>(N, G.skey.p, gidx.p, G.gstart.p);
+    HHX_HIP(hipMemcpyAsync(G.gstart.p + K, &N, sizeof(i64), hipMemcpyHostToDevice, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+extern "C" int hhx_ingest_fetch_pairs(hhx_ingest *h, i64 max_read_pairs, i64 *clm_ptr, i64 *clm, i64 *crd_ptr, i64 *crd) {
+    if (!h || !h->finalized) return fail("ingest handle not finalized");
+    if (!h->keep_pairs) return fail("hhx_ingest_fetch_pairs: the handle was not created with hhx_ingest_keep_pairs");
+    if (max_read_pairs < 0) max_read_pairs = 0;
+    if (clm_ptr) clm_ptr[0] = 0;
+    if (crd_ptr) crd_ptr[0] = 0;
+    PairGroups G;
+    HHX_TRY(group_pairs(h, G, "hhx_ingest_fetch_pairs"));
+    const i64 K = G.K, N = G.N;
+    if (K == 0) return 0;
+    DevBuf<i64> cnt_r, cap_r, clm_off, crd_off;
+    DevBuf<unsigned int> mismatch;
+    if (cnt_r.alloc((size_t)K + 1) || cap_r.alloc((size_t)K + 1) || clm_off.alloc((size_t)K + 2) || crd_off.alloc((size_t)K + 2) || mismatch.alloc(1)) return 1;
+    HHX_HIP(hipMemsetAsync(mismatch.p, 0, sizeof(unsigned int), g_stream));
+    k_group_counts<<<grid_for((u64)K), 256, 0, g_stream>>>(K, G.stk.p, G.skey.p, G.gstart.p, G.srank.p, max_read_pairs, cnt_r.p, cap_r.p, mismatch.p);
     HHX_LAUNCH_CHECK();
     i64 clm_total = 0, crd_total = 0;
     HHX_TRY(exclusive_scan_i64(cnt_r.p, clm_off.p, K, &clm_total));
@@ -244,7 +265,7 @@ extern "C" int hhx_ingest_fetch_pairs(hhx_ingest *h, i64 max_read_pairs, i64 *cl
     if (mm || clm_total != N) return fail("hhx_ingest_fetch_pairs: records and table disagree");
     DevBuf<i64> d_clm, d_crd;
     if (d_clm.alloc((size_t)N * 4) || d_crd.alloc((size_t)crd_total * 2 + 2)) return 1;
-    k_emit_pairs<<<grid_for((u64)K * 64), 256, 0, g_stream>>>(K, stk.p, gstart.p, srank.p, sxy.p, h->t.ctg, clm_off.p, crd_off.p, max_read_pairs, d_clm.p, d_crd.p);
+    k_emit_pairs<<<grid_for((u64)K * 64), 256, 0, g_stream>>>(K, G.stk.p, G.gstart.p, G.srank.p, G.sxy.p, h->t.ctg, clm_off.p, crd_off.p, max_read_pairs, d_clm.p, d_crd.p);
     HHX_LAUNCH_CHECK();
     if (clm_ptr) HHX_HIP(hipMemcpyAsync(clm_ptr, clm_off.p, sizeof(i64) * ((size_t)K + 1), hipMemcpyDeviceToHost, g_stream));
     if (crd_ptr) HHX_HIP(hipMemcpyAsync(crd_ptr, crd_off.p, sizeof(i64) * ((size_t)K + 1), hipMemcpyDeviceToHost, g_stream));
@@ -297,6 +318,302 @@ extern "C" int hhx_ingest_fetch_ht_order(hhx_ingest *h, i64 *first) {
     k_ht_first<<<grid_for((u64)K * 64), 256, 0, g_stream>>>(K, stk.p, gstart.p, srank.p, sidx.p, xy.p, h->t.ctg, d_first.p);
     HHX_LAUNCH_CHECK();
     HHX_HIP(hipMemcpyAsync(first, d_first.p, sizeof(i64) * (size_t)K * 4, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+// ================================================================================================ paired_links.clm
+// output_clm :376-392 on the device.  For every contig pair with at least two read pairs (`len(list_) < 8: continue`), in
+// full_link_dict order, four lines — one per orientation n of update_clm_dict's distances :395-401 —
+//     {ctg_i}{+|-} {ctg_j}{+|-}\t{2 * links}\t{d d d d ...}\n      with the distances ascending, each written twice.
+// The read pairs are already grouped by contig pair (group_pairs).  The kept groups are numbered in dict order and cut into
+// chunks of at most CLM_CHUNK distances; per chunk: one 64-bit word (line << dbits | distance) per distance, a keys-only stable
+// radix sort of those words (= every line's distances ascending, lines in order), the byte length of every distance (+ the
+// line header on the first of a line), a scan, and a formatting kernel that builds each block's bytes in LDS and stores them
+// with 16-byte writes.  The text leaves through two pinned host buffers, written by a host thread while the next piece is copied.
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <condition_variable>
+#include <deque>
+#include <thread>
+
+namespace {
+
+constexpr i64 CLM_CHUNK = (i64)1 << 27;            // distances per chunk (1 GB of sort keys, ~2 GB of text)
+constexpr int CW_T = 256, CW_OUT_CAP = 24 * 1024;
+
+__device__ __forceinline__ i32 dlen(u64 a) { i32 n = 0; do { ++n; a /= 10; } while (a); return n; }
+__device__ __forceinline__ unsigned char *dput(unsigned char *o, u64 a) {
+    const i32 n = dlen(a);
+    for (i32 k = n - 1; k >= 0; --k) { o[k] = (unsigned char)('0' + a % 10); a /= 10; }
+    return o + n;
+}
+
+__global__ __launch_bounds__(256) void k_clm_by_r(i64 K, const i64 *__restrict__ gstart, const u64 *__restrict__ srank, i64 *__restrict__ keep_r,
+                                                  i64 *__restrict__ g_of_r) {
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < K; g += (i64)gridDim.x * blockDim.x) {
+        const i64 r = (i64)srank[g];
+        keep_r[r] = gstart[g + 1] - gstart[g] >= 2 ? 1 : 0;          // :385
+        g_of_r[r] = g;
+    }
+}
+__global__ __launch_bounds__(256) void k_clm_kept(i64 K, const i64 *__restrict__ keep_r, const i64 *__restrict__ kidx, const i64 *__restrict__ g_of_r,
+                                                  const i64 *__restrict__ gstart, const u64 *__restrict__ stk, const i64 *__restrict__ name_off,
+                                                  i64 *__restrict__ kept_g, i64 *__restrict__ kept_cnt, i32 *__restrict__ hdr_len) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < K; r += (i64)gridDim.x * blockDim.x) {
+        if (!keep_r[r]) continue;
+        const i64 kr = kidx[r], g = g_of_r[r], c = gstart[g + 1] - gstart[g];
+        const u64 key = stk[g];
+        const i64 ci = (i64)(key >> ID_BITS), cj = (i64)(key & ID_MASK);
+        kept_g[kr] = g;
+        kept_cnt[kr] = c;
+        // "{ctg_i}{s} {ctg_j}{s}\t{2c}\t"
+        hdr_len[kr] = (i32)((name_off[ci + 1] - name_off[ci]) + (name_off[cj + 1] - name_off[cj]) + 5 + dlen((u64)(2 * c)));
+    }
+}
+// one wavefront per kept contig pair: its 4 * cnt sort keys, orientation-major
+__global__ __launch_bounds__(256) void k_clm_keys(i64 kr0, i64 kr1, const i64 *__restrict__ kept_g, const i64 *__restrict__ eoff, const i64 *__restrict__ gstart,
+                                                  const u64 *__restrict__ stk, const u64 *__restrict__ sxy, const UnitInfo *__restrict__ ctg, int dbits,
+                                                  u64 *__restrict__ keys, unsigned int *__restrict__ bad) {
+    const int lane = lane_id();
+    const i64 e0 = eoff[kr0];
+    for (i64 kr = kr0 + (i64)blockIdx.x * 4 + threadIdx.x / HHX_WAVE; kr < kr1; kr += (i64)gridDim.x * 4) {
+        const i64 g = kept_g[kr], b = gstart[g], cnt = gstart[g + 1] - b;
+        const u64 key = stk[g];
+        const i64 li = ctg[key >> ID_BITS].lenf & LEN_MASK, lj = ctg[key & ID_MASK].lenf & LEN_MASK;
+        u64 *o = keys + 4 * (eoff[kr] - e0);
+        const u64 line = (u64)(kr - kr0) * 4;
+        for (i64 t = lane; t < cnt; t += HHX_WAVE) {
+            const u64 xy = sxy[b + t];
+            const i64 a = (i64)(xy >> 32) - 1, c = (i64)(xy & 0xffffffffu) - 1;      // 0-based (:1643)
+            if (a >= li || c >= lj) atomicExch(bad, 1u);                             // a coordinate beyond the contig's end: negative distances
+            o[t] = (line << dbits) | (u64)(li - a + c);
+            o[cnt + t] = ((line + 1) << dbits) | (u64)(li - a + lj - c);
+            o[2 * cnt + t] = ((line + 2) << dbits) | (u64)(a + c);
+            o[3 * cnt + t] = ((line + 3) << dbits) | (u64)(a + lj - c);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_clm_len(i64 E, const u64 *__restrict__ sk, int dbits, i64 kr0, const i32 *__restrict__ hdr_len, i64 *__restrict__ len) {
+    const u64 dmask = (1ull << dbits) - 1;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (i64)gridDim.x * blockDim.x) {
+        const u64 k = sk[e];
+        const u64 line = k >> dbits;
+        const bool first = e == 0 || (sk[e - 1] >> dbits) != line;
+        len[e] = 2 * dlen(k & dmask) + 2 + (first ? hdr_len[kr0 + (i64)(line >> 2)] : 0);
+    }
+}
+// bytes of CW_T consecutive distances are built in LDS at (offset - out_bias), out_bias chosen so that LDS and HBM addresses
+// agree mod 16, and leave with 16-byte stores (bytes at the two ragged ends); a block whose span exceeds the LDS window (long
+// contig names) writes to HBM directly
+__global__ __launch_bounds__(CW_T) void k_clm_write(i64 E, const u64 *__restrict__ sk, int dbits, i64 kr0, const i64 *__restrict__ kept_g,
+                                                    const i64 *__restrict__ kept_cnt, const u64 *__restrict__ stk, const unsigned char *__restrict__ names,
+                                                    const i64 *__restrict__ name_off, const i64 *__restrict__ off, unsigned char *__restrict__ text) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_out[CW_OUT_CAP];
+    const u64 dmask = (1ull << dbits) - 1;
+    for (i64 e0 = (i64)blockIdx.x * CW_T; e0 < E; e0 += (i64)gridDim.x * CW_T) {
+        const i64 e1 = e0 + CW_T < E ? e0 + CW_T : E;
+        const i64 b0 = off[e0], b1 = off[e1];
+        const i64 out_bias = b0 & ~(i64)15;                      // text is 16-byte aligned (pool allocation)
+        const bool staged = b1 - out_bias <= CW_OUT_CAP;
+        const i64 e = e0 + threadIdx.x;
+        if (e < e1) {
+            const u64 k = sk[e];
+            const u64 line = k >> dbits;
+            const bool first = e == 0 || (sk[e - 1] >> dbits) != line;
+            const bool last = e + 1 == E || (sk[e + 1] >> dbits) != line;
+            unsigned char *o = staged ? s_out + (off[e] - out_bias) : text + off[e];
+            if (first) {
+                const i64 kr = kr0 + (i64)(line >> 2);
+                const u64 key = stk[kept_g[kr]];
+                const i64 ci = (i64)(key >> ID_BITS), cj = (i64)(key & ID_MASK);
+                const int n = (int)(line & 3);
+                for (i64 q = name_off[ci]; q < name_off[ci + 1]; ++q) *o++ = names[q];
+                *o++ = (n & 2) ? '-' : '+'; *o++ = ' ';
+                for (i64 q = name_off[cj]; q < name_off[cj + 1]; ++q) *o++ = names[q];
+                *o++ = (n & 1) ? '-' : '+'; *o++ = '\t';
+                o = dput(o, (u64)(2 * kept_cnt[kr]));
+                *o++ = '\t';
+            }
+            const u64 d = k & dmask;
+            o = dput(o, d); *o++ = ' ';
+            o = dput(o, d); *o++ = last ? '\n' : ' ';
+        }
+        __syncthreads();
+        if (staged) {
+            for (i64 o = (i64)threadIdx.x * 16; out_bias + o < b1; o += (i64)CW_T * 16) {
+                const i64 gpos = out_bias + o;
+                if (gpos >= b0 && gpos + 16 <= b1) *reinterpret_cast<uint4 *>(text + gpos) = *reinterpret_cast<const uint4 *>(s_out + o);
+                else for (int q = 0; q < 16; ++q) if (gpos + q >= b0 && gpos + q < b1) text[gpos + q] = s_out[o + q];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// device bytes -> file: pieces through two pinned buffers, pwrite() on a host thread while the next piece is copied
+struct FileSink {
+    static constexpr size_t PIECE = (size_t)64 << 20;
+    int fd = -1;
+    i64 pos = 0;
+    void *pin[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int next = 0, err = 0;
+    bool stop = false;
+    struct Job { int buf; size_t n; i64 at; };
+    std::deque<Job> q;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread worker;
+
+    int open(const char *path) {
+        fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (fd < 0) return fail("cannot open %s for writing: %s", path, strerror(errno));
+        for (int b = 0; b < 2; ++b) HHX_HIP(hipHostMalloc(&pin[b], PIECE, hipHostMallocDefault));
+        worker = std::thread([this] {
+            for (;;) {
+                Job j;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [this] { return stop || !q.empty(); });
+                    if (q.empty()) return;
+                    j = q.front(); q.pop_front();
+                }
+                const char *p = (const char *)pin[j.buf];
+                size_t left = j.n; i64 at = j.at;
+                while (left) {
+                    const ssize_t w = ::pwrite(fd, p, left, at);
+                    if (w <= 0) { std::lock_guard<std::mutex> lk(mu); err = errno ? errno : EIO; break; }
+                    p += w; left -= (size_t)w; at += w;
+                }
+                { std::lock_guard<std::mutex> lk(mu); busy[j.buf] = false; }
+                cv.notify_all();
+            }
+        });
+        return 0;
+    }
+    int write_device(const unsigned char *dev, size_t n) {
+        for (size_t o = 0; o < n; o += PIECE) {
+            const size_t m = n - o < PIECE ? n - o : PIECE;
+            const int b = next; next ^= 1;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !busy[b]; }); if (err) return fail("write failed: %s", strerror(err)); }
+            HHX_HIP(hipMemcpyAsync(pin[b], dev + o, m, hipMemcpyDeviceToHost, g_stream));
+            HHX_HIP(hipStreamSynchronize(g_stream));
+            { std::lock_guard<std::mutex> lk(mu); busy[b] = true; q.push_back(Job{b, m, pos}); }
+            cv.notify_all();
+            pos += (i64)m;
+        }
+        return 0;
+    }
+    int close() {
+        int rc = 0;
+        if (worker.joinable()) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return !busy[0] && !busy[1]; }); stop = true; }
+            cv.notify_all();
+            worker.join();
+        }
+        if (err) rc = fail("write failed: %s", strerror(err));
+        for (int b = 0; b < 2; ++b) if (pin[b]) { (void)hipHostFree(pin[b]); pin[b] = nullptr; }
+        if (fd >= 0) { if (::close(fd) != 0 && !rc) rc = fail("close failed: %s", strerror(errno)); fd = -1; }
+        return rc;
+    }
+    ~FileSink() { (void)close(); }
+};
+
+int bits_for(u64 v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; }
+
+}  // namespace
+
+extern "C" int hhx_ingest_write_clm(hhx_ingest *h, const char *path, const uint8_t *names_blob, const int64_t *name_off, int64_t *n_lines, int64_t *n_bytes) {
+    if (!h || !h->finalized) return fail("ingest handle not finalized");
+    if (!h->keep_pairs) return fail("hhx_ingest_write_clm: the handle was not created with hhx_ingest_keep_pairs");
+    if (!path || !names_blob || !name_off) return fail("hhx_ingest_write_clm: null pointer");
+    if (n_lines) *n_lines = 0;
+    if (n_bytes) *n_bytes = 0;
+    FileSink sink;
+    HHX_TRY(sink.open(path));
+    PairGroups G;
+    HHX_TRY(group_pairs(h, G, "hhx_ingest_write_clm"));
+    const i64 K = G.K;
+    if (K == 0) return sink.close();
+    KTimer kt("clm_text");
+    // contig names on the device
+    const i32 n_ctg = h->t.n_ctg;
+    DevBuf<unsigned char> d_names;
+    DevBuf<i64> d_noff;
+    const size_t blob_bytes = (size_t)name_off[n_ctg];
+    if (d_names.alloc(blob_bytes + 1) || d_noff.alloc((size_t)n_ctg + 1)) return 1;
+    if (blob_bytes) HHX_HIP(hipMemcpyAsync(d_names.p, names_blob, blob_bytes, hipMemcpyHostToDevice, g_stream));
+    HHX_HIP(hipMemcpyAsync(d_noff.p, name_off, sizeof(i64) * ((size_t)n_ctg + 1), hipMemcpyHostToDevice, g_stream));
+    // kept groups (two read pairs or more) in dict order
+    DevBuf<i64> keep_r, kidx, g_of_r;
+    if (keep_r.alloc((size_t)K + 1) || kidx.alloc((size_t)K + 2) || g_of_r.alloc((size_t)K)) return 1;
+    k_clm_by_r<<<grid_for((u64)K), 256, 0, g_stream>>>(K, G.gstart.p, G.srank.p, keep_r.p, g_of_r.p);
+    HHX_LAUNCH_CHECK();
+    i64 nk = 0;
+    HHX_TRY(exclusive_scan_i64(keep_r.p, kidx.p, K, &nk));
+    if (nk == 0) return sink.close();
+    DevBuf<i64> kept_g, kept_cnt, eoff;
+    DevBuf<i32> hdr_len;
+    if (kept_g.alloc((size_t)nk) || kept_cnt.alloc((size_t)nk + 1) || eoff.alloc((size_t)nk + 2) || hdr_len.alloc((size_t)nk)) return 1;
+    k_clm_kept<<<grid_for((u64)K), 256, 0, g_stream>>>(K, keep_r.p, kidx.p, g_of_r.p, G.gstart.p, G.stk.p, d_noff.p, kept_g.p, kept_cnt.p, hdr_len.p);
+    HHX_LAUNCH_CHECK();
+    i64 n_kept_pairs = 0;
+    HHX_TRY(exclusive_scan_i64(kept_cnt.p, eoff.p, nk, &n_kept_pairs));
+    keep_r.release(); kidx.release(); g_of_r.release();
+    std::vector<i64> h_eoff((size_t)nk + 1);
+    HHX_HIP(hipMemcpyAsync(h_eoff.data(), eoff.p, sizeof(i64) * ((size_t)nk + 1), hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    const int dbits = bits_for((u64)(2 * h->max_ctg_len));           // every distance is at most len_i + len_j
+    DevBuf<unsigned int> bad;
+    if (bad.alloc(1)) return 1;
+    HHX_HIP(hipMemsetAsync(bad.p, 0, sizeof(unsigned int), g_stream));
+    i64 lines = 0;
+    for (i64 kr0 = 0; kr0 < nk;) {
+        // as many whole groups as fit CLM_CHUNK distances (at least one)
+        const i64 limit = h_eoff[(size_t)kr0] + CLM_CHUNK / 4;
+        i64 kr1 = (i64)(std::upper_bound(h_eoff.begin() + kr0 + 1, h_eoff.end(), limit) - h_eoff.begin()) - 1;
+        if (kr1 <= kr0) kr1 = kr0 + 1;
+        const i64 E = 4 * (h_eoff[(size_t)kr1] - h_eoff[(size_t)kr0]);
+        const int lbits = bits_for((u64)(4 * (kr1 - kr0)));
+        if (dbits + lbits > 64) return fail("hhx_ingest_write_clm: %d + %d key bits", dbits, lbits);
+        DevBuf<u64> keys, skeys;
+        DevBuf<i64> len, off;
+        if (keys.alloc((size_t)E) || skeys.alloc((size_t)E)) return 1;
+        k_clm_keys<<<grid_for((u64)(kr1 - kr0) * 64), 256, 0, g_stream>>>(kr0, kr1, kept_g.p, eoff.p, G.gstart.p, G.stk.p, G.sxy.p, h->t.ctg, dbits, keys.p, bad.p);
+        HHX_LAUNCH_CHECK();
+        unsigned int hb = 0;
+        HHX_HIP(hipMemcpyAsync(&hb, bad.p, sizeof hb, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));
+        if (hb) return fail("hhx_ingest_write_clm: a read position lies beyond the end of its contig");
+        HHX_TRY(stable_sort_pairs_u64(keys.p, skeys.p, nullptr, nullptr, E, dbits + lbits));
+        keys.release();
+        if (len.alloc((size_t)E + 1) || off.alloc((size_t)E + 2)) return 1;
+        k_clm_len<<<grid_for((u64)E), 256, 0, g_stream>>>(E, skeys.p, dbits, kr0, hdr_len.p, len.p);
+        HHX_LAUNCH_CHECK();
+        i64 B = 0;
+        HHX_TRY(exclusive_scan_i64(len.p, off.p, E, &B));
+        len.release();
+        DevBuf<unsigned char> text;
+        if (text.alloc((size_t)B + 16)) return 1;
+        k_clm_write<<<(unsigned)std::min<i64>((E + CW_T - 1) / CW_T, 256 * 32), CW_T, 0, g_stream>>>(E, skeys.p, dbits, kr0, kept_g.p, kept_cnt.p, G.stk.p,
+                                                                                                      d_names.p, d_noff.p, off.p, text.p);
+        HHX_LAUNCH_CHECK();
+        HHX_TRY(sink.write_device(text.p, (size_t)B));
+        lines += 4 * (kr1 - kr0);
+        kr0 = kr1;
+    }
+    if (n_lines) *n_lines = lines;
+    if (n_bytes) *n_bytes = sink.pos;
+    return sink.close();
+}
+
+extern "C" int hhx_ingest_fetch_flank_values(hhx_ingest *h, double *value) {
+    if (!h || !h->finalized) return fail("ingest handle not finalized");
+    void *val = nullptr;
+    HHX_TRY(hhx_ingest_flank_device(h, nullptr, nullptr, &val));
+    if (value && h->n_flank) HHX_HIP(hipMemcpyAsync(value, val, sizeof(double) * (size_t)h->n_flank, hipMemcpyDeviceToHost, g_stream));
     HHX_HIP(hipStreamSynchronize(g_stream));
     return 0;
 }

@@ -32,6 +32,7 @@ static __global__ __launch_bounds__(RS_T) void k_rs_hist(const u64 *__restrict__
     }
 }
 
+template <bool HAS_VAL>
 static __global__ __launch_bounds__(RS_T) void k_rs_scatter(const u64 *__restrict__ key, const u64 *__restrict__ val, i64 n, int shift, i64 n_tiles,
                                                      const i64 *__restrict__ table, u64 *__restrict__ okey, u64 *__restrict__ oval) {
     __shared__ i64 base[RS_BINS];                 // global position of the next item of every digit of this tile
@@ -48,7 +49,7 @@ static __global__ __launch_bounds__(RS_T) void k_rs_scatter(const u64 *__restric
             const i64 i = first + r * RS_T + threadIdx.x;
             const bool in = i < n;
             u64 k = 0, v = 0;
-            if (in) { k = key[i]; v = val[i]; }
+            if (in) { k = key[i]; if (HAS_VAL) v = val[i]; }
             const u32 d = (u32)(k >> shift) & (RS_BINS - 1);
             u64 peers = __ballot(in);             // lanes of this wave holding the same digit
 #pragma unroll
@@ -63,7 +64,7 @@ static __global__ __launch_bounds__(RS_T) void k_rs_scatter(const u64 *__restric
                 i64 pos = base[d] + rank;
                 for (int w = 0; w < wave; ++w) pos += wcnt[w][d];
                 okey[pos] = k;
-                oval[pos] = v;
+                if (HAS_VAL) oval[pos] = v;
             }
             __syncthreads();
             {
@@ -78,15 +79,16 @@ static __global__ __launch_bounds__(RS_T) void k_rs_scatter(const u64 *__restric
 }
 
 // kout / vout receive the pairs sorted by the low `bits` bits of the key; equal keys keep their input order.
-// kin / vin are left untouched.
+// kin / vin are left untouched.  vin == nullptr: keys only (vout is not written).
 inline int stable_sort_pairs_u64(const u64 *kin, u64 *kout, const u64 *vin, u64 *vout, i64 n, int bits) {
     if (n <= 0) return 0;
+    const bool has_val = vin != nullptr;
     const int passes = std::max(1, (bits + 7) / 8);
     const i64 n_tiles = (n + RS_TILE - 1) / RS_TILE;
     DevBuf<u64> tk, tv;
     DevBuf<i64> table, offs;
     if (table.alloc((size_t)n_tiles * RS_BINS + 1) || offs.alloc((size_t)n_tiles * RS_BINS + 2)) return 1;
-    if (passes > 1 && (tk.alloc((size_t)n) || tv.alloc((size_t)n))) return 1;
+    if (passes > 1 && (tk.alloc((size_t)n) || (has_val && tv.alloc((size_t)n)))) return 1;
     const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(n_tiles, 256 * 8));
     // ping-pong so that the LAST pass writes kout / vout
     const u64 *sk = kin, *sv = vin;
@@ -98,7 +100,8 @@ inline int stable_sort_pairs_u64(const u64 *kin, u64 *kout, const u64 *vin, u64 
         i64 total = 0;
         HHX_TRY(exclusive_scan_i64(table.p, offs.p, n_tiles * RS_BINS, &total));
         if (total != n) return fail("radix sort: histogram total %lld != %lld", (long long)total, (long long)n);
-        k_rs_scatter<<<grid, RS_T, 0, g_stream>>>(sk, sv, n, 8 * p, n_tiles, offs.p, dk, dv);
+        if (has_val) k_rs_scatter<true><<<grid, RS_T, 0, g_stream>>>(sk, sv, n, 8 * p, n_tiles, offs.p, dk, dv);
+        else k_rs_scatter<false><<<grid, RS_T, 0, g_stream>>>(sk, nullptr, n, 8 * p, n_tiles, offs.p, dk, nullptr);
         HHX_LAUNCH_CHECK();
         sk = dk; sv = dv;
     }

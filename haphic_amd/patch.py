@@ -24,6 +24,12 @@ SEAMS = {
     'normalize_by_length': ('HapHiC_cluster.py:727-738', cluster.normalize_by_length),  # a6 (dead code in the reference)
     'reduce_inter_hap_HiC_links': ('HapHiC_cluster.py:695-707', cluster.reduce_inter_hap_HiC_links),   # a6 (GFA phasing)
 }
+# f2 / f3: the two writers run() calls on the S5 containers (:2879, :2888, :2929).  They only differ from the reference's functions
+# for the array-backed containers of the S5 mirrors (haphic_amd/containers.py), so they travel with `ingest`.
+WRITERS = {
+    'output_pickle': ('HapHiC_cluster.py:710-715', cluster.output_pickle),
+    'output_clm': ('HapHiC_cluster.py:376-392', cluster.output_clm),
+}
 # S4/S5: dict_to_matrix is also called in dense mode by the filters (:603) — the mirror returns `.toarray()` then;
 # the device ingest returns all of the reference's containers (link tables, HT counts, CLM distance lists, first
 # coordinates, ctg_pair_to_frag :1731 for split contigs + --remove_allelic_links).
@@ -54,6 +60,15 @@ def _dense_dispatch(ours, original, idx):
     return seam
 
 
+def _with_original(ours, original):
+    def seam(*args):
+        return ours(*args, _original=original)
+    seam.__wrapped__ = ours
+    seam.__name__ = ours.__name__
+    seam.__doc__ = ours.__doc__
+    return seam
+
+
 def patch_reference(H, ingest=True, matrix_build=True):
     """H: the imported reference module (HapHiC_cluster).  Returns {name: original} so the caller can undo."""
     from . import _lib
@@ -68,8 +83,11 @@ def patch_reference(H, ingest=True, matrix_build=True):
         seams['pairs_generator'] = OPTIONAL['pairs_generator']                # a1: only together with S5, which consumes it
         seams['pairs_generator_inter_ctgs'] = OPTIONAL['pairs_generator_inter_ctgs']
         seams['bam_generator'] = OPTIONAL['bam_generator']                    # f4: consumed by the same S5 mirrors
+        seams.update(WRITERS)
     for name, (_cite, fn) in seams.items():
         saved[name] = getattr(H, name, None)
+        if name in WRITERS:
+            fn = _with_original(fn, saved[name])
         setattr(H, name, _dense_dispatch(fn, saved[name], DENSE_ARG[name]) if name in DENSE_ARG else fn)
     saved['INTEL_MKL'] = getattr(H, 'INTEL_MKL', None)
     H.INTEL_MKL = True                   # :2764-2768 would otherwise force the dense (numpy) mode

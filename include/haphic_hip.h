@@ -428,6 +428,27 @@ int hhx_ingest_table_device(hhx_ingest *h, int which, int64_t *n_rows, void **de
 int hhx_ingest_push_table(hhx_ingest *h, int which, int64_t n_rows, const uint64_t *dev_key, const uint64_t *dev_ord_full,
                           const uint64_t *dev_ord_flank, const uint32_t *dev_ht, const uint32_t *dev_flank);
 
+
+/* ---------------------------------------------------------------- the files run() writes from the S5 containers (:2879-2929)
+ * With the link tables held as arrays (haphic_amd/containers.py) the reference's writers have array forms:
+ *
+ * output_clm :376-392 — paired_links.clm from the read pairs kept in HBM (hhx_ingest_keep_pairs): for every contig pair with at
+ * least two read pairs (:385), in full_link_dict order, four lines "{ctg_i}{+|-} {ctg_j}{+|-}\t{2 * links}\t{d d d d ...}\n",
+ * the distances of update_clm_dict :395-401 for that orientation ascending, each written twice (:388).  Grouping, sorting and
+ * the text are made on the device; contig names = UTF-8 bytes back to back (host), name k = [name_off[k], name_off[k + 1]).
+ * Returns the numbers of lines and bytes written.  Fails (and leaves a partial file) if a read position lies beyond its contig. */
+int hhx_ingest_write_clm(hhx_ingest *h, const char *path, const uint8_t *names_blob, const int64_t *name_off, int64_t *n_lines,
+                         int64_t *n_bytes);
+/* the float64 values of the flank table in dict order (host buffer [n_flank_keys]): the counts, or what hhx_link_weights
+ * (on_device, over hhx_ingest_flank_device's arrays) left there — normalize_by_nlinks :718-724 on the resident table */
+int hhx_ingest_fetch_flank_values(hhx_ingest *h, double *value);
+/* output_pickle :710-715 for a link dict given as arrays — full_links.pkl, HT_links.pkl: a protocol-4 pickle of
+ * `collections.defaultdict(int)` {(names[name_i[k]], names[name_j[k]]): count[k]}, keys in array order (= dict insertion order),
+ * written by host code without a Python object per key; names as for hhx_ingest_write_clm.  pickle.load gives the dict the
+ * reference's loops :1605-1615 build.  All pointers host. */
+int hhx_write_link_pickle(const char *path, int64_t n_keys, const int32_t *name_i, const int32_t *name_j, const int64_t *count,
+                          int32_t n_names, const uint8_t *names_blob, const int64_t *name_off, int64_t *n_bytes);
+
 #ifdef __cplusplus
 }
 #endif

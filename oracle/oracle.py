@@ -500,3 +500,30 @@ def group_link_sums(fi, fj, links, group, n_groups):
                 if first[row, g] < 0:
                     first[row, g] = 2 * k + side
     return sums, first
+
+
+def clm_text(names, full_i, full_j, clm_ptr, clm):
+    """output_clm (scripts/HapHiC_cluster.py:376-392) on the arrays of ingest(want_clm=True): the bytes of paired_links.clm.
+    clm_ptr[k] .. clm_ptr[k + 1] delimit the VALUES (four per read pair, update_clm_dict :395-401) of contig pair k in dict order.
+    Pure-Python restatement, small inputs only."""
+    ori = (('+', '+'), ('+', '-'), ('-', '+'), ('-', '-'))                                     # :380
+    out = []
+    for k, (a, b) in enumerate(zip(np.asarray(full_i).tolist(), np.asarray(full_j).tolist())):
+        list_ = np.asarray(clm[clm_ptr[k]:clm_ptr[k + 1]]).tolist()
+        if len(list_) < 8:                                                                     # :385
+            continue
+        for n in range(4):
+            new_list = ['{0} {0}'.format(v) for v in sorted(list_[n::4])]                      # :388
+            out.append('{}{} {}{}\t{}\t{}\n'.format(names[a], ori[n][0], names[b], ori[n][1], len(new_list) * 2, ' '.join(new_list)))
+    return ''.join(out).encode()
+
+
+def link_pickle(names, fi, fj, count):
+    """output_pickle (scripts/HapHiC_cluster.py:710-715) of a link dict given as arrays: pickle.dumps of the defaultdict(int) the
+    reference's loops build (:1605 :1615), keys in array order."""
+    import pickle
+    from collections import defaultdict
+    d = defaultdict(int)
+    for a, b, c in zip(np.asarray(fi).tolist(), np.asarray(fj).tolist(), np.asarray(count).tolist()):
+        d[(names[a], names[b])] = c
+    return pickle.dumps(d)

@@ -174,6 +174,13 @@ def link_weights(frag_i, frag_j, value, mode, n_frag, per_frag=None, tag=None, p
     return zeros
 
 
+def write_link_pickle(path, i, j, count, names):
+    data = orc.link_pickle(names, i, j, count)
+    with open(path, 'wb') as f:
+        f.write(data)
+    return len(data)
+
+
 def group_link_sums(frag_i, frag_j, links, group, n_groups):
     return orc.group_link_sums(frag_i, frag_j, links, group, n_groups)
 
@@ -225,6 +232,7 @@ class Ingest:
         self.pairs = self.frag = False
         self.n_frag = table.n_frag
         self.out = None
+        self.weights = None
 
     def keep_pairs(self, on=True):
         self.pairs = bool(on)
@@ -251,12 +259,40 @@ class Ingest:
         self.fetch()
         return self.n_full, self.n_flank
 
-    def fetch(self, max_read_pairs=0):
+    def fetch(self, max_read_pairs=0, want=None):
         a = self._stream()
         self.out = orc.ingest(self.t, a[0].astype(np.int32), a[1], a[2].astype(np.int32), a[3], self.flank, bins=self.bins,
                               want_clm=self.pairs, max_read_pairs=max_read_pairs)
         self.n_full, self.n_flank = len(self.out['full_i']), len(self.out['flank_i'])
-        return self.out
+        return self.out if want is None else {k: self.out[k] for k in want}
+
+    def fetch_flank_values(self):
+        o = self.out if self.out is not None else self.fetch()
+        return self.weights.copy() if self.weights is not None else o['flank_cnt'].astype(np.float64)
+
+    def weigh_flank(self, mode, per_frag=None, tag=None, param=0.0):
+        o = self.out if self.out is not None else self.fetch()
+        self.weights = self.fetch_flank_values()
+        return link_weights(o['flank_i'], o['flank_j'], self.weights, mode, self.n_frag, per_frag=per_frag, tag=tag, param=param)
+
+    def link_matrix(self, in_set, n_rest=-1, add_self_loops=True, weighted=False):
+        o = self.out if self.out is not None else self.fetch()
+        assert weighted == (self.weights is not None)
+        in_set = np.ascontiguousarray(in_set, np.uint8)
+        if n_rest < 0:
+            ok = in_set[o['flank_i']].astype(bool) & in_set[o['flank_j']].astype(bool)
+            linked = np.zeros(len(in_set), bool)
+            linked[o['flank_i'][ok]] = True
+            linked[o['flank_j'][ok]] = True
+            n_rest = int(in_set.sum() - linked.sum())
+        return dict_to_matrix(o['flank_i'], o['flank_j'], self.fetch_flank_values(), self.n_frag, in_set, n_rest, add_self_loops)
+
+    def write_clm(self, path, ctg_names):
+        o = self.fetch()
+        text = orc.clm_text(ctg_names, o['full_i'], o['full_j'], o['clm_ptr'], o['clm'])
+        with open(path, 'wb') as f:
+            f.write(text)
+        return text.count(b'\n'), len(text)
 
     def fetch_pairs(self, max_read_pairs, full_cnt):
         o = self.fetch(max_read_pairs)
