@@ -54,6 +54,8 @@ def parse():
     ap.add_argument('--sweep', type=int, default=20, help='after the timed region: the inflation sweep of run_mcl_clustering :2155-2158 (1.1, 1.2, ... this many '
                     'values) with ONE expansion — iteration 0 of every inflation from the dense row blocks of M^2 (0 = skip)')
     ap.add_argument('--sweep-tail-seconds', type=float, default=20.0, help='sweep leg: wall-time budget for the mcl() tails (run from the highest inflation down)')
+    ap.add_argument('--no-seam', action='store_true', help='skip the seam_e2e leg (the reference\'s own operator sequence S5 -> filter_fragments -> S4 on host id arrays, after the timed region)')
+    ap.add_argument('--no-seam-files', action='store_true', help='seam_e2e: skip the three files run() writes between S5 and S4 (HT_links.pkl, paired_links.clm, full_links.pkl)')
     ap.add_argument('--transport', choices=('rccl', 'host'), default='rccl',
                     help='rccl: one rank per GPU over RCCL / xGMI (the product path).  host: the same ranks and the same exchanges, every collective '
                          'staged through host memory over gloo (haphic_amd.host_transport) — runs N ranks on ONE GPU, a functional proof of '
@@ -290,7 +292,7 @@ def main():
                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
                'dtype': 'u64 keys + u32 counts (ingest); f32 values, exact u64 fixed-point accumulation (MCL)',
                'data': 'synthetic',
-               'config': {'workload': '%d contigs / %d pairs (whole job, %d per GPU), %d chr, mean contig %d bp, inflation %.1f, dense-block off'
+               'config': {'workload': '%d contigs / %d pairs (whole job, %d per GPU), %d chr, mean contig %d bp, inflation %.1f, no MFMA dense-block expansion (iteration 0 accumulates M^2 into a dense float32 block in HBM)'
                                       % (n, local_pairs * world, local_pairs, args.nchrs, args.mean_len, args.inflation),
                           'contigs': int(n), 'pairs_per_gpu': local_pairs, 'full_keys': int(state['n_full']),
                           'flank_keys': int(state['n_flank']), 'link_matrix_nnz': int(state['nnz_link'])},
@@ -308,6 +310,11 @@ def main():
             out['parity'] = parity_leg(args, state.pop('matrix'))
         elif state.get('matrix') is not None:
             state.pop('matrix').free()
+        if world == 1 and not sharded_path and not args.no_seam:
+            try:
+                out['seam_e2e'] = seam_leg(args, gen, id1, p1, id2, p2)
+            except Exception as e:                       # noqa: BLE001 — a leg after the timed region must never take the line down
+                out['seam_e2e'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
         if not args.no_cpu_baseline and world == 1:          # a reported baseline of the N = 1 line only
             out['cpu_baseline'] = cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state)
         final_out = out
@@ -431,6 +438,113 @@ def text_leg(args, gen, id1, p1, id2, p2, dev):
         assert np.array_equal(out[c].reshape(args.text_tile, k), np.broadcast_to(h[c], (args.text_tile, k))), 'text leg mismatch'
     ps.destroy()
     return res
+
+
+def seam_leg(args, gen, id1, p1, id2, p2):
+    """The drop-in as run() :2869-2935 drives it, through the reference's own operator API (the mirrors of haphic_amd/cluster.py
+    that patch_reference binds over HapHiC_cluster): the read pairs as HOST id arrays (what a generator hands over; PCIe included)
+    -> parse_alignments_for_ctgs (S5: the six containers, CLM side records kept) -> filter_fragments (f1, the reference's default
+    thresholds) -> dict_to_matrix (S4), and beside it the three files run() writes on the way (HT_links.pkl :2879, paired_links.clm
+    :2888, full_links.pkl :2929).  The containers are array-backed (haphic_amd/containers.py): no Python object per key."""
+    import shutil
+    import tempfile
+    import types
+    import torch
+    from haphic_amd import _lib, cluster
+    t_prep = time.perf_counter()
+    host = [a.cpu().numpy() for a in (id1, p1, id2, p2)]
+    names = list(gen.names)
+    lengths = gen.length.tolist()
+    fa_dict = {nm: [None, int(ln), int(ln) // 256 + 1] for nm, ln in zip(names, lengths)}      # GATC density of uniform ACGT (SURVEY §8d)
+    ctg_len_dict = {nm: v[1] for nm, v in fa_dict.items()}
+    re_dict = {nm: v[2] for nm, v in fa_dict.items()}
+    nx = set(names)
+    aln = cluster.IdArrays(names, *host)
+    aln.inter_only = True                       # pairs_generator_inter_ctgs :1582: ref == mref never reaches the loop
+    a = types.SimpleNamespace(flank=500, remove_allelic_links=0, remove_concentrated_links=False, max_read_pairs=200, nwindows=50)
+    prep_s = time.perf_counter() - t_prep
+    P = len(aln)
+    import logging
+    lg = logging.getLogger('HapHiC_cluster')
+    level = lg.level
+    lg.setLevel(logging.WARNING)
+    sync = lambda: _lib.check(_lib.load().hhx_synchronize())            # noqa: E731
+    files = None
+    try:
+        t0 = time.perf_counter()
+        full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(aln, fa_dict, a, ctg_len_dict, nx, 'int32', 'int32')
+        sync()
+        t1 = time.perf_counter()
+        kept = cluster.filter_fragments(nx, re_dict, 5, frag_link, '0.2X', '1.9X', 10, '1.5X', 0, flank, {}, '1.5X', set())
+        sync()
+        t2 = time.perf_counter()
+        m, idx = cluster.dict_to_matrix(flank, kept, dense_matrix=False, add_self_loops=True)
+        sync()
+        t3 = time.perf_counter()
+        frozen = all(c.frozen for c in (full, flank, HT, clm))
+        dev = m.take_device()
+        shape = dev.shape3
+        dev.free()
+        out = {'pairs': P, 'pairs_per_s': P / (t3 - t0), 'seconds': t3 - t0,
+               's5_parse_alignments_for_ctgs_s': t1 - t0, 'filter_fragments_s': t2 - t1, 'dict_to_matrix_s': t3 - t2,
+               'fragments_kept': len(kept), 'matrix_order': int(shape[0]), 'matrix_nnz': int(shape[2]), 'containers_still_frozen': frozen,
+               'host_prep_s_untimed': prep_s,
+               'what': 'cluster.parse_alignments_for_ctgs(IdArrays on the HOST, all %d pairs, CLM / HT side records on) -> cluster.filter_fragments '
+                       '(reference defaults) -> cluster.dict_to_matrix(add_self_loops): the seam sequence of run() :2869-2935 as patch_reference binds it; '
+                       'wall clock, PCIe included' % P}
+        if not args.no_seam_files:
+            # where the three files go: a RAM disk when it has the room (the pipeline, not the box's disk, is what is measured; said so)
+            need = 60 * P                       # ~40 B of CLM text + ~14 B of pickles per pair, with margin
+            where = None
+            for cand in ('/dev/shm', tempfile.gettempdir()):
+                try:
+                    if shutil.disk_usage(cand).free > need + (4 << 30):
+                        where = cand
+                        break
+                except OSError:
+                    pass
+            if where is None:
+                out['files'] = {'skipped': 'no directory with %.0f GB free' % (need / 1e9)}
+            else:
+                d = tempfile.mkdtemp(prefix='hhx_seam_', dir=where)
+                cwd = os.getcwd()
+                os.chdir(d)
+                try:
+                    f0 = time.perf_counter()
+                    cluster.output_pickle(HT, 'HT_link_dict', 'HT_links.pkl')
+                    f1 = time.perf_counter()
+                    cluster.output_clm(clm)
+                    f2 = time.perf_counter()
+                    cluster.output_pickle(full, 'full_link_dict', 'full_links.pkl')
+                    f3 = time.perf_counter()
+                    size = {f: os.path.getsize(f) for f in ('HT_links.pkl', 'paired_links.clm', 'full_links.pkl')}
+                    files = {'directory': where, 'HT_links_pkl_s': f1 - f0, 'paired_links_clm_s': f2 - f1, 'full_links_pkl_s': f3 - f2, 'bytes': size,
+                             'HT_keys': len(HT), 'full_keys': len(full), 'clm_GBs': size['paired_links.clm'] / (f2 - f1) / 1e9,
+                             'containers_still_frozen': all(c.frozen for c in (full, flank, HT, clm))}
+                    out['files'] = files
+                    out['run_shaped_pairs_per_s'] = P / ((t3 - t0) + (f3 - f0))
+                    out['run_shaped_seconds'] = (t3 - t0) + (f3 - f0)
+                finally:
+                    os.chdir(cwd)
+                    shutil.rmtree(d, ignore_errors=True)
+        del full, flank, HT, clm, coord, frag_link
+        # what the generic dict path costs when something thaws a table (remove_allelic_HiC_links, --remove_concentrated_links, user
+        # code): measured on a 20 M-pair prefix of the stream — thawing is linear in the keys, and 1.2e8 tuples would take ~25 GB of host RAM
+        small = cluster.IdArrays(names, *[h[:20_000_000] for h in host])
+        small.inter_only = True
+        full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(small, fa_dict, a, ctg_len_dict, nx, 'int32', 'int32')
+        th0 = time.perf_counter()
+        n_keys = len(flank) + len(full)
+        flank._thaw()
+        full._thaw()
+        th = time.perf_counter() - th0
+        out['thaw'] = {'keys': n_keys, 'seconds': th, 'keys_per_s': n_keys / th if th else None, 'sample_pairs': len(small),
+                       'what': 'full_link_dict + flank_link_dict of a 20 M-pair prefix turned into real dicts (dict.update(zip(...)) at C speed)'}
+        del full, flank, HT, clm, coord
+        return out
+    finally:
+        lg.setLevel(level)
+        torch.cuda.empty_cache()
 
 
 def sweep_leg(args, m, one_mcl_s):

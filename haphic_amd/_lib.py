@@ -135,6 +135,7 @@ SIGNATURES = {
     'hhx_ingest_table_device': (C.c_int, [C.c_void_p, C.c_int, c_i64p, c_vpp, c_vpp, c_vpp, c_vpp, c_vpp]),
     'hhx_ingest_push_table': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'hhx_ingest_fetch_flank_values': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'hhx_ingest_fetch_ht_items': (C.c_int, [C.c_void_p, c_i64p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'hhx_ingest_write_clm': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, c_i64p, c_i64p]),
     'hhx_write_link_pickle': (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, c_i64p]),
 }
@@ -834,6 +835,20 @@ class Ingest:
         first = np.full((max(self.n_full, 1), 4), np.iinfo(np.int64).max, np.int64)
         check(load().hhx_ingest_fetch_ht_order(self.h, ptr(first)))
         return first[:self.n_full]
+
+    def fetch_ht_items(self):
+        """HT_link_dict in insertion order: (name_i, name_j, count) with name ids 2 * contig + (1 for '_T'); ordered on the device"""
+        n = C.c_int64(0)
+        check(load().hhx_ingest_fetch_ht_items(self.h, C.byref(n), None, None, None))
+        ni, nj, cnt = np.empty(n.value, np.int32), np.empty(n.value, np.int32), np.empty(n.value, np.int64)
+        if n.value:
+            check(load().hhx_ingest_fetch_ht_items(self.h, C.byref(n), ptr(ni), ptr(nj), ptr(cnt)))
+        return ni, nj, cnt
+
+    def n_ht_items(self):
+        n = C.c_int64(0)
+        check(load().hhx_ingest_fetch_ht_items(self.h, C.byref(n), None, None, None))
+        return n.value
 
     def keep_frag_pairs(self, on=True):
         check(load().hhx_ingest_keep_frag_pairs(self.h, int(on)))

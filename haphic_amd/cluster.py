@@ -1029,6 +1029,8 @@ class IdArrays:
     positions — accepted wherever the S5 mirrors take the reference's (ref, mref, pos, mpos) iterator (:1539-1593); iterating
     yields those tuples.  The arrays go to the device ingest as they are, without a pass through Python objects."""
 
+    inter_only = False          # True: the stream stands for pairs_generator_inter_ctgs :1562-1583 (ref == mref is dropped on the device)
+
     def __init__(self, names, id1, pos1, id2, pos2):
         self.names = list(names)
         self.id1, self.id2 = np.ascontiguousarray(id1, np.int32), np.ascontiguousarray(id2, np.int32)
@@ -1073,7 +1075,7 @@ def _ingest_handle(alignments, table, flank, bins, chunk=1 << 22, want_pairs=Fal
     ends of this package) through the device ingest; returns the finalized handle (_lib.Ingest), tables resident in HBM."""
     text = isinstance(alignments, PairsText)
     bam = isinstance(alignments, BamRecords)
-    ing = _lib.Ingest(table, flank, bins=bins, skip_intra=(text or bam) and alignments.inter_only)      # :1582 / refid != mrefid
+    ing = _lib.Ingest(table, flank, bins=bins, skip_intra=bool(getattr(alignments, 'inter_only', False)))      # :1582 / refid != mrefid
     try:
         if want_pairs:
             ing.keep_pairs()
@@ -1092,8 +1094,9 @@ def _ingest_handle(alignments, table, flank, bins, chunk=1 << 22, want_pairs=Fal
             pos_t = np.int64 if table.wide else np.int32
             if len(alignments) and max(int(alignments.pos1.max()), int(alignments.pos2.max())) >= np.iinfo(pos_t).max:
                 raise RuntimeError('a position does not fit the {} coordinates of the MI355X ingest'.format(pos_t.__name__))
-            for lo in range(0, len(alignments), chunk):
-                hi = min(len(alignments), lo + chunk)
+            step = max(chunk, 1 << 28)       # whole arrays are at hand: few, large pushes (every push is one aggregated run to merge)
+            for lo in range(0, len(alignments), step):
+                hi = min(len(alignments), lo + step)
                 ing.push(alignments.id1[lo:hi], alignments.pos1[lo:hi].astype(pos_t, copy=False), alignments.id2[lo:hi],
                          alignments.pos2[lo:hi].astype(pos_t, copy=False), wide=table.wide)
         else:
@@ -1179,7 +1182,7 @@ class IngestSession:
 
     def n_keys(self, kind):
         if kind == 'HT':
-            return int(np.count_nonzero(self._fetch('ht_cnt')[0]))
+            return len(self._host['ht_items'][0]) if 'ht_items' in self._host else self.ing.n_ht_items()
         return self.ing.n_full if kind == 'full' else self.ing.n_flank
 
     def link_arrays(self, kind):
@@ -1193,19 +1196,12 @@ class IngestSession:
                 return fi, fj, self._host['flank_val'], self.table.frag_names
             return fi, fj, self._fetch('flank_cnt')[0], self.table.frag_names
         # HT_link_dict: the (contig pair, quadrant) entries in the order of the stream position of their first read pair
-        # (update_HT_link_dict :404-416); names carry the '_H' / '_T' suffix of the quadrant's two ends
-        fi, fj, ht_cnt = self._fetch('full_i', 'full_j', 'ht_cnt')
-        k, q = np.nonzero(ht_cnt)
-        order = np.argsort(self.ht_first()[k, q], kind='stable')
-        k, q = k[order], q[order]
+        # (update_HT_link_dict :404-416), ordered on the device; names carry the '_H' / '_T' suffix of the quadrant's two ends
+        if 'ht_items' not in self._host:
+            self._host['ht_items'] = self.ing.fetch_ht_items()
         if self._ht_names is None:
             self._ht_names = [n + s for n in self.table.ctg_names for s in ('_H', '_T')]
-        return 2 * fi[k] + (q >> 1).astype(np.int32), 2 * fj[k] + (q & 1).astype(np.int32), ht_cnt[k, q], self._ht_names
-
-    def ht_first(self):
-        if 'ht_first' not in self._host:
-            self._host['ht_first'] = self.ing.fetch_ht_order()
-        return self._host['ht_first']
+        return (*self._host['ht_items'], self._ht_names)
 
     def pairs(self):
         """(clm_ptr, clm, crd_ptr, crd): hhx_ingest_fetch_pairs, lists in full_link_dict order"""

@@ -63,11 +63,18 @@ class _Frozen(defaultdict):
     def _thaw(self):
         if type(self) is Thawed:
             return
+        import gc
         items = self._source_items()
         session = self._session
         self.__dict__.clear()
         self.__class__ = Thawed
-        dict.update(self, items)
+        collect = gc.isenabled()
+        gc.disable()                      # millions of fresh tuples: the generational collector would walk them again and again
+        try:
+            dict.update(self, items)
+        finally:
+            if collect:
+                gc.enable()
         session.note_thawed()
 
     # answered from the arrays

@@ -280,14 +280,13 @@ extern "C" int hhx_ingest_fetch_pairs(hhx_ingest *h, i64 max_read_pairs, i64 *cl
 // (INT64_MAX: that quadrant never occurred).  Positions count the pairs that entered full_link_dict, in stream order, so
 // sorting the non-empty (pair, quadrant) entries by them gives the dict order.  Same grouping as hhx_ingest_fetch_pairs
 // (stable sort of the kept pairs by key), with the stream position carried as the sorted value.
-extern "C" int hhx_ingest_fetch_ht_order(hhx_ingest *h, i64 *first) {
+static int ht_first_device(hhx_ingest *h, DevBuf<i64> &d_first, const char *who) {
     if (!h || !h->finalized) return fail("ingest handle not finalized");
-    if (!h->keep_pairs) return fail("hhx_ingest_fetch_ht_order: the handle was not created with hhx_ingest_keep_pairs");
+    if (!h->keep_pairs) return fail("%s: the handle was not created with hhx_ingest_keep_pairs", who);
     const i32 *fi = nullptr, *fj = nullptr;
     HHX_TRY(hhx_ingest_ordered_full_device(h, &fi, &fj));
     const i64 K = h->n_full, N = h->n_side;
     if (K == 0) return 0;
-    if (!first) return fail("hhx_ingest_fetch_ht_order: null output");
     DevBuf<u64> key, xy, skey, idx, sidx, tkey, trnk, stk, srank;
     if (key.alloc((size_t)N) || xy.alloc((size_t)N) || skey.alloc((size_t)N) || idx.alloc((size_t)N) || sidx.alloc((size_t)N) || tkey.alloc((size_t)K) ||
         trnk.alloc((size_t)K) || stk.alloc((size_t)K) || srank.alloc((size_t)K)) return 1;
@@ -306,21 +305,95 @@ extern "C" int hhx_ingest_fetch_ht_order(hhx_ingest *h, i64 *first) {
     k_table_keys<<<grid_for((u64)K), 256, 0, g_stream>>>(K, fi, fj, tkey.p, trnk.p);
     HHX_LAUNCH_CHECK();
     HHX_TRY(sort_pairs_u64(tkey.p, stk.p, trnk.p, srank.p, K));
-    DevBuf<i64> flag, gidx, gstart, d_first;
+    DevBuf<i64> flag, gidx, gstart;
     if (flag.alloc((size_t)N + 1) || gidx.alloc((size_t)N + 2) || gstart.alloc((size_t)K + 2) || d_first.alloc((size_t)K * 4)) return 1;
     k_boundary_flags<<<grid_for((u64)N), 256, 0, g_stream>>>(N, skey.p, flag.p);
     HHX_LAUNCH_CHECK();
     i64 n_groups = 0;
     HHX_TRY(exclusive_scan_i64(flag.p, gidx.p, N, &n_groups));
-    if (n_groups != K) return fail("hhx_ingest_fetch_ht_order: %lld contig pairs in the records, %lld in the table", (long long)n_groups, (long long)K);
+    if (n_groups != K) return fail("%s: %lld contig pairs in the records, %lld in the table", who, (long long)n_groups, (long long)K);
     k_group_starts<<<grid_for((u64)N), 256, 0, g_stream>>>(N, skey.p, gidx.p, gstart.p);
     HHX_HIP(hipMemcpyAsync(gstart.p + K, &N, sizeof(i64), hipMemcpyHostToDevice, g_stream));
     k_ht_first<<<grid_for((u64)K * 64), 256, 0, g_stream>>>(K, stk.p, gstart.p, srank.p, sidx.p, xy.p, h->t.ctg, d_first.p);
     HHX_LAUNCH_CHECK();
-    HHX_HIP(hipMemcpyAsync(first, d_first.p, sizeof(i64) * (size_t)K * 4, hipMemcpyDeviceToHost, g_stream));
     HHX_HIP(hipStreamSynchronize(g_stream));
     return 0;
 }
+
+extern "C" int hhx_ingest_fetch_ht_order(hhx_ingest *h, i64 *first) {
+    DevBuf<i64> d_first;
+    HHX_TRY(ht_first_device(h, d_first, "hhx_ingest_fetch_ht_order"));
+    if (h->n_full == 0) return 0;
+    if (!first) return fail("hhx_ingest_fetch_ht_order: null output");
+    HHX_HIP(hipMemcpyAsync(first, d_first.p, sizeof(i64) * (size_t)h->n_full * 4, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+// HT_link_dict as items in insertion order: entry e = (contig pair k, quadrant q) with a non-zero count, sorted by the stream
+// position of its first read pair; name ids are 2 * contig + (1 if that end is the tail '_T'), i.e. indices into
+// [c0_H, c0_T, c1_H, c1_T, ...].  name_i == nullptr: only the number of items.
+namespace {
+__global__ __launch_bounds__(256) void k_ht_flag(i64 n, const i64 *__restrict__ ht, i64 *__restrict__ flag) {
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (i64)gridDim.x * blockDim.x) flag[e] = ht[e] != 0 ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_ht_compact(i64 n, const i64 *__restrict__ ht, const i64 *__restrict__ pos, const i64 *__restrict__ first,
+                                                    u64 *__restrict__ key, u64 *__restrict__ val) {
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (i64)gridDim.x * blockDim.x)
+        if (ht[e] != 0) { key[pos[e]] = (u64)first[e]; val[pos[e]] = (u64)e; }
+}
+__global__ __launch_bounds__(256) void k_ht_items(i64 n, const u64 *__restrict__ sval, const i32 *__restrict__ fi, const i32 *__restrict__ fj,
+                                                  const i64 *__restrict__ ht, i32 *__restrict__ ni, i32 *__restrict__ nj, i64 *__restrict__ cnt) {
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        const i64 e = (i64)sval[t], k = e >> 2;
+        const int q = (int)(e & 3);
+        ni[t] = 2 * fi[k] + (q >> 1);
+        nj[t] = 2 * fj[k] + (q & 1);
+        cnt[t] = ht[e];
+    }
+}
+}  // namespace
+
+extern "C" int hhx_ingest_fetch_ht_items(hhx_ingest *h, int64_t *n_items, int32_t *name_i, int32_t *name_j, int64_t *count) {
+    if (!h || !h->finalized) return fail("ingest handle not finalized");
+    if (!n_items) return fail("hhx_ingest_fetch_ht_items: null pointer");
+    const i32 *fi = nullptr, *fj = nullptr;
+    HHX_TRY(hhx_ingest_ordered_full_device(h, &fi, &fj));
+    const i64 K = h->n_full, E = 4 * K;
+    *n_items = 0;
+    if (K == 0) return 0;
+    const i64 *ht = h->ordered.ht.p;
+    DevBuf<i64> flag, pos;
+    if (flag.alloc((size_t)E + 1) || pos.alloc((size_t)E + 2)) return 1;
+    k_ht_flag<<<grid_for((u64)E), 256, 0, g_stream>>>(E, ht, flag.p);
+    HHX_LAUNCH_CHECK();
+    i64 n = 0;
+    HHX_TRY(exclusive_scan_i64(flag.p, pos.p, E, &n));
+    *n_items = n;
+    if (!name_i || !name_j || !count || n == 0) return 0;
+    flag.release();
+    DevBuf<i64> d_first;
+    HHX_TRY(ht_first_device(h, d_first, "hhx_ingest_fetch_ht_items"));
+    DevBuf<u64> key, val, skey, sval;
+    if (key.alloc((size_t)n) || val.alloc((size_t)n) || skey.alloc((size_t)n) || sval.alloc((size_t)n)) return 1;
+    k_ht_compact<<<grid_for((u64)E), 256, 0, g_stream>>>(E, ht, pos.p, d_first.p, key.p, val.p);
+    HHX_LAUNCH_CHECK();
+    int bits = 1;
+    while (bits < 63 && ((u64)h->n_side >> bits)) ++bits;
+    HHX_TRY(stable_sort_pairs_u64(key.p, skey.p, val.p, sval.p, n, bits));
+    key.release(); val.release(); skey.release(); d_first.release(); pos.release();
+    DevBuf<i32> ni, nj;
+    DevBuf<i64> cnt;
+    if (ni.alloc((size_t)n) || nj.alloc((size_t)n) || cnt.alloc((size_t)n)) return 1;
+    k_ht_items<<<grid_for((u64)n), 256, 0, g_stream>>>(n, sval.p, fi, fj, ht, ni.p, nj.p, cnt.p);
+    HHX_LAUNCH_CHECK();
+    HHX_HIP(hipMemcpyAsync(name_i, ni.p, sizeof(i32) * (size_t)n, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipMemcpyAsync(name_j, nj.p, sizeof(i32) * (size_t)n, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipMemcpyAsync(count, cnt.p, sizeof(i64) * (size_t)n, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
 
 // ================================================================================================ paired_links.clm
 // output_clm :376-392 on the device.  For every contig pair with at least two read pairs (`len(list_) < 8: continue`), in

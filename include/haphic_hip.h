@@ -439,6 +439,11 @@ int hhx_ingest_push_table(hhx_ingest *h, int which, int64_t n_rows, const uint64
  * Returns the numbers of lines and bytes written.  Fails (and leaves a partial file) if a read position lies beyond its contig. */
 int hhx_ingest_write_clm(hhx_ingest *h, const char *path, const uint8_t *names_blob, const int64_t *name_off, int64_t *n_lines,
                          int64_t *n_bytes);
+/* HT_link_dict (update_HT_link_dict :404-416) as items in dict insertion order, sorted on the device: item t = the t-th (contig
+ * pair, quadrant) entry to enter the dict, i.e. ordered by the stream position of its first read pair (hhx_ingest_fetch_ht_order);
+ * name_i / name_j = 2 * contig id + (1 if that end is '_T', 0 for '_H'), count = its links.  *n_items is always set; the arrays
+ * (host, [*n_items] from a first call with null arrays) are optional.  Needs hhx_ingest_keep_pairs. */
+int hhx_ingest_fetch_ht_items(hhx_ingest *h, int64_t *n_items, int32_t *name_i, int32_t *name_j, int64_t *count);
 /* the float64 values of the flank table in dict order (host buffer [n_flank_keys]): the counts, or what hhx_link_weights
  * (on_device, over hhx_ingest_flank_device's arrays) left there — normalize_by_nlinks :718-724 on the resident table */
 int hhx_ingest_fetch_flank_values(hhx_ingest *h, double *value);

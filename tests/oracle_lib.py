@@ -304,6 +304,18 @@ class Ingest:
         o = self.out if self.out is not None else self.fetch()
         return orc.ht_first(self.t, a[0], a[1], a[2], a[3], o['full_i'], o['full_j'])
 
+    def fetch_ht_items(self):
+        o = self.out if self.out is not None else self.fetch()
+        first = self.fetch_ht_order()
+        k, q = np.nonzero(o['ht_cnt'])
+        order = np.argsort(first[k, q], kind='stable')
+        k, q = k[order], q[order]
+        return (2 * o['full_i'][k] + (q >> 1)).astype(np.int32), (2 * o['full_j'][k] + (q & 1)).astype(np.int32), o['ht_cnt'][k, q]
+
+    def n_ht_items(self):
+        o = self.out if self.out is not None else self.fetch()
+        return int(np.count_nonzero(o['ht_cnt']))
+
     def fetch_frag_pairs(self):
         a = self._stream()
         return orc.frag_pairs(self.t, a[0], a[1], a[2], a[3])

@@ -160,11 +160,28 @@ def test_reference_run_with_and_without_the_seams(tmp_path, monkeypatch, split, 
     saved = patch.patch_reference(H)
     h_ours = Collect(seen['ours'])
     H.logger.addHandler(h_ours)
+    # which of the array-backed S5 containers (haphic_amd/containers.py) had to become real dicts during run()
+    from haphic_amd import containers
+    thawed = []
+    real_thaw = containers._Frozen._thaw
+    monkeypatch.setattr(containers._Frozen, '_thaw', lambda self: (thawed.append(self._kind), real_thaw(self))[1])
     try:
         _run(H, str(tmp_path / 'ours'), extra, pairs, nchrs)
     finally:
         H.logger.removeHandler(h_ours)
         patch.unpatch_reference(H, saved)
+    # run() itself never needs a Python object per key: with the default options the seams (output_pickle, output_clm, normalize_by_nlinks,
+    # filter_fragments, dict_to_matrix) work on the arrays.  What thaws a table is the reference's own dict code: remove_allelic_HiC_links
+    # :474-689 (full, flank, the coordinate lists), the --remove_concentrated_links loop :2899-2902, output_statistics :2279 (full, after
+    # the clustering)
+    expected = set()
+    if '--remove_allelic_links' in extra:
+        expected |= {'full', 'flank', 'crd'}
+    if '--remove_concentrated_links' in extra:
+        expected |= {'full', 'crd'}
+    if '--quick_view' not in extra and '--skip_clustering' not in extra:
+        expected |= {'full'}
+    assert set(thawed) == expected, (thawed, expected)
     # the log is an interface (users read it, HapHiC_pipeline.py:385 parses it): every message of the filtering and
     # clustering stages must come out of the mirrors word for word, in the same order (timings aside)
     def stable(msgs):

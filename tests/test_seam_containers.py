@@ -272,6 +272,15 @@ def test_device_clm_and_pickles_against_the_oracle(tmp_path):
     assert nbytes == len(got) and lines == got.count(b'\n')
     assert got == text
     out = ing.fetch()
+    # HT_link_dict's items, ordered on the device, against the host ordering of the stream positions
+    ni, nj, cnt = ing.fetch_ht_items()
+    first = ing.fetch_ht_order()
+    k, q = np.nonzero(out['ht_cnt'])
+    order = np.argsort(first[k, q], kind='stable')
+    k, q = k[order], q[order]
+    assert ing.n_ht_items() == len(k) == len(ni) and np.array_equal(out['ht_cnt'], want['ht_cnt'])
+    assert np.array_equal(ni, 2 * out['full_i'][k] + (q >> 1)) and np.array_equal(nj, 2 * out['full_j'][k] + (q & 1)) and np.array_equal(cnt, out['ht_cnt'][k, q])
+    assert np.array_equal(first, orc.ht_first(t, id1, p1, id2, p2, want['full_i'], want['full_j']))
     _lib.write_link_pickle(str(tmp_path / 'f.pkl'), out['full_i'], out['full_j'], out['full_cnt'], names)
     assert pickle.load(open(tmp_path / 'f.pkl', 'rb')) == pickle.loads(orc.link_pickle(names, want['full_i'], want['full_j'], want['full_cnt']))
     ing.destroy()
