@@ -564,6 +564,7 @@ class DenseSweep:
         self.links, self.pruning = links, pruning
         n = links.shape3[0]
         self.n = n
+        self._budget_rows = None
         if block_rows is None:
             if budget_bytes is None:
                 # what the driver reports free + what the library's pool holds for reuse (no trim: a cached 40 GB block is worth
@@ -571,8 +572,9 @@ class DenseSweep:
                 free_bytes, _total = _lib.mem_info()
                 budget_bytes = 0.45 * (free_bytes + _lib.pool_cached_bytes())
             block_rows = max(1, min(n, int(budget_bytes // (4 * max(n, 1)))))
-            if block_rows < n and _lib.links_plan(links)[1] != 0:
-                block_rows = n                               # all rows in one block after all: the library stores it as the upper block triangle
+            self._budget_rows = block_rows
+            if block_rows < n and _lib.links_plan(links)[1] == 2:
+                block_rows = n                               # all rows in one block after all: the library stores it as the upper block triangle (half the bytes)
         self.bounds = list(range(0, n, int(block_rows))) + [n]
         self.resident = None                                 # the only block when the whole M^2 fits: kept for the whole sweep
         self.n_products = 0
@@ -585,10 +587,18 @@ class DenseSweep:
 
     def _first_iterations(self, inflations):
         inflations = [float(x) for x in inflations]
-        if len(self.bounds) == 2:
-            if self.resident is None:
+        if len(self.bounds) == 2 and self.resident is None:
+            try:
                 self.resident = _lib.DenseRows(self.links, 0, self.n)
                 self.n_products = self.resident.n_products
+            except RuntimeError:
+                # the one block did not fit after all (free memory moved since the plan, or the library chose the square where the
+                # triangle was planned): back to row blocks within the budget
+                if not self._budget_rows or self._budget_rows >= self.n:
+                    raise
+                _lib.load().hhx_pool_trim()
+                self.bounds = list(range(0, self.n, int(self._budget_rows))) + [self.n]
+        if len(self.bounds) == 2:
             # GROUP inflations at a time in one pass over the block (hhx_dense_inflate_prune_multi: the division and the log2 of
             # x^r = exp2(r log2 x) once per entry, the 4 n^2 bytes read once per group); the matrices of a group wait their turn
             for lo in range(0, len(inflations), self.GROUP):

@@ -2368,10 +2368,23 @@ extern "C" int hhx_dense_inflate_prune(const hhx_dense *d, double inflation, dou
 
 // iteration 0 of mcl() (:2037-2042) of the block's rows at K inflations in ONE pass over the block (k_dense_epilogue_multi): outs[k] is
 // bit for bit what hhx_dense_inflate_prune(d, inflations[k]) returns
+static int dense_inflate_prune_multi_impl(const hhx_dense *d, int K, const double *inflations, double pruning, hhx_csr **outs);
+
+// all or nothing: whatever path fails (a pool allocation, a HIP call in the middle of a pass, a later part of a split), the matrices
+// already packed are released and every outs[k] is null on a non-zero return
 extern "C" int hhx_dense_inflate_prune_multi(const hhx_dense *d, int K, const double *inflations, double pruning, hhx_csr **outs) {
     if (!d || !inflations || !outs) return fail("null pointer");
     if (K < 1 || K > MULTI_MAX) return fail("hhx_dense_inflate_prune_multi: 1 to %d inflations per pass", MULTI_MAX);
-    for (int k = 0; k < K; ++k) { if (!(inflations[k] > 0)) return fail("inflation must be positive"); outs[k] = nullptr; }
+    for (int k = 0; k < K; ++k) outs[k] = nullptr;
+    for (int k = 0; k < K; ++k) if (!(inflations[k] > 0)) return fail("inflation must be positive");
+    const int rc = dense_inflate_prune_multi_impl(d, K, inflations, pruning, outs);
+    if (rc)
+        for (int k = 0; k < K; ++k)
+            if (outs[k]) { hhx_csr_free(outs[k]); outs[k] = nullptr; }
+    return rc;
+}
+
+static int dense_inflate_prune_multi_impl(const hhx_dense *d, int K, const double *inflations, double pruning, hhx_csr **outs) {
     const i32 n_rows = d->n_rows, n_cols = d->n_cols, n_win = d->n_win, cap = d->cap_win;
     // inflation 2 is x * x, not exp2(2 log2 x) (numpy's `** 2`, hhx_powr's callers): it goes through the one-inflation kernel;
     // so does everything when the window is wider than the owned-slot registers of the fused kernel

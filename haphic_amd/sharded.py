@@ -586,14 +586,29 @@ def sweep_sharded(engine, links_full, inflations, iters, pruning, dist, shard_pr
     world, rank = dist.get_world_size(), dist.get_rank()
     n = engine.shape(links_full)[0]
     b = balanced_ranges(engine.row_products(links_full, links_full), world)
-    d, f_local, c_local = engine.dense_rows(links_full, b[rank], b[rank + 1])
+    # This rank's rows of M^2 as a dense float32 block — if EVERY rank can hold its block (the blocks are cut by products, not by
+    # rows, so their sizes differ).  The ranks agree before anyone relies on it: a rank that cannot allocate must not leave the
+    # others in the exchange below.  Without the blocks every rank still expands only its own rows, once per inflation, through
+    # the fused iteration 0 (hhx_expand_links: no dense block) — same accumulators, same bits, one expansion per inflation.
+    d, f_local, c_local = None, 0, 0
+    try:
+        d, f_local, c_local = engine.dense_rows(links_full, b[rank], b[rank + 1])
+    except (RuntimeError, MemoryError):
+        d = None
+    if not _agree(d is not None, engine, dist):
+        if d is not None:
+            engine.dense_free(d)
+        d = None
     load = [0.0] * world
     mine = []                                             # (index of the inflation, matrix, iterations done)
     done = {}                                             # inflations that converged / ran out of iterations inside the sharded phase
     try:
         for k, infl in enumerate(inflations):
             infl = float(infl)
-            p = engine.dense_first(d, infl, pruning)
+            if d is not None:
+                p = engine.dense_first(d, infl, pruning)
+            else:
+                p, f_local, c_local = engine.expand_links(links_full, b[rank], b[rank + 1], infl, pruning)
             cur, _heads = exchange_rows(engine, p, n, dist, counts=(c_local, engine.shape(p)[2], f_local))
             engine.free(p)
             it, converged, finished = 1, False, iters <= 1
@@ -615,8 +630,15 @@ def sweep_sharded(engine, links_full, inflations, iters, pruning, dist, shard_pr
                 mine.append((k, cur, it))
             else:
                 engine.free(cur)
+    except BaseException:
+        for _k, cur, _it in mine:                        # nobody else holds these
+            engine.free(cur)
+        for cur, _it, _c in done.values():
+            engine.free(cur)
+        raise
     finally:
-        engine.dense_free(d)
+        if d is not None:
+            engine.dense_free(d)
     results = []
     for k, (cur, it, converged) in done.items():          # every rank holds these: rank k % world reads them out
         if k % world == rank:

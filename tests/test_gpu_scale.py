@@ -398,11 +398,8 @@ def test_c3_inflation_sweep_against_oracle(c3):
             assert width.max() > 3072, 'no sampled row beyond the hash class (widest: %d columns)' % width.max()
             first.free()
             continue
-        if r == 1.4 and late(margin=200):
-            # the tail at 1.4 costs the oracle ~10^12 products; the driver's limit for the whole gpu run must not be overrun
-            first.free()
-            import warnings
-            warnings.warn('C3 sweep: the oracle tail at inflation 1.4 was SKIPPED (the session is late); run this test alone for it')
+        if r == 1.4:
+            first.free()                                 # its whole tail: test_c3_sweep_tail_at_1_4_against_oracle (skips itself, visibly, when late)
             continue
         res, n_iter, conv, stats = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4, want_stats=True)
         first.free()
@@ -417,6 +414,68 @@ def test_c3_inflation_sweep_against_oracle(c3):
         assert np.abs(stats[:, 2] - o[5][:, 2]).max() <= 8, 'C3 sweep, inflation %r: survivors per iteration' % r
         res.free()
     sweep.close()
+
+
+def _whole_tail_against_oracle(first, r, what, label):
+    """mcl() :2026-2062 continued from the device's iteration-0 output `first` (consumed) to convergence, device against oracle"""
+    from haphic_amd import _lib
+    f_host = first.to_arrays()
+    res, n_iter, conv, stats = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4, want_stats=True)
+    first.free()
+    with tick(label):
+        o = orc.mcl(f_host, 2, r, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
+    assert (n_iter, conv) == (o[3], o[4]), '%s: iteration count / convergence flag (%d %s against %d %s)' % (what, n_iter, conv, o[3], o[4])
+    got = res.to_arrays()
+    assert np.array_equal(got[0], o[0]) and np.array_equal(got[1], o[1]), '%s: final pattern' % what
+    np.testing.assert_allclose(got[2], o[2], rtol=POW_RTOL, atol=0)
+    assert _clusters(*_lib.interpret(res)) == _clusters(*orc.interpret(o[:3])), '%s: clusters' % what
+    assert np.abs(stats[:, 2] - o[5][:, 2]).max() <= 8, '%s: survivors per iteration' % what
+    res.free()
+    return n_iter, stats
+
+
+def test_c3_sweep_tail_at_1_4_against_oracle(c3):
+    """the WHOLE tail of mcl() at inflation 1.4 from the device's iteration-0 output, continued by the oracle (~10^12 products on the
+    host cores: the most expensive optional leg of the suite).  When the session is already late it is SKIPPED — as a skip in the
+    summary, not as a warning inside a passing test (VERDICT r04 weak #4)."""
+    from haphic_amd import cluster
+    if late(margin=200):
+        pytest.skip('the gpu session is late (HHX_TEST_BUDGET_S): the oracle tail at inflation 1.4 was not run; run this test alone for it')
+    sweep = cluster.DenseSweep(c3.m, 1e-4)
+    try:
+        first = next(iter(sweep.first_iterations([1.4])))
+        _whole_tail_against_oracle(first, 1.4, 'C3 sweep, inflation 1.4', 'c3 sweep oracle tail at 1.4')
+    finally:
+        sweep.close()
+
+
+def test_low_inflation_whole_tails_against_oracle():
+    """run_mcl_clustering's lowest inflations (1.1 / 1.2 / 1.3, :2155-2158) to convergence on a 3.4k-contig assembly: the tails in which
+    rows of T hold thousands of entries and leave the hash class for the generic-stream window class in iterations >= 1 (VERDICT r04
+    missing #3; at C2 / 24k contigs / C3 the same check is tools/gpu_pass.sh lowtails, an opt-in leg: the oracle walks 10^11..10^12
+    products per tail there).  Iteration count, convergence flag, final pattern, values within 1e-6, clusters, survivors per iteration."""
+    import torch
+    from haphic_amd import _lib, cluster, synth
+    gen = synth.make_genome(8, 425 * 40_000, 40_000, seed=31)
+    id1, p1, id2, p2 = synth.sample_pairs(gen, 10_000_000, seed=32, device='cuda:0')
+    ing = _lib.Ingest(_table(gen), 500_000, bins=False, skip_intra=True)
+    ing.push_device(len(id1), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+    torch.cuda.synchronize()
+    m, _fidx, _nl = ing.link_matrix(np.ones(gen.n, np.uint8))
+    ing.destroy()
+    n = m.shape3[0]
+    assert 3100 < n < 3800
+    sweep = cluster.DenseSweep(m, 1e-4)
+    widest = 0
+    try:
+        for r, first in zip((1.1, 1.2, 1.3), sweep.first_iterations((1.1, 1.2, 1.3))):
+            widest = max(widest, int(np.diff(first.to_arrays()[0]).max()))
+            n_iter, stats = _whole_tail_against_oracle(first, r, '3.4k contigs, inflation %r' % r, '3.4k whole tail at %r' % r)
+            assert n_iter > 10
+    finally:
+        sweep.close()
+        m.free()
+    assert widest > 3072, 'no row of T1 beyond the hash class (widest: %d entries)' % widest
 
 
 def test_c5_200k_contigs_four_pushes():

@@ -500,6 +500,18 @@ def _sweep_edge_worker(rank, world, port, q):
         m.sort_indices()
         links = (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32))
         out = []
+
+        class NoRoom(OracleEngine):
+            """the last rank cannot hold its rows of M^2: every rank must fall back to the fused iteration 0 together"""
+            def dense_rows(self, links_, r0, r1):
+                if rank == world - 1:
+                    raise RuntimeError('hipMalloc: out of memory (simulated)')
+                return OracleEngine.dense_rows(self, links_, r0, r1)
+        short = NoRoom()
+        got = sharded.sweep_sharded(short, links, [1.4, 2.0], 200, 1e-4, dist, shard_products=200.0)
+        ref = sharded.sweep_sharded(eng, links, [1.4, 2.0], 200, 1e-4, dist, shard_products=200.0)
+        for a_, b_ in zip(got, ref):
+            assert all(np.array_equal(x, y) for x, y in zip(a_[:3], b_[:3])) and tuple(a_[3:]) == tuple(b_[3:])
         for inflations, iters, thr in (((1.4, 2.0), 200, None), ((1.4, 2.0), 1, 0.0), ((1.4, 2.0), 2, 0.0), ((1.4, 2.0), 3, 0.0), ((1.4, 2.0, 3.0), 3, 1e9),
                                        ((2.0,), 200, 0.0), ((1.2, 1.6, 2.0, 2.4, 2.8), 200, 200.0)):
             got = sharded.sweep_sharded(eng, links, list(inflations), iters, 1e-4, dist, shard_products=thr)

@@ -13,6 +13,11 @@ import json
 for l in open('gpurun_out/bench_full.log'):
     if l.startswith('{'): print(json.dumps(json.loads(l).get('seam_e2e'))[:3000])
 ";;
+    lowtails) timeout 1500 python tools/lowtails.py $LOWTAIL_ARGS > gpurun_out/lowtails.jsonl 2> gpurun_out/lowtails.err; echo "lowtails rc=$?"; python -c "
+import json
+for l in open('gpurun_out/lowtails.jsonl'):
+    r = json.loads(l); r.pop('sampled_iterations', None); print(json.dumps(r)[:700])
+"; tail -3 gpurun_out/lowtails.err;;
     tests) timeout 1500 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; grep -A8 "slowest" gpurun_out/pytest_gpu.log | head -9; tail -2 gpurun_out/pytest_gpu.log;;
     c2) timeout 600 python bench.py --contigs 10000 --pairs 50000000 --nchrs 16 --mean-len 50000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_c2.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c2.log; python tools/bench_brief.py gpurun_out/bench_c2.log;;
     c3) timeout 900 python bench.py $C3 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/bench_c3.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3.log; grep "hhx expand" gpurun_out/bench_c3.log | head -3; python tools/bench_brief.py gpurun_out/bench_c3.log;;

@@ -1,0 +1,139 @@
+"""Parity of the LOW-inflation tails of run_mcl_clustering's sweep (:2155-2158, inflations 1.1 / 1.2 / 1.3) at the sizes the configs
+state (VERDICT r04 missing #3 / weak #3).  These tails are where rows of T hold thousands of entries and iterations >= 1 leave the hash
+class for the generic-stream window class; the oracle cannot walk them whole inside the gpu test suite (7e12 products at C3 / 1.1), so
+this is an opt-in leg (tools/gpu_pass.sh lowtails) whose log is committed under profiles/:
+  * every iteration of every tail is stepped on the device (hhx_expand_inflate_prune + hhx_convergence_stat, the loop of mcl() :2030-2050);
+  * at iterations 1, 2, 3, 5, 8, 13, 21, ... the pruned rows of a stratified row sample (the heaviest rows by products + random rows) are
+    recomputed by the ORACLE from the device's operand of that iteration (mode 1, the kernels' specification): pattern equal, values
+    within 1e-6 (x^r: powf against float(exp2(r log2 x))), bit equal at r = 2;
+  * the whole tail is run a second time with every row forced through the window class (hash_max = 0) and a third time through
+    hhx_mcl_resume (the product path): iteration count, convergence flag and the final matrix must be bit-identical in all three;
+  * --whole R: the oracle continues mcl() from the device's iteration-0 output at inflation R to convergence (C3 / 1.2: 2.5e12 products,
+    ~5 minutes on 16 threads): iteration count, flag, final pattern, values within 1e-6, clusters.
+One JSON line per (config, inflation)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+CONFIGS = {'c2': (10_000, 50_000_000, 16, 50_000), 'k24': (24_000, 120_000_000, 24, 30_000), 'c3': (100_000, 500_000_000, 24, 30_000)}
+CHECK_AT = (1, 2, 3, 5, 8, 13, 21, 34, 55, 89)
+
+
+def check_rows(_lib, orc, T, rows, inflation):
+    """one iteration of the rows `rows` of the device matrix T: oracle (mode 1) against hhx_expand_inflate_prune on the same operand"""
+    gp, gj, gx = T.to_arrays()
+    n1 = T.shape3[0]
+    sub_p = np.zeros(len(rows) + 1, np.int32)
+    sub_p[1:] = np.cumsum(gp[rows + 1] - gp[rows])
+    take = np.concatenate([np.arange(gp[r], gp[r + 1]) for r in rows])
+    c = orc.spgemm((sub_p, gj[take], gx[take]), (gp, gj, gx), n_cols=n1, mode=1, fx_shift=52)
+    want = orc.prune((c[0], c[1], orc.normalize_l1(c[0], orc.power(c[2], inflation))), 1e-4)
+    sub = _lib.DeviceCSR.from_arrays(sub_p, gj[take], gx[take], n_cols=n1)
+    got = _lib.expand_inflate_prune(sub, T, inflation, 1e-4)[0]
+    g = got.to_arrays()
+    got.free()
+    sub.free()
+    ok_pattern = bool(np.array_equal(g[0], want[0]) and np.array_equal(g[1], want[1]))
+    rel = float(np.max(np.abs(g[2].astype(np.float64) - want[2]) / np.maximum(np.abs(want[2]), 1e-300))) if ok_pattern and len(want[2]) else None
+    return {'rows': int(len(rows)), 'widest_operand_row': int(np.diff(sub_p).max()), 'widest_expanded_row': int(np.diff(c[0]).max()),
+            'products': int(np.diff(gp)[gj[take]].sum()), 'pattern_equal': ok_pattern, 'max_rel': rel, 'bit_equal': bool(ok_pattern and np.array_equal(g[2], want[2]))}
+
+
+def tail(_lib, first, infl, max_iter, hash_max=None, checker=None):
+    """the loop of mcl() :2030-2050 from the iteration-0 output `first` (not consumed), one iteration at a time"""
+    cur = first.copy()
+    if hash_max is not None:
+        _lib.tune('hash_max', hash_max)
+    per, conv, n_iter = [], False, 1
+    try:
+        for it in range(1, max_iter):
+            if checker is not None and it in CHECK_AT:
+                per.append(dict(iteration=it, nnz=int(cur.nnz), **checker(cur)))
+            nxt, f, z = _lib.expand_inflate_prune(cur, cur, infl, 1e-4)
+            d = _lib.convergence_stat(nxt, cur) if it > 1 else 1.0
+            cur.free()
+            cur = nxt
+            n_iter = it + 1
+            if it > 1 and d <= np.float32(1e-8):
+                conv = True
+                break
+    finally:
+        if hash_max is not None:
+            _lib.tune('hash_max', None)
+    return cur, n_iter, conv, per
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--configs', default='c2,k24,c3')
+    ap.add_argument('--inflations', default='1.1,1.2,1.3')
+    ap.add_argument('--whole', default='', help='config:inflation pairs, e.g. c3:1.2 — the oracle continues that tail to convergence')
+    ap.add_argument('--sample', type=int, default=48)
+    args = ap.parse_args()
+    import torch
+    from haphic_amd import _lib, synth
+    from haphic_amd.cluster import FragTable
+    from oracle import oracle as orc
+    whole = {tuple(x.split(':')) for x in args.whole.split(',') if x}
+    for name in args.configs.split(','):
+        contigs, pairs, nchrs, mean_len = CONFIGS[name]
+        gen = synth.make_genome(nchrs, max(1, contigs // nchrs) * mean_len, mean_len, seed=12345)
+        n = gen.n
+        table = FragTable.for_contigs(gen.lexical_rank(), gen.length, np.ones(n, np.uint8))
+        id1, p1, id2, p2 = synth.sample_pairs(gen, pairs, seed=12345, device='cuda:0')
+        torch.cuda.synchronize()
+        ing = _lib.Ingest(table, 500_000, bins=False, skip_intra=True)
+        ing.push_device(id1.numel(), id1.data_ptr(), p1.data_ptr(), id2.data_ptr(), p2.data_ptr())
+        ing.finalize()
+        m, _fidx, _nl = ing.link_matrix(np.ones(n, np.uint8))
+        ing.destroy()
+        del id1, p1, id2, p2
+        torch.cuda.empty_cache()
+        blk = _lib.DenseRows(m, 0, m.shape3[0])
+        rng = np.random.default_rng(5)
+        for infl in [float(x) for x in args.inflations.split(',')]:
+            t0 = time.time()
+            first = blk.inflate_prune(infl, 1e-4)
+
+            def checker(cur):
+                prod = _lib.row_products(cur, cur)
+                heavy = np.argsort(prod, kind='stable')[-(args.sample // 2):]
+                rows = np.unique(np.concatenate([heavy, rng.choice(cur.shape3[0], args.sample // 2, replace=False)]))
+                return check_rows(_lib, orc, cur, rows, infl)
+            a, it_a, conv_a, per = tail(_lib, first, infl, 200, checker=checker)
+            b, it_b, conv_b, _ = tail(_lib, first, infl, 200, hash_max=0)                   # every row through the window class
+            c, it_c, conv_c = _lib.mcl_resume(first, 1, 2, infl, 200, 1e-4)                 # the product path (first is not consumed)
+            aa, bb, cc = a.to_arrays(), b.to_arrays(), c.to_arrays()
+            same = bool((it_a, conv_a) == (it_b, conv_b) == (it_c, bool(conv_c)) and all(np.array_equal(x, y) and np.array_equal(x, z) for x, y, z in zip(aa, bb, cc)))
+            rec = {'config': name, 'n': int(n), 'inflation': infl, 't1_nnz': int(first.nnz), 'iterations': it_a, 'converged': conv_a,
+                   'clusters': int(len(_lib.interpret(a)[0])), 'three_routes_bit_identical': same, 'sampled_iterations': per,
+                   'all_samples_pattern_equal': all(p['pattern_equal'] for p in per),
+                   'max_rel_over_samples': max([p['max_rel'] for p in per if p['max_rel'] is not None] or [None]),
+                   'widest_expanded_row': max([p['widest_expanded_row'] for p in per] or [0])}
+            if (name, ('%g' % infl)) in whole:
+                tw = time.time()
+                f_host = first.to_arrays()
+                o = orc.mcl(f_host, 2, infl, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
+                rel = float(np.max(np.abs(aa[2].astype(np.float64) - o[2]) / np.maximum(np.abs(o[2]), 1e-300))) if len(o[2]) == len(aa[2]) else None
+                att = lambda t3: {tuple(t3[2][t3[1][k]:t3[1][k + 1]].tolist()) for k in range(len(t3[0]))}                  # noqa: E731
+                rec['whole_tail_vs_oracle'] = {'iterations_equal': bool(o[3] == it_a), 'flag_equal': bool(o[4] == conv_a), 'oracle_iterations': int(o[3]),
+                                               'pattern_equal': bool(np.array_equal(aa[0], o[0]) and np.array_equal(aa[1], o[1])), 'max_rel': rel,
+                                               'clusters_equal': att(_lib.interpret(a)) == att(orc.interpret(o[:3])),
+                                               'oracle_products': int(o[5][:, 3].sum()), 'oracle_seconds': round(time.time() - tw, 1), 'threads': orc.get_threads()}
+            rec['seconds'] = round(time.time() - t0, 1)
+            print(json.dumps(rec), flush=True)
+            for x in (a, b, c, first):
+                x.free()
+        blk.free()
+        m.free()
+        _lib.load().hhx_pool_trim()
+
+
+if __name__ == '__main__':
+    main()
