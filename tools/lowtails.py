@@ -10,6 +10,10 @@ this is an opt-in leg (tools/gpu_pass.sh lowtails) whose log is committed under 
     hhx_mcl_resume (the product path): iteration count, convergence flag and the final matrix must be bit-identical in all three;
   * --whole R: the oracle continues mcl() from the device's iteration-0 output at inflation R to convergence (C3 / 1.2: 2.5e12 products,
     ~5 minutes on 16 threads): iteration count, flag, final pattern, values within 1e-6, clusters.
+  * --reuse: for the sampled iterations, what RE-USE of B rows across output rows could save: the rows are ordered by
+    their current attractor (the column of the row maximum) and taken R = 2 / 4 / 8 at a time; a workgroup that accumulated R output
+    rows per walk would stream every B row of the UNION of their patterns once instead of once per row — the table gives
+    bytes(union) / bytes(separate), the bound on what such a kernel can save of the 6 B per product it streams.
 One JSON line per (config, inflation)."""
 import argparse
 import json
@@ -45,6 +49,29 @@ def check_rows(_lib, orc, T, rows, inflation):
             'products': int(np.diff(gp)[gj[take]].sum()), 'pattern_equal': ok_pattern, 'max_rel': rel, 'bit_equal': bool(ok_pattern and np.array_equal(g[2], want[2]))}
 
 
+def reuse_stats(torch, eng, cur, groups=(2, 4, 8)):
+    """stream bytes of an iteration with R output rows per B-row walk, relative to one row per walk (rows grouped by attractor)"""
+    indptr, indices, data = eng.tensors(cur)
+    n = indptr.numel() - 1
+    rowlen = (indptr[1:] - indptr[:-1]).to(torch.int64)
+    row = torch.repeat_interleave(torch.arange(n, device=indices.device), rowlen)
+    rmax = torch.zeros(n, dtype=data.dtype, device=data.device).scatter_reduce(0, row, data, 'amax', include_self=False)
+    is_max = data == rmax[row]
+    att = torch.full((n,), n, dtype=torch.int64, device=indices.device).scatter_reduce(0, row[is_max], indices[is_max].to(torch.int64), 'amin', include_self=True)
+    order = torch.argsort(att * n + torch.arange(n, device=att.device), stable=True)           # rows by (attractor, row)
+    pos = torch.empty_like(order)
+    pos[order] = torch.arange(n, device=order.device)
+    cols = indices.to(torch.int64)
+    separate = int(rowlen[cols].sum())                       # entries of B streamed with one output row per walk (= the products)
+    out = {'products': separate, 'attractors': int(torch.unique(att).numel())}
+    for R in groups:
+        key = (pos[row] // R) * n + cols
+        uniq = torch.unique(key)
+        out['R%d' % R] = round(int(rowlen[uniq % n].sum()) / max(separate, 1), 4)
+        del key, uniq
+    return out
+
+
 def tail(_lib, first, infl, max_iter, hash_max=None, checker=None):
     """the loop of mcl() :2030-2050 from the iteration-0 output `first` (not consumed), one iteration at a time"""
     cur = first.copy()
@@ -75,11 +102,14 @@ def main():
     ap.add_argument('--inflations', default='1.1,1.2,1.3')
     ap.add_argument('--whole', default='', help='config:inflation pairs, e.g. c3:1.2 — the oracle continues that tail to convergence')
     ap.add_argument('--sample', type=int, default=48)
+    ap.add_argument('--reuse', action='store_true')
     args = ap.parse_args()
     import torch
     from haphic_amd import _lib, synth
     from haphic_amd.cluster import FragTable
     from oracle import oracle as orc
+    from haphic_amd import sharded
+    eng = sharded.HipEngine('cuda:0')
     whole = {tuple(x.split(':')) for x in args.whole.split(',') if x}
     for name in args.configs.split(','):
         contigs, pairs, nchrs, mean_len = CONFIGS[name]
@@ -105,7 +135,13 @@ def main():
                 prod = _lib.row_products(cur, cur)
                 heavy = np.argsort(prod, kind='stable')[-(args.sample // 2):]
                 rows = np.unique(np.concatenate([heavy, rng.choice(cur.shape3[0], args.sample // 2, replace=False)]))
-                return check_rows(_lib, orc, cur, rows, infl)
+                res = check_rows(_lib, orc, cur, rows, infl)
+                if args.reuse:
+                    _lib.check(_lib.load().hhx_synchronize())
+                    res['reuse_bytes_ratio'] = reuse_stats(torch, eng, cur)
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+                return res
             a, it_a, conv_a, per = tail(_lib, first, infl, 200, checker=checker)
             b, it_b, conv_b, _ = tail(_lib, first, infl, 200, hash_max=0)                   # every row through the window class
             c, it_c, conv_c = _lib.mcl_resume(first, 1, 2, infl, 200, 1e-4)                 # the product path (first is not consumed)
