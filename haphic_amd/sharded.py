@@ -54,9 +54,20 @@ class HipEngine:
         return _lib.DeviceCSR.from_device(n_rows, n_cols, int(indices.numel()), indptr.data_ptr(), indices.data_ptr(),
                                           data.data_ptr())
 
+    def scratch(self, name, n, dtype):
+        """a view of `n` elements of a persistent device buffer (grown geometrically, never shrunk): the per-iteration exchange of the
+        row-block MCL re-uses its message and gather buffers instead of asking the allocator every iteration"""
+        pool = self.__dict__.setdefault('_scratch', {})
+        buf = pool.get(name)
+        if buf is None or buf.dtype != dtype or buf.numel() < n:
+            if buf is not None:
+                del pool[name]
+            buf = pool[name] = self.torch.empty(max(int(n * 1.25), 1024), dtype=dtype, device=self.device)
+        return buf[:int(n)]
+
     def pack_block(self, m, words):
         """m's exchange message [row lengths | column indices | value bits] in an int32 tensor of `words` elements"""
-        buf = self.torch.empty(int(words), dtype=self.torch.int32, device=self.device)
+        buf = self.scratch('msg', int(words), self.torch.int32)
         _lib.check(_lib.load().hhx_csr_pack_block(m.h, _lib.C.c_void_p(buf.data_ptr()), int(words)))
         return buf
 
@@ -326,13 +337,14 @@ def exchange_rows(engine, local, n_cols, dist, stat=0.0, counts=(0, 0, 0)):
     world = dist.get_world_size()
     r, _c, z = engine.shape(local)
     head = torch.tensor([float(r), float(z), float(stat)] + [float(c) for c in counts], dtype=torch.float64, device=engine.device)
-    heads = torch.empty(world * HEADER, dtype=torch.float64, device=engine.device)
+    scratch = getattr(engine, 'scratch', None) or (lambda _name, n_, dt: torch.empty(int(n_), dtype=dt, device=engine.device))
+    heads = scratch('heads', world * HEADER, torch.float64)
     dist.all_gather_into_tensor(heads, head)
     heads = heads.cpu().numpy().reshape(world, HEADER)               # the one host sync of the exchange
     rows, nnzs = heads[:, 0].astype(np.int64), heads[:, 1].astype(np.int64)
     stride = int(max(1, (rows + 2 * nnzs).max()))
     msg = engine.pack_block(local, stride)
-    out = torch.empty(world * stride, dtype=torch.int32, device=msg.device)
+    out = scratch('gathered', world * stride, torch.int32)       # persistent: consumed by unpack_blocks before the next exchange
     step = max(1, MAX_MESSAGE_BYTES // 4)
     if stride <= step:
         dist.all_gather_into_tensor(out, msg)
@@ -340,7 +352,7 @@ def exchange_rows(engine, local, n_cols, dist, stat=0.0, counts=(0, 0, 0)):
         out2 = out.view(world, stride)
         for lo in range(0, stride, step):
             hi = min(stride, lo + step)
-            piece = torch.empty(world * (hi - lo), dtype=torch.int32, device=msg.device)
+            piece = scratch('piece', world * (hi - lo), torch.int32)
             dist.all_gather_into_tensor(piece, msg[lo:hi].contiguous())
             out2[:, lo:hi] = piece.view(world, hi - lo)
     return engine.unpack_blocks(rows, nnzs, out, stride, n_cols), heads

@@ -420,7 +420,13 @@ def _whole_tail_against_oracle(first, r, what, label):
     """mcl() :2026-2062 continued from the device's iteration-0 output `first` (consumed) to convergence, device against oracle"""
     from haphic_amd import _lib
     f_host = first.to_arrays()
-    res, n_iter, conv, stats = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4, want_stats=True)
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    try:
+        res, n_iter, conv, stats = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4, want_stats=True)
+    finally:
+        _lib.profile_enable(False)
+    window_products = _lib.profile_counter('expand_window_short_products') + _lib.profile_counter('expand_window_products')
     first.free()
     with tick(label):
         o = orc.mcl(f_host, 2, r, 200, 1e-4, spgemm_mode=1, fx_shift=52, want_stats=True, first_it=1)
@@ -431,7 +437,7 @@ def _whole_tail_against_oracle(first, r, what, label):
     assert _clusters(*_lib.interpret(res)) == _clusters(*orc.interpret(o[:3])), '%s: clusters' % what
     assert np.abs(stats[:, 2] - o[5][:, 2]).max() <= 8, '%s: survivors per iteration' % what
     res.free()
-    return n_iter, stats
+    return n_iter, stats, window_products
 
 
 def test_c3_sweep_tail_at_1_4_against_oracle(c3):
@@ -466,16 +472,18 @@ def test_low_inflation_whole_tails_against_oracle():
     n = m.shape3[0]
     assert 3100 < n < 3800
     sweep = cluster.DenseSweep(m, 1e-4)
-    widest = 0
+    through_window = 0
     try:
         for r, first in zip((1.1, 1.2, 1.3), sweep.first_iterations((1.1, 1.2, 1.3))):
-            widest = max(widest, int(np.diff(first.to_arrays()[0]).max()))
-            n_iter, stats = _whole_tail_against_oracle(first, r, '3.4k contigs, inflation %r' % r, '3.4k whole tail at %r' % r)
+            n_iter, stats, window_products = _whole_tail_against_oracle(first, r, '3.4k contigs, inflation %r' % r, '3.4k whole tail at %r' % r)
+            through_window += window_products
             assert n_iter > 10
     finally:
         sweep.close()
         m.free()
-    assert widest > 3072, 'no row of T1 beyond the hash class (widest: %d entries)' % widest
+    # the class the low-inflation tails of C3 spend their time in (the kernel's own product counter): rows whose expansion holds more
+    # distinct columns than the hash table takes, or more products than hash_max, walk the generic (column, value) stream of the window class
+    assert through_window > 0, 'no row of iterations >= 1 went through the window class'
 
 
 def test_c5_200k_contigs_four_pushes():
@@ -675,19 +683,22 @@ def test_c4_40k_cluster_files_against_the_reference(tmp_path):
         groups = sorted(f for f in os.listdir(d) if f.startswith('group'))
         assert groups == [str(x) for x in g['group_files_' + tag]]
         assert [c4_40k.file_digest(os.path.join(d, f)) for f in groups] == [str(x) for x in g['group_sha_' + tag]], 'group files at inflation ' + tag
-    # the convergence lines (:2047): same text; the ROUND COUNT may differ by one — the convergence test `d.max() <= 1e-8` sits on the
-    # float32 accumulation noise of the reference's own SpGEMM (measured: two of the four inflations one round apart, e.g. 39 against 40 at 1.5; same files)
+    # the convergence lines (:2047): same text.  The ROUND COUNT is a property of the arithmetic of the expansion: the test `d.max() <= 1e-8`
+    # (:2045-2046) sits on the float32 accumulation noise of the reference's own SpGEMM.  tools/c4_40k_rounds.py (CPU only; log in
+    # profiles/r05_c4_40k_rounds.json) replays this matrix in the oracle: in mode 0 — the float32 accumulation of the scipy product the
+    # reference run used — it converges after exactly the reference's 40 / 20 / 17 / 16 rounds; in the exact arithmetic the device
+    # implements (integer pre-expansion, then mode 1) after 39 / 21 / 17 / 16.  The device must give the latter, to the round.
     import re
+    exact_rounds = {'1.5': 39, '2.0': 21, '2.5': 17, '3.0': 16}
     got_lines = [m for m in records if 'rounds of iterations' in m]
     want_lines = [str(x) for x in g['log_mcl']]
     assert len(got_lines) == len(want_lines)
     for a, b in zip(got_lines, want_lines):
         ra, rb = int(re.search(r'after (\d+) rounds', a).group(1)), int(re.search(r'after (\d+) rounds', b).group(1))
-        assert abs(ra - rb) <= 1 and re.sub(r'after \d+ rounds', 'after N rounds', a) == re.sub(r'after \d+ rounds', 'after N rounds', b), (a, b)
-    if got_lines != want_lines:
-        import warnings
-        warnings.warn('C4 40k: %d of %d inflations converge one round apart from the reference run (files identical)' % (
-            sum(a != b for a, b in zip(got_lines, want_lines)), len(want_lines)))
+        tag = re.search(r'inflation: ([0-9.]+)', a).group(1)
+        assert re.sub(r'after \d+ rounds', 'after N rounds', a) == re.sub(r'after \d+ rounds', 'after N rounds', b), (a, b)
+        assert abs(ra - rb) <= 1 and ra == exact_rounds.get(tag, ra), 'inflation %s: %d rounds on the device, %d in the reference run, %s in the exact specification' % (
+            tag, ra, rb, exact_rounds.get(tag))
     want = str(g['log_recommend'][0])
     if want:
         assert want in records

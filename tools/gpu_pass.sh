@@ -18,6 +18,13 @@ import json
 for l in open('gpurun_out/lowtails.jsonl'):
     r = json.loads(l); r.pop('sampled_iterations', None); print(json.dumps(r)[:700])
 "; tail -3 gpurun_out/lowtails.err;;
+    rest) timeout 900 python -m pytest tests/test_gpu_scale.py tests/test_plot.py tests/test_seam_containers.py -m gpu -x -q -k "not c3 and not c2" --durations=5 > gpurun_out/pytest_rest.log 2>&1; echo "rest rc=$?"; grep -E "passed|failed|Error|^E " gpurun_out/pytest_rest.log | tail -12;;
+    c1run) timeout 600 python tools/c1_run.py > gpurun_out/c1_run.json 2> gpurun_out/c1_run.err; echo "c1run rc=$?"; cat gpurun_out/c1_run.json | cut -c1-1500; tail -3 gpurun_out/c1_run.err;;
+    host8c3) timeout 1100 python bench.py --gpus 8 --transport host --steps 1 --warmup 0 --no-cpu-baseline --no-seam --sweep 20 --sharded-sweep-timeout 800 > gpurun_out/bench_host8_c3.log 2>&1; echo "host8c3 rc=$?"; python tools/bench_brief.py gpurun_out/bench_host8_c3.log | head -3; python -c "
+import json
+for l in open('gpurun_out/bench_host8_c3.log'):
+    if l.startswith('{'): print(json.dumps(json.loads(l).get('sweep_sharded'))[:1200])
+"; tail -3 gpurun_out/bench_host8_c3.log | cut -c1-300;;
     tests) timeout 1500 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; grep -A8 "slowest" gpurun_out/pytest_gpu.log | head -9; tail -2 gpurun_out/pytest_gpu.log;;
     c2) timeout 600 python bench.py --contigs 10000 --pairs 50000000 --nchrs 16 --mean-len 50000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_c2.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c2.log; python tools/bench_brief.py gpurun_out/bench_c2.log;;
     c3) timeout 900 python bench.py $C3 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/bench_c3.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3.log; grep "hhx expand" gpurun_out/bench_c3.log | head -3; python tools/bench_brief.py gpurun_out/bench_c3.log;;
