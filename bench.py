@@ -494,9 +494,14 @@ def seam_leg(args, gen, id1, p1, id2, p2):
                        'wall clock, PCIe included' % P}
         if not args.no_seam_files:
             # where the three files go: a RAM disk when it has the room (the pipeline, not the box's disk, is what is measured; said so)
-            need = 60 * P                       # ~40 B of CLM text + ~14 B of pickles per pair, with margin
+            need = 70 * P                       # ~52 B of CLM text + ~10 B of pickles per pair, with margin
             where = None
-            for cand in ('/dev/shm', tempfile.gettempdir()):
+            try:
+                import psutil
+                ram_ok = psutil.virtual_memory().available > 3 * need       # a RAM disk's pages count as this process's memory
+            except ImportError:
+                ram_ok = False
+            for cand in (['/dev/shm'] if ram_ok else []) + [tempfile.gettempdir()]:
                 try:
                     if shutil.disk_usage(cand).free > need + (4 << 30):
                         where = cand
@@ -794,6 +799,19 @@ def cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state):
             ref_py['stored'] = True
         except (OSError, ValueError):
             pass
+    # the unmodified `haphic cluster` on configs[0] (tools/reference_c1_baseline.py, dev container) beside the same command
+    # through the mirrors on one MI355X (tools/c1_run.py) — both stored measurements
+    if isinstance(ref_py, dict):
+        for key, fn in (('c1_haphic_cluster', 'r05_reference_c1_baseline.json'), ('c1_mirrors_mi355x', 'r05_c1_run_mi355x.json')):
+            try:
+                with open(os.path.join(ROOT, 'profiles', fn)) as f:
+                    c1 = json.load(f)
+                c1.pop('inflation_dirs', None)
+                c1.pop('log_tail', None)
+                c1['stored'] = True
+                ref_py[key] = c1
+            except (OSError, ValueError):
+                pass
     return {'value': S / dt, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port', 'reference_python': ref_py,
             'sample': 'ingest: first %d pairs of the rank-0 shard through the C oracle (hash-map port of '
                       'parse_alignments_for_ctgs); mcl: oracle mcl() on the %d-contig sub-assembly (first quarter '

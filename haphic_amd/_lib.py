@@ -756,8 +756,16 @@ class Ingest:
         """host arrays.  wide=True: 64-bit positions through hhx_ingest_push64 (contigs of 2^31 bp and more, :116-147).  wide=None:
         decided by the VALUES, not the dtype — default-int64 numpy arrays whose positions fit 32 bits take the packed 32-bit path
         (half the host-to-device bytes, four pairs per lane in the map kernel)."""
+        pos = [np.asarray(pos1), np.asarray(pos2)]
+        i32max = np.iinfo(np.int32).max
+        # by VALUE, whatever the dtype (a uint32 array can hold 2^31 and more; an int64 array usually does not)
+        beyond = any(a.dtype != np.int32 and a.size and int(a.max()) > i32max for a in pos)
         if wide is None:
-            wide = any(a.dtype.itemsize > 4 and a.size and int(a.max()) > np.iinfo(np.int32).max for a in (np.asarray(pos1), np.asarray(pos2)))
+            wide = beyond
+        elif not wide and beyond:
+            raise ValueError('Ingest.push(wide=False): a position exceeds the int32 range; pass wide=True (hhx_ingest_push64)')
+        if any(a.dtype != np.int32 and a.dtype.kind == 'i' and a.size and int(a.min()) < -i32max - 1 for a in pos):
+            raise ValueError('Ingest.push: a position below the int32 range')
         if wide:
             ids = [np.ascontiguousarray(a, np.int32) for a in (id1, id2)]
             pos = [np.ascontiguousarray(a, np.int64) for a in (pos1, pos2)]

@@ -474,6 +474,52 @@ def parse_link_dict(link_dict, ctg_group_dict, normalize_by_nlinks=False, _origi
     return ctg_group_link_dict, linked_ctg_dict
 
 
+def group_link_dict(link_dict, ctg_group_dict, _original=None):
+    """parse_link_dict() of HapHiC_cluster.py :2252-2268 (output_statistics :2279 calls it once per inflation on full_link_dict):
+    ctg_group_link_dict[ctg][group] = summed links between the contig and the group's contigs, 'ungrouped' partners skipped; the outer
+    dict in the order contigs first receive a contribution, each inner dict in the order its groups do (sorted(...) at :2362 is
+    stable, so that order decides ties).  A full_link_dict that is still array-backed is summed from its arrays — one sort of the
+    (contig, group) cells — instead of being turned into 10^8 Python tuples first; a real dict goes to the reference's loop."""
+    if not (_frozen(link_dict) and link_dict._kind == 'full'):
+        if _original is not None:
+            return _original(link_dict, ctg_group_dict)
+        out = defaultdict(dict)
+        for (ctg_i, ctg_j), links in link_dict.items():
+            for ctg, group in ((ctg_i, ctg_group_dict[ctg_j]), (ctg_j, ctg_group_dict[ctg_i])):
+                if group != 'ungrouped':
+                    out[ctg][group] = out[ctg].get(group, 0) + links
+        return out
+    i, j, v, names = link_dict.arrays()
+    gid = {}
+    grp = np.fromiter((-1 if g == 'ungrouped' else gid.setdefault(g, len(gid)) for g in map(ctg_group_dict.__getitem__, names)),
+                      np.int64, len(names))
+    group_names = list(gid)
+    G = max(len(group_names), 1)
+    # contributions in the reference's order: (ctg_i, group_j) at position 2k, (ctg_j, group_i) at 2k + 1
+    ctg = np.stack([i, j], axis=1).ravel().astype(np.int64)
+    other = np.stack([grp[j], grp[i]], axis=1).ravel()
+    links = np.repeat(np.asarray(v, np.int64), 2)
+    keep = other >= 0
+    cell = ctg[keep] * G + other[keep]
+    uniq, first, inverse = np.unique(cell, return_index=True, return_inverse=True)
+    sums = np.bincount(inverse, weights=links[keep], minlength=len(uniq)).astype(np.int64)        # exact: link totals stay far below 2^53
+    by_first = np.argsort(first, kind='stable')                      # cells in the order they first receive a contribution
+    c_ctg, c_grp, c_sum = uniq[by_first] // G, uniq[by_first] % G, sums[by_first]
+    # contigs in the order of their first cell; inside a contig the cells keep that order
+    _u, ctg_first = np.unique(c_ctg, return_index=True)
+    rank = np.empty(len(names), np.int64)
+    rank[_u[np.argsort(ctg_first, kind='stable')]] = np.arange(len(_u))
+    order = np.argsort(rank[c_ctg], kind='stable')
+    c_ctg, c_grp, c_sum = c_ctg[order], c_grp[order], c_sum[order]
+    bounds = np.flatnonzero(np.diff(c_ctg, prepend=-1)).tolist() + [len(c_ctg)]
+    gnames = list(map(group_names.__getitem__, c_grp.tolist()))
+    totals = c_sum.tolist()
+    out = defaultdict(dict)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        out[names[c_ctg[a]]] = dict(zip(gnames[a:b], totals[a:b]))
+    return out
+
+
 # ------------------------------------------------------------------ S1 / S3: matrix-level seams
 def _to_device(matrix):
     return _lib.DeviceCSR.from_scipy_csc(matrix)

@@ -24,11 +24,12 @@ SEAMS = {
     'normalize_by_length': ('HapHiC_cluster.py:727-738', cluster.normalize_by_length),  # a6 (dead code in the reference)
     'reduce_inter_hap_HiC_links': ('HapHiC_cluster.py:695-707', cluster.reduce_inter_hap_HiC_links),   # a6 (GFA phasing)
 }
-# f2 / f3: the two writers run() calls on the S5 containers (:2879, :2888, :2929).  They only differ from the reference's functions
+# f2 / f3: the two writers run() calls on the S5 containers (:2879, :2888, :2929) and the per-group link sums of output_statistics (:2354).  They only differ from the reference's functions
 # for the array-backed containers of the S5 mirrors (haphic_amd/containers.py), so they travel with `ingest`.
 WRITERS = {
     'output_pickle': ('HapHiC_cluster.py:710-715', cluster.output_pickle),
     'output_clm': ('HapHiC_cluster.py:376-392', cluster.output_clm),
+    'parse_link_dict': ('HapHiC_cluster.py:2252-2268', cluster.group_link_dict),     # per-group link sums of output_statistics :2279
 }
 # S4/S5: dict_to_matrix is also called in dense mode by the filters (:603) — the mirror returns `.toarray()` then;
 # the device ingest returns all of the reference's containers (link tables, HT counts, CLM distance lists, first

@@ -930,6 +930,17 @@ def test_wide_positions_int64_path(tmp_path):
     for lo, hi in ((0, cut), (cut, len(tup))):
         ing.push(tup[lo:hi, 0].astype(np.int32), tup[lo:hi, 1], tup[lo:hi, 2].astype(np.int32), tup[lo:hi, 3])
     check(ing)
+    # the width is decided by the VALUES whatever the dtype: uint32 positions of 2^31 and more take the 64-bit path too,
+    # and an explicit wide=False refuses them instead of wrapping them negative
+    assert int(tup[:, 1].max()) > 2 ** 31 and int(tup[:, 1].max()) < 2 ** 32
+    ing = _lib.Ingest(table, int(g['flank']), bins=False, skip_intra=True)
+    ing.keep_pairs()
+    ing.push(tup[:, 0].astype(np.int32), tup[:, 1].astype(np.uint32), tup[:, 2].astype(np.int32), tup[:, 3].astype(np.uint32))
+    check(ing)
+    ing = _lib.Ingest(table, int(g['flank']), bins=False, skip_intra=True)
+    with pytest.raises(ValueError, match='int32'):
+        ing.push(tup[:, 0].astype(np.int32), tup[:, 1], tup[:, 2].astype(np.int32), tup[:, 3], wide=False)
+    ing.destroy()
     # device arrays straight from the tokeniser (every line: headers and intra-contig pairs are dropped on the device)
     ing = _lib.Ingest(table, int(g['flank']), bins=False, skip_intra=True)
     ing.keep_pairs()

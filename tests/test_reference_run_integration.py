@@ -172,15 +172,13 @@ def test_reference_run_with_and_without_the_seams(tmp_path, monkeypatch, split, 
         patch.unpatch_reference(H, saved)
     # run() itself never needs a Python object per key: with the default options the seams (output_pickle, output_clm, normalize_by_nlinks,
     # filter_fragments, dict_to_matrix) work on the arrays.  What thaws a table is the reference's own dict code: remove_allelic_HiC_links
-    # :474-689 (full, flank, the coordinate lists), the --remove_concentrated_links loop :2899-2902, output_statistics :2279 (full, after
-    # the clustering)
+    # :474-689 (full, flank, the coordinate lists) and the --remove_concentrated_links loop :2899-2902; output_statistics :2279 gets its
+    # per-group link sums (parse_link_dict :2252) from the arrays too
     expected = set()
     if '--remove_allelic_links' in extra:
         expected |= {'full', 'flank', 'crd'}
     if '--remove_concentrated_links' in extra:
         expected |= {'full', 'crd'}
-    if '--quick_view' not in extra and '--skip_clustering' not in extra:
-        expected |= {'full'}
     assert set(thawed) == expected, (thawed, expected)
     # the log is an interface (users read it, HapHiC_pipeline.py:385 parses it): every message of the filtering and
     # clustering stages must come out of the mirrors word for word, in the same order (timings aside)

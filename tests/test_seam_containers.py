@@ -123,6 +123,20 @@ def body_frozen_seams_equal_dict_seams(tmp_path, monkeypatch, normalize):
     m3.free()
     m4.free()
     assert flank.frozen and full.frozen
+    # parse_link_dict :2252-2268 (output_statistics): per-group link sums from the arrays == the reference's loop on the dict,
+    # outer and inner insertion orders included (ties at :2362 are broken by them); some contigs 'ungrouped'
+    names = list(fa_dict)
+    rng = np.random.default_rng(2)
+    ctg_group = {c: ('ungrouped' if rng.random() < 0.2 else int(rng.integers(0, 7))) for c in names}
+    got = cluster.group_link_dict(full, ctg_group)
+    want = defaultdict(dict)
+    for (ci, cj), links in full2.items():                    # the loop of :2263-2266
+        for ctg, group in ((ci, ctg_group[cj]), (cj, ctg_group[ci])):
+            if group != 'ungrouped':
+                want[ctg][group] = want[ctg].get(group, 0) + links
+    assert full.frozen and type(got) is defaultdict and got == want and list(got) == list(want)
+    assert all(list(got[c].items()) == list(want[c].items()) and all(type(x) is int for x in got[c].values()) for c in want)
+    assert cluster.group_link_dict(full2, ctg_group) == want
 
 
 def body_mutation_thaws_and_falls_back(tmp_path, monkeypatch):
