@@ -21,6 +21,7 @@
 #include <chrono>
 
 #include "hhx_common.h"
+#include "hhx_sort.h"
 
 using namespace hhx;
 
@@ -806,6 +807,231 @@ __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__re
     n_a = wave_sum_i64(n_a);
     if (lane_id() == 0 && n_a) atomicAdd(&P.cursors[9], (unsigned long long)n_a);
     if (PROBE == 1 && sink == 0x123456789abcdefull) l.acc[0] = sink;
+}
+
+// ---- RE-USE of B rows across output rows (iterations >= 1, generic stream) ------------------------------------------------------
+// The generic-stream window kernel above streams 6 B per product at the fabric's ceiling (1.1e12 products/s, §4.4 of DESIGN.md): the
+// low-inflation tails of run_mcl_clustering's sweep are bound by the bytes of B they walk.  From iteration 2 on the rows of T that
+// share an attractor (the column of their maximum) have nearly the same pattern (tools/lowtails.py --reuse: the union of four such
+// rows' patterns holds 0.27-0.37 of the entries the four hold one by one), and output row i = sum_k a_ik B_k — so a workgroup that
+// accumulates R output rows at once walks every B row of the UNION of their patterns once instead of once per row.
+//   * the rows of the window class are sorted by attractor and taken R at a time (same attractor only; hhx_expand_impl);
+//   * k_group_count / k_group_fill merge the R patterns of a group (LDS bitmap + rank) into a union row with R values per entry
+//     (0 where a member has no entry);
+//   * k_expand_group<R>: R accumulator windows of cap columns side by side in LDS (the column windows are R times narrower), one
+//     (column, value) load of B per R products, R exact fixed-point adds (a member whose weight is 0 is skipped: the weights are
+//     wave-uniform), then the window epilogue of k_expand_window once per member over its own accumulators.
+// The sums are the same exact integers; the epilogue is the same code per (row, window).
+struct GroupOp {
+    const i32 *rows;        // [n_groups][R] member rows (-1: none)
+    const i32 *Gp;          // [n_groups + 1] union rows
+    const i32 *Gj;          // union columns k
+    const float *Gx;        // [entries][R] a_ik of every member (0: no entry)
+    i32 n_groups;
+};
+// one wave per row: key = column of the row maximum (first by column), value = the row
+__global__ __launch_bounds__(256) void k_row_attractor(i32 n_list, const i32 *__restrict__ rows, const i32 *__restrict__ Ap, const i32 *__restrict__ Aj,
+                                                       const float *__restrict__ Ax, u64 *__restrict__ key, u64 *__restrict__ val) {
+    const int lane = lane_id();
+    for (i32 li = blockIdx.x * 4 + threadIdx.x / HHX_WAVE; li < n_list; li += gridDim.x * 4) {
+        const i32 row = rows[li];
+        float bq = -1.0f; i32 bc = 0x7fffffff;
+        for (i32 p = Ap[row] + lane; p < Ap[row + 1]; p += HHX_WAVE) {
+            const float x = Ax[p];
+            const i32 c = Aj[p];
+            if (x > bq || (x == bq && c < bc)) { bq = x; bc = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float oq = __shfl_down(bq, o, HHX_WAVE);
+            const i32 oc = __shfl_down(bc, o, HHX_WAVE);
+            if (oq > bq || (oq == bq && oc < bc)) { bq = oq; bc = oc; }
+        }
+        if (lane == 0) { key[li] = (u64)(u32)bc; val[li] = (u64)(u32)row; }
+    }
+}
+// union pattern of a group: bitmap in LDS (dynamic: W words of bits + W words of prefix + scan scratch)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_group_union(i32 n_groups, i32 R, const i32 *__restrict__ grp_rows, const i32 *__restrict__ Ap,
+                                                     const i32 *__restrict__ Aj, const float *__restrict__ Ax, i32 W, i32 *__restrict__ cnt,
+                                                     const i32 *__restrict__ Gp, i32 *__restrict__ Gj, float *__restrict__ Gx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32 *bitmap = (u32 *)smem, *prefix = bitmap + W;
+    i32 *red = (i32 *)(prefix + W);
+    const int tid = threadIdx.x;
+    for (i32 g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        for (i32 w = tid; w < W; w += 256) bitmap[w] = 0;
+        __syncthreads();
+        for (int r = 0; r < R; ++r) {
+            const i32 row = grp_rows[(size_t)g * R + r];
+            if (row < 0) continue;
+            for (i32 p = Ap[row] + tid; p < Ap[row + 1]; p += 256) { const i32 c = Aj[p]; atomicOr(&bitmap[c >> 5], 1u << (c & 31)); }
+        }
+        __syncthreads();
+        const i32 per = (W + 255) / 256;
+        const i32 w0 = min(W, tid * per), w1 = min(W, w0 + per);
+        i32 local = 0;
+        for (i32 w = w0; w < w1; ++w) local += __popc(bitmap[w]);
+        // exclusive scan over the 256 threads
+        i32 incl = local;
+#pragma unroll
+        for (int o = 1; o < HHX_WAVE; o <<= 1) { const i32 t = __shfl_up(incl, o, HHX_WAVE); if (lane_id() >= o) incl += t; }
+        if (lane_id() == HHX_WAVE - 1) red[tid / HHX_WAVE] = incl;
+        __syncthreads();
+        i32 off = 0, total = 0;
+        for (int k = 0; k < 4; ++k) { if (k < tid / HHX_WAVE) off += red[k]; total += red[k]; }
+        i32 run = off + incl - local;
+        if (!FILL) {
+            if (tid == 0) cnt[g] = total;
+            __syncthreads();
+            continue;
+        }
+        const i32 base = Gp[g];
+        for (i32 w = w0; w < w1; ++w) {
+            prefix[w] = (u32)run;
+            u32 bits = bitmap[w];
+            while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; Gj[base + run] = (w << 5) + b; ++run; }
+        }
+        for (i32 t = tid; t < total * R; t += 256) Gx[(size_t)base * R + t] = 0.0f;
+        __syncthreads();
+        for (int r = 0; r < R; ++r) {
+            const i32 row = grp_rows[(size_t)g * R + r];
+            if (row < 0) continue;
+            for (i32 p = Ap[row] + tid; p < Ap[row + 1]; p += 256) {
+                const i32 c = Aj[p];
+                const i32 rk = (i32)(prefix[c >> 5] + __popc(bitmap[c >> 5] & ((1u << (c & 31)) - 1u)));
+                Gx[((size_t)base + rk) * R + r] = Ax[p];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int R>
+struct GBatch { i32 b3, b4; u32 da_lo[R], da_hi[R]; };             // one union entry per lane
+template <int R>
+__device__ __forceinline__ void gbatch_load(const ExParams &P, const GroupOp &op, i32 a_b, i32 a_e, i32 batch, i32 wv, GBatch<R> &r) {
+    const i32 e = a_b + batch * P.wb + lane_id();
+    const bool ok = lane_id() < P.wb && e < a_e;
+    const i32 ec = ok ? e : a_b;
+    const i32 k = op.Gj[ec];
+    const int4 *rp = P.rec + ((size_t)k * P.n_win + wv) * 2;
+    const int4 r0 = rp[0], r1 = rp[1];
+    r.b3 = ok ? r0.w : 0; r.b4 = ok ? r1.x : 0;
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+        const u64 d = (u64)__double_as_longlong((double)op.Gx[(size_t)ec * R + m] * P.scale);
+        r.da_lo[m] = (u32)d; r.da_hi[m] = (u32)(d >> 32);
+    }
+}
+template <int UX, int R>
+struct GTile { u32 j[UX], v[UX]; i32 n; u32 da_lo[R], da_hi[R]; bool valid; };
+template <int R>
+struct GCursor { i32 l, q, qe; u32 da_lo[R], da_hi[R]; };
+template <int UX, int R>
+__device__ __forceinline__ void gtile_fetch(const ExParams &P, const GBatch<R> &r, i32 cnt, GCursor<R> &c, GTile<UX, R> &t) {
+    while (c.q >= c.qe && c.l + 1 < cnt) {
+        ++c.l;
+        c.q = (__builtin_amdgcn_readlane(r.b3, c.l) + 63) & ~63;
+        c.qe = __builtin_amdgcn_readlane(r.b4, c.l);
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            c.da_lo[m] = __builtin_amdgcn_readlane(r.da_lo[m], c.l);
+            c.da_hi[m] = __builtin_amdgcn_readlane(r.da_hi[m], c.l);
+        }
+    }
+    t.valid = c.q < c.qe;
+    t.n = t.valid ? c.qe - c.q : 0;
+#pragma unroll
+    for (int m = 0; m < R; ++m) { t.da_lo[m] = c.da_lo[m]; t.da_hi[m] = c.da_hi[m]; }
+    const i32 base = t.valid ? c.q : 0;
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+        const i32 pos = lane_id() + u * HHX_WAVE;
+        const i32 qs = pos < t.n ? base + pos : 0;
+        t.j[u] = (u32)P.Sc16[qs];
+        t.v[u] = __float_as_uint(P.Sx[qs]);
+    }
+    c.q += UX * HHX_WAVE;
+}
+template <int UX, int R>
+__device__ __forceinline__ void gtile_consume(const ExLds &l, const GTile<UX, R> &t, i32 cap, i32 dummy) {
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+        if ((t.da_lo[m] | t.da_hi[m]) == 0u) continue;            // wave-uniform: this member has no entry in column k
+        const double da = __longlong_as_double((long long)(((u64)t.da_hi[m] << 32) | t.da_lo[m]));
+#pragma unroll
+        for (int u = 0; u < UX; ++u) {
+            const bool ok = lane_id() + u * HHX_WAVE < t.n;
+            const u64 g = fx_bits(da * (double)__uint_as_float(t.v[u]));
+            atomicAdd((unsigned long long *)&l.acc[ok ? m * cap + (i32)t.j[u] : dummy], (unsigned long long)g);
+        }
+    }
+}
+template <int R, int UX, int G>
+__global__ __launch_bounds__(EX_T_WIN) void k_expand_group(ExParams P, GroupOp op, i32 cap, i32 wv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ExLds l = win_carve(smem, R * cap);
+    const int tid = threadIdx.x;
+    i64 nnzc = 0, n_prod = 0, n_a = 0;
+    const i32 n_win = P.n_win;
+    const i32 c0 = wv * cap, c1 = min(P.n_cols, c0 + cap), wlen = max(0, c1 - c0);
+    const i32 dummy = R * cap + lane_id();
+    for (i32 g = blockIdx.x; g < op.n_groups; g += gridDim.x) {
+        const i32 a_b = op.Gp[g], a_e = op.Gp[g + 1];
+        const i32 n_batches = (a_e - a_b + P.wb - 1) / P.wb;
+        if (tid == 0) l.ctr[0] = 0;
+        for (i32 t = tid; t < R * cap; t += EX_T) l.acc[t] = 0;
+        __syncthreads();
+        i32 batch = 0;
+        if (lane_id() == 0) batch = atomicAdd(&l.ctr[0], 1);
+        batch = __builtin_amdgcn_readfirstlane(batch);
+        GBatch<R> nxt;
+        if (batch < n_batches) gbatch_load<R>(P, op, a_b, a_e, batch, wv, nxt);
+        while (batch < n_batches) {
+            const GBatch<R> cur = nxt;
+            const i32 cnt = min(P.wb, a_e - (a_b + batch * P.wb));
+            i32 nb = 0;
+            if (lane_id() == 0) nb = atomicAdd(&l.ctr[0], 1);
+            nb = __builtin_amdgcn_readfirstlane(nb);
+            if (nb < n_batches) gbatch_load<R>(P, op, a_b, a_e, nb, wv, nxt);
+            n_prod += max(0, cur.b4 - ceil64(cur.b3));
+            n_a += lane_id() == 0 ? cnt : 0;
+            GCursor<R> c;
+            c.l = -1; c.q = 0; c.qe = 0;
+#pragma unroll
+            for (int m = 0; m < R; ++m) { c.da_lo[m] = 0u; c.da_hi[m] = 0u; }
+            auto fetch = [&](GTile<UX, R> &t) { gtile_fetch<UX, R>(P, cur, cnt, c, t); };
+            auto consume = [&](const GTile<UX, R> &t) { gtile_consume<UX, R>(l, t, cap, dummy); };
+            for (;;) {
+                GTile<UX, R> t[G];
+                group_fetch<0, G>(t, fetch);
+                if (!group_consume<0, G>(t, consume)) break;
+            }
+            batch = nb;
+        }
+        __syncthreads();
+        for (int m = 0; m < R; ++m) {                              // the epilogue of k_expand_window, once per member over its own accumulators
+            const i32 row = op.rows[(size_t)g * R + m];
+            if (row < 0) continue;
+            ExLds lm = l;
+            lm.acc = l.acc + (size_t)m * cap;
+            i32 nz;
+            const double sw = window_power_sum<false>(P, lm, wlen, &nz, 0.0);
+            nnzc += nz;
+            const double s_run = (wv == 0 ? 0.0 : P.s_run[row]) + sw;
+            window_emit_candidates<false>(P, lm, wlen, c0, 0, s_run, &P.g_win_off[(size_t)row * n_win + wv], &P.g_win_cnt[(size_t)row * n_win + wv]);
+            __syncthreads();
+            if (tid == 0) P.s_run[row] = s_run;
+        }
+        __syncthreads();
+    }
+    nnzc = wave_sum_i64(nnzc);
+    if (lane_id() == 0 && nnzc) atomicAdd(&P.cursors[3], (unsigned long long)nnzc);
+    n_prod = wave_sum_i64(n_prod);
+    if (lane_id() == 0 && n_prod) atomicAdd(&P.cursors[8], (unsigned long long)n_prod);
+    n_a = wave_sum_i64(n_a);
+    if (lane_id() == 0 && n_a) atomicAdd(&P.cursors[9], (unsigned long long)n_a);
 }
 
 // Layout of the window kernel's operand stream, two passes with a scan between them.  One wave per (B row, column
@@ -1907,6 +2133,19 @@ static int launch_window(const ExParams &P, const i32 *rows, i32 n_list, i32 cap
     return launch_window_fx<PROBE, UX, RX, RW, false>(P, rows, n_list, cap, lds, grid);
 }
 
+template <int R, int UX, int G>
+static int launch_group(const ExParams &P, const GroupOp &op, i32 cap, size_t lds, unsigned grid) {
+    static int attr_dev = -1;
+    int dev = 0;
+    HHX_HIP(hipGetDevice(&dev));
+    if (attr_dev != dev) {
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_group<R, UX, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_dev = dev;
+    }
+    for (i32 wv = 0; wv < P.n_win; ++wv) k_expand_group<R, UX, G><<<grid, EX_T_WIN, lds, g_stream>>>(P, op, cap, wv);
+    return 0;
+}
+
 // the bump-allocated rows -> CSR: scan of the row counts, ordered copy
 static int pack_rows_to_csr(i32 n_rows, i32 n_cols, const i32 *row_cnt, i32 *indptr, const i64 *row_off, const i32 *pool_col, const float *pool_val,
                             hhx_csr **out) {
@@ -1989,11 +2228,30 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     DevBuf<double> s_run;
     DevBuf<unsigned int> counts;
     DevBuf<unsigned long long> cursors;
+    // re-use of B rows across output rows (k_expand_group): R rows of one attractor per workgroup, column windows R times narrower.
+    // Generic stream only (iterations >= 1 of mcl(), hhx_spgemm excluded); tune "reuse": 0 off, 2 or 4 rows per group (default 4)
+    int reuse_R = (!use_cls && !dense && !coded.raw && a == b) ? (int)tune_get("reuse", 4) : 0;
+    if (reuse_R != 2 && reuse_R != 4) reuse_R = 0;
+    i32 cap_g = 0, n_win_g = 0;
+    if (reuse_R) {
+        const i32 cap_max = (i32)((160 * 1024 - fixed_win) / 8) & ~63;
+        for (i64 wn = std::max<i64>(1, ((i64)n_cols * reuse_R + cap_max - 1) / cap_max);; ++wn) {
+            const i32 c = (i32)((((i64)n_cols + wn - 1) / wn + 63) & ~63);
+            if ((i64)c * reuse_R <= cap_max) { cap_g = c; n_win_g = (n_cols + c - 1) / c; break; }
+        }
+        if (cap_g < 1024) reuse_R = 0;                      // windows too narrow to be worth a launch each
+    }
+    const i32 n_win_tab = std::max(n_win, n_win_g);
     if (list_w.alloc((size_t)n_rows + 1) || list_c.alloc((size_t)n_rows + 1) || list_t.alloc((size_t)n_rows + 1) ||
         list_h.alloc((size_t)n_rows + 1) || row_f.alloc((size_t)n_rows + 1) || row_cnt.alloc((size_t)n_rows + 1) ||
         indptr.alloc((size_t)n_rows + 1) || row_off.alloc((size_t)n_rows + 1) || counts.alloc(4) || cursors.alloc(12) ||
-        s_run.alloc((size_t)n_rows + 1) || g_win_off.alloc((size_t)n_rows * n_win + 1) || g_win_cnt.alloc((size_t)n_rows * n_win + 1))
+        s_run.alloc((size_t)n_rows + 1) || g_win_off.alloc((size_t)n_rows * n_win_tab + 1) || g_win_cnt.alloc((size_t)n_rows * n_win_tab + 1))
         return 1;
+    DevBuf<i32> grp_rows, Gp, Gj;
+    DevBuf<float> Gx;
+    i32 n_groups = 0;
+    i64 group_entries = 0;              // entries of the union rows
+    int group_mode = -1;                // -1: not decided yet (first attempt), 0: one row per workgroup, 1: groups
     DevBuf<int4> rec;                   // window kernel: records + stream of the right operand, built once per call
     DevBuf<unsigned short> c16;
     DevBuf<float> cls_x;
@@ -2074,15 +2332,84 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             HHX_HIP(hipStreamSynchronize(g_stream));
         }
         const unsigned n_hash_rows = hc[3];
+        // ---- rows of the window class grouped by attractor (k_expand_group): decided once per call
+        if (group_mode < 0 || (group_mode == 1 && attempt > 0)) {
+            group_mode = 0;
+            n_groups = 0;
+            const double a_len0 = hc[0] ? (double)hw[1] / (double)hc[0] : 0.0;
+            if (reuse_R && hc[0] >= 1024 && a_len0 >= 128.0) {
+                KTimer kt("group_build");
+                const i64 nl = (i64)hc[0];
+                DevBuf<u64> key, val, skey, sval;
+                if (key.alloc((size_t)nl) || val.alloc((size_t)nl) || skey.alloc((size_t)nl) || sval.alloc((size_t)nl)) return 1;
+                k_row_attractor<<<(unsigned)std::min<i64>((nl + 3) / 4, 4096), 256, 0, g_stream>>>((i32)nl, list_w.p, a->indptr.p, a->indices.p, a->data.p, key.p, val.p);
+                HHX_LAUNCH_CHECK();
+                // rows in list order are not ascending (the classification appends by wave): sort by (attractor, row)
+                int rbits = 1;
+                while (rbits < 31 && (n_rows >> rbits)) ++rbits;
+                int cbits = 1;
+                while (cbits < 31 && (n_cols >> cbits)) ++cbits;
+                HHX_TRY(stable_sort_pairs_u64(val.p, sval.p, key.p, skey.p, nl, rbits));              // by row ...
+                HHX_TRY(stable_sort_pairs_u64(skey.p, key.p, sval.p, val.p, nl, cbits));              // ... then, stably, by attractor
+                std::vector<u64> h_att((size_t)nl), h_row((size_t)nl);
+                HHX_HIP(hipMemcpyAsync(h_att.data(), key.p, 8 * (size_t)nl, hipMemcpyDeviceToHost, g_stream));
+                HHX_HIP(hipMemcpyAsync(h_row.data(), val.p, 8 * (size_t)nl, hipMemcpyDeviceToHost, g_stream));
+                HHX_HIP(hipStreamSynchronize(g_stream));
+                std::vector<i32> h_grp;
+                h_grp.reserve((size_t)nl + (size_t)reuse_R);
+                for (i64 p0 = 0; p0 < nl;) {
+                    i64 p1 = p0 + 1;
+                    while (p1 < nl && p1 - p0 < reuse_R && h_att[(size_t)p1] == h_att[(size_t)p0]) ++p1;
+                    for (i64 q = p0; q < p0 + reuse_R; ++q) h_grp.push_back(q < p1 ? (i32)h_row[(size_t)q] : -1);
+                    p0 = p1;
+                }
+                n_groups = (i32)(h_grp.size() / (size_t)reuse_R);
+                if ((i64)n_groups * 2 <= nl) {                // on average two rows or more per group: the walk is shared
+                    const i32 Wb = (n_cols + 31) / 32;
+                    const size_t lds_u = (size_t)Wb * 8 + 64;
+                    DevBuf<i32> gcnt;
+                    if (grp_rows.alloc(h_grp.size()) || gcnt.alloc((size_t)n_groups + 1) || Gp.alloc((size_t)n_groups + 2)) return 1;
+                    HHX_HIP(hipMemcpyAsync(grp_rows.p, h_grp.data(), sizeof(i32) * h_grp.size(), hipMemcpyHostToDevice, g_stream));
+                    static int gu_attr = -1;
+                    int gu_dev = 0;
+                    HHX_HIP(hipGetDevice(&gu_dev));
+                    if (gu_attr != gu_dev) {
+                        HHX_HIP(hipFuncSetAttribute((const void *)k_group_union<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        HHX_HIP(hipFuncSetAttribute((const void *)k_group_union<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        gu_attr = gu_dev;
+                    }
+                    if (lds_u <= 160 * 1024) {
+                        const unsigned ggrid = (unsigned)std::min<i32>(n_groups, 256 * 8);
+                        k_group_union<false><<<ggrid, 256, lds_u, g_stream>>>(n_groups, reuse_R, grp_rows.p, a->indptr.p, a->indices.p, a->data.p, Wb, gcnt.p, nullptr, nullptr, nullptr);
+                        HHX_LAUNCH_CHECK();
+                        i64 union_nnz = 0;
+                        HHX_TRY(exclusive_scan_i32(gcnt.p, Gp.p, n_groups, &union_nnz));
+                        if (union_nnz < (i64)INT32_MAX / 8) {
+                            if (Gj.alloc((size_t)union_nnz + 1) || Gx.alloc((size_t)union_nnz * (size_t)reuse_R + 1)) return 1;
+                            k_group_union<true><<<ggrid, 256, lds_u, g_stream>>>(n_groups, reuse_R, grp_rows.p, a->indptr.p, a->indices.p, a->data.p, Wb, nullptr, Gp.p, Gj.p, Gx.p);
+                            HHX_LAUNCH_CHECK();
+                            HHX_HIP(hipStreamSynchronize(g_stream));      // h_grp dies with this scope
+                            group_mode = 1;
+                            group_entries = union_nnz;
+                            if (debug) fprintf(stderr, "[hhx expand] re-use: %lld rows in %d groups of <= %d, union rows hold %lld entries (the rows: %llu)\n",
+                                               (long long)nl, n_groups, reuse_R, (long long)union_nnz, hw[1]);
+                        }
+                    }
+                }
+            }
+        }
+        const i32 cap_use = group_mode == 1 ? cap_g : cap_win;
+        const i32 n_win_use = group_mode == 1 ? n_win_g : n_win;
+        P.n_win = n_win_use;
         // mean length of a B-row segment inside one column window: tiles of 2 / 4 / 8 entries per lane
         const int tile_env = (int)tune_get("tile_u", 0);
-        const double seg_len = hw[1] ? (double)hw[0] / (double)hw[1] / (double)n_win : 0.0;
+        const double seg_len = hw[1] ? (double)hw[0] / (double)hw[1] / (double)n_win_use : 0.0;
         int tile_u = 0;
         const bool long_segments = seg_len >= 192.0;          // iteration 0 (the link matrix is the operand) vs the pruned iterations: timed apart
         if (hc[0]) {
             const unsigned grid = std::min<unsigned>(hc[0], 256);
             if (!rec.p) {                                 // the operand stream of b, built once per call
-                const i64 segs = (i64)b->n_rows * n_win;
+                const i64 segs = (i64)b->n_rows * n_win_use;
                 DevBuf<int4> cnt4;
                 DevBuf<i64> sizes, offs;
                 DevBuf<unsigned long long> n_uni;
@@ -2091,7 +2418,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 HHX_HIP(hipMemsetAsync(n_uni.p, 0, sizeof(unsigned long long), g_stream));
                 const unsigned lgrid = (unsigned)std::max<i64>(1, std::min<i64>((segs + 3) / 4, 65536));
                 KTimer kt("class_layout");
-                k_layout_sizes<<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win, cap_win, n_classes, b->indptr.p, b->indices.p, use_cls ? coded.n16 : nullptr,
+                k_layout_sizes<<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win_use, cap_use, n_classes, b->indptr.p, b->indices.p, use_cls ? coded.n16 : nullptr,
                                                             cnt4.p, sizes.p, n_uni.p);
                 HHX_LAUNCH_CHECK();
                 i64 slots = 0;
@@ -2105,10 +2432,10 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 if (slots + STREAM_PREFIX > (i64)INT32_MAX - 4096) return fail("expand: the padded operand stream needs %lld slots (int32 cursors)", (long long)slots);
                 if (c16.alloc((size_t)slots + STREAM_PREFIX + 64) || cls_x.alloc((size_t)slots + STREAM_PREFIX + 64)) return 1;
                 if (use_cls && tune_get("cls_balance", 1))
-                    k_layout_write<true><<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win, cap_win, n_classes, b->indptr.p, b->indices.p, b->data.p, coded.n16,
+                    k_layout_write<true><<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win_use, cap_use, n_classes, b->indptr.p, b->indices.p, b->data.p, coded.n16,
                                                                       coded.row_sum, cnt4.p, offs.p, c16.p, cls_x.p, rec.p, fx ? 1 : 0);
                 else
-                    k_layout_write<false><<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win, cap_win, n_classes, b->indptr.p, b->indices.p, b->data.p,
+                    k_layout_write<false><<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win_use, cap_use, n_classes, b->indptr.p, b->indices.p, b->data.p,
                                                                        use_cls ? coded.n16 : nullptr, use_cls ? coded.row_sum : nullptr, cnt4.p, offs.p, c16.p, cls_x.p, rec.p, fx ? 1 : 0);
                 HHX_LAUNCH_CHECK();
                 HHX_HIP(hipStreamSynchronize(g_stream));         // cnt4 / sizes / offs die here
@@ -2117,7 +2444,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             P.narrow_classes = use_cls ? (n_classes > 1 ? 1 : 0) : -1;
             // batches: 32 A entries per wave draw when the rows are long; for the few-hundred-entry rows of the later iterations
             // 8, so that all sixteen waves of the workgroup get work out of one row
-            const double a_len = hc[0] ? (double)hw[1] / (double)hc[0] : 0.0;
+            const double a_len = group_mode == 1 ? (double)group_entries / (double)std::max(n_groups, 1) : (hc[0] ? (double)hw[1] / (double)hc[0] : 0.0);
             P.wb = (i32)tune_get("win_batch", a_len >= 1536.0 ? 32 : (a_len >= 512.0 ? 16 : 8));
             if (P.wb < 1 || P.wb > WB_MAX) P.wb = WB_MAX;
             // explicit tiles: UX x 64 entries, sized to the mean explicit sub-segment (a tile costs its 2 UX loads and UX
@@ -2125,7 +2452,21 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             const double xlen = seg_len * explicit_frac;
             const int ux = tile_env ? tile_env : (xlen > 288.0 ? 8 : (xlen > 200.0 ? 4 : (xlen > 136.0 ? 3 : (xlen > 68.0 ? 2 : 1))));
             tile_u = ux;
-            {
+            if (group_mode == 1) {
+                KTimer kt("expand_group", n_win_use);
+                GroupOp op{grp_rows.p, Gp.p, Gj.p, Gx.p, n_groups};
+                const size_t lds_g = (size_t)reuse_R * cap_use * 8 + fixed_win;
+                const unsigned ggrid = (unsigned)std::min<i32>(n_groups, 256);
+                if (reuse_R == 4) {
+                    if (ux >= 4) HHX_TRY((launch_group<4, 4, 4>(P, op, cap_use, lds_g, ggrid)));
+                    else if (ux >= 2) HHX_TRY((launch_group<4, 2, 8>(P, op, cap_use, lds_g, ggrid)));
+                    else HHX_TRY((launch_group<4, 1, 8>(P, op, cap_use, lds_g, ggrid)));
+                } else {
+                    if (ux >= 4) HHX_TRY((launch_group<2, 4, 4>(P, op, cap_use, lds_g, ggrid)));
+                    else if (ux >= 2) HHX_TRY((launch_group<2, 2, 8>(P, op, cap_use, lds_g, ggrid)));
+                    else HHX_TRY((launch_group<2, 1, 8>(P, op, cap_use, lds_g, ggrid)));
+                }
+            } else {
                 KTimer kt(long_segments ? "expand_window" : "expand_window_short", n_win);
 #ifdef HHX_PROBE_BUILD             // measurement build only (-DHHX_PROBE_BUILD): the atomics switched off, results are garbage
                 if (probe == 1 && ux >= 4) HHX_TRY((launch_window<1, 8, 3, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
@@ -2187,7 +2528,11 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             if ((i64)cur[1] > pool_cap) pool_cap = std::max<i64>(pool_cap * 2, (i64)cur[1] + (i64)n_rows);
             continue;
         }
-        if (prof_enabled() && hc[0]) {
+        if (prof_enabled() && hc[0] && group_mode == 1) {
+            prof_count("expand_group_loaded_entries", (i64)cur[8]);           // entries of B streamed (each serves up to R products)
+            prof_count("expand_group_products", (i64)hw[0]);                  // products of the rows of the class
+            prof_count("expand_group_a_reads", (i64)cur[9]);
+        } else if (prof_enabled() && hc[0]) {
             const bool longseg = long_segments;
             prof_count(longseg ? "expand_window_products" : "expand_window_short_products", (i64)cur[8]);
             prof_count(longseg ? "expand_window_a_reads" : "expand_window_short_a_reads", (i64)cur[9]);

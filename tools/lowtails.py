@@ -103,6 +103,7 @@ def main():
     ap.add_argument('--whole', default='', help='config:inflation pairs, e.g. c3:1.2 — the oracle continues that tail to convergence')
     ap.add_argument('--sample', type=int, default=48)
     ap.add_argument('--reuse', action='store_true')
+    ap.add_argument('--reuse-ab', action='store_true', help='time the tails with the re-use kernel (hhx_tune reuse = 4 / 2) against one row per walk, compare bits')
     args = ap.parse_args()
     import torch
     from haphic_amd import _lib, synth
@@ -145,6 +146,32 @@ def main():
             a, it_a, conv_a, per = tail(_lib, first, infl, 200, checker=checker)
             b, it_b, conv_b, _ = tail(_lib, first, infl, 200, hash_max=0)                   # every row through the window class
             c, it_c, conv_c = _lib.mcl_resume(first, 1, 2, infl, 200, 1e-4)                 # the product path (first is not consumed)
+            ab = None
+            if args.reuse_ab:
+                # k_expand_group (R output rows of one attractor per B-row walk) against one row per walk: same bits, wall times
+                sync = lambda: _lib.check(_lib.load().hhx_synchronize())                    # noqa: E731
+                ab = {}
+                for label, R in (('rows_per_walk_1', 0), ('rows_per_walk_4', 4), ('rows_per_walk_2', 2)):
+                    _lib.tune('reuse', R)
+                    try:
+                        _lib.profile_reset()
+                        _lib.profile_enable(True)
+                        sync()
+                        ta = time.perf_counter()
+                        d_, it_d, conv_d = _lib.mcl_resume(first, 1, 2, infl, 200, 1e-4)
+                        sync()
+                        dt = time.perf_counter() - ta
+                        _lib.profile_enable(False)
+                    finally:
+                        _lib.tune('reuse', None)
+                    dd = d_.to_arrays()
+                    d_.free()
+                    ab[label] = {'seconds': round(dt, 3), 'iterations': it_d, 'same_bits_as_default': bool((it_d, bool(conv_d)) == (it_c, bool(conv_c)) and
+                                                                                                             all(np.array_equal(x, y) for x, y in zip(dd, c.to_arrays()))),
+                                 'group_ms': round(_lib.profile_get('expand_group')[0], 1), 'group_build_ms': round(_lib.profile_get('group_build')[0], 1),
+                                 'window_short_ms': round(_lib.profile_get('expand_window_short')[0] + _lib.profile_get('expand_window')[0], 1),
+                                 'hash_ms': round(_lib.profile_get('expand_hash')[0], 1),
+                                 'group_loaded_entries': _lib.profile_counter('expand_group_loaded_entries'), 'group_products': _lib.profile_counter('expand_group_products')}
             aa, bb, cc = a.to_arrays(), b.to_arrays(), c.to_arrays()
             same = bool((it_a, conv_a) == (it_b, conv_b) == (it_c, bool(conv_c)) and all(np.array_equal(x, y) and np.array_equal(x, z) for x, y, z in zip(aa, bb, cc)))
             rec = {'config': name, 'n': int(n), 'inflation': infl, 't1_nnz': int(first.nnz), 'iterations': it_a, 'converged': conv_a,
@@ -152,6 +179,8 @@ def main():
                    'all_samples_pattern_equal': all(p['pattern_equal'] for p in per),
                    'max_rel_over_samples': max([p['max_rel'] for p in per if p['max_rel'] is not None] or [None]),
                    'widest_expanded_row': max([p['widest_expanded_row'] for p in per] or [0])}
+            if ab is not None:
+                rec['reuse_ab'] = ab
             if (name, ('%g' % infl)) in whole:
                 tw = time.time()
                 f_host = first.to_arrays()
