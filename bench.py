@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--sweep', type=int, default=20, help='after the timed region: the inflation sweep of run_mcl_clustering :2155-2158 (1.1, 1.2, ... this many '
                     'values) with ONE expansion — iteration 0 of every inflation from the dense row blocks of M^2 (0 = skip)')
     ap.add_argument('--sweep-tail-seconds', type=float, default=20.0, help='sweep leg: wall-time budget for the mcl() tails (run from the highest inflation down)')
+    ap.add_argument('--check-sweep', action='store_true', help='N > 1: rank 0 also runs the one-GPU sweep on the all-gathered link matrix and compares every inflation (functional runs)')
     ap.add_argument('--no-seam', action='store_true', help='skip the seam_e2e leg (the reference\'s own operator sequence S5 -> filter_fragments -> S4 on host id arrays, after the timed region)')
     ap.add_argument('--no-seam-files', action='store_true', help='seam_e2e: skip the three files run() writes between S5 and S4 (HT_links.pkl, paired_links.clm, full_links.pkl)')
     ap.add_argument('--transport', choices=('rccl', 'host'), default='rccl',
@@ -348,6 +349,26 @@ def main():
                         'clusters': [int(len(r[0])) for r in res_sw], 'ranks': world,
                         'what': 'sharded.sweep_sharded: one expansion shared by the ranks (each holds its rows of M^2), dense epilogue + exchange per '
                                 'inflation, heavy iterations row-sharded (>= %.0e products), light remainders dealt by predicted cost' % sharded.SWEEP_SHARD_PRODUCTS}
+            if args.check_sweep and rank == 0:
+                # functional runs (--transport host): the SAME all-gathered link matrix through the one-GPU sweep — iteration counts,
+                # convergence flags and the attractor arrays (= the cluster sets) of every inflation must be those of the ranks' sweep
+                from haphic_amd import cluster as _cl
+                tc = time.perf_counter()
+                sw1 = _cl.DenseSweep(full, 1e-4)
+                same = []
+                try:
+                    for k_, first in enumerate(sw1.first_iterations(infl)):
+                        r1, n1, c1 = _lib.mcl_resume(first, 1, 2, infl[k_], 200, 1e-4)
+                        first.free()
+                        a1 = _lib.interpret(r1)
+                        r1.free()
+                        rs = res_sw[k_]
+                        same.append(bool(n1 == rs[4] and bool(c1) == bool(rs[5]) and all(np.array_equal(x, y) for x, y in zip(a1, rs[:3]))))
+                finally:
+                    sw1.close()
+                sweep_sh['equals_one_gpu_sweep_on_the_same_matrix'] = same
+                sweep_sh['all_equal'] = all(same)
+                sweep_sh['one_gpu_sweep_seconds'] = time.perf_counter() - tc
             full.free()
         except Exception as e:                           # noqa: BLE001 — this leg must never take the line of the timed region down
             sweep_sh = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}

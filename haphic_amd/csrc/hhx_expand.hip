@@ -2229,8 +2229,11 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     DevBuf<unsigned int> counts;
     DevBuf<unsigned long long> cursors;
     // re-use of B rows across output rows (k_expand_group): R rows of one attractor per workgroup, column windows R times narrower.
-    // Generic stream only (iterations >= 1 of mcl(), hhx_spgemm excluded); tune "reuse": 0 off, 2 or 4 rows per group (default 4)
-    int reuse_R = (!use_cls && !dense && !coded.raw && a == b) ? (int)tune_get("reuse", 4) : 0;
+    // Generic stream only (iterations >= 1 of mcl(), hhx_spgemm excluded); tune "reuse": 0 off (the default), 2 or 4 rows per group.
+    // OFF by default: measured (tools/lowtails.py --reuse-ab, profiles/r05_lowtails_reuse.jsonl) it streams 3.5-3.9 x fewer bytes, gives
+    // the same bits, and is no faster — the per-product path of distinct 64-bit addends caps at ~1.1e12 products/s, the rate the
+    // fabric-bound one-row kernel already reaches
+    int reuse_R = (!use_cls && !dense && !coded.raw && a == b) ? (int)tune_get("reuse", 0) : 0;
     if (reuse_R != 2 && reuse_R != 4) reuse_R = 0;
     i32 cap_g = 0, n_win_g = 0;
     if (reuse_R) {

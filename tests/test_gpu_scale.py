@@ -475,6 +475,23 @@ def test_low_inflation_whole_tails_against_oracle():
     through_window = 0
     try:
         for r, first in zip((1.1, 1.2, 1.3), sweep.first_iterations((1.1, 1.2, 1.3))):
+            if r == 1.2:
+                # the re-use kernel (k_expand_group, opt-in: hhx_tune("reuse", 4) — four output rows of one attractor per walk of a B
+                # row): the same tail, bit for bit, and rows did take the grouped path (its own product counter)
+                plain = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4)
+                _lib.tune('reuse', 4)
+                _lib.profile_reset()
+                _lib.profile_enable(True)
+                try:
+                    grouped = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4)
+                finally:
+                    _lib.profile_enable(False)
+                    _lib.tune('reuse', None)
+                assert _lib.profile_counter('expand_group_products') > 0, 'hhx_tune("reuse", 4) did not reach k_expand_group'
+                assert plain[1:] == grouped[1:] and all(np.array_equal(u, v) for u, v in zip(plain[0].to_arrays(), grouped[0].to_arrays())), \
+                    'k_expand_group: the tail at 1.2 differs from the one-row-per-walk kernel'
+                plain[0].free()
+                grouped[0].free()
             n_iter, stats, window_products = _whole_tail_against_oracle(first, r, '3.4k contigs, inflation %r' % r, '3.4k whole tail at %r' % r)
             through_window += window_products
             assert n_iter > 10

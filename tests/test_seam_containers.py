@@ -270,7 +270,8 @@ def test_device_clm_and_pickles_against_the_oracle(tmp_path):
     t = orc.FragTable(rank, length, np.arange(n, dtype=np.int32), np.zeros(n, np.uint8), 0, rank, length, np.ones(n, np.uint8))
     npairs = 300_000
     id1 = rng.integers(0, n, npairs).astype(np.int32)
-    id2 = np.where(rng.random(npairs) < 0.5, (id1 + 1) % n, rng.integers(0, n, npairs)).astype(np.int32)   # some heavy groups
+    id2 = np.where(rng.random(npairs) < 0.5, (id1 + 1) % n, (id1 + 1 + rng.integers(0, n - 1, npairs)) % n).astype(np.int32)   # some heavy groups; never id1 (what
+    assert (id1 != id2).all()                                                # pairs_generator_inter_ctgs :1582 hands to the loop)
     p1 = (rng.random(npairs) * length[id1]).astype(np.int32)
     p2 = (rng.random(npairs) * length[id2]).astype(np.int32)
     p2[::5] = p1[::5] % np.maximum(length[id2[::5]], 1)                     # ties
@@ -299,9 +300,9 @@ def test_device_clm_and_pickles_against_the_oracle(tmp_path):
     assert pickle.load(open(tmp_path / 'f.pkl', 'rb')) == pickle.loads(orc.link_pickle(names, want['full_i'], want['full_j'], want['full_cnt']))
     ing.destroy()
     # nothing to write: an empty file, like the reference
-    ing = _lib.Ingest(t, 10_000)
+    ing = _lib.Ingest(t, 10_000, skip_intra=True)
     ing.keep_pairs()
-    ing.push(id1[:4], p1[:4], id1[:4], p2[:4])                               # intra-contig pairs only
+    ing.push(id1[:4], p1[:4], id1[:4], p2[:4])                               # intra-contig pairs only: dropped
     ing.finalize()
     assert ing.write_clm(str(tmp_path / 'e.clm'), names) == (0, 0) and os.path.getsize(tmp_path / 'e.clm') == 0
     ing.destroy()

@@ -20,7 +20,7 @@ for l in open('gpurun_out/lowtails.jsonl'):
 "; tail -3 gpurun_out/lowtails.err;;
     rest) timeout 900 python -m pytest tests/test_gpu_scale.py tests/test_plot.py tests/test_seam_containers.py -m gpu -x -q -k "not c3 and not c2" --durations=5 > gpurun_out/pytest_rest.log 2>&1; echo "rest rc=$?"; grep -E "passed|failed|Error|^E " gpurun_out/pytest_rest.log | tail -12;;
     c1run) timeout 600 python tools/c1_run.py > gpurun_out/c1_run.json 2> gpurun_out/c1_run.err; echo "c1run rc=$?"; cat gpurun_out/c1_run.json | cut -c1-1500; tail -3 gpurun_out/c1_run.err;;
-    host8c3) timeout 1100 python bench.py --gpus 8 --transport host --steps 1 --warmup 0 --no-cpu-baseline --no-seam --sweep 20 --sharded-sweep-timeout 800 > gpurun_out/bench_host8_c3.log 2>&1; echo "host8c3 rc=$?"; python tools/bench_brief.py gpurun_out/bench_host8_c3.log | head -3; python -c "
+    host8c3) timeout 1100 python bench.py --gpus 8 --transport host --steps 1 --warmup 0 --no-cpu-baseline --no-seam --sweep 20 --sharded-sweep-timeout 900 --check-sweep > gpurun_out/bench_host8_c3.log 2>&1; echo "host8c3 rc=$?"; python tools/bench_brief.py gpurun_out/bench_host8_c3.log | head -3; python -c "
 import json
 for l in open('gpurun_out/bench_host8_c3.log'):
     if l.startswith('{'): print(json.dumps(json.loads(l).get('sweep_sharded'))[:1200])
