@@ -924,26 +924,19 @@ __device__ __forceinline__ void gbatch_load(const ExParams &P, const GroupOp &op
         r.da_lo[m] = (u32)d; r.da_hi[m] = (u32)(d >> 32);
     }
 }
+template <int UX>
+struct GTile { u32 j[UX], v[UX]; i32 n, l; bool valid; };        // l: the union entry of the batch this tile belongs to (wave-uniform)
+struct GCursor { i32 l, q, qe; };
 template <int UX, int R>
-struct GTile { u32 j[UX], v[UX]; i32 n; u32 da_lo[R], da_hi[R]; bool valid; };
-template <int R>
-struct GCursor { i32 l, q, qe; u32 da_lo[R], da_hi[R]; };
-template <int UX, int R>
-__device__ __forceinline__ void gtile_fetch(const ExParams &P, const GBatch<R> &r, i32 cnt, GCursor<R> &c, GTile<UX, R> &t) {
+__device__ __forceinline__ void gtile_fetch(const ExParams &P, const GBatch<R> &r, i32 cnt, GCursor &c, GTile<UX> &t) {
     while (c.q >= c.qe && c.l + 1 < cnt) {
         ++c.l;
         c.q = (__builtin_amdgcn_readlane(r.b3, c.l) + 63) & ~63;
         c.qe = __builtin_amdgcn_readlane(r.b4, c.l);
-#pragma unroll
-        for (int m = 0; m < R; ++m) {
-            c.da_lo[m] = __builtin_amdgcn_readlane(r.da_lo[m], c.l);
-            c.da_hi[m] = __builtin_amdgcn_readlane(r.da_hi[m], c.l);
-        }
     }
     t.valid = c.q < c.qe;
     t.n = t.valid ? c.qe - c.q : 0;
-#pragma unroll
-    for (int m = 0; m < R; ++m) { t.da_lo[m] = c.da_lo[m]; t.da_hi[m] = c.da_hi[m]; }
+    t.l = c.l;
     const i32 base = t.valid ? c.q : 0;
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
@@ -954,34 +947,44 @@ __device__ __forceinline__ void gtile_fetch(const ExParams &P, const GBatch<R> &
     }
     c.q += UX * HHX_WAVE;
 }
+// the weights of the tile's union entry are read from the batch registers when the tile is consumed (two v_readlane per member):
+// carrying them inside every tile of a group of G tiles in flight cost 2 R G scalar registers and spilled them
 template <int UX, int R>
-__device__ __forceinline__ void gtile_consume(const ExLds &l, const GTile<UX, R> &t, i32 cap, i32 dummy) {
+__device__ __forceinline__ void gtile_consume(const ExLds &l, const GBatch<R> &r, const GTile<UX> &t, i32 cap, i32 dummy) {
+    i32 idx[UX];
+    double x[UX];
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+        idx[u] = lane_id() + u * HHX_WAVE < t.n ? (i32)t.j[u] : dummy;       // a masked lane: its scratch slot behind the R windows, minus m * cap below
+        x[u] = (double)__uint_as_float(t.v[u]);
+    }
 #pragma unroll
     for (int m = 0; m < R; ++m) {
-        if ((t.da_lo[m] | t.da_hi[m]) == 0u) continue;            // wave-uniform: this member has no entry in column k
-        const double da = __longlong_as_double((long long)(((u64)t.da_hi[m] << 32) | t.da_lo[m]));
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)r.da_lo[m], t.l), hi = (u32)__builtin_amdgcn_readlane((int)r.da_hi[m], t.l);
+        if ((lo | hi) == 0u) continue;                            // wave-uniform: this member has no entry in column k
+        const double da = __longlong_as_double((long long)(((u64)hi << 32) | lo));
 #pragma unroll
-        for (int u = 0; u < UX; ++u) {
-            const bool ok = lane_id() + u * HHX_WAVE < t.n;
-            const u64 g = fx_bits(da * (double)__uint_as_float(t.v[u]));
-            atomicAdd((unsigned long long *)&l.acc[ok ? m * cap + (i32)t.j[u] : dummy], (unsigned long long)g);
-        }
+        for (int u = 0; u < UX; ++u)
+            atomicAdd((unsigned long long *)&l.acc[m * cap + idx[u]], (unsigned long long)fx_bits(da * x[u]));
     }
 }
 template <int R, int UX, int G>
 __global__ __launch_bounds__(EX_T_WIN) void k_expand_group(ExParams P, GroupOp op, i32 cap, i32 wv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ExLds l = win_carve(smem, R * cap);
+    // every member's window is followed by its own N_DUMMY scratch slots (a masked lane adds to slot cap + lane of the member's region),
+    // so that a slot index is "member offset + index" for real and masked entries alike
+    const i32 stride = cap + N_DUMMY;
+    const ExLds l = win_carve(smem, R * stride);
     const int tid = threadIdx.x;
     i64 nnzc = 0, n_prod = 0, n_a = 0;
     const i32 n_win = P.n_win;
     const i32 c0 = wv * cap, c1 = min(P.n_cols, c0 + cap), wlen = max(0, c1 - c0);
-    const i32 dummy = R * cap + lane_id();
+    const i32 dummy = cap + lane_id();
     for (i32 g = blockIdx.x; g < op.n_groups; g += gridDim.x) {
         const i32 a_b = op.Gp[g], a_e = op.Gp[g + 1];
         const i32 n_batches = (a_e - a_b + P.wb - 1) / P.wb;
         if (tid == 0) l.ctr[0] = 0;
-        for (i32 t = tid; t < R * cap; t += EX_T) l.acc[t] = 0;
+        for (i32 t = tid; t < R * stride; t += EX_T) l.acc[t] = 0;
         __syncthreads();
         i32 batch = 0;
         if (lane_id() == 0) batch = atomicAdd(&l.ctr[0], 1);
@@ -997,14 +1000,11 @@ __global__ __launch_bounds__(EX_T_WIN) void k_expand_group(ExParams P, GroupOp o
             if (nb < n_batches) gbatch_load<R>(P, op, a_b, a_e, nb, wv, nxt);
             n_prod += max(0, cur.b4 - ceil64(cur.b3));
             n_a += lane_id() == 0 ? cnt : 0;
-            GCursor<R> c;
-            c.l = -1; c.q = 0; c.qe = 0;
-#pragma unroll
-            for (int m = 0; m < R; ++m) { c.da_lo[m] = 0u; c.da_hi[m] = 0u; }
-            auto fetch = [&](GTile<UX, R> &t) { gtile_fetch<UX, R>(P, cur, cnt, c, t); };
-            auto consume = [&](const GTile<UX, R> &t) { gtile_consume<UX, R>(l, t, cap, dummy); };
+            GCursor c = {-1, 0, 0};
+            auto fetch = [&](GTile<UX> &t) { gtile_fetch<UX, R>(P, cur, cnt, c, t); };
+            auto consume = [&](const GTile<UX> &t) { gtile_consume<UX, R>(l, cur, t, stride, dummy); };
             for (;;) {
-                GTile<UX, R> t[G];
+                GTile<UX> t[G];
                 group_fetch<0, G>(t, fetch);
                 if (!group_consume<0, G>(t, consume)) break;
             }
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(EX_T_WIN) void k_expand_group(ExParams P, GroupOp o
             const i32 row = op.rows[(size_t)g * R + m];
             if (row < 0) continue;
             ExLds lm = l;
-            lm.acc = l.acc + (size_t)m * cap;
+            lm.acc = l.acc + (size_t)m * stride;
             i32 nz;
             const double sw = window_power_sum<false>(P, lm, wlen, &nz, 0.0);
             nnzc += nz;
@@ -2240,7 +2240,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         const i32 cap_max = (i32)((160 * 1024 - fixed_win) / 8) & ~63;
         for (i64 wn = std::max<i64>(1, ((i64)n_cols * reuse_R + cap_max - 1) / cap_max);; ++wn) {
             const i32 c = (i32)((((i64)n_cols + wn - 1) / wn + 63) & ~63);
-            if ((i64)c * reuse_R <= cap_max) { cap_g = c; n_win_g = (n_cols + c - 1) / c; break; }
+            if ((i64)(c + N_DUMMY) * reuse_R <= cap_max) { cap_g = c; n_win_g = (n_cols + c - 1) / c; break; }
         }
         if (cap_g < 1024) reuse_R = 0;                      // windows too narrow to be worth a launch each
     }
@@ -2458,7 +2458,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             if (group_mode == 1) {
                 KTimer kt("expand_group", n_win_use);
                 GroupOp op{grp_rows.p, Gp.p, Gj.p, Gx.p, n_groups};
-                const size_t lds_g = (size_t)reuse_R * cap_use * 8 + fixed_win;
+                const size_t lds_g = (size_t)reuse_R * (cap_use + N_DUMMY) * 8 + fixed_win;
                 const unsigned ggrid = (unsigned)std::min<i32>(n_groups, 256);
                 if (reuse_R == 4) {
                     if (ux >= 4) HHX_TRY((launch_group<4, 4, 4>(P, op, cap_use, lds_g, ggrid)));
