@@ -25,6 +25,31 @@ import json
 for l in open('gpurun_out/bench_host8_c3.log'):
     if l.startswith('{'): print(json.dumps(json.loads(l).get('sweep_sharded'))[:1200])
 "; tail -3 gpurun_out/bench_host8_c3.log | cut -c1-300;;
+    grouppmc) # SQ counters of the generic-stream window kernel and of the re-use kernel on the same tail (24k contigs, inflation 1.1)
+        for spec in "insts:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" "sq:SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "lds:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA"; do
+            name="${spec%%:*}"; ctrs="${spec#*:}"; rm -rf gpurun_out/gpmc_$name
+            timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/gpmc_$name -o p -- python tools/lowtails.py --configs ${GROUP_CFG:-k24} --inflations 1.1 --reuse-ab > gpurun_out/gpmc_$name.jsonl 2> gpurun_out/gpmc_$name.err; echo "grouppmc $name rc=$?"
+        done
+        python - <<'PYEOF'
+import collections, csv, glob, json
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(int)
+for f in glob.glob('gpurun_out/gpmc_*/p_counter_collection.csv'):
+    seen = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
+        if not (k.startswith('k_expand_group') or k.startswith('k_expand_window<0, ') or k.startswith('k_expand_hash')):
+            continue
+        agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+        seen[k].add(r['Dispatch_Id'])
+    for k, s_ in seen.items():
+        cnt[k] = max(cnt[k], len(s_))
+out = {k: dict(v, launches=cnt[k]) for k, v in agg.items()}
+json.dump(out, open('gpurun_out/group_pmc.json', 'w'), indent=1)
+for k, v in out.items():
+    print(k, json.dumps(v))
+PYEOF
+        ;;
     tests) timeout 1500 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; grep -A8 "slowest" gpurun_out/pytest_gpu.log | head -9; tail -2 gpurun_out/pytest_gpu.log;;
     c2) timeout 600 python bench.py --contigs 10000 --pairs 50000000 --nchrs 16 --mean-len 50000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_c2.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c2.log; python tools/bench_brief.py gpurun_out/bench_c2.log;;
     c3) timeout 900 python bench.py $C3 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/bench_c3.log 2>&1; echo "rc=$?" >> gpurun_out/bench_c3.log; grep "hhx expand" gpurun_out/bench_c3.log | head -3; python tools/bench_brief.py gpurun_out/bench_c3.log;;
