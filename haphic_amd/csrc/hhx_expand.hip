@@ -122,7 +122,7 @@ __device__ __forceinline__ ExLds ex_carve(unsigned char *smem, i32 cap, i32 W, i
 }
 // window kernel: the accumulators, one scratch slot per lane, the reduction scratch — no staging arrays (every wave
 // fetches its own batches of A entries), so a window is (160 KiB - 1 KiB) / 8 = 20k columns wide
-__host__ __device__ inline size_t win_fixed_bytes() {
+__host__ __device__ constexpr size_t win_fixed_bytes() {
     return (size_t)N_DUMMY * 8 + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + 8;
 }
 __device__ __forceinline__ ExLds win_carve(unsigned char *smem, i32 cap) {
@@ -222,6 +222,11 @@ __device__ __forceinline__ void stage_chunk(const ExParams &P, const ExLds &l, i
 // sum of rint(a * b * 2^shift), one rounding to float32 at the end.
 __device__ __forceinline__ u64 fx_bits(double p) {
     return (u64)__double_as_longlong(p + 1.0) - 0x3ff0000000000000ull;
+}
+// fx_bits(a * b) with ONE instruction for the product and the rounding add: a and b are float32 values (a scaled by a power of two), so
+// a * b is exact in a double and fma(a, b, 1.0) rounds the same exact number once — the same bits as (a * b) + 1.0
+__device__ __forceinline__ u64 fx_bits_prod(double a, double b) {
+    return (u64)__double_as_longlong(__builtin_fma(a, b, 1.0)) - 0x3ff0000000000000ull;
 }
 __device__ __forceinline__ void acc_add(u64 *slot, double p) {
     atomicAdd((unsigned long long *)slot, (unsigned long long)fx_bits(p));
@@ -948,14 +953,20 @@ __device__ __forceinline__ void gtile_fetch(const ExParams &P, const GBatch<R> &
     c.q += UX * HHX_WAVE;
 }
 // the weights of the tile's union entry are read from the batch registers when the tile is consumed (two v_readlane per member):
-// carrying them inside every tile of a group of G tiles in flight cost 2 R G scalar registers and spilled them
+// carrying them inside every tile of a group of G tiles in flight cost 2 R G scalar registers and spilled them.
+// Member m's accumulators start at slot m * STRIDE with STRIDE a compile-time constant, so that the member offset is the immediate
+// offset field of ds_add_u64 (or one add for offsets beyond 64 KB) instead of an index computation per product; the last N_DUMMY
+// slots of every member's region are the scratch slots of masked lanes.  Per product: v_fma_f64, the high-word fix, ds_add_u64.
+template <int R>
+struct GroupStride { static constexpr int value = (((160 * 1024 - 784) / 8 / R) & ~63); };       // 784 = win_fixed_bytes()
 template <int UX, int R>
-__device__ __forceinline__ void gtile_consume(const ExLds &l, const GBatch<R> &r, const GTile<UX> &t, i32 cap, i32 dummy) {
+__device__ __forceinline__ void gtile_consume(const ExLds &l, const GBatch<R> &r, const GTile<UX> &t, int probe, u64 &sink) {
+    constexpr int STRIDE = GroupStride<R>::value;
     i32 idx[UX];
     double x[UX];
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
-        idx[u] = lane_id() + u * HHX_WAVE < t.n ? (i32)t.j[u] : dummy;       // a masked lane: its scratch slot behind the R windows, minus m * cap below
+        idx[u] = lane_id() + u * HHX_WAVE < t.n ? (i32)t.j[u] : STRIDE - N_DUMMY + lane_id();
         x[u] = (double)__uint_as_float(t.v[u]);
     }
 #pragma unroll
@@ -964,22 +975,24 @@ __device__ __forceinline__ void gtile_consume(const ExLds &l, const GBatch<R> &r
         if ((lo | hi) == 0u) continue;                            // wave-uniform: this member has no entry in column k
         const double da = __longlong_as_double((long long)(((u64)hi << 32) | lo));
 #pragma unroll
-        for (int u = 0; u < UX; ++u)
-            atomicAdd((unsigned long long *)&l.acc[m * cap + idx[u]], (unsigned long long)fx_bits(da * x[u]));
+        for (int u = 0; u < UX; ++u) {
+            const u64 g = fx_bits_prod(da, x[u]);
+            if (probe & 1) sink += g + (u64)idx[u];              // measurement only (HHX_GROUP_PROBE): the LDS atomics switched off
+            else atomicAdd((unsigned long long *)&l.acc[m * STRIDE + idx[u]], (unsigned long long)g);
+        }
     }
 }
 template <int R, int UX, int G>
-__global__ __launch_bounds__(EX_T_WIN) void k_expand_group(ExParams P, GroupOp op, i32 cap, i32 wv) {
+__global__ __launch_bounds__(EX_T_WIN) void k_expand_group(ExParams P, GroupOp op, i32 cap, i32 wv, int probe) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // every member's window is followed by its own N_DUMMY scratch slots (a masked lane adds to slot cap + lane of the member's region),
-    // so that a slot index is "member offset + index" for real and masked entries alike
-    const i32 stride = cap + N_DUMMY;
+    // member m owns the slots [m * STRIDE, (m + 1) * STRIDE): its window of cap <= STRIDE - N_DUMMY columns, then scratch slots
+    constexpr int stride = GroupStride<R>::value;
     const ExLds l = win_carve(smem, R * stride);
     const int tid = threadIdx.x;
     i64 nnzc = 0, n_prod = 0, n_a = 0;
+    u64 sink = 0;
     const i32 n_win = P.n_win;
     const i32 c0 = wv * cap, c1 = min(P.n_cols, c0 + cap), wlen = max(0, c1 - c0);
-    const i32 dummy = cap + lane_id();
     for (i32 g = blockIdx.x; g < op.n_groups; g += gridDim.x) {
         const i32 a_b = op.Gp[g], a_e = op.Gp[g + 1];
         const i32 n_batches = (a_e - a_b + P.wb - 1) / P.wb;
@@ -1002,7 +1015,7 @@ __global__ __launch_bounds__(EX_T_WIN) void k_expand_group(ExParams P, GroupOp o
             n_a += lane_id() == 0 ? cnt : 0;
             GCursor c = {-1, 0, 0};
             auto fetch = [&](GTile<UX> &t) { gtile_fetch<UX, R>(P, cur, cnt, c, t); };
-            auto consume = [&](const GTile<UX> &t) { gtile_consume<UX, R>(l, cur, t, stride, dummy); };
+            auto consume = [&](const GTile<UX> &t) { gtile_consume<UX, R>(l, cur, t, probe, sink); };
             for (;;) {
                 GTile<UX> t[G];
                 group_fetch<0, G>(t, fetch);
@@ -1032,6 +1045,7 @@ __global__ __launch_bounds__(EX_T_WIN) void k_expand_group(ExParams P, GroupOp o
     if (lane_id() == 0 && n_prod) atomicAdd(&P.cursors[8], (unsigned long long)n_prod);
     n_a = wave_sum_i64(n_a);
     if (lane_id() == 0 && n_a) atomicAdd(&P.cursors[9], (unsigned long long)n_a);
+    if (probe && sink == 0x123456789abcdefull) l.acc[0] = sink;
 }
 
 // Layout of the window kernel's operand stream, two passes with a scan between them.  One wave per (B row, column
@@ -2142,7 +2156,8 @@ static int launch_group(const ExParams &P, const GroupOp &op, i32 cap, size_t ld
         HHX_HIP(hipFuncSetAttribute((const void *)k_expand_group<R, UX, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_dev = dev;
     }
-    for (i32 wv = 0; wv < P.n_win; ++wv) k_expand_group<R, UX, G><<<grid, EX_T_WIN, lds, g_stream>>>(P, op, cap, wv);
+    static const int probe = getenv("HHX_GROUP_PROBE") ? (atoi(getenv("HHX_GROUP_PROBE")) & 1) : 0;     // 1, measurement only: the LDS atomics off, garbage results
+    for (i32 wv = 0; wv < P.n_win; ++wv) k_expand_group<R, UX, G><<<grid, EX_T_WIN, lds, g_stream>>>(P, op, cap, wv, probe);
     return 0;
 }
 
@@ -2237,10 +2252,11 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     if (reuse_R != 2 && reuse_R != 4) reuse_R = 0;
     i32 cap_g = 0, n_win_g = 0;
     if (reuse_R) {
-        const i32 cap_max = (i32)((160 * 1024 - fixed_win) / 8) & ~63;
-        for (i64 wn = std::max<i64>(1, ((i64)n_cols * reuse_R + cap_max - 1) / cap_max);; ++wn) {
+        static_assert(win_fixed_bytes() == 784, "GroupStride assumes the window kernel's fixed LDS bytes");
+        const i32 cols_max = (reuse_R == 4 ? GroupStride<4>::value : GroupStride<2>::value) - N_DUMMY;      // columns of a member's window
+        for (i64 wn = std::max<i64>(1, ((i64)n_cols + cols_max - 1) / cols_max);; ++wn) {
             const i32 c = (i32)((((i64)n_cols + wn - 1) / wn + 63) & ~63);
-            if ((i64)(c + N_DUMMY) * reuse_R <= cap_max) { cap_g = c; n_win_g = (n_cols + c - 1) / c; break; }
+            if (c <= cols_max) { cap_g = c; n_win_g = (n_cols + c - 1) / c; break; }
         }
         if (cap_g < 1024) reuse_R = 0;                      // windows too narrow to be worth a launch each
     }
@@ -2458,7 +2474,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             if (group_mode == 1) {
                 KTimer kt("expand_group", n_win_use);
                 GroupOp op{grp_rows.p, Gp.p, Gj.p, Gx.p, n_groups};
-                const size_t lds_g = (size_t)reuse_R * (cap_use + N_DUMMY) * 8 + fixed_win;
+                const size_t lds_g = (size_t)reuse_R * (reuse_R == 4 ? GroupStride<4>::value : GroupStride<2>::value) * 8 + fixed_win;
                 const unsigned ggrid = (unsigned)std::min<i32>(n_groups, 256);
                 if (reuse_R == 4) {
                     if (ux >= 4) HHX_TRY((launch_group<4, 4, 4>(P, op, cap_use, lds_g, ggrid)));
