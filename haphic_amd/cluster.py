@@ -766,7 +766,7 @@ class ResidentMatrix:
         return self._csc
 
     def __getattr__(self, name):
-        if name.startswith('__') and name.endswith('__'):
+        if name in ('_dev', '_csc') or (name.startswith('__') and name.endswith('__')):
             raise AttributeError(name)
         return getattr(self._scipy(), name)
 
@@ -870,9 +870,15 @@ def output_clm(clm_dict, _original=None):
     in HBM (grouping, the per-orientation sorts and the text on the device: hhx_ingest_write_clm); a real dict takes the
     reference's loop."""
     if _frozen(clm_dict, 'clm'):
-        logger.info('Writing clm_dict to paired_links.clm...')
-        clm_dict._session.write_clm('paired_links.clm')
-        return
+        try:
+            clm_dict._session.write_clm('paired_links.clm')
+            logger.info('Writing clm_dict to paired_links.clm...')
+            return
+        except RuntimeError as e:
+            # the device writer refuses streams with read positions beyond their contig's end (the reference would print negative
+            # distances): such a clm_dict takes the reference's loop, like any real dict (the access below thaws it)
+            if 'beyond the end' not in str(e):
+                raise
     if _original is not None:
         return _original(clm_dict)
     logger.info('Writing clm_dict to paired_links.clm...')
