@@ -95,8 +95,8 @@ for l in open('gpurun_out/bench_host8.log'):
     c5) timeout 1500 python bench.py --contigs 200000 --pairs 2000000000 --pushes 4 --steps 1 --warmup 1 --no-cpu-baseline --text-lines 0 --sweep 0 > gpurun_out/bench_c5.log 2>&1; echo "c5 rc=$?"; python tools/bench_brief.py gpurun_out/bench_c5.log; tail -2 gpurun_out/bench_c5.log | cut -c1-300;;
     asan) # the host side of the library under AddressSanitizer (haphic_amd/build.py build_asan), a subset of the gpu tests
         RT=$(python -c "from haphic_amd import build; print(build.asan_runtime())")
-        LD_PRELOAD="$RT /usr/lib/x86_64-linux-gnu/libstdc++.so.6" ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:verify_asan_link_order=0:halt_on_error=1 LD_LIBRARY_PATH=$(python -c "import torch, os; print(os.path.join(os.path.dirname(torch.__file__), 'lib'))"):$LD_LIBRARY_PATH HAPHIC_HIP_SO=haphic_amd/libhaphic_hip_asan.so \
-          timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py tests/test_bam.py tests/test_plot.py -m gpu -q -p no:cacheprovider > gpurun_out/pytest_asan.log 2>&1
+        LD_PRELOAD="$RT /usr/lib/x86_64-linux-gnu/libstdc++.so.6" ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:verify_asan_link_order=0:halt_on_error=1 LD_LIBRARY_PATH=$(python -c "import torch, os; print(os.path.join(os.path.dirname(torch.__file__), 'lib'))"):$LD_LIBRARY_PATH HAPHIC_HIP_SO=${GRAFT_REPO_ROOT:-$PWD}/haphic_amd/libhaphic_hip_asan.so \
+          timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py tests/test_seam_containers.py tests/test_bam.py tests/test_plot.py -m gpu -q -p no:cacheprovider > gpurun_out/pytest_asan.log 2>&1
         echo "asan rc=$?"; grep -E "passed|failed|ERROR: AddressSanitizer|SUMMARY" gpurun_out/pytest_asan.log | tail -5; tail -3 gpurun_out/pytest_asan.log | cut -c1-300;;
     tails) rm -rf gpurun_out/prof_tails; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_tails -o t -- python tools/tail_probe.py $TAIL_ARGS > gpurun_out/tail_probe.jsonl 2> gpurun_out/tail_probe.err; echo "tails rc=$?"; cut -c1-400 gpurun_out/tail_probe.jsonl; tail -3 gpurun_out/tail_probe.err; find gpurun_out/prof_tails -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | cut -c1-200;;
     tailpmc) # fabric bytes of the tail kernels at inflation 1.2 (generic-stream window class, hash class): two PMC passes of the first iterations
