@@ -24,9 +24,10 @@ SEAMS = {
     'normalize_by_length': ('HapHiC_cluster.py:727-738', cluster.normalize_by_length),  # a6 (dead code in the reference)
     'reduce_inter_hap_HiC_links': ('HapHiC_cluster.py:695-707', cluster.reduce_inter_hap_HiC_links),   # a6 (GFA phasing)
 }
-# f2 / f3: the two writers run() calls on the S5 containers (:2879, :2888, :2929) and the per-group link sums of output_statistics (:2354).  They only differ from the reference's functions
+# f2 / f3: what run() does with the S5 containers besides the seams above — the two writers (:2879, :2888, :2929) and the per-group link sums of
+# output_statistics (:2354).  They only differ from the reference's functions
 # for the array-backed containers of the S5 mirrors (haphic_amd/containers.py), so they travel with `ingest`.
-WRITERS = {
+CONTAINER_SEAMS = {
     'output_pickle': ('HapHiC_cluster.py:710-715', cluster.output_pickle),
     'output_clm': ('HapHiC_cluster.py:376-392', cluster.output_clm),
     'parse_link_dict': ('HapHiC_cluster.py:2252-2268', cluster.group_link_dict),     # per-group link sums of output_statistics :2279
@@ -84,10 +85,10 @@ def patch_reference(H, ingest=True, matrix_build=True):
         seams['pairs_generator'] = OPTIONAL['pairs_generator']                # a1: only together with S5, which consumes it
         seams['pairs_generator_inter_ctgs'] = OPTIONAL['pairs_generator_inter_ctgs']
         seams['bam_generator'] = OPTIONAL['bam_generator']                    # f4: consumed by the same S5 mirrors
-        seams.update(WRITERS)
+        seams.update(CONTAINER_SEAMS)
     for name, (_cite, fn) in seams.items():
         saved[name] = getattr(H, name, None)
-        if name in WRITERS:
+        if name in CONTAINER_SEAMS:
             fn = _with_original(fn, saved[name])
         setattr(H, name, _dense_dispatch(fn, saved[name], DENSE_ARG[name]) if name in DENSE_ARG else fn)
     saved['INTEL_MKL'] = getattr(H, 'INTEL_MKL', None)
