@@ -1274,9 +1274,10 @@ class IngestSession:
     def pair_items(self, kind):
         """(key, array) items of clm_dict (update_clm_dict :395-401) / ctg_coord_dict (record_coord_pairs :454-471)"""
         from .containers import slices_as_arrays
-        cn = self.table.ctg_names
+        cn = np.empty(len(self.table.ctg_names), object)
+        cn[:] = self.table.ctg_names
         fi, fj = self._fetch('full_i', 'full_j')
-        keys = list(zip(map(cn.__getitem__, fi.tolist()), map(cn.__getitem__, fj.tolist())))
+        keys = list(zip(cn[fi].tolist(), cn[fj].tolist()))
         clm_ptr, clm, crd_ptr, crd = self.pairs()
         if kind == 'clm':
             return zip(keys, slices_as_arrays(self.dist[0], clm.astype(self.dist[1], copy=False), clm_ptr, 4))
