@@ -64,17 +64,19 @@ class _Frozen(defaultdict):
         if type(self) is Thawed:
             return
         import gc
-        items = self._source_items()
         session = self._session
-        self.__dict__.clear()
-        self.__class__ = Thawed
         collect = gc.isenabled()
         gc.disable()                      # millions of fresh tuples: the generational collector would walk them again and again
         try:
-            dict.update(self, items)
+            dict.update(self, self._source_items())
+        except BaseException:             # a MemoryError half-way: stay frozen (and retryable), never a truncated plain dict
+            dict.clear(self)
+            raise
         finally:
             if collect:
                 gc.enable()
+        self.__dict__.clear()
+        self.__class__ = Thawed
         session.note_thawed()
 
     # answered from the arrays

@@ -63,8 +63,8 @@ def _dense_dispatch(ours, original, idx):
 
 
 def _with_original(ours, original):
-    def seam(*args):
-        return ours(*args, _original=original)
+    def seam(*args, **kwargs):
+        return ours(*args, _original=original, **kwargs)
     seam.__wrapped__ = ours
     seam.__name__ = ours.__name__
     seam.__doc__ = ours.__doc__

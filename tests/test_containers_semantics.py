@@ -8,7 +8,7 @@ from array import array
 from collections import defaultdict
 
 import numpy as np
-from hypothesis import given, settings
+from hypothesis import example, given, settings
 from hypothesis import strategies as st
 
 from haphic_amd import containers
@@ -142,6 +142,8 @@ def test_link_table_behaves_like_the_defaultdict(draw_pairs, counts, ops, as_flo
 
 @settings(max_examples=100, deadline=None)
 @given(pairs, st.lists(st.lists(st.integers(0, 2 ** 31 - 1), max_size=6), min_size=30, max_size=30), st.lists(op, max_size=8))
+@example([], [[]] * 30, [('update', [(('ctg0', 'ctg0'), 0)])])         # round 5's red case: an op may store a non-array under any NAMES key
+@example([(0, 1)], [[1, 2]] * 30, [('set', ('ctg0', 'ctg0'), 7), ('setdefault', ('ctg1', 'ctg1'), 1.5)])
 def test_pair_lists_behave_like_the_defaultdict(draw_pairs, lists, ops):
     i, j = _keys(draw_pairs)
     session = FakeSession(i, j, np.zeros(len(i), np.int64), lists[:len(i)])
@@ -155,7 +157,8 @@ def test_pair_lists_behave_like_the_defaultdict(draw_pairs, lists, ops):
     for o in ops:
         assert _apply(table, o, twin) == _apply(plain, o, twin), o
     assert list(table.items()) == list(plain.items())
-    assert table[('ctg0', 'ctg0')] == array('i') and ('ctg0', 'ctg0') in table                 # still a defaultdict of arrays
+    absent = ('absent', 'absent')                             # a key no strategy above can write
+    assert table[absent] == array('i') and absent in table    # still a defaultdict of arrays
 
 
 def test_slices_as_arrays():
