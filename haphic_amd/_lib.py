@@ -115,6 +115,7 @@ SIGNATURES = {
     'hhx_pairs_parser_fetch64': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     'hhx_pairs_parser_bed_host': (C.c_int, [C.c_void_p, c_vpp, c_i64p]),
     'hhx_pairs_parser_destroy': (C.c_int, [C.c_void_p]),
+    'hhx_pairs_format': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, c_i64p]),
     'hhx_bam_open': (C.c_int, [C.c_char_p, C.c_int, c_vpp]),
     'hhx_bam_header': (C.c_int, [C.c_void_p, c_i32p, C.POINTER(C.c_char_p), c_i64p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     'hhx_bam_next': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_int64, c_i64p, c_vpp, c_vpp, c_vpp, c_vpp]),
@@ -138,6 +139,14 @@ SIGNATURES = {
     'hhx_ingest_fetch_ht_items': (C.c_int, [C.c_void_p, c_i64p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'hhx_ingest_write_clm': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, c_i64p, c_i64p]),
     'hhx_write_link_pickle': (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, c_i64p]),
+    'hhx_ingest_write_clm_async': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]),
+    'hhx_ingest_write_link_pickle_async': (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'hhx_write_link_pickle_async': (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'hhx_byte_sink_open': (C.c_int, [C.c_char_p, C.c_int64, c_vpp]),
+    'hhx_pairs_parser_bed_to_sink': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'hhx_byte_sink_close': (C.c_int, [C.c_void_p, c_i64p]),
+    'hhx_files_pending': (C.c_int, [c_i64p, c_i64p]),
+    'hhx_files_join': (C.c_int, [c_i64p]),
 }
 
 _lib = None
@@ -483,6 +492,76 @@ def write_link_pickle(path, i, j, count, names):
     return n_bytes.value
 
 
+# ---- the file-writer thread of the library (hhx_jobs.hip): output_pickle / output_clm return at once, the files are complete after files_join()
+_pending_arrays = []                 # arrays of hhx_write_link_pickle_async that the library reads until the join
+_join_registered = False
+
+
+def files_async():
+    """False: HAPHIC_SYNC_FILES=1 in the environment — the writers run on the caller's thread as they did before round 6"""
+    return os.environ.get('HAPHIC_SYNC_FILES', '') not in ('1', 'true', 'yes')
+
+
+def _register_join():
+    global _join_registered
+    if not _join_registered:
+        import atexit
+        atexit.register(_join_at_exit)
+        _join_registered = True
+
+
+def _join_at_exit():
+    try:
+        files_join()
+    except RuntimeError as e:        # nobody is left to catch it: say it where a user sees it
+        import sys
+        print('haphic_amd: a file queued by output_pickle / output_clm was not written: %s' % e, file=sys.stderr)
+
+
+def files_pending():
+    """(files queued or being written, files finished since the library was loaded)"""
+    a, b = C.c_int64(0), C.c_int64(0)
+    check(load().hhx_files_pending(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def files_join():
+    """wait for every queued file (hhx_files_join); RuntimeError with the first failure if a writer failed"""
+    if _lib is None:
+        return
+    n = C.c_int64(0)
+    rc = _lib.hhx_files_join(C.byref(n))
+    del _pending_arrays[:]
+    check(rc)
+
+
+class ByteSink:
+    """hhx_byte_sink: a file fed from device buffers through the library's file-writer thread (alignments.bed, deferred)"""
+
+    def __init__(self, path, hbm_budget_bytes=0):
+        self.h = C.c_void_p()
+        _register_join()
+        check(load().hhx_byte_sink_open(os.fsencode(path), int(hbm_budget_bytes), C.byref(self.h)))
+
+    def close(self):
+        """queue the close (the file is complete after files_join()); returns the bytes handed to the sink"""
+        n = C.c_int64(0)
+        if self.h is not None and self.h.value:
+            check(load().hhx_byte_sink_close(self.h, C.byref(n)))
+            self.h = None
+        return n.value
+
+
+def write_link_pickle_async(path, i, j, count, names):
+    """write_link_pickle on the library's file-writer thread; the arrays are kept alive here until files_join()"""
+    fi, fj = np.ascontiguousarray(i, np.int32), np.ascontiguousarray(j, np.int32)
+    cnt = np.ascontiguousarray(count, np.int64)
+    blob, off = names_blob(names)
+    _register_join()
+    _pending_arrays.append((fi, fj, cnt))
+    check(load().hhx_write_link_pickle_async(os.fsencode(path), fi.size, ptr(fi), ptr(fj), ptr(cnt), len(names), ptr(blob), ptr(off)))
+
+
 def group_link_sums(frag_i, frag_j, links, group, n_groups):
     """hhx_group_link_sums: (sums, first) int64 [n_ctg, n_groups]; first == -1 where a cell got no contribution"""
     fi, fj = np.ascontiguousarray(frag_i, np.int32), np.ascontiguousarray(frag_j, np.int32)
@@ -702,6 +781,20 @@ class PairsParser:
         check(fn(self.h, *[ptr(a) for a in out], ptr(bed) if bed.size else None))
         return out + [bed.tobytes()]
 
+    def format_pairs(self, n, id1_ptr, pos1_ptr, id2_ptr, pos2_ptr, first_read=0, text_ptr=None, capacity=0):
+        """measurement only: device id / position arrays -> .pairs text on the device (hhx_pairs_format); returns the byte count
+        (text_ptr None: just the size)"""
+        nb = C.c_int64(0)
+        check(load().hhx_pairs_format(self.h, int(n), C.c_void_p(id1_ptr), C.c_void_p(pos1_ptr), C.c_void_p(id2_ptr), C.c_void_p(pos2_ptr), int(first_read),
+                                      C.c_void_p(text_ptr) if text_ptr else None, int(capacity), C.byref(nb)))
+        return nb.value
+
+    def bed_to_sink(self, sink):
+        """the BED bytes of the last parse(want_bed=True) handed to a ByteSink where they lie, in HBM; returns their number"""
+        n = self.bed_bytes
+        check(load().hhx_pairs_parser_bed_to_sink(self.h, sink.h))
+        return n
+
     def bed_host(self):
         """the alignments.bed bytes of the last parse as a uint8 VIEW of pinned memory owned by the parser (valid until the
         second following call)"""
@@ -898,6 +991,22 @@ class Ingest:
         n_lines, n_bytes = C.c_int64(0), C.c_int64(0)
         check(load().hhx_ingest_write_clm(self.h, os.fsencode(path), ptr(blob), ptr(off), C.byref(n_lines), C.byref(n_bytes)))
         return n_lines.value, n_bytes.value
+
+    def write_clm_async(self, path, ctg_names, drop_pairs=False):
+        """write_clm on the library's file-writer thread (hhx_ingest_write_clm_async): checked and opened here, complete after
+        files_join(); drop_pairs: the kept read pairs leave HBM when the file is done"""
+        blob, off = names_blob(ctg_names)
+        _register_join()
+        check(load().hhx_ingest_write_clm_async(self.h, os.fsencode(path), ptr(blob), ptr(off), int(bool(drop_pairs))))
+
+    PICKLE_KINDS = {'full': 0, 'HT': 1, 'flank': 2}
+
+    def write_link_pickle_async(self, kind, path, names):
+        """full_links.pkl / HT_links.pkl (output_pickle :710-715) of this handle's table on the file-writer thread: the items are
+        fetched (HT: ordered on the device) and encoded there; complete after files_join()"""
+        blob, off = names_blob(names)
+        _register_join()
+        check(load().hhx_ingest_write_link_pickle_async(self.h, self.PICKLE_KINDS[kind], os.fsencode(path), len(names), ptr(blob), ptr(off)))
 
     def table_device(self, which=0):
         """aggregated table (unordered): (n_rows, key_ptr, ord_full_ptr, ord_flank_ptr, ht_ptr, flank_ptr)"""

@@ -34,13 +34,40 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+OBJ = os.path.join(CSRC, '_obj')
+
+
+def _stale(obj, src, headers):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src] + headers)
+
+
+def build(force=False, verbose=False, jobs=None):
+    """every csrc/*.hip -> its own object (in parallel, only the stale ones), then one link: the whole library from scratch in the time of
+    its largest file (hhx_expand.hip), an edit of one file in the time of that file"""
     if not force and not needs_build():
         return SO
-    cmd = [HIPCC] + FLAGS + sources() + ['-lz', '-lpthread', '-o', SO]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ, exist_ok=True)
+    headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, '..', 'include', '*.h'))
+    compile_flags = [f for f in FLAGS if f != '-shared']
+    todo, objs = [], []
+    for src in sources():
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
+        objs.append(obj)
+        if force or _stale(obj, src, headers):
+            todo.append([HIPCC] + compile_flags + ['-c', src, '-o', obj])
+    todo.sort(key=lambda c: -os.path.getsize(c[-3]))             # the largest file first
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(jobs or min(8, os.cpu_count() or 1)) as pool:
+        list(pool.map(run, todo))
+    run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-lz', '-lpthread', '-o', SO])
     return SO
 
 

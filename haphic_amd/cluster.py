@@ -17,6 +17,7 @@ reference's observable ordering depends on CPython for: the set-of-tuples in int
 """
 import logging
 import os
+import time
 from array import array
 from collections import defaultdict
 from decimal import Decimal
@@ -853,22 +854,28 @@ def dict_to_matrix(link_dict, frag_set, dense_matrix=True, add_self_loops=False,
 def output_pickle(dict_, from_, to, _original=None):
     """output_pickle() :710-715.  A link table that is still frozen (full_links.pkl, HT_links.pkl) is serialised from its arrays
     by the library's host code — the same `defaultdict(int)` pickle (protocol 4, keys in dict order, int values) without a Python
-    object per key; any other object is pickled as the reference does."""
+    object per key — on the library's file-writer thread: the call returns once the file is open and queued, the file is complete
+    after `_lib.files_join()` (run() re-bound by patch_reference joins before it returns; HAPHIC_SYNC_FILES=1 writes it here).  Any
+    other object is pickled as the reference does."""
     import pickle
     logger.info('Writing {} to {}...'.format(from_, to))
     if _frozen(dict_) and dict_._kind in ('full', 'HT', 'flank'):
-        i, j, v, names = dict_.arrays()
-        if v.dtype.kind in 'iu':
-            _lib.write_link_pickle(to, i, j, v, names)
-            return
+        session = dict_._session
+        if not (dict_._kind == 'flank' and session.weighted):            # float weights: the generic pickle below
+            if _lib.files_async() and session.queue_pickle(dict_._kind, to):
+                return
+            i, j, v, names = dict_.arrays()
+            if v.dtype.kind in 'iu':
+                _lib.write_link_pickle(to, i, j, v, names)
+                return
     with open(to, 'wb') as fpkl:
         pickle.dump(dict_, fpkl)
 
 
 def output_clm(clm_dict, _original=None):
     """output_clm() :376-392 — paired_links.clm.  The frozen clm_dict of the S5 mirrors is written from the read pairs kept
-    in HBM (grouping, the per-orientation sorts and the text on the device: hhx_ingest_write_clm); a real dict takes the
-    reference's loop."""
+    in HBM (grouping, the per-orientation sorts and the text on the device: hhx_ingest_write_clm), on the library's file-writer
+    thread like the pickles above; a real dict takes the reference's loop."""
     if _frozen(clm_dict, 'clm'):
         try:
             clm_dict._session.write_clm('paired_links.clm')
@@ -876,9 +883,11 @@ def output_clm(clm_dict, _original=None):
             return
         except RuntimeError as e:
             # the device writer refuses streams with read positions beyond their contig's end (the reference would print negative
-            # distances): such a clm_dict takes the reference's loop, like any real dict (the access below thaws it)
-            if 'beyond the end' not in str(e):
+            # distances), and may run out of device memory: such a clm_dict takes the reference's loop, like any real dict (the
+            # access below thaws it).  A file system that refuses the file would refuse the loop's too.
+            if 'cannot open' in str(e):
                 raise
+            logger.warning('paired_links.clm is written by the host loop: {}'.format(e))
     if _original is not None:
         return _original(clm_dict)
     logger.info('Writing clm_dict to paired_links.clm...')
@@ -956,14 +965,38 @@ class PairsText:
                 yield carry
 
     def batches(self, names, wide=False):
-        """per chunk: (parser, n_lines) with the id / position arrays of the chunk on the device (wide: int64 positions).  The BED bytes of the
-        chunk come back through the parser's pinned double buffer (PCIe rate) and are written to alignments.bed by a
-        pool of threads, each with its own pwrite() at its own offset of the file, while the next chunk is parsed:
-        the reference writes alignments.bed inside its generator loop (:1549-1557), so this is part of the a1 cost."""
-        from concurrent.futures import ThreadPoolExecutor, wait
+        """per chunk: (parser, n_lines) with the id / position arrays of the chunk on the device (wide: int64 positions).  The reference writes
+        alignments.bed inside its generator loop (:1549-1557) and nothing in run() reads it: the BED bytes of a chunk stay in HBM, where the kernel
+        formatted them, and are handed to the library's file-writer thread (hhx_byte_sink: the file is complete after _lib.files_join(), which the
+        re-bound run() calls) — a RAM disk takes ~4.5 GB/s into one file, the tokeniser makes 19 GB/s of BED.  HAPHIC_SYNC_FILES=1: the bytes
+        come back through the parser's pinned double buffer and are written here by a pool of pwrite() threads while the next chunk is parsed."""
+        clock = time.perf_counter
+        st = self.stats = {'chunks': 0, 'text_bytes': 0, 'bed_bytes': 0, 'parse_s': 0.0, 'bed_fetch_s': 0.0, 'bed_wait_s': 0.0, 'consumer_s': 0.0,
+                           'bed': 'deferred' if _lib.files_async() else 'in place'}
         parser = _lib.PairsParser(names)
         if wide:
             parser.set_wide(True)
+        if self.bed_path and _lib.files_async():
+            sink = _lib.ByteSink(self.bed_path)
+            try:
+                for chunk in self._chunks():
+                    t = clock()
+                    st['chunks'] += 1
+                    st['text_bytes'] += len(chunk)
+                    n = parser.parse(chunk, want_bed=True)
+                    st['parse_s'] += clock() - t
+                    del chunk
+                    t = clock()
+                    st['bed_bytes'] += parser.bed_to_sink(sink)        # returns at once unless the sink's HBM budget is used up
+                    st['bed_wait_s'] += clock() - t
+                    t = clock()
+                    yield parser, n
+                    st['consumer_s'] += clock() - t
+            finally:
+                sink.close()
+                parser.destroy()
+            return
+        from concurrent.futures import ThreadPoolExecutor, wait
         fd = os.open(self.bed_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644) if self.bed_path else None
         pool = ThreadPoolExecutor(self.bed_writers) if fd is not None else None
         pending = []                                             # [futures of chunk k - 1, futures of chunk k]
@@ -971,19 +1004,30 @@ class PairsText:
         piece = 8 << 20
 
         def drain(keep):
+            t = clock()
             while len(pending) > keep:
                 for f in wait(pending.pop(0)).done:
                     f.result()                                   # a failed write surfaces on the caller's thread
+            st['bed_wait_s'] += clock() - t
         try:
             for chunk in self._chunks():
+                t = clock()
+                st['chunks'] += 1
+                st['text_bytes'] += len(chunk)
                 n = parser.parse(chunk, want_bed=fd is not None)
+                st['parse_s'] += clock() - t
                 del chunk
                 if fd is not None and parser.bed_bytes:
                     drain(1)                                     # the buffer handed out two calls ago is free again
+                    t = clock()
                     buf = memoryview(parser.bed_host())
+                    st['bed_fetch_s'] += clock() - t
+                    st['bed_bytes'] += len(buf)
                     pending.append([pool.submit(_pwrite_all, fd, buf[a:a + piece], offset + a) for a in range(0, len(buf), piece)])
                     offset += len(buf)
+                t = clock()
                 yield parser, n
+                st['consumer_s'] += clock() - t
             drain(0)
         finally:
             if pool is not None:
@@ -1231,6 +1275,7 @@ class IngestSession:
         self._host = {}
         self._pairs = None
         self._ht_names = None
+        self._ht_queued = False
 
     # ---- host copies, on demand
     def _fetch(self, *keys):
@@ -1313,7 +1358,26 @@ class IngestSession:
         return self.ing.link_matrix(in_set, n_rest, add_self_loops=add_self_loops, weighted=self.weighted)
 
     def write_clm(self, path):
-        return self.ing.write_clm(path, self.table.ctg_names)
+        """paired_links.clm: queued on the library's file-writer thread (or written here with HAPHIC_SYNC_FILES=1).  The kept read pairs are
+        released with the file when nothing else of run() can ask for them: no coordinate lists (--remove_allelic_links /
+        --remove_concentrated_links) and HT_link_dict already on its way to HT_links.pkl (:2879 precedes :2888)."""
+        if not _lib.files_async():
+            return self.ing.write_clm(path, self.table.ctg_names)
+        return self.ing.write_clm_async(path, self.table.ctg_names, drop_pairs=not self.record and self._ht_queued)
+
+    def queue_pickle(self, kind, path):
+        """full_links.pkl / HT_links.pkl of a frozen table on the file-writer thread, from the device tables; False: not possible (the caller
+        writes it from the host arrays)"""
+        if kind == 'HT':
+            if self._ht_names is None:
+                self._ht_names = [n + s for n in self.table.ctg_names for s in ('_H', '_T')]
+            names = self._ht_names
+        else:
+            names = self.table.ctg_names if kind == 'full' else self.table.frag_names
+        self.ing.write_link_pickle_async(kind, path, names)
+        if kind == 'HT':
+            self._ht_queued = True
+        return True
 
 
 def ingest_session(alignments, table, fa_dict, args, bins, pos_int_type, dist_int_type, chunk=1 << 22, want_frag_pairs=False):

@@ -49,14 +49,14 @@ struct ByteFile {
 
 }  // namespace
 
-extern "C" int hhx_write_link_pickle(const char *path, int64_t n_keys, const int32_t *name_i, const int32_t *name_j, const int64_t *count, int32_t n_names,
-                                     const uint8_t *names_blob, const int64_t *name_off, int64_t *n_bytes) {
-    if (!path || (n_keys && (!name_i || !name_j || !count)) || !name_off || (n_names && !names_blob)) return fail("hhx_write_link_pickle: null pointer");
+// the pickle into an open file descriptor (closed here, whatever happens); `path` only names the file in messages
+int hhx::write_link_pickle_fd(int fd, const char *path, i64 n_keys, const i32 *name_i, const i32 *name_j, const i64 *count, i32 n_names,
+                              const uint8_t *names_blob, const i64 *name_off, i64 *n_bytes) {
+    if ((n_keys && (!name_i || !name_j || !count)) || !name_off || (n_names && !names_blob)) { ::close(fd); return fail("hhx_write_link_pickle: null pointer"); }
     for (i64 k = 0; k < n_keys; ++k)
-        if ((u32)name_i[k] >= (u32)n_names || (u32)name_j[k] >= (u32)n_names) return fail("hhx_write_link_pickle: key %lld names an unknown id", (long long)k);
+        if ((u32)name_i[k] >= (u32)n_names || (u32)name_j[k] >= (u32)n_names) { ::close(fd); return fail("hhx_write_link_pickle: key %lld names an unknown id", (long long)k); }
     ByteFile f((size_t)8 << 20);
-    f.fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
-    if (f.fd < 0) return fail("cannot open %s for writing: %s", path, strerror(errno));
+    f.fd = fd;
     static const unsigned char head[] = "\x80\x04"                                    // PROTO 4
                                         "\x8c\x0b" "collections" "\x94" "\x8c\x0b" "defaultdict" "\x94" "\x93" "\x94"   // STACK_GLOBAL, memo 0-2
                                         "\x8c\x08" "builtins" "\x94" "\x8c\x03" "int" "\x94" "\x93" "\x94"              // memo 3-5
@@ -64,7 +64,7 @@ extern "C" int hhx_write_link_pickle(const char *path, int64_t n_keys, const int
     memcpy(f.room(sizeof head - 1), head, sizeof head - 1);
     // memo slot of every name = 8 + its rank by first use (i before j, key by key): fixed before any byte is written, so that
     // the keys can be encoded in independent slices by several threads and the slices concatenated
-    const int n_thr = (int)std::max<i64>(1, std::min<i64>({(i64)std::thread::hardware_concurrency(), (i64)16, n_keys / 200000 + 1}));
+    const int n_thr = (int)std::max<i64>(1, std::min<i64>({(i64)std::thread::hardware_concurrency(), (i64)8, n_keys / 200000 + 1}));
     std::vector<i64> first((size_t)n_names, INT64_MAX);
     {
         std::vector<std::vector<i64>> local((size_t)n_thr);
@@ -174,4 +174,12 @@ extern "C" int hhx_write_link_pickle(const char *path, int64_t n_keys, const int
     if (f.err || cerr) return fail("writing %s failed: %s", path, strerror(f.err ? f.err : cerr));
     if (n_bytes) *n_bytes = f.total;
     return 0;
+}
+
+extern "C" int hhx_write_link_pickle(const char *path, int64_t n_keys, const int32_t *name_i, const int32_t *name_j, const int64_t *count, int32_t n_names,
+                                     const uint8_t *names_blob, const int64_t *name_off, int64_t *n_bytes) {
+    if (!path) return fail("hhx_write_link_pickle: null pointer");
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return fail("cannot open %s for writing: %s", path, strerror(errno));
+    return write_link_pickle_fd(fd, path, n_keys, name_i, name_j, count, n_names, names_blob, name_off, n_bytes);
 }

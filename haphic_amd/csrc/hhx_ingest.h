@@ -156,6 +156,7 @@ struct hhx_ingest {
     bool keep_pairs = false;
     std::vector<hhx::DevBuf<u64>> side_key, side_xy;     // one pair of arrays per push: key, (xi << 32 | xj)
     i64 n_side = 0;
+    bool pairs_dropped = false;            // side_key / side_xy were released after paired_links.clm was written (hhx_ingest_write_clm_async)
     i64 max_ctg_len = 0;                   // longest contig (bounds the CLM distances: hhx_ingest_write_clm)
     hhx::DevBuf<i32> stage[4];             // staging for host-side inputs
     hhx::DevBuf<i64> stage64[2];           // ... of 64-bit positions (hhx_ingest_push64)
@@ -177,3 +178,9 @@ int hhx_side_records_push(hhx_ingest *h, i64 n_pairs, const i32 *id1, const POS 
 // hhx_matrix.hip: dict_to_matrix on a run (flank rows, first-seen order taken from ord_flank)
 int hhx_link_matrix_from_run(const hhx::LinkRun *run, i32 n_frag, u64 ord_limit, const uint8_t *in_set_host, i32 n_rest, int add_self_loops,
                              i32 *frag_index_host, i32 *n_linked_out, hhx_csr **out);
+
+// hhx_pairs.hip: paired_links.clm into an open file descriptor (closed there); hhx_ingest.hip: the dict-ordered tables (made on first use)
+namespace hhx {
+int ingest_write_clm_fd(hhx_ingest *h, int fd, const uint8_t *names_blob, const i64 *name_off, i64 *n_lines, i64 *n_bytes);
+}
+int hhx_ingest_ordered_full_device(hhx_ingest *h, const i32 **fi, const i32 **fj);

@@ -848,6 +848,7 @@ extern "C" int hhx_ingest_link_matrix(hhx_ingest *h, const uint8_t *in_set_host,
 }
 
 extern "C" int hhx_ingest_destroy(hhx_ingest *h) {
+    if (h) files_wait_handle(h);             // a queued file (hhx_jobs.hip) still reads the tables / the kept pairs
     delete h;
     return 0;
 }

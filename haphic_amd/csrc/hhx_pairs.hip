@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "hhx_ingest.h"
+#include "hhx_filesink.h"
 #include "hhx_sort.h"
 
 using namespace hhx;
@@ -203,6 +204,7 @@ struct PairGroups {
 };
 
 static int group_pairs(hhx_ingest *h, PairGroups &G, const char *who) {
+    if (h->pairs_dropped) return fail("%s: the kept read pairs were released after paired_links.clm was written", who);
     const i32 *fi = nullptr, *fj = nullptr;
     HHX_TRY(hhx_ingest_ordered_full_device(h, &fi, &fj));
     const i64 K = h->n_full, N = h->n_side;
@@ -283,6 +285,7 @@ extern "C" int hhx_ingest_fetch_pairs(hhx_ingest *h, i64 max_read_pairs, i64 *cl
 static int ht_first_device(hhx_ingest *h, DevBuf<i64> &d_first, const char *who) {
     if (!h || !h->finalized) return fail("ingest handle not finalized");
     if (!h->keep_pairs) return fail("%s: the handle was not created with hhx_ingest_keep_pairs", who);
+    if (h->pairs_dropped) return fail("%s: the kept read pairs were released after paired_links.clm was written", who);
     const i32 *fi = nullptr, *fj = nullptr;
     HHX_TRY(hhx_ingest_ordered_full_device(h, &fi, &fj));
     const i64 K = h->n_full, N = h->n_side;
@@ -409,6 +412,7 @@ extern "C" int hhx_ingest_fetch_ht_items(hhx_ingest *h, int64_t *n_items, int32_
 
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <thread>
 
 namespace {
@@ -525,87 +529,16 @@ __global__ __launch_bounds__(CW_T) void k_clm_write(i64 E, const u64 *__restrict
     }
 }
 
-// device bytes -> file: pieces through two pinned buffers, pwrite() on a host thread while the next piece is copied
-struct FileSink {
-    static constexpr size_t PIECE = (size_t)64 << 20;
-    int fd = -1;
-    i64 pos = 0;
-    void *pin[2] = {nullptr, nullptr};
-    bool busy[2] = {false, false};
-    int next = 0, err = 0;
-    bool stop = false;
-    struct Job { int buf; size_t n; i64 at; };
-    std::deque<Job> q;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::thread worker;
-
-    int open(const char *path) {
-        fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
-        if (fd < 0) return fail("cannot open %s for writing: %s", path, strerror(errno));
-        for (int b = 0; b < 2; ++b) HHX_HIP(hipHostMalloc(&pin[b], PIECE, hipHostMallocDefault));
-        worker = std::thread([this] {
-            for (;;) {
-                Job j;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [this] { return stop || !q.empty(); });
-                    if (q.empty()) return;
-                    j = q.front(); q.pop_front();
-                }
-                const char *p = (const char *)pin[j.buf];
-                size_t left = j.n; i64 at = j.at;
-                while (left) {
-                    const ssize_t w = ::pwrite(fd, p, left, at);
-                    if (w <= 0) { std::lock_guard<std::mutex> lk(mu); err = errno ? errno : EIO; break; }
-                    p += w; left -= (size_t)w; at += w;
-                }
-                { std::lock_guard<std::mutex> lk(mu); busy[j.buf] = false; }
-                cv.notify_all();
-            }
-        });
-        return 0;
-    }
-    int write_device(const unsigned char *dev, size_t n) {
-        for (size_t o = 0; o < n; o += PIECE) {
-            const size_t m = n - o < PIECE ? n - o : PIECE;
-            const int b = next; next ^= 1;
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !busy[b]; }); if (err) return fail("write failed: %s", strerror(err)); }
-            HHX_HIP(hipMemcpyAsync(pin[b], dev + o, m, hipMemcpyDeviceToHost, g_stream));
-            HHX_HIP(hipStreamSynchronize(g_stream));
-            { std::lock_guard<std::mutex> lk(mu); busy[b] = true; q.push_back(Job{b, m, pos}); }
-            cv.notify_all();
-            pos += (i64)m;
-        }
-        return 0;
-    }
-    int close() {
-        int rc = 0;
-        if (worker.joinable()) {
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return !busy[0] && !busy[1]; }); stop = true; }
-            cv.notify_all();
-            worker.join();
-        }
-        if (err) rc = fail("write failed: %s", strerror(err));
-        for (int b = 0; b < 2; ++b) if (pin[b]) { (void)hipHostFree(pin[b]); pin[b] = nullptr; }
-        if (fd >= 0) { if (::close(fd) != 0 && !rc) rc = fail("close failed: %s", strerror(errno)); fd = -1; }
-        return rc;
-    }
-    ~FileSink() { (void)close(); }
-};
-
 int bits_for(u64 v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; }
 
 }  // namespace
 
-extern "C" int hhx_ingest_write_clm(hhx_ingest *h, const char *path, const uint8_t *names_blob, const int64_t *name_off, int64_t *n_lines, int64_t *n_bytes) {
-    if (!h || !h->finalized) return fail("ingest handle not finalized");
-    if (!h->keep_pairs) return fail("hhx_ingest_write_clm: the handle was not created with hhx_ingest_keep_pairs");
-    if (!path || !names_blob || !name_off) return fail("hhx_ingest_write_clm: null pointer");
+// paired_links.clm into an open file descriptor (closed here, whatever happens)
+int hhx::ingest_write_clm_fd(hhx_ingest *h, int fd, const uint8_t *names_blob, const i64 *name_off, i64 *n_lines, i64 *n_bytes) {
     if (n_lines) *n_lines = 0;
     if (n_bytes) *n_bytes = 0;
     FileSink sink;
-    HHX_TRY(sink.open(path));
+    HHX_TRY(sink.open_fd(fd));
     PairGroups G;
     HHX_TRY(group_pairs(h, G, "hhx_ingest_write_clm"));
     const i64 K = G.K;
@@ -680,6 +613,72 @@ extern "C" int hhx_ingest_write_clm(hhx_ingest *h, const char *path, const uint8
     if (n_lines) *n_lines = lines;
     if (n_bytes) *n_bytes = sink.pos;
     return sink.close();
+}
+
+static int clm_preconditions(hhx_ingest *h, const char *who) {
+    if (!h || !h->finalized) return fail("ingest handle not finalized");
+    if (!h->keep_pairs) return fail("%s: the handle was not created with hhx_ingest_keep_pairs", who);
+    if (h->pairs_dropped) return fail("%s: the kept read pairs were released after paired_links.clm was written", who);
+    return 0;
+}
+
+extern "C" int hhx_ingest_write_clm(hhx_ingest *h, const char *path, const uint8_t *names_blob, const int64_t *name_off, int64_t *n_lines, int64_t *n_bytes) {
+    HHX_TRY(clm_preconditions(h, "hhx_ingest_write_clm"));
+    if (!path || !names_blob || !name_off) return fail("hhx_ingest_write_clm: null pointer");
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return fail("cannot open %s for writing: %s", path, strerror(errno));
+    return ingest_write_clm_fd(h, fd, names_blob, name_off, n_lines, n_bytes);
+}
+
+// ---- the same on the library's file-writer thread (hhx_jobs.hip).  What can be refused is refused here, on the caller's thread: a read position
+// beyond the end of its contig (the device writer does not print negative distances; the caller then takes the reference's loop).
+namespace {
+__global__ __launch_bounds__(256) void k_clm_range_check(i64 n, const u64 *__restrict__ key, const u64 *__restrict__ xy, const UnitInfo *__restrict__ ctg,
+                                                         unsigned int *__restrict__ bad) {
+    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (i64)gridDim.x * blockDim.x) {
+        const u64 k = key[p], v = xy[p];
+        const i64 li = ctg[k >> ID_BITS].lenf & LEN_MASK, lj = ctg[k & ID_MASK].lenf & LEN_MASK;
+        if ((i64)(v >> 32) - 1 >= li || (i64)(v & 0xffffffffu) - 1 >= lj) atomicExch(bad, 1u);
+    }
+}
+}  // namespace
+
+extern "C" int hhx_ingest_write_clm_async(hhx_ingest *h, const char *path, const uint8_t *names_blob, const int64_t *name_off, int drop_pairs_after) {
+    HHX_TRY(clm_preconditions(h, "hhx_ingest_write_clm_async"));
+    if (!path || !names_blob || !name_off) return fail("hhx_ingest_write_clm_async: null pointer");
+    const i32 *fi = nullptr, *fj = nullptr;
+    HHX_TRY(hhx_ingest_ordered_full_device(h, &fi, &fj));            // the ordered tables are made here, not on the writer thread
+    {
+        DevBuf<unsigned int> bad;
+        if (bad.alloc(1)) return 1;
+        HHX_HIP(hipMemsetAsync(bad.p, 0, sizeof(unsigned int), g_stream));
+        for (size_t b = 0; b < h->side_key.size(); ++b) {
+            const i64 nb = (i64)h->side_key[b].n;
+            if (!nb) continue;
+            k_clm_range_check<<<grid_for((u64)nb), 256, 0, g_stream>>>(nb, h->side_key[b].p, h->side_xy[b].p, h->t.ctg, bad.p);
+            HHX_LAUNCH_CHECK();
+        }
+        unsigned int hb = 0;
+        HHX_HIP(hipMemcpyAsync(&hb, bad.p, sizeof hb, hipMemcpyDeviceToHost, g_stream));
+        HHX_HIP(hipStreamSynchronize(g_stream));                      // also: everything the writer thread will read is complete
+        if (hb) return fail("hhx_ingest_write_clm: a read position lies beyond the end of its contig");
+    }
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return fail("cannot open %s for writing: %s", path, strerror(errno));
+    const i32 n_ctg = h->t.n_ctg;
+    auto blob = std::make_shared<std::vector<uint8_t>>(names_blob, names_blob + (size_t)name_off[n_ctg] + 1);
+    auto off = std::make_shared<std::vector<i64>>(name_off, name_off + n_ctg + 1);
+    const bool drop = drop_pairs_after != 0;
+    return files_submit(std::string("paired_links.clm -> ") + path, h, [h, fd, blob, off, drop]() -> int {
+        const int rc = ingest_write_clm_fd(h, fd, blob->data(), off->data(), nullptr, nullptr);
+        if (drop) {                                                   // 16 B per read pair of HBM that nothing reads after this file
+            (void)hipStreamSynchronize(g_stream);
+            for (auto *v : {&h->side_key, &h->side_xy})
+                for (auto &buf : *v) { void *p = buf.p; buf.p = nullptr; buf.n = 0; pool_free_synced(p); }
+            h->pairs_dropped = true;
+        }
+        return rc;
+    });
 }
 
 extern "C" int hhx_ingest_fetch_flank_values(hhx_ingest *h, double *value) {

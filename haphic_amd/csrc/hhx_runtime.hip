@@ -7,10 +7,18 @@ thread_local std::string g_err;
 thread_local hipStream_t g_stream = nullptr;
 
 // ------------------------------------------------------------------ pool
+// Blocks are recycled in stream order, so a free list belongs to ONE stream.  The caller's thread(s) share the global list
+// (include/haphic_hip.h: one stream at a time); a library thread that launches on a stream of its own (the file-writer thread,
+// hhx_jobs.hip) installs a private Arena: its blocks are taken from and returned to that arena alone, and are handed to the global
+// list (arena_donate) only after the thread has synchronised its stream.
+thread_local Arena *g_arena = nullptr;
+
 namespace {
 std::mutex g_pool_mu;
-std::multimap<size_t, void *> g_free;           // size class -> block
-std::map<void *, size_t> g_live;                // block -> size class
+std::multimap<size_t, void *> g_free;           // size class -> block (the callers' stream)
+struct Live { size_t size; Arena *owner; };
+std::map<void *, Live> g_live;                  // block -> size class, arena it was taken from
+std::vector<void *> g_quarantine;               // freed on another thread than the owner's: no stream order to rely on, released by pool_trim
 
 size_t size_class(size_t bytes) {
     size_t c = 256;
@@ -25,6 +33,7 @@ size_t size_class(size_t bytes) {
 
 void *pool_alloc(size_t bytes) {
     size_t c = size_class(bytes);
+    Arena *const arena = g_arena;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         // best fit: the smallest cached block that is large enough and wastes at most 3/4 of itself.
@@ -32,11 +41,12 @@ void *pool_alloc(size_t bytes) {
         // somewhat larger block beats a fresh allocation by orders of magnitude.
         // (multi-GB blocks: at most 1/4 wasted — a cached 88 GB dense block must not be handed to a 25 GB request while the rest
         // of the device fills up behind it)
-        auto it = g_free.lower_bound(c);
-        if (it != g_free.end() && (it->first <= 4 * c && (it->first < (size_t(16) << 30) || it->first <= c + c / 4))) {
+        std::multimap<size_t, void *> &fl = arena ? arena->free : g_free;
+        auto it = fl.lower_bound(c);
+        if (it != fl.end() && (it->first <= 4 * c && (it->first < (size_t(16) << 30) || it->first <= c + c / 4))) {
             void *p = it->second;
-            g_live[p] = it->first;
-            g_free.erase(it);
+            g_live[p] = Live{it->first, arena};
+            fl.erase(it);
             return p;
         }
     }
@@ -53,7 +63,7 @@ void *pool_alloc(size_t bytes) {
         }
     }
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_live[p] = c;
+    g_live[p] = Live{c, arena};
     return p;
 }
 
@@ -62,10 +72,30 @@ void pool_free(void *p) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     auto it = g_live.find(p);
     if (it == g_live.end()) return;
-    // Stream-ordered reuse: every consumer runs on g_stream (one stream per thread), so a recycled
-    // block is only ever touched by work enqueued after its previous user.
-    g_free.emplace(it->second, p);
+    // Stream-ordered reuse: every consumer of a free list runs on one stream, so a recycled block is only ever touched by work
+    // enqueued after its previous user.  A block that is freed from another thread than the one it was handed to has no such
+    // order: it waits in quarantine for the next pool_trim (device-wide synchronisation).
+    if (it->second.owner == g_arena) (g_arena ? g_arena->free : g_free).emplace(it->second.size, p);
+    else g_quarantine.push_back(p);
     g_live.erase(it);
+}
+
+// the caller guarantees that NO work on any stream still touches p (it synchronised every stream that used it): reusable by the callers' stream at once
+void pool_free_synced(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_live.find(p);
+    if (it == g_live.end()) return;
+    g_free.emplace(it->second.size, p);
+    g_live.erase(it);
+}
+
+// after the arena's thread synchronised its stream: its cached blocks go to the callers' list
+void arena_donate(Arena *a) {
+    if (!a) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &kv : a->free) g_free.emplace(kv.first, kv.second);
+    a->free.clear();
 }
 
 i64 pool_cached_bytes() {
@@ -79,8 +109,14 @@ void pool_trim() {
     std::vector<void *> blocks;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        for (auto &kv : g_free) blocks.push_back(kv.second);
-        g_free.clear();
+        // only the list of the calling thread's stream and the quarantine: another thread's arena is in use by that thread
+        std::multimap<size_t, void *> &fl = g_arena ? g_arena->free : g_free;
+        for (auto &kv : fl) blocks.push_back(kv.second);
+        fl.clear();
+        if (g_arena)                             // out of memory on the arena's thread: the callers' cache goes too
+            { for (auto &kv : g_free) blocks.push_back(kv.second); g_free.clear(); }
+        blocks.insert(blocks.end(), g_quarantine.begin(), g_quarantine.end());
+        g_quarantine.clear();
     }
     if (!blocks.empty()) (void)hipDeviceSynchronize();
     for (void *p : blocks) (void)hipFree(p);

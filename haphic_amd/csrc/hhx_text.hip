@@ -585,6 +585,18 @@ extern "C" int hhx_pairs_parser_bed_host(hhx_pairs_parser *p, void **host, i64 *
     return 0;
 }
 
+// alignments.bed of the last parse handed to a byte sink (hhx_jobs.hip): the device buffer changes owner, the next parse allocates its own
+extern "C" int hhx_pairs_parser_bed_to_sink(hhx_pairs_parser *p, hhx_byte_sink *sink) {
+    if (!p || !sink) return fail("null pointer");
+    if (!p->bed_bytes) return 0;
+    void *block = p->bed.p;
+    p->bed.p = nullptr;
+    p->bed.n = 0;
+    const i64 n = p->bed_bytes;
+    p->bed_bytes = 0;
+    return byte_sink_push_block(sink, block, n);
+}
+
 // positions as 64-bit integers from the next parse on (contigs beyond 2^31 bp: determine_int_type :116-147 picks int64 there);
 // hhx_pairs_parser_arrays then hands out int64 position arrays (for hhx_ingest_push64) and hhx_pairs_parser_fetch64 copies them
 extern "C" int hhx_pairs_parser_set_wide(hhx_pairs_parser *p, int on) {
@@ -617,6 +629,66 @@ extern "C" int hhx_pairs_parser_fetch(hhx_pairs_parser *p, i32 *id1, i32 *pos1, 
         if (pos2) HHX_HIP(hipMemcpyAsync(pos2, p->pos2.p, nb, hipMemcpyDeviceToHost, g_stream));
     }
     if (bed && p->bed_bytes) HHX_HIP(hipMemcpyAsync(bed, p->bed.p, (size_t)p->bed_bytes, hipMemcpyDeviceToHost, g_stream));
+    HHX_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------- id / position arrays -> .pairs text (synthetic inputs)
+// The writer counterpart of hhx_pairs_parse, for measurement only: SURVEY §8(d) quotes C3 / C5 on read pairs "written as .pairs text", and
+// formatting 5e8 lines on the host is not an option.  Line k = "r{first_read + k}\t{names[id1]}\t{pos1 + 1}\t{names[id2]}\t{pos2 + 1}\t+\t-\n"
+// (the format tools/c1_run.py and the reference's simulation write; positions 1-based in the file, :1556).  One thread per line, two passes.
+namespace {
+__device__ __forceinline__ int dec_len(u64 a) { int n = 0; do { ++n; a /= 10; } while (a); return n; }
+__device__ __forceinline__ unsigned char *dec_put(unsigned char *o, u64 a) {
+    const int n = dec_len(a);
+    for (int k = n - 1; k >= 0; --k) { o[k] = (unsigned char)('0' + a % 10); a /= 10; }
+    return o + n;
+}
+__global__ __launch_bounds__(256) void k_pairs_line_len(i64 n, const i32 *__restrict__ id1, const i32 *__restrict__ pos1, const i32 *__restrict__ id2,
+                                                        const i32 *__restrict__ pos2, const i32 *__restrict__ name_len, i64 first_read, i64 *__restrict__ len) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x)
+        len[k] = 1 + dec_len((u64)(first_read + k)) + 1 + name_len[id1[k]] + 1 + dec_len((u64)pos1[k] + 1) + 1 + name_len[id2[k]] + 1 + dec_len((u64)pos2[k] + 1) + 5;
+}
+__global__ __launch_bounds__(256) void k_pairs_line_write(i64 n, const i32 *__restrict__ id1, const i32 *__restrict__ pos1, const i32 *__restrict__ id2,
+                                                          const i32 *__restrict__ pos2, const u64 *__restrict__ names, const i64 *__restrict__ name_off,
+                                                          const i32 *__restrict__ name_len, i64 first_read, const i64 *__restrict__ off,
+                                                          unsigned char *__restrict__ text) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) {
+        unsigned char *o = text + off[k];
+        *o++ = 'r';
+        o = dec_put(o, (u64)(first_read + k));
+        *o++ = '\t';
+        const i32 ids[2] = {id1[k], id2[k]};
+        const i32 ps[2] = {pos1[k], pos2[k]};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned char *nm = reinterpret_cast<const unsigned char *>(names + name_off[ids[s]]);
+            for (i32 q = 0; q < name_len[ids[s]]; ++q) *o++ = nm[q];
+            *o++ = '\t';
+            o = dec_put(o, (u64)ps[s] + 1);
+            *o++ = '\t';
+        }
+        *o++ = '+'; *o++ = '\t'; *o++ = '-'; *o++ = '\n';
+    }
+}
+}  // namespace
+
+extern "C" int hhx_pairs_format(hhx_pairs_parser *p, int64_t n, const int32_t *dev_id1, const int32_t *dev_pos1, const int32_t *dev_id2, const int32_t *dev_pos2,
+                                int64_t first_read, uint8_t *dev_text, int64_t capacity, int64_t *n_bytes) {
+    if (!p || !n_bytes || n < 0 || (n && (!dev_id1 || !dev_pos1 || !dev_id2 || !dev_pos2))) return fail("hhx_pairs_format: bad argument");
+    *n_bytes = 0;
+    if (n == 0) return 0;
+    DevBuf<i64> len, off;
+    if (len.alloc((size_t)n + 1) || off.alloc((size_t)n + 2)) return 1;
+    k_pairs_line_len<<<grid_for(n, 256), 256, 0, g_stream>>>(n, dev_id1, dev_pos1, dev_id2, dev_pos2, p->name_len.p, first_read, len.p);
+    HHX_LAUNCH_CHECK();
+    i64 total = 0;
+    HHX_TRY(exclusive_scan_i64(len.p, off.p, n, &total));
+    *n_bytes = total;
+    if (!dev_text) return 0;
+    if (capacity < total) return fail("hhx_pairs_format: %lld bytes of text, buffer of %lld", (long long)total, (long long)capacity);
+    k_pairs_line_write<<<grid_for(n, 256), 256, 0, g_stream>>>(n, dev_id1, dev_pos1, dev_id2, dev_pos2, p->names.p, p->name_off.p, p->name_len.p, first_read, off.p, dev_text);
+    HHX_LAUNCH_CHECK();
     HHX_HIP(hipStreamSynchronize(g_stream));
     return 0;
 }

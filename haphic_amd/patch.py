@@ -71,6 +71,30 @@ def _with_original(ours, original):
     return seam
 
 
+def _run_then_join(original):
+    """run() :2738-2959 with the library's file-writer thread joined before it returns: output_pickle / output_clm of the array-backed
+    containers only QUEUE HT_links.pkl, paired_links.clm and full_links.pkl (haphic_amd/csrc/hhx_jobs.hip), so the files must be complete —
+    and a writer's failure raised, as the reference's own writers would raise inside run() — before the caller (main :2967,
+    HapHiC_pipeline.py:358, which starts `haphic reassign` on full_links.pkl next) goes on."""
+    from . import _lib
+
+    def run(*args, **kwargs):
+        try:
+            out = original(*args, **kwargs)
+        except BaseException:
+            try:
+                _lib.files_join()             # the run failed for its own reason: that one is raised, the queue is only drained
+            except RuntimeError:
+                pass
+            raise
+        _lib.files_join()
+        return out
+    run.__wrapped__ = original
+    run.__name__ = 'run'
+    run.__doc__ = original.__doc__
+    return run
+
+
 def patch_reference(H, ingest=True, matrix_build=True):
     """H: the imported reference module (HapHiC_cluster).  Returns {name: original} so the caller can undo."""
     from . import _lib
@@ -91,6 +115,9 @@ def patch_reference(H, ingest=True, matrix_build=True):
         if name in CONTAINER_SEAMS:
             fn = _with_original(fn, saved[name])
         setattr(H, name, _dense_dispatch(fn, saved[name], DENSE_ARG[name]) if name in DENSE_ARG else fn)
+    if ingest and getattr(H, 'run', None) is not None:
+        saved['run'] = H.run
+        H.run = _run_then_join(H.run)    # main() :2967 and HapHiC_pipeline.py:358 resolve `run` through the module, like every seam
     saved['INTEL_MKL'] = getattr(H, 'INTEL_MKL', None)
     H.INTEL_MKL = True                   # :2764-2768 would otherwise force the dense (numpy) mode
     return saved

@@ -361,6 +361,11 @@ int hhx_pairs_parser_fetch64(hhx_pairs_parser *p, int32_t *id1, int64_t *pos1, i
  * pointer stays valid until the SECOND following call (the caller writes buffer k to the file while chunk k + 1 is parsed) */
 int hhx_pairs_parser_bed_host(hhx_pairs_parser *p, void **host, int64_t *n_bytes);
 int hhx_pairs_parser_destroy(hhx_pairs_parser *p);
+/* measurement only — the writer counterpart of hhx_pairs_parse for synthetic read pairs ("pairs written as .pairs text"): line k =
+ * "r{first_read + k}\t{names[id1[k]]}\t{pos1[k] + 1}\t{names[id2[k]]}\t{pos2[k] + 1}\t+\t-\n" from device arrays (ids must be valid: 0 <= id < n_names).
+ * *n_bytes = the size of the text; dev_text == NULL: only that.  Not on the product path. */
+int hhx_pairs_format(hhx_pairs_parser *p, int64_t n, const int32_t *dev_id1, const int32_t *dev_pos1, const int32_t *dev_id2, const int32_t *dev_pos2,
+                     int64_t first_read, uint8_t *dev_text, int64_t capacity, int64_t *n_bytes);
 
 /* ------------------------------------------------------------------ f4: BAM front end
  * bam_generator :1586-1593 = pysam.AlignmentFile(bam, threads=..., format_options=[b'filter=...']) yielding
@@ -453,6 +458,42 @@ int hhx_ingest_fetch_flank_values(hhx_ingest *h, double *value);
  * reference's loops :1605-1615 build.  All pointers host. */
 int hhx_write_link_pickle(const char *path, int64_t n_keys, const int32_t *name_i, const int32_t *name_j, const int64_t *count,
                           int32_t n_names, const uint8_t *names_blob, const int64_t *name_off, int64_t *n_bytes);
+
+
+/* ---------------------------------------------------------------- the same files, off the caller's critical path
+ * run() :2879 / :2888 / :2929 writes HT_links.pkl, paired_links.clm and full_links.pkl between its seams and reads none of them again
+ * (the next readers are `haphic sort` / `haphic reassign`, other processes).  The *_async entry points check their arguments, refuse
+ * what the writer would refuse (a read position beyond its contig's end) and open the file on the CALLER's thread, then queue the work
+ * on ONE host thread owned by the library — jobs run in submission order on a non-blocking stream of their own, with a memory-pool arena
+ * of their own, so the device half of a job (grouping / sorting / formatting, hhx_ingest_write_clm; ordering the HT items,
+ * hhx_ingest_fetch_ht_items) overlaps the caller's next kernels — and return at once.  hhx_files_join waits for every queued file and
+ * returns non-zero with the first failure as hhx_last_error() (*n_failed = how many files failed; the failures are forgotten after the
+ * call); hhx_ingest_destroy waits for the jobs that read its handle.  A process that exits without hhx_files_join still gets its
+ * files: the library's destructor works the queue off.
+ *
+ * hhx_ingest_write_clm_async: output_clm :376-392.  drop_pairs_after != 0: the kept read pairs (16 B per pair of HBM) are released when
+ * the file is complete — afterwards hhx_ingest_fetch_pairs / _ht_order / _ht_items / _write_clm on this handle fail (with that message).
+ * hhx_ingest_write_link_pickle_async: output_pickle :710-715 of a table of the handle — which = 0 full_link_dict (names = contigs),
+ * 1 HT_link_dict (names = [c0 + "_H", c0 + "_T", c1 + "_H", ...], items ordered on the device), 2 flank_link_dict with its integer counts
+ * (names = fragments); the writer thread fetches the items into host memory of its own.
+ * hhx_write_link_pickle_async: hhx_write_link_pickle of arrays the CALLER owns: name_i / name_j / count must stay valid and unchanged until
+ * hhx_files_join returns (names_blob / name_off are copied). */
+int hhx_ingest_write_clm_async(hhx_ingest *h, const char *path, const uint8_t *names_blob, const int64_t *name_off, int drop_pairs_after);
+int hhx_ingest_write_link_pickle_async(hhx_ingest *h, int which, const char *path, int32_t n_names, const uint8_t *names_blob,
+                                       const int64_t *name_off);
+int hhx_write_link_pickle_async(const char *path, int64_t n_keys, const int32_t *name_i, const int32_t *name_j, const int64_t *count,
+                                int32_t n_names, const uint8_t *names_blob, const int64_t *name_off);
+/* alignments.bed (pairs_generator* :1549-1557: two records per read pair, written inside the generator's loop, read by nothing in run()), deferred:
+ * a byte sink is a file fed from DEVICE buffers through the same writer thread.  hhx_pairs_parser_bed_to_sink hands the BED bytes of the last
+ * hhx_pairs_parse(want_bed) over where they lie, in HBM (the buffer changes owner; no copy), and returns at once while fewer than hbm_budget_bytes
+ * are waiting to be written (<= 0: a quarter of the device, or HHX_BED_HBM_GB); beyond that the caller is held at the writer's pace.
+ * hhx_byte_sink_close queues the close and frees the handle when it has run: the file is complete after hhx_files_join. */
+typedef struct hhx_byte_sink hhx_byte_sink;
+int hhx_byte_sink_open(const char *path, int64_t hbm_budget_bytes, hhx_byte_sink **out);
+int hhx_pairs_parser_bed_to_sink(hhx_pairs_parser *p, hhx_byte_sink *sink);
+int hhx_byte_sink_close(hhx_byte_sink *sink, int64_t *n_bytes_pushed);
+int hhx_files_pending(int64_t *n_pending, int64_t *n_done);
+int hhx_files_join(int64_t *n_failed);
 
 #ifdef __cplusplus
 }

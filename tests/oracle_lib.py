@@ -69,6 +69,14 @@ def ptr(a):
     return a
 
 
+def files_async():
+    return False                      # the CPU stand-in writes every file on the caller's thread
+
+
+def files_join():
+    pass
+
+
 def links_plan(links):
     return False, 0
 

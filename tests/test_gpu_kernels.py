@@ -387,6 +387,7 @@ def test_pairs_text_through_ingest(tmp_path, monkeypatch):
                                                                                    'int32', 'int32')
         assert list(full.items()) == [((names[i], names[j]), c) for i, j, c in zip(want['full_i'], want['full_j'], want['full_cnt'].tolist())]
         assert list(flank.items()) == [((names[i], names[j]), c) for i, j, c in zip(want['flank_i'], want['flank_j'], want['flank_cnt'].tolist())]
+        cluster._lib.files_join()                               # alignments.bed leaves HBM through the library's file-writer thread
         assert (tmp_path / 'alignments.bed').read_bytes() == g['bed_all'].tobytes()
     assert ok.any()
 
@@ -978,6 +979,7 @@ def test_wide_positions_file_front_end_and_mirror(tmp_path):
         full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(aln, fa_dict, A(), frag_len, set(names), 'int64', 'int64')
     finally:
         C_.cal_concordance_ratio = orig
+    cluster._lib.files_join()
     assert (tmp_path / 'alignments.bed').read_bytes() == g['bed'].tobytes()
     assert [(names.index(a), names.index(b)) for a, b in full] == list(zip(g['full_i'].tolist(), g['full_j'].tolist()))
     assert list(full.values()) == g['full_cnt'].tolist() and list(flank.values()) == g['flank_cnt'].tolist()

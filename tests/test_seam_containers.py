@@ -75,12 +75,14 @@ def body_frozen_seams_equal_dict_seams(tmp_path, monkeypatch, normalize):
     for name, a, b in (('HT', HT, HT2), ('full', full, full2)):
         cluster.output_pickle(a, name, name + '_a.pkl')
         cluster.output_pickle(b, name, name + '_b.pkl')
+        cluster._lib.files_join()                                   # a frozen table's file is queued on the library's writer thread
         da, db = pickle.load(open(name + '_a.pkl', 'rb')), pickle.load(open(name + '_b.pkl', 'rb'))
         assert type(da) is defaultdict and type(db) is defaultdict and da.default_factory is int
         assert list(da.items()) == list(db.items()) and all(type(v) is int for v in da.values())
         assert pickle.loads(pickle.dumps(a)) == db and type(pickle.loads(pickle.dumps(a))) is defaultdict      # plain pickle of a frozen table
     # output_clm
     cluster.output_clm(clm)
+    cluster._lib.files_join()
     os.rename('paired_links.clm', 'a.clm')
     cluster.output_clm(clm2)
     assert open('a.clm', 'rb').read() == open('paired_links.clm', 'rb').read() and os.path.getsize('a.clm') > 1000
@@ -206,6 +208,7 @@ def body_split_contigs(tmp_path, monkeypatch):
         c._thaw()
     assert any('_bin' in a or '_bin' in b for a, b in ref[1])
     cluster.output_clm(clm)
+    cluster._lib.files_join()
     os.rename('paired_links.clm', 'a.clm')
     cluster.output_clm(ref[3])
     assert open('a.clm', 'rb').read() == open('paired_links.clm', 'rb').read()
@@ -306,6 +309,92 @@ def test_device_clm_and_pickles_against_the_oracle(tmp_path):
     ing.finalize()
     assert ing.write_clm(str(tmp_path / 'e.clm'), names) == (0, 0) and os.path.getsize(tmp_path / 'e.clm') == 0
     ing.destroy()
+
+
+@pytest.mark.gpu
+def test_queued_files_equal_the_files_written_in_place(tmp_path, monkeypatch):
+    """output_pickle / output_clm on frozen containers only queue the file (hhx_jobs.hip: one writer thread, its own stream and
+    pool arena) and the seams that follow run meanwhile.  The queued files are byte for byte the files the same calls write in place
+    (HAPHIC_SYNC_FILES=1), the seams in between see the same tables, the kept read pairs leave HBM with paired_links.clm, and what a
+    writer cannot do surfaces as RuntimeError — at the call when it can be known there, at files_join() otherwise."""
+    from haphic_amd import _lib
+    monkeypatch.chdir(tmp_path)
+    gen, fa_dict, aln = _case(n_pairs=400_000, seed=21)
+    args = _args()
+    re_dict = {c: v[2] for c, v in fa_dict.items()}
+
+    def sequence(tag):
+        os.makedirs(tag)
+        os.chdir(tag)
+        full, flank, HT, clm, frag_link, coord, ctg_len, nx = _s5(fa_dict, aln, args)
+        cluster.output_pickle(HT, 'HT_link_dict', 'HT_links.pkl')
+        cluster.output_clm(clm)
+        kept = cluster.filter_fragments(nx, re_dict, 5, frag_link, '0.2X', '1.9X', 10, '1.5X', 0, flank, {}, '1.5X', set())
+        cluster.output_pickle(full, 'full_link_dict', 'full_links.pkl')
+        m, idx = cluster.dict_to_matrix(flank, kept, dense_matrix=False, add_self_loops=True)
+        arrays = m.take_device().to_arrays()
+        assert all(c.frozen for c in (full, flank, HT, clm))
+        os.chdir('..')
+        return kept, idx, arrays, (full, flank, HT, clm)
+
+    monkeypatch.setenv('HAPHIC_SYNC_FILES', '1')
+    kept0, idx0, arrays0, _c0 = sequence('in_place')
+    assert _lib.files_pending()[0] == 0
+    monkeypatch.delenv('HAPHIC_SYNC_FILES')
+    done_before = _lib.files_pending()[1]
+    kept1, idx1, arrays1, held = sequence('queued')
+    _lib.files_join()
+    assert _lib.files_pending() == (0, done_before + 3)
+    assert kept0 == kept1 and idx0 == idx1 and all(np.array_equal(a, b) for a, b in zip(arrays0, arrays1))
+    for f in ('HT_links.pkl', 'paired_links.clm', 'full_links.pkl'):
+        a, b = open(os.path.join('in_place', f), 'rb').read(), open(os.path.join('queued', f), 'rb').read()
+        assert a == b and len(a) > 1000, f
+    # the read pairs went with the CLM file (no coordinate lists asked for, HT already queued): what needs them says so
+    session = held[0]._session
+    assert session.ing is not None
+    with pytest.raises(RuntimeError, match='released'):
+        session.ing.fetch_ht_order()
+    assert held[0].frozen and len(held[0]) == len(pickle.load(open('queued/full_links.pkl', 'rb')))
+    # failures: at the call (the directory does not exist) ...
+    full, flank, HT, clm = _s5(fa_dict, aln, args)[:4]
+    with pytest.raises(RuntimeError, match='cannot open'):
+        cluster.output_pickle(HT, 'HT_link_dict', 'no_such_dir/HT_links.pkl')
+    # ... and at the join (the device is full: /dev/full accepts the open and refuses every write)
+    cluster.output_pickle(full, 'full_link_dict', '/dev/full')
+    with pytest.raises(RuntimeError, match='/dev/full'):
+        _lib.files_join()
+    _lib.files_join()                                                # the failure was reported once
+    # a handle is not destroyed under a queued job
+    cluster.output_pickle(HT, 'HT_link_dict', 'late.pkl')
+    del full, flank, HT, clm
+    import gc
+    gc.collect()
+    _lib.files_join()
+    assert type(pickle.load(open('late.pkl', 'rb'))) is defaultdict
+
+
+def test_library_pickle_writer_queued(tmp_path):
+    """hhx_write_link_pickle_async + hhx_files_join are host code: same bytes as the call in place, failures raised by the join"""
+    from haphic_amd import _lib
+    rng = np.random.default_rng(3)
+    names = ['ctg%d' % k for k in range(900)]
+    n = 700_000
+    i, j = rng.integers(0, len(names), n).astype(np.int32), rng.integers(0, len(names), n).astype(np.int32)
+    cnt = rng.integers(1, 1 << 33, n)
+    _lib.write_link_pickle(str(tmp_path / 'a.pkl'), i, j, cnt, names)
+    _lib.write_link_pickle_async(str(tmp_path / 'b.pkl'), i, j, cnt, names)
+    _lib.write_link_pickle_async(str(tmp_path / 'c.pkl'), i[:10], j[:10], cnt[:10], names)
+    _lib.files_join()
+    assert (tmp_path / 'a.pkl').read_bytes() == (tmp_path / 'b.pkl').read_bytes()
+    assert len(pickle.load(open(tmp_path / 'c.pkl', 'rb'))) == len(set(zip(i[:10].tolist(), j[:10].tolist())))
+    with pytest.raises(RuntimeError, match='cannot open'):
+        _lib.write_link_pickle_async(str(tmp_path / 'nope' / 'd.pkl'), i, j, cnt, names)
+    _lib.write_link_pickle_async('/dev/full', i, j, cnt, names)
+    _lib.write_link_pickle_async(str(tmp_path / 'e.pkl'), i, j, cnt, names)         # the queue goes on after a failed file
+    with pytest.raises(RuntimeError, match='No space left'):
+        _lib.files_join()
+    assert (tmp_path / 'a.pkl').read_bytes() == (tmp_path / 'e.pkl').read_bytes() and _lib.files_pending()[0] == 0
+    _lib.files_join()
 
 
 def test_library_pickle_writer_against_pickle(tmp_path):

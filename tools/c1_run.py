@@ -64,6 +64,7 @@ def main():
             m, fidx = cluster.dict_to_matrix(flank, kept, dense_matrix=False, add_self_loops=True)
             t.append(time.perf_counter())
             res, rounds = cluster.run_mcl_clustering(m, bin_set, frag_len_dict, fidx, 2, 1.1, 3.0, 0.1, 200, 1e-4, fa_dict, 4, False)
+            _lib.files_join()                 # alignments.bed, HT_links.pkl, paired_links.clm, full_links.pkl: queued on the library's writer thread, complete here
             t.append(time.perf_counter())
             frozen = all(c.frozen for c in (full, flank, HT, clm))
         out.update(wall_s=t[-1] - t[0], parse_fasta_s=t[1] - t[0], stat_fragments_s=t[2] - t[1], parse_alignments_for_ctgs_s=t[3] - t[2],
