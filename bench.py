@@ -56,6 +56,7 @@ def parse():
     ap.add_argument('--sweep-tail-seconds', type=float, default=20.0, help='sweep leg: wall-time budget for the mcl() tails (run from the highest inflation down)')
     ap.add_argument('--check-sweep', action='store_true', help='N > 1: rank 0 also runs the one-GPU sweep on the all-gathered link matrix and compares every inflation (functional runs)')
     ap.add_argument('--no-seam', action='store_true', help='skip the seam_e2e leg (the reference\'s own operator sequence S5 -> filter_fragments -> S4 on host id arrays, after the timed region)')
+    ap.add_argument('--no-run-e2e', action='store_true', help='skip the run_e2e leg (the whole seam sequence of run() :2829-2945 from the .pairs FILE, 20-inflation sweep and every file included; tools/c3_run.py)')
     ap.add_argument('--no-seam-files', action='store_true', help='seam_e2e: skip the three files run() writes between S5 and S4 (HT_links.pkl, paired_links.clm, full_links.pkl)')
     ap.add_argument('--transport', choices=('rccl', 'host'), default='rccl',
                     help='rccl: one rank per GPU over RCCL / xGMI (the product path).  host: the same ranks and the same exchanges, every collective '
@@ -318,6 +319,17 @@ def main():
                 out['seam_e2e'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
         if not args.no_cpu_baseline and world == 1:          # a reported baseline of the N = 1 line only
             out['cpu_baseline'] = cpu_baseline(args, gen, table, flank, id1, p1, id2, p2, state)
+        if world == 1 and not sharded_path and not args.no_run_e2e:
+            # ONE wall clock over run()'s own sequence from the .pairs file (a1 + alignments.bed -> S5 -> HT_links.pkl -> paired_links.clm ->
+            # filter_fragments -> full_links.pkl -> dict_to_matrix -> run_mcl_clustering with its 20 inflation directories), after everything else
+            try:
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+                import c3_run
+                torch.cuda.empty_cache()
+                _lib.check(_lib.load().hhx_pool_trim())
+                out['run_e2e'] = c3_run.run_job(pairs=local_pairs, nchrs=args.nchrs, gen=gen, arrays=[id1, p1, id2, p2], device=dev)
+            except Exception as e:                       # noqa: BLE001 — a leg after the timed region must never take the line down
+                out['run_e2e'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
         final_out = out
     # ---- outside the timed region, every rank: run_mcl_clustering's inflation sweep (:2155-2158) shared out over the ranks
     # (sharded.sweep_sharded: ONE expansion across the ranks, the heavy iterations of the low inflations row-sharded, the light

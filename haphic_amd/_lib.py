@@ -142,9 +142,14 @@ SIGNATURES = {
     'hhx_ingest_write_clm_async': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]),
     'hhx_ingest_write_link_pickle_async': (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'hhx_write_link_pickle_async': (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    'hhx_byte_sink_open': (C.c_int, [C.c_char_p, C.c_int64, c_vpp]),
-    'hhx_pairs_parser_bed_to_sink': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'hhx_byte_sink_open': (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, c_vpp]),
+    'hhx_byte_sink_reserve': (C.c_int, [C.c_void_p, C.c_int64, c_vpp]),
+    'hhx_byte_sink_commit': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     'hhx_byte_sink_close': (C.c_int, [C.c_void_p, c_i64p]),
+    'hhx_pairs_parser_set_bed_sink': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'hhx_text_reader_open': (C.c_int, [C.c_char_p, C.c_int64, C.c_int, c_vpp]),
+    'hhx_text_reader_next': (C.c_int, [C.c_void_p, c_vpp, c_i64p]),
+    'hhx_text_reader_close': (C.c_int, [C.c_void_p]),
     'hhx_files_pending': (C.c_int, [c_i64p, c_i64p]),
     'hhx_files_join': (C.c_int, [c_i64p]),
 }
@@ -538,10 +543,10 @@ def files_join():
 class ByteSink:
     """hhx_byte_sink: a file fed from device buffers through the library's file-writer thread (alignments.bed, deferred)"""
 
-    def __init__(self, path, hbm_budget_bytes=0):
+    def __init__(self, path, hbm_budget_bytes=0, expected_bytes=0):
         self.h = C.c_void_p()
         _register_join()
-        check(load().hhx_byte_sink_open(os.fsencode(path), int(hbm_budget_bytes), C.byref(self.h)))
+        check(load().hhx_byte_sink_open(os.fsencode(path), int(hbm_budget_bytes), int(expected_bytes), C.byref(self.h)))
 
     def close(self):
         """queue the close (the file is complete after files_join()); returns the bytes handed to the sink"""
@@ -550,6 +555,34 @@ class ByteSink:
             check(load().hhx_byte_sink_close(self.h, C.byref(n)))
             self.h = None
         return n.value
+
+
+class TextReader:
+    """hhx_text_reader: a text file as chunks of whole lines in pinned host memory, read ahead by threads of the library"""
+
+    def __init__(self, path, chunk_bytes=256 << 20, threads=4):
+        self.h = C.c_void_p()
+        check(load().hhx_text_reader_open(os.fsencode(path), int(chunk_bytes), int(threads), C.byref(self.h)))
+
+    def __iter__(self):
+        """(host pointer, bytes) per chunk; a pointer is valid until the next one is asked for"""
+        host, n = C.c_void_p(), C.c_int64(0)
+        while True:
+            check(load().hhx_text_reader_next(self.h, C.byref(host), C.byref(n)))
+            if n.value == 0:
+                return
+            yield host.value, n.value
+
+    def close(self):
+        if self.h is not None and self.h.value:
+            load().hhx_text_reader_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def write_link_pickle_async(path, i, j, count, names):
@@ -751,11 +784,13 @@ class PairsParser:
         check(load().hhx_pairs_parser_set_wide(self.h, int(on)))
         self.wide = bool(on)
 
-    def parse(self, text, want_bed=False, device_ptr=None, n_bytes=None):
-        """text: bytes-like holding whole lines (or device_ptr + n_bytes); raises IndexError / ValueError like
+    def parse(self, text, want_bed=False, device_ptr=None, n_bytes=None, host_ptr=None):
+        """text: bytes-like holding whole lines (or device_ptr / host_ptr + n_bytes); raises IndexError / ValueError like
         the reference's cols[k] / int() do"""
         nl, nb = C.c_int64(0), C.c_int64(0)
-        if device_ptr is None:
+        if host_ptr is not None:
+            rc = load().hhx_pairs_parse(self.h, C.c_void_p(host_ptr), int(n_bytes), 0, int(want_bed), C.byref(nl), C.byref(nb))
+        elif device_ptr is None:
             buf = np.frombuffer(text, np.uint8)
             rc = load().hhx_pairs_parse(self.h, ptr(buf) if buf.size else None, buf.size, 0, int(want_bed), C.byref(nl), C.byref(nb))
         else:
@@ -789,11 +824,10 @@ class PairsParser:
                                       C.c_void_p(text_ptr) if text_ptr else None, int(capacity), C.byref(nb)))
         return nb.value
 
-    def bed_to_sink(self, sink):
-        """the BED bytes of the last parse(want_bed=True) handed to a ByteSink where they lie, in HBM; returns their number"""
-        n = self.bed_bytes
-        check(load().hhx_pairs_parser_bed_to_sink(self.h, sink.h))
-        return n
+    def set_bed_sink(self, sink):
+        """from the next parse(want_bed=True) on the BED records are formatted into the ByteSink's ring in HBM and queued for the file-writer
+        thread (None: back to the parser's own buffer)"""
+        check(load().hhx_pairs_parser_set_bed_sink(self.h, sink.h if sink is not None else None))
 
     def bed_host(self):
         """the alignments.bed bytes of the last parse as a uint8 VIEW of pinned memory owned by the parser (valid until the

@@ -713,9 +713,16 @@ def mcl(matrix, expansion, inflation, iters, pruning, dense_matrix=False):
 
 def _clusters_from_arrays(att, att_ptr, members, shape):
     # :2073-2095 — the SET of tuples (its iteration order decides group numbering on length ties)
+    ptr, mem = np.asarray(att_ptr).tolist(), np.asarray(members).tolist()
     clusters = set()
     for a in range(len(att)):
-        clusters.add(tuple(members[att_ptr[a]:att_ptr[a + 1]].tolist()))
+        clusters.add(tuple(mem[ptr[a]:ptr[a + 1]]))
+    if len(clusters) == len(att) and len(att):
+        # no two attractors with the same members: "every node in exactly one cluster, all nodes present" (:2086-2093) is a count per node
+        used = np.asarray(members[:ptr[len(att)]], np.int64)
+        if len(used) != shape or len(np.unique(used)) != len(used):
+            return None
+        return list(clusters)
     nodes = set()
     for cluster in clusters:
         for node in cluster:
@@ -725,6 +732,28 @@ def _clusters_from_arrays(att, att_ptr, members, shape):
     if len(nodes) != shape:
         return None
     return list(clusters)
+
+
+def _groups_from_arrays(clusters, names_by_index, len_by_index, line_by_index):
+    """:2172-2218 for clusters of whole contigs: every cluster's contigs in ascending matrix-index order (:2172-2187), its total length, the
+    clusters sorted by total length (descending, stable: :2197), the contigs of each by length (descending, stable: :2208).  Returns
+    (result_clusters as the reference builds it — [[contigs], total length] per group —, the body of each group's file)."""
+    clusters = [c for c in clusters if c]                                   # an empty cluster never touches `groups` (:2172): no group
+    sizes = np.fromiter(map(len, clusters), np.int64, len(clusters))
+    flat = np.fromiter((i for c in clusters for i in c), np.int64, int(sizes.sum()))
+    start = np.concatenate([[0], np.cumsum(sizes)])
+    lens = len_by_index[flat]
+    total = np.add.reduceat(lens, start[:-1]) if len(flat) else np.zeros(0, np.int64)
+    rank = np.argsort(-total, kind='stable')                                # position in result_clusters -> cluster
+    place = np.empty(len(clusters), np.int64)
+    place[rank] = np.arange(len(clusters))
+    group_of = np.repeat(place, sizes)                                      # where every entry of `flat` ends up
+    order = np.lexsort((-lens, group_of))                                   # by group, then length descending; stable in the original (cluster) order
+    flat = flat[order]
+    bounds = np.concatenate([[0], np.cumsum(sizes[rank])]).tolist()
+    names, lines, totals = names_by_index[flat].tolist(), line_by_index[flat].tolist(), total[rank].tolist()
+    result = [[names[a:b], t] for a, b, t in zip(bounds[:-1], bounds[1:], totals)]
+    return result, [''.join(lines[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
 
 
 def interpret_result_device(result):
@@ -976,24 +1005,32 @@ class PairsText:
         parser = _lib.PairsParser(names)
         if wide:
             parser.set_wide(True)
-        if self.bed_path and _lib.files_async():
-            sink = _lib.ByteSink(self.bed_path)
+        if _lib.files_async() and self.aln_format == 'pairs':
+            # the native front end: the file read ahead into pinned memory by threads of the library (hhx_text_reader), alignments.bed deferred
+            size = os.path.getsize(self.path)
+            sink = _lib.ByteSink(self.bed_path, expected_bytes=int(1.45 * size)) if self.bed_path else None       # two BED records ~ 1.35 x the line
+            reader = _lib.TextReader(self.path, self.chunk_bytes, threads=8)
             try:
-                for chunk in self._chunks():
+                if sink is not None:
+                    parser.set_bed_sink(sink)
+                t = clock()
+                for host, nbytes in reader:
+                    st['read_wait_s'] = st.get('read_wait_s', 0.0) + clock() - t
                     t = clock()
                     st['chunks'] += 1
-                    st['text_bytes'] += len(chunk)
-                    n = parser.parse(chunk, want_bed=True)
+                    st['text_bytes'] += nbytes
+                    n = parser.parse(None, want_bed=sink is not None, host_ptr=host, n_bytes=nbytes)
+                    st['bed_bytes'] += parser.bed_bytes
                     st['parse_s'] += clock() - t
-                    del chunk
-                    t = clock()
-                    st['bed_bytes'] += parser.bed_to_sink(sink)        # returns at once unless the sink's HBM budget is used up
-                    st['bed_wait_s'] += clock() - t
                     t = clock()
                     yield parser, n
                     st['consumer_s'] += clock() - t
+                    t = clock()
             finally:
-                sink.close()
+                if sink is not None:
+                    parser.set_bed_sink(None)
+                    sink.close()
+                reader.close()
                 parser.destroy()
             return
         from concurrent.futures import ThreadPoolExecutor, wait
@@ -1209,7 +1246,16 @@ def _ingest_handle(alignments, table, flank, bins, chunk=1 << 22, want_pairs=Fal
             cid = {n: i for i, n in enumerate(table.ctg_names)}
             for b1, p1, b2, p2, k in _ids_from_alignments(alignments, cid, chunk, wide=table.wide):
                 ing.push(b1, p1, b2, p2, wide=table.wide)     # unknown names (-1) and intra-contig pairs are filtered on the device
+        t_fin = time.perf_counter()
         ing.finalize()
+        if text or bam:
+            # the front end's transient blocks (chunk buffers, partition scratch: ~90 GB at 5e8 pairs) sit in the pool's cache, where nothing
+            # that follows is of their sizes (lending them to the file-writer thread was tried: its sorts want 4 GB blocks, these are smaller, and
+            # it ended up holding both); the device is idle here: back to the driver, before the sweep and the file-writer threads want the room
+            _lib.check(_lib.load().hhx_pool_trim())
+        if hasattr(alignments, 'stats'):
+            _lib.check(_lib.load().hhx_synchronize())
+            alignments.stats['finalize_s'] = time.perf_counter() - t_fin
         return ing
     except BaseException:
         ing.destroy()
@@ -1405,9 +1451,15 @@ def parse_alignments_for_ctgs(alignments, fa_dict, args, ctg_len_dict, Nx_ctg_se
     CLM distance lists and the first coordinates of every contig pair.  The big ones come back FROZEN (containers.py): their
     entries stay in HBM / numpy arrays until something other than the next seams of run() touches them."""
     logger.info('Parsing input alignments...')
+    t_start = time.perf_counter()
     table = FragTable.from_reference(fa_dict, ctg_len_dict, Nx_ctg_set)
+    t_table = time.perf_counter()
     session = ingest_session(alignments, table, fa_dict, args, False, pos_int_type, dist_int_type)
-    return _s5_containers(session)
+    t_session = time.perf_counter()
+    out = _s5_containers(session)
+    if hasattr(alignments, 'stats'):
+        alignments.stats.update(frag_table_s=t_table - t_start, ingest_s=t_session - t_table, containers_s=time.perf_counter() - t_session)
+    return out
 
 
 def parse_alignments(alignments, fa_dict, args, bin_size, frag_len_dict, Nx_frag_set, split_ctg_set, pos_int_type,
@@ -1466,6 +1518,9 @@ def recommend_inflation(result_stat, nchrs, len_ratio):
                 'then try to tune the parameters for assembly correction, contig / Hi-C link '
                 'filtration, or Markov clustering'.format(len_ratio))
     return True
+
+
+SWEEP_TIMING = []      # of the last run_mcl_clustering: [inflation, seconds of mcl() + interpret_result, seconds of its cluster / group files] (measurement only)
 
 
 def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, expansion, min_inflation,
@@ -1558,47 +1613,66 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
     else:
         attractor_arrays = None
         write_files = True
+    timing = SWEEP_TIMING
+    del timing[:]
+    # the per-contig half of :2172-2218 on arrays when no fragment is a bin (the loops below otherwise): names, lengths and the group-file line of
+    # every matrix index, gathered once; per inflation the clusters are cut out of them with numpy instead of one Python statement per contig
+    by_index = None
+    if not bin_set:
+        order = sorted(index_frag)
+        if order == list(range(len(order))):
+            names_by_index = np.empty(len(order), object)
+            names_by_index[:] = [index_frag[i] for i in order]
+            by_index = (names_by_index, np.fromiter((fa_dict[f][1] for f in names_by_index), np.int64, len(order)),
+                        np.array(['{}\t{}\t{}\n'.format(f, fa_dict[f][2], fa_dict[f][1]) for f in names_by_index], object))
     for k_infl, inflation in enumerate(inflations):
+        t_start = time.perf_counter()
         att, att_ptr, members, shape = attractor_arrays[k_infl] if attractor_arrays is not None else run_one(inflation)
+        timing.append([str(inflation), time.perf_counter() - t_start, 0.0])          # [inflation, seconds of mcl() + interpret, seconds of the files]
+        t_start = time.perf_counter()
         mcl_nrounds += 1
         clusters = _clusters_from_arrays(att, att_ptr, members, shape)
         if not clusters:
             logger.info('Some fragments are missing / redundant, result of inflation {} will NOT be output'.format(inflation))
             continue
-        groups = defaultdict(lambda: [[], 0])       # cluster number -> [contigs, total length]
-        split_votes = defaultdict(dict)             # split contig -> {cluster number: summed bin length}
-        for k, indexes in enumerate(clusters):
-            for i in indexes:
-                frag = index_frag[i]
-                if frag in bin_set:                                  # :2176-2183
-                    ctg = frag.rsplit('_bin', 1)[0]
-                    split_votes[ctg][k] = split_votes[ctg].get(k, 0) + frag_len_dict[frag]
-                else:
-                    groups[k][0].append(frag)
-                    groups[k][1] += fa_dict[frag][1]
-        for ctg, votes in split_votes.items():                       # :2190-2194
-            best = sorted(votes.keys(), key=lambda c: votes[c], reverse=True)[0]
-            groups[best][0].append(ctg)
-            groups[best][1] += fa_dict[ctg][1]
-        result_clusters = sorted(tuple(groups.values()), key=lambda g: g[1], reverse=True)   # stable, :2197
         outdir = os.path.join(outdir_root, 'inflation_{}'.format(inflation))
-        if not write_files:
+        if by_index is not None:
+            result_clusters, group_lines = _groups_from_arrays(clusters, *by_index)
+        else:
+            group_lines = None
+            groups = defaultdict(lambda: [[], 0])       # cluster number -> [contigs, total length]
+            split_votes = defaultdict(dict)             # split contig -> {cluster number: summed bin length}
+            for k, indexes in enumerate(clusters):
+                for i in indexes:
+                    frag = index_frag[i]
+                    if frag in bin_set:                                  # :2176-2183
+                        ctg = frag.rsplit('_bin', 1)[0]
+                        split_votes[ctg][k] = split_votes[ctg].get(k, 0) + frag_len_dict[frag]
+                    else:
+                        groups[k][0].append(frag)
+                        groups[k][1] += fa_dict[frag][1]
+            for ctg, votes in split_votes.items():                       # :2190-2194
+                best = sorted(votes.keys(), key=lambda c: votes[c], reverse=True)[0]
+                groups[best][0].append(ctg)
+                groups[best][1] += fa_dict[ctg][1]
+            result_clusters = sorted(tuple(groups.values()), key=lambda g: g[1], reverse=True)   # stable, :2197
             for ctgs, group_len in result_clusters:
-                ctgs.sort(key=lambda c: fa_dict[c][1], reverse=True)
+                ctgs.sort(key=lambda c: fa_dict[c][1], reverse=True)                            # :2208 (and :2214 for the file below: same order)
+        if not write_files:
             result_clusters_list.append((inflation, result_clusters))
             continue
         os.makedirs(outdir, exist_ok=True)
         with open(os.path.join(outdir, 'mcl_inflation_{}.clusters.txt'.format(inflation)), 'w') as fout:
             fout.write('#Group\tnContigs\tContigs\n')
-            for k, (ctgs, group_len) in enumerate(result_clusters, 1):
-                ctgs.sort(key=lambda c: fa_dict[c][1], reverse=True)
-                fout.write('group{}_{}bp\t{}\t{}\n'.format(k, group_len, len(ctgs), ' '.join(ctgs)))
+            fout.write(''.join('group{}_{}bp\t{}\t{}\n'.format(k, group_len, len(ctgs), ' '.join(ctgs)) for k, (ctgs, group_len) in enumerate(result_clusters, 1)))
         for k, (ctgs, group_len) in enumerate(result_clusters, 1):
             with open(os.path.join(outdir, 'group{}_{}bp.txt'.format(k, group_len)), 'w') as fout:
-                fout.write('#Contig\tRECounts\tLength\n')
-                for ctg in ctgs:
-                    fout.write('{}\t{}\t{}\n'.format(ctg, fa_dict[ctg][2], fa_dict[ctg][1]))
+                if group_lines is not None:
+                    fout.write('#Contig\tRECounts\tLength\n' + group_lines[k - 1])
+                else:
+                    fout.write('#Contig\tRECounts\tLength\n' + ''.join('{}\t{}\t{}\n'.format(ctg, fa_dict[ctg][2], fa_dict[ctg][1]) for ctg in ctgs))
         result_clusters_list.append((inflation, result_clusters))
+        timing[-1][2] = time.perf_counter() - t_start
     if pre is not None and pre is not m:
         pre.free()
     if sweep is not None:

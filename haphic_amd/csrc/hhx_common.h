@@ -60,6 +60,7 @@ void pool_trim();
 struct Arena { std::multimap<size_t, void *> free; };
 extern thread_local Arena *g_arena;
 void pool_free_synced(void *p);   // p is idle on every stream: straight to the callers' list
+void pool_free_to_driver(void *p);  // p is idle on every stream: hipFree (waits for the device)
 void arena_donate(Arena *a);      // the arena's thread has synchronised its stream: its cached blocks go to the callers' list
 
 template <class T>
@@ -115,11 +116,10 @@ int exclusive_scan_i64(const i64 *in, i64 *out, i64 n, i64 *total_host);
 
 // ------------------------------------------------------------------ the file-writer thread (hhx_jobs.hip)
 // run() writes HT_links.pkl, paired_links.clm and full_links.pkl between the seams (:2879 :2888 :2929) and reads none of them: the *_async entry
-// points queue the file on ONE library-owned host thread (its own non-blocking stream, its own pool arena; jobs run in submission
-// order) and return; hhx_files_join waits and reports the first failure.  `handle`: the ingest handle a job reads (hhx_ingest_destroy waits for it).
-int files_submit(const std::string &what, const void *handle, std::function<int()> job);
+// points queue the file on a library-owned host thread (two lanes, each with its own non-blocking stream and pool arena; the jobs of a lane run in
+// submission order) and return; hhx_files_join waits and reports the first failure.  `handle`: the ingest handle a job reads (hhx_ingest_destroy waits for it).
+int files_submit(const std::string &what, const void *handle, std::function<int()> job, int lane = 1);      // lane 0: the byte sinks, lane 1: everything else
 void files_wait_handle(const void *handle);
-int byte_sink_push_block(hhx_byte_sink *s, void *dev_block, i64 n_bytes);        // the block (of the library's pool) is taken over
 // the writers behind the synchronous and the queued entry points: an open file descriptor in (closed by the callee, whatever happens)
 int write_link_pickle_fd(int fd, const char *path, i64 n_keys, const i32 *name_i, const i32 *name_j, const i64 *count, i32 n_names,
                          const uint8_t *names_blob, const i64 *name_off, i64 *n_bytes);

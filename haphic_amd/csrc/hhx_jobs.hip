@@ -8,6 +8,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -26,6 +27,15 @@ struct Job {
     int device;
     std::function<int()> run;
 };
+
+// the writers' kernels (sorts, text formatting) and copies must not take compute units from the caller's kernels: the lowest stream priority
+hipError_t create_low_priority_stream(hipStream_t *s) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+    hipError_t e = hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+    return e;
+}
 
 struct Writer {
     std::mutex mu;
@@ -58,7 +68,7 @@ struct Writer {
             if (j.device < 0) s = nullptr;
             else if (hipSetDevice(j.device) != hipSuccess) err = "hipSetDevice failed on the file-writer thread";
             else if (it != streams.end()) s = it->second;
-            else if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) err = "hipStreamCreateWithFlags failed on the file-writer thread";
+            else if (create_low_priority_stream(&s) != hipSuccess) err = "creating the stream of the file-writer thread failed";
             else streams[j.device] = s;
             if (err.empty()) {
                 g_stream = s;
@@ -88,17 +98,22 @@ struct Writer {
     }
 };
 
-Writer &writer() {
-    static Writer w;
-    return w;
+// Two lanes, each a thread with its own stream and arena: ONE file takes ~4.3 GB/s on the RAM disk of the MI355X boxes however many threads write it
+// (the inode's write lock), two files take 7.8 and four 12.7 (tools/fs_write_bench2.c) — so alignments.bed (the byte sink: lane 0) and the files made
+// from the ingest handle (HT_links.pkl, paired_links.clm, full_links.pkl: lane 1) are written side by side.  Jobs of one lane run in submission order.
+constexpr int N_LANES = 2;
+Writer &writer(int lane) {
+    static Writer w[N_LANES];
+    static const int lanes = (int)std::max<i64>(1, std::min<i64>(N_LANES, tune_get("file_lanes", N_LANES)));     // HHX_FILE_LANES=1: one writer thread for everything
+    return w[lane < lanes ? lane : lanes - 1];
 }
 
 }  // namespace
 
-int hhx::files_submit(const std::string &what, const void *handle, std::function<int()> job) {
+int hhx::files_submit(const std::string &what, const void *handle, std::function<int()> job, int lane) {
     int dev = -1;                                // -1: no device (host-only jobs: the pickle of caller-owned arrays on a machine without a GPU)
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
-    Writer &w = writer();
+    Writer &w = writer(lane < 0 || lane >= N_LANES ? 1 : lane);
     {
         std::lock_guard<std::mutex> lk(w.mu);
         if (!w.started) {
@@ -112,30 +127,38 @@ int hhx::files_submit(const std::string &what, const void *handle, std::function
 }
 
 void hhx::files_wait_handle(const void *handle) {
-    Writer &w = writer();
-    std::unique_lock<std::mutex> lk(w.mu);
-    w.cv_done.wait(lk, [&] {
-        if (w.running && w.running_handle == handle) return false;
-        for (const Job &j : w.q) if (j.handle == handle) return false;
-        return true;
-    });
+    for (int lane = 0; lane < N_LANES; ++lane) {
+        Writer &w = writer(lane);
+        std::unique_lock<std::mutex> lk(w.mu);
+        w.cv_done.wait(lk, [&] {
+            if (w.running && w.running_handle == handle) return false;
+            for (const Job &j : w.q) if (j.handle == handle) return false;
+            return true;
+        });
+    }
 }
 
 extern "C" int hhx_files_pending(int64_t *n_pending, int64_t *n_done) {
-    Writer &w = writer();
-    std::lock_guard<std::mutex> lk(w.mu);
-    if (n_pending) *n_pending = (i64)w.q.size() + (w.running ? 1 : 0);
-    if (n_done) *n_done = w.n_done;
+    i64 pend = 0, done = 0;
+    for (int lane = 0; lane < N_LANES; ++lane) {
+        Writer &w = writer(lane);
+        std::lock_guard<std::mutex> lk(w.mu);
+        pend += (i64)w.q.size() + (w.running ? 1 : 0);
+        done += w.n_done;
+    }
+    if (n_pending) *n_pending = pend;
+    if (n_done) *n_done = done;
     return 0;
 }
 
 extern "C" int hhx_files_join(int64_t *n_failed) {
-    Writer &w = writer();
     std::vector<std::string> errs;
-    {
+    for (int lane = 0; lane < N_LANES; ++lane) {
+        Writer &w = writer(lane);
         std::unique_lock<std::mutex> lk(w.mu);
         w.cv_done.wait(lk, [&] { return w.q.empty() && !w.running; });
-        errs.swap(w.errors);
+        errs.insert(errs.end(), w.errors.begin(), w.errors.end());
+        w.errors.clear();
     }
     if (n_failed) *n_failed = (i64)errs.size();
     if (errs.empty()) return 0;
@@ -202,26 +225,59 @@ extern "C" int hhx_write_link_pickle_async(const char *path, int64_t n_keys, con
 
 // ---------------------------------------------------------------- alignments.bed, deferred
 // pairs_generator* :1549-1557 write two BED records per read pair inside their loop: 67 GB next to a 50 GB .pairs file at C3, and a RAM disk of the
-// MI355X boxes takes ~4.5 GB/s into one file — 15 s on the critical path of a stage that tokenises the text in 3.5 s.  Nothing in run() reads the file.
-// A byte sink keeps the chunks WHERE THEY ARE MADE, in HBM (288 GB: the 67 GB fit beside everything else), and hands them to the file-writer thread:
-// hhx_byte_sink_push_device takes the device buffer over (no copy), returns at once while fewer than `hbm_budget` bytes are waiting, and blocks the
-// producer at the writer's pace beyond that.  The chunk jobs run in the queue like every other file; hhx_byte_sink_close queues the close.
+// MI355X boxes takes ~4.5 GB/s into one file — 15 s on the critical path of a stage that tokenises the text in 3 s.  Nothing in run() reads the file.
+// A byte sink keeps the bytes WHERE THEY ARE MADE, in HBM (288 GB: the 67 GB fit beside everything else): the producer reserves room in a ring of
+// device slabs (hhx_byte_sink_reserve: blocks only when `hbm_budget` bytes are waiting, i.e. at the writer's pace beyond that), its kernel
+// formats into the slab, and hhx_byte_sink_commit queues the range on the file-writer thread, which copies it out through pinned buffers and writes
+// it.  The slabs come from the library's pool — taken ahead of use by a helper thread (a fresh block costs ~30 ms per GB) — and go back to it when
+// their last range is on disk.  hhx_byte_sink_close queues the close; the handle is freed by that job.
 struct hhx_byte_sink {
+    struct Slab { unsigned char *p = nullptr; size_t cap = 0, used = 0; int outstanding = 0; bool sealed = false; };
     std::string path;
     FileSink out;                        // used by the writer thread only
     bool opened = false, failed = false;
     std::mutex mu;
     std::condition_variable cv;
-    i64 waiting = 0, budget = 0, pushed = 0;
+    std::vector<Slab *> all;
+    std::deque<Slab *> free_;
+    Slab *cur = nullptr;
+    size_t slab_bytes = 0;
+    i64 budget = 0, allocated = 0, target = 0, pushed = 0;
+    bool stop_alloc = false, alloc_failed = false;
+    int device = 0;
+    std::thread allocator;
+    std::string alloc_err;
+
+    void alloc_loop() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this] { return stop_alloc || (free_.size() < 2 && allocated + (i64)slab_bytes <= target); });
+                if (stop_alloc) return;
+            }
+            void *p = pool_alloc(slab_bytes);                        // the callers' list (g_arena is null on this thread): the first user of the block is the caller's kernel
+            std::lock_guard<std::mutex> lk(mu);
+            if (!p) { alloc_failed = true; alloc_err = g_err; cv.notify_all(); return; }
+            Slab *s = new Slab();
+            s->p = (unsigned char *)p; s->cap = slab_bytes;
+            all.push_back(s); free_.push_back(s);
+            allocated += (i64)slab_bytes;
+            cv.notify_all();
+        }
+    }
 };
 
-extern "C" int hhx_byte_sink_open(const char *path, int64_t hbm_budget_bytes, hhx_byte_sink **out) {
+extern "C" int hhx_byte_sink_open(const char *path, int64_t hbm_budget_bytes, int64_t expected_bytes, hhx_byte_sink **out) {
     if (!path || !out) return fail("hhx_byte_sink_open: null pointer");
+    int dev = 0;
+    HHX_HIP(hipGetDevice(&dev));
     const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
     if (fd < 0) return fail("cannot open %s for writing: %s", path, strerror(errno));
     auto *s = new hhx_byte_sink();
     s->path = path;
-    s->out.fd = fd;                      // the pinned buffers and the pwrite() threads are made by the first chunk's job, on the writer thread
+    s->device = dev;
+    s->out.fd = fd;                      // the pinned buffers and the pwrite() threads are made by the first range's job, on the writer thread
     if (hbm_budget_bytes <= 0) {
         size_t f = 0, t = 0;
         if (hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); t = (size_t)64 << 30; }
@@ -229,49 +285,99 @@ extern "C" int hhx_byte_sink_open(const char *path, int64_t hbm_budget_bytes, hh
         const i64 env = tune_get("bed_hbm_gb", 0);
         if (env > 0) hbm_budget_bytes = env << 30;
     }
-    s->budget = hbm_budget_bytes;
+    const size_t G64 = (size_t)64 << 20;
+    size_t slab = expected_bytes > 0 ? ((size_t)expected_bytes + G64 - 1) / G64 * G64 : (size_t)1 << 30;
+    slab = std::min<size_t>(std::max<size_t>(slab, G64), (size_t)4 << 30);
+    s->slab_bytes = slab;
+    s->budget = std::max<i64>(hbm_budget_bytes, 2 * (i64)slab);
+    s->target = std::min<i64>(s->budget, std::max<i64>(expected_bytes > 0 ? expected_bytes + (i64)slab : s->budget, 2 * (i64)slab));
+    s->allocator = std::thread([s] { s->alloc_loop(); });
     *out = s;
     return 0;
 }
 
-// dev (a block of the library's pool, `bytes` long; n_bytes of it are the payload) now belongs to the sink.  Used by hhx_pairs_parser_bed_to_sink.
-int hhx::byte_sink_push_block(hhx_byte_sink *s, void *dev, i64 n_bytes) {
-    if (!s || !dev) return fail("hhx_byte_sink: null pointer");
+// room for n_bytes in the ring (16-byte aligned): waits for a slab when the current one is full
+extern "C" int hhx_byte_sink_reserve(hhx_byte_sink *s, int64_t n_bytes, void **dev) {
+    if (!s || !dev || n_bytes < 0) return fail("hhx_byte_sink_reserve: bad argument");
+    std::unique_lock<std::mutex> lk(s->mu);
+    if (s->cur) s->cur->used = (s->cur->used + 255) & ~(size_t)255;
+    if (!s->cur || s->cur->used + (size_t)n_bytes > s->cur->cap) {
+        if (s->cur) {                                                // full: goes back to the ring when its last range is written
+            s->cur->sealed = true;
+            if (s->cur->outstanding == 0) { s->cur->used = 0; s->cur->sealed = false; s->free_.push_back(s->cur); }
+            s->cur = nullptr;
+        }
+        if ((size_t)n_bytes > s->slab_bytes) return fail("hhx_byte_sink_reserve: %lld bytes in one piece, slabs of %zu", (long long)n_bytes, s->slab_bytes);
+        if (s->allocated + (i64)s->slab_bytes <= s->budget) s->target = std::max<i64>(s->target, std::min<i64>(s->budget, s->allocated + 2 * (i64)s->slab_bytes));   // more than was expected
+        s->cv.notify_all();
+        s->cv.wait(lk, [&] { return !s->free_.empty() || (s->alloc_failed && s->all.empty()); });
+        if (s->free_.empty()) return fail("hhx_byte_sink: no device memory for a slab: %s", s->alloc_err.c_str());
+        s->cur = s->free_.front();
+        s->free_.pop_front();
+        s->cv.notify_all();                                           // the helper thread allocates the next one
+    }
+    *dev = s->cur->p + s->cur->used;
+    return 0;
+}
+
+// the n_bytes at `dev` (the last reservation) are being written by a kernel in flight on the caller's stream: queue them for the file
+extern "C" int hhx_byte_sink_commit(hhx_byte_sink *s, void *dev, int64_t n_bytes) {
+    if (!s || !dev || n_bytes < 0) return fail("hhx_byte_sink_commit: bad argument");
+    if (n_bytes == 0) return 0;
     hipEvent_t ev = nullptr;
     HHX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HHX_HIP(hipEventRecord(ev, g_stream));                           // the kernel that fills the block is in flight on the caller's stream
+    HHX_HIP(hipEventRecord(ev, g_stream));
+    hhx_byte_sink::Slab *slab = nullptr;
     {
-        std::unique_lock<std::mutex> lk(s->mu);
-        s->cv.wait(lk, [&] { return s->waiting == 0 || s->waiting + n_bytes <= s->budget; });
-        s->waiting += n_bytes;
+        std::lock_guard<std::mutex> lk(s->mu);
+        slab = s->cur;
+        if (!slab || (unsigned char *)dev != slab->p + slab->used) { (void)hipEventDestroy(ev); return fail("hhx_byte_sink_commit: not the last reservation"); }
+        slab->used += (size_t)n_bytes;
+        ++slab->outstanding;
         s->pushed += n_bytes;
     }
-    return files_submit("bytes -> " + s->path, s, [s, dev, n_bytes, ev]() -> int {
+    return files_submit("bytes -> " + s->path, s, [s, slab, dev, n_bytes, ev]() -> int {
         int rc = 0;
         if (!s->failed) {
             if (!s->opened) { rc = s->out.open_fd(s->out.fd); s->opened = true; }
             if (!rc && hipStreamWaitEvent(g_stream, ev, 0) != hipSuccess) rc = fail("hipStreamWaitEvent failed");
             if (!rc) rc = s->out.write_device((const unsigned char *)dev, (size_t)n_bytes);      // synchronises the stream piece by piece
-            if (rc) s->failed = true;                                // the first failure is the one reported; later chunks are dropped
+            if (rc) s->failed = true;                                // the first failure is the one reported; later ranges are dropped
         }
         (void)hipStreamSynchronize(g_stream);
         (void)hipEventDestroy(ev);
-        pool_free_synced(dev);                                       // idle on both streams: back to the callers' list
-        { std::lock_guard<std::mutex> lk(s->mu); s->waiting -= n_bytes; }
+        void *give_back = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            if (--slab->outstanding == 0 && slab->sealed) {
+                if (s->stop_alloc || s->free_.size() >= 2) {         // the producer has finished (or is slower than the file): the slab leaves HBM for good —
+                    give_back = slab->p;                             // to the driver, not to the pool's cache, where 4 GB blocks would starve what runs next
+                    s->all.erase(std::find(s->all.begin(), s->all.end(), slab));
+                    s->allocated -= (i64)slab->cap;
+                    delete slab;
+                } else { slab->used = 0; slab->sealed = false; s->free_.push_back(slab); }
+            }
+        }
+        if (give_back) pool_free_to_driver(give_back);
         s->cv.notify_all();
         return rc;
-    });
+    }, 0);
 }
 
 extern "C" int hhx_byte_sink_close(hhx_byte_sink *s, int64_t *n_bytes_pushed) {
     if (!s) return 0;
     if (n_bytes_pushed) *n_bytes_pushed = s->pushed;
+    { std::lock_guard<std::mutex> lk(s->mu); s->stop_alloc = true; if (s->cur) s->cur->sealed = true; }
+    s->cv.notify_all();
+    if (s->allocator.joinable()) s->allocator.join();
     return files_submit("close " + s->path, s, [s]() -> int {
         int rc = 0;
         if (s->opened) rc = s->out.close();
         else if (s->out.fd >= 0) { if (::close(s->out.fd) != 0) rc = fail("close failed: %s", strerror(errno)); s->out.fd = -1; }
+        (void)hipStreamSynchronize(g_stream);
+        for (auto *slab : s->all) { pool_free_to_driver(slab->p); delete slab; }      // every range is on disk: idle on both streams
         const bool failed = s->failed;
         delete s;
-        return failed ? 0 : rc;                                       // a failed chunk has already been reported
-    });
+        return failed ? 0 : rc;                                       // a failed range has already been reported
+    }, 0);
 }

@@ -90,6 +90,16 @@ void pool_free_synced(void *p) {
     g_live.erase(it);
 }
 
+// p is idle on every stream and will not be needed again soon: back to the driver (hipFree waits for the device: call it from a thread that can wait)
+void pool_free_to_driver(void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_live.erase(p);
+    }
+    (void)hipFree(p);
+}
+
 // after the arena's thread synchronised its stream: its cached blocks go to the callers' list
 void arena_donate(Arena *a) {
     if (!a) return;

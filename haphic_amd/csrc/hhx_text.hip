@@ -44,6 +44,7 @@ struct hhx_pairs_parser {
     unsigned char *pin[2] = {nullptr, nullptr};
     size_t pin_cap[2] = {0, 0};
     int pin_next = 0;
+    hhx_byte_sink *sink = nullptr;          // hhx_pairs_parser_set_bed_sink
     ~hhx_pairs_parser() {
         for (int k = 0; k < 2; ++k)
             if (pin[k]) (void)hipHostFree(pin[k]);
@@ -544,11 +545,14 @@ extern "C" int hhx_pairs_parse(hhx_pairs_parser *p, const uint8_t *text, i64 n_b
         if (p->bed_off.n < (size_t)nl + 1 && p->bed_off.alloc((size_t)nl + 1)) return 1;
         i64 total = 0;
         HHX_TRY(exclusive_scan_i64(bed_len.p, p->bed_off.p, nl, &total));
-        if (p->bed.n < (size_t)total + 16 && p->bed.alloc((size_t)total + 16)) return 1;
+        unsigned char *dst = nullptr;
+        if (p->sink) { void *room = nullptr; HHX_TRY(hhx_byte_sink_reserve(p->sink, total + 16, &room)); dst = (unsigned char *)room; }
+        else { if (p->bed.n < (size_t)total + 16 && p->bed.alloc((size_t)total + 16)) return 1; dst = p->bed.p; }
         { KTimer kt("text_bed");
         k_bed_write<<<grid_for(nl, LN_BLOCK), LN_BLOCK, 0, g_stream>>>(t, n_bytes, p->starts.p, nl, p->pos1.p, p->pos2.p, p->wide ? p->pos1w.p : nullptr,
-                                                                          p->wide ? p->pos2w.p : nullptr, p->bed_off.p, p->bed.p); }
+                                                                          p->wide ? p->pos2w.p : nullptr, p->bed_off.p, dst); }
         HHX_LAUNCH_CHECK();
+        if (p->sink) HHX_TRY(hhx_byte_sink_commit(p->sink, dst, total));
         p->bed_bytes = total;
         if (bed_bytes) *bed_bytes = total;
     }
@@ -585,16 +589,12 @@ extern "C" int hhx_pairs_parser_bed_host(hhx_pairs_parser *p, void **host, i64 *
     return 0;
 }
 
-// alignments.bed of the last parse handed to a byte sink (hhx_jobs.hip): the device buffer changes owner, the next parse allocates its own
-extern "C" int hhx_pairs_parser_bed_to_sink(hhx_pairs_parser *p, hhx_byte_sink *sink) {
-    if (!p || !sink) return fail("null pointer");
-    if (!p->bed_bytes) return 0;
-    void *block = p->bed.p;
-    p->bed.p = nullptr;
-    p->bed.n = 0;
-    const i64 n = p->bed_bytes;
-    p->bed_bytes = 0;
-    return byte_sink_push_block(sink, block, n);
+// alignments.bed into a byte sink (hhx_jobs.hip) from the next parse on: the records are formatted straight into the sink's ring in HBM and
+// queued for the file-writer thread; nullptr: back to the parser's own buffer (hhx_pairs_parser_bed_host / _fetch)
+extern "C" int hhx_pairs_parser_set_bed_sink(hhx_pairs_parser *p, hhx_byte_sink *sink) {
+    if (!p) return fail("null parser");
+    p->sink = sink;
+    return 0;
 }
 
 // positions as 64-bit integers from the next parse on (contigs beyond 2^31 bp: determine_int_type :116-147 picks int64 there);

@@ -361,6 +361,14 @@ int hhx_pairs_parser_fetch64(hhx_pairs_parser *p, int32_t *id1, int64_t *pos1, i
  * pointer stays valid until the SECOND following call (the caller writes buffer k to the file while chunk k + 1 is parsed) */
 int hhx_pairs_parser_bed_host(hhx_pairs_parser *p, void **host, int64_t *n_bytes);
 int hhx_pairs_parser_destroy(hhx_pairs_parser *p);
+/* the .pairs file as chunks of whole lines in PINNED host memory (what pairs_generator* :1543 / :1566 iterate line by line): read with pread() by
+ * n_threads (<= 0: 4) threads into one of two buffers while the caller tokenises the other; a chunk holds at most ~2 x chunk_bytes and ends after its
+ * last line break.  hhx_text_reader_next: *host is valid until the next call; *n_bytes == 0 at the end of the file.  hhx_pairs_parse(on_device = 0)
+ * takes such a chunk to the device at PCIe rate. */
+typedef struct hhx_text_reader hhx_text_reader;
+int hhx_text_reader_open(const char *path, int64_t chunk_bytes, int n_threads, hhx_text_reader **out);
+int hhx_text_reader_next(hhx_text_reader *r, const uint8_t **host, int64_t *n_bytes);
+int hhx_text_reader_close(hhx_text_reader *r);
 /* measurement only — the writer counterpart of hhx_pairs_parse for synthetic read pairs ("pairs written as .pairs text"): line k =
  * "r{first_read + k}\t{names[id1[k]]}\t{pos1[k] + 1}\t{names[id2[k]]}\t{pos2[k] + 1}\t+\t-\n" from device arrays (ids must be valid: 0 <= id < n_names).
  * *n_bytes = the size of the text; dev_text == NULL: only that.  Not on the product path. */
@@ -464,8 +472,8 @@ int hhx_write_link_pickle(const char *path, int64_t n_keys, const int32_t *name_
  * run() :2879 / :2888 / :2929 writes HT_links.pkl, paired_links.clm and full_links.pkl between its seams and reads none of them again
  * (the next readers are `haphic sort` / `haphic reassign`, other processes).  The *_async entry points check their arguments, refuse
  * what the writer would refuse (a read position beyond its contig's end) and open the file on the CALLER's thread, then queue the work
- * on ONE host thread owned by the library — jobs run in submission order on a non-blocking stream of their own, with a memory-pool arena
- * of their own, so the device half of a job (grouping / sorting / formatting, hhx_ingest_write_clm; ordering the HT items,
+ * on a host thread owned by the library — two lanes (the byte sinks below; everything else), each running its jobs in submission order on a
+ * non-blocking stream of its own with a memory-pool arena of its own, so the device half of a job (grouping / sorting / formatting, hhx_ingest_write_clm; ordering the HT items,
  * hhx_ingest_fetch_ht_items) overlaps the caller's next kernels — and return at once.  hhx_files_join waits for every queued file and
  * returns non-zero with the first failure as hhx_last_error() (*n_failed = how many files failed; the failures are forgotten after the
  * call); hhx_ingest_destroy waits for the jobs that read its handle.  A process that exits without hhx_files_join still gets its
@@ -484,14 +492,18 @@ int hhx_ingest_write_link_pickle_async(hhx_ingest *h, int which, const char *pat
 int hhx_write_link_pickle_async(const char *path, int64_t n_keys, const int32_t *name_i, const int32_t *name_j, const int64_t *count,
                                 int32_t n_names, const uint8_t *names_blob, const int64_t *name_off);
 /* alignments.bed (pairs_generator* :1549-1557: two records per read pair, written inside the generator's loop, read by nothing in run()), deferred:
- * a byte sink is a file fed from DEVICE buffers through the same writer thread.  hhx_pairs_parser_bed_to_sink hands the BED bytes of the last
- * hhx_pairs_parse(want_bed) over where they lie, in HBM (the buffer changes owner; no copy), and returns at once while fewer than hbm_budget_bytes
- * are waiting to be written (<= 0: a quarter of the device, or HHX_BED_HBM_GB); beyond that the caller is held at the writer's pace.
- * hhx_byte_sink_close queues the close and frees the handle when it has run: the file is complete after hhx_files_join. */
+ * a byte sink is a file fed from DEVICE memory through the same writer thread.  The producer reserves room in the sink's ring of HBM slabs
+ * (hhx_byte_sink_reserve: returns at once while fewer than hbm_budget_bytes are waiting to be written — <= 0: a quarter of the device, or
+ * HHX_BED_HBM_GB — and holds the caller at the writer's pace beyond that), launches the kernel that fills it on its own stream, and commits
+ * (hhx_byte_sink_commit: the range is queued; the writer waits for the kernel through an event).  expected_bytes (0: unknown) sizes the slabs.
+ * hhx_pairs_parser_set_bed_sink makes hhx_pairs_parse(want_bed) do exactly that with the BED records of every chunk.  hhx_byte_sink_close
+ * queues the close and frees the handle when it has run: the file is complete after hhx_files_join. */
 typedef struct hhx_byte_sink hhx_byte_sink;
-int hhx_byte_sink_open(const char *path, int64_t hbm_budget_bytes, hhx_byte_sink **out);
-int hhx_pairs_parser_bed_to_sink(hhx_pairs_parser *p, hhx_byte_sink *sink);
+int hhx_byte_sink_open(const char *path, int64_t hbm_budget_bytes, int64_t expected_bytes, hhx_byte_sink **out);
+int hhx_byte_sink_reserve(hhx_byte_sink *sink, int64_t n_bytes, void **dev);
+int hhx_byte_sink_commit(hhx_byte_sink *sink, void *dev, int64_t n_bytes);
 int hhx_byte_sink_close(hhx_byte_sink *sink, int64_t *n_bytes_pushed);
+int hhx_pairs_parser_set_bed_sink(hhx_pairs_parser *p, hhx_byte_sink *sink);
 int hhx_files_pending(int64_t *n_pending, int64_t *n_done);
 int hhx_files_join(int64_t *n_failed);
 

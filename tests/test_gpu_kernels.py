@@ -392,6 +392,38 @@ def test_pairs_text_through_ingest(tmp_path, monkeypatch):
     assert ok.any()
 
 
+def test_text_reader_chunks_are_the_file(tmp_path):
+    """hhx_text_reader (the native front of a1): the chunks, concatenated, are the file; every chunk but the last ends on a line break; sizes around
+    the chunk size, files without a final newline, '\r\n' and lone '\r' endings, a line longer than a chunk, the empty file"""
+    import ctypes
+    rng = np.random.default_rng(11)
+    for case, (n_lines, chunk, ending, final_newline) in enumerate([(0, 4096, b'\n', True), (1, 4096, b'\n', False), (5000, 4096, b'\n', True), (5000, 10_000, b'\r\n', False),
+                                                                     (3000, 65_536, b'\r', True), (200_000, 1 << 20, b'\n', True), (70_000, 300_000, b'\n', False)]):
+        lines = [b'r%d\tctg%d\t%d\tctg%d\t%d\t+\t-' % (k, rng.integers(0, 1000), rng.integers(1, 10**7), rng.integers(0, 1000), rng.integers(1, 10**7)) for k in range(n_lines)]
+        if case == 5:
+            lines[777] = b'#' + b'x' * 1_500_000                  # a comment line longer than the chunk: the chunk grows (up to twice its size)
+        text = ending.join(lines) + (ending if final_newline and lines else b'')
+        path = tmp_path / ('t%d.txt' % case)
+        path.write_bytes(text)
+        reader = _lib.TextReader(str(path), chunk, threads=3)
+        got = []
+        for host, n in reader:
+            piece = ctypes.string_at(host, n)
+            got.append(piece)
+        reader.close()
+        assert b''.join(got) == text, case
+        assert all(p[-1:] in (b'\n', b'\r') for p in got[:-1]) and all(len(p) <= 2 * chunk + 4096 for p in got), case
+        assert len(got) >= len(text) // (2 * chunk + 4096), case
+    with pytest.raises(RuntimeError, match='cannot open'):
+        _lib.TextReader(str(tmp_path / 'absent.txt'))
+    path = tmp_path / 'long.txt'
+    path.write_bytes(b'y' * 50_000 + b'\n')
+    reader = _lib.TextReader(str(path), 4096)
+    with pytest.raises(RuntimeError, match='longer than a chunk'):
+        list(reader)
+    reader.close()
+
+
 @pytest.mark.parametrize('seed,flank,npairs,chunk', [(101, 0, 5000, None), (102, 1000, 60000, 9973), (103, 30000, 200000, None),
                                                       (104, 7000, 1, None), (105, 12000, 300000, 65536)])
 def test_ingest_bins_randomised_vs_oracle(seed, flank, npairs, chunk):

@@ -173,3 +173,57 @@ def test_oracle_threads_respect_the_cpu_quota():
     orc.set_threads(1)
     assert orc.get_threads() == 1
     orc.set_threads(0)
+
+
+def test_cluster_files_array_path_equals_the_loops():
+    """run_mcl_clustering's per-contig half (:2073-2095, :2172-2218) on arrays (cluster._clusters_from_arrays / _groups_from_arrays) against the
+    reference's loops restated here: validity of the partition, the set of tuples, group order (total length descending, stable over the set's
+    iteration order), contig order within a group (length descending, stable over ascending matrix index), the bytes of every group file"""
+    from collections import defaultdict
+    from haphic_amd import cluster
+    rng = np.random.default_rng(7)
+
+    def loop_clusters(att, att_ptr, members, shape):
+        clusters = set()
+        for a in range(len(att)):
+            clusters.add(tuple(members[att_ptr[a]:att_ptr[a + 1]].tolist()))
+        nodes = set()
+        for c in clusters:
+            for node in c:
+                if node in nodes:
+                    return None
+                nodes.add(node)
+        return list(clusters) if len(nodes) == shape else None
+
+    for trial in range(400):
+        shape = int(rng.integers(0, 40))
+        k = int(rng.integers(0, 8))
+        if rng.random() < 0.7 and shape:
+            parts = np.split(rng.permutation(shape), np.sort(rng.integers(0, shape + 1, max(k - 1, 0)))) if k else []
+            if rng.random() < 0.15 and len(parts) > 1:
+                parts.append(parts[0])                              # two attractors, one cluster
+        else:
+            parts = [rng.integers(0, max(shape, 1), int(rng.integers(0, 6))) for _ in range(k)]
+        members = np.concatenate(parts).astype(np.int32) if parts else np.zeros(0, np.int32)
+        ptr = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int32)
+        got = cluster._clusters_from_arrays(np.arange(len(parts)), ptr, members, shape)
+        want = loop_clusters(np.arange(len(parts)), ptr, members, shape)
+        assert (got is None) == (want is None) and (got is None or got == want)
+        if not got:
+            continue
+        names = np.empty(shape, object)
+        names[:] = ['ctg%d' % i for i in range(shape)]
+        lens = rng.choice([5000, 7000, 7000, 9000, 12000], shape)            # many ties, in contig lengths and in group totals
+        lines = np.array(['%s\t%d\t%d\n' % (names[i], lens[i] // 256 + 1, lens[i]) for i in range(shape)], object)
+        result, bodies = cluster._groups_from_arrays(got, names, lens, lines)
+        groups = defaultdict(lambda: [[], 0])
+        for kk, indexes in enumerate(got):
+            for i in indexes:
+                groups[kk][0].append(names[i])
+                groups[kk][1] += int(lens[i])
+        ref = sorted(tuple(groups.values()), key=lambda g: g[1], reverse=True)
+        length = dict(zip(names.tolist(), lens.tolist()))
+        for ctgs, _t in ref:
+            ctgs.sort(key=lambda c: length[c], reverse=True)
+        assert result == [list(g) for g in ref] and all(type(t) is int for _c, t in result)
+        assert bodies == [''.join('%s\t%d\t%d\n' % (c, length[c] // 256 + 1, length[c]) for c in ctgs) for ctgs, _t in ref]

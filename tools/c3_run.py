@@ -170,16 +170,31 @@ def run_sequence(pairs_path, gen, nchrs, workdir, sweep=True, log=None):
                'flank_keys': n_flank, 'files_still_queued_when_the_matrix_is_ready': pend_at_matrix,
                'containers_frozen_until_the_clustering': frozen}
         rounds = None
+        # a 2 Hz timeline of the writer thread's queue and of the device memory, beside the sweep (who finishes when)
+        import threading
+        timeline, stop = [], threading.Event()
+
+        def sample():
+            while not stop.wait(0.5):
+                try:
+                    timeline.append([round(time.perf_counter() - t0, 2), _lib.files_pending()[0], round(_lib.mem_info()[0] / 1e9, 1)])
+                except Exception:                # noqa: BLE001
+                    break
+        sampler = threading.Thread(target=sample, daemon=True)
+        sampler.start()
         if sweep:
             res, rounds = cluster.run_mcl_clustering(m, bin_set, frag_len_dict, fidx, 2, 1.1, 3.0, 0.1, 200, 1e-4, fa_dict, nchrs, False)
             sync()
             t['run_mcl_clustering_s'] = time.perf_counter() - t_matrix
             out['mcl_rounds'] = rounds
             out['inflations_with_a_valid_partition'] = len(res)
+            out['per_inflation_mcl_s_files_s'] = [[a, round(b, 3), round(c, 3)] for a, b, c in cluster.SWEEP_TIMING]
         pend_at_end = _lib.files_pending()[0]
         tj = time.perf_counter()
         _lib.files_join()
         t['files_join_wait_s'] = time.perf_counter() - tj
+        stop.set()
+        out['timeline_s_filesqueued_freeGB'] = timeline[::4] if len(timeline) > 40 else timeline[::2]
         t['whole_job_s'] = time.perf_counter() - t0
         out['files_still_queued_when_the_clustering_ended'] = pend_at_end
         del full
