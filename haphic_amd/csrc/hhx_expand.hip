@@ -25,6 +25,12 @@
 
 using namespace hhx;
 
+// pool demand of the last fused iteration on this thread, and the hint for the next one (set by mcl()'s loop, consumed by hhx_expand_impl)
+struct ExpandDemand { i64 out = 0, cand = 0; };
+thread_local ExpandDemand g_expand_hint, g_expand_demand;
+void hhx_expand_set_hint(i64 out, i64 cand) { g_expand_hint.out = out; g_expand_hint.cand = cand; }
+void hhx_expand_last_demand(i64 *out, i64 *cand) { *out = g_expand_demand.out; *cand = g_expand_demand.cand; }
+
 int hhx_csr_alloc_internal(i32 n_rows, i32 n_cols, i64 nnz, hhx_csr **out);
 namespace hhx { i64 pool_cached_bytes(); }
 
@@ -2279,6 +2285,17 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     // candidate pool: early windows test against a partial row sum and admit more than finally survive
     i64 pool_cap = dense ? 64 : std::max<i64>(4 * a->nnz + 16 * (i64)n_rows, (i64)1 << 22);
     i64 cand_cap = dense ? 64 : (n_win > 1 ? 2 * pool_cap : pool_cap);
+    // Inside mcl()'s loop (hhx_mcl.hip) the iteration before says what this one will need: its demand + 50 % instead of 4 and 8 entries per entry of
+    // A.  The guess above made the tail at inflation 1.1 of a 100k-contig matrix ask for 22 GB of pools per iteration, of sizes that change every
+    // iteration — 67-97 GB of FRESH device memory per tail, 1.2-1.8 s of its 7.4 s on the caller's thread (tools/tail_alloc_probe.py,
+    // profiles/r06_tail_alloc_probe.json).  An overflow costs one retry of the iteration with the exact demand, as before.
+    if (!dense && !coded.raw) {
+        if (g_expand_hint.out > 0) {
+            pool_cap = std::max<i64>(g_expand_hint.out + g_expand_hint.out / 2 + 16 * (i64)n_rows, (i64)1 << 22);
+            cand_cap = std::max<i64>(g_expand_hint.cand + g_expand_hint.cand / 2 + 16 * (i64)n_rows, (i64)1 << 22);
+        }
+        g_expand_hint = ExpandDemand();
+    }
     if (coded.plan_out) { coded.plan_out[0] = cap_win; coded.plan_out[1] = n_win; }
     if (coded.raw) {                    // every entry is kept: at most dense, and at most one entry per product
         HHX_HIP(hipMemsetAsync(counts.p, 0, 4 * sizeof(unsigned int), g_stream));
@@ -2560,6 +2577,9 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
         }
         if (n_products) *n_products = (i64)cur[4];
         if (nnz_expanded) *nnz_expanded = (i64)cur[3];
+        g_expand_demand.out = (i64)cur[1];
+        g_expand_demand.cand = (i64)cur[0];
+        if (attempt) prof_count("expand_pool_retries", attempt);
         return pack_rows_to_csr(n_rows, n_cols, row_cnt.p, indptr.p, row_off.p, out_col.p, out_val.p, out);
     }
     return fail("expand: survivor pool kept overflowing");

@@ -14,6 +14,8 @@ int hhx_expand_class_stream(const hhx_csr *a, const hhx_csr *b, const hhx_links_
                      double inflation, double pruning, hhx_csr **out, i64 *n_products, i64 *nnz_expanded);
 int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const hhx_links_operand *lk, int fx_shift, hhx_dense **out, i64 *n_products,
                           i64 *nnz_expanded);
+void hhx_expand_set_hint(i64 out, i64 cand);            // hhx_expand.hip: the pools of the next fused iteration sized from the one before
+void hhx_expand_last_demand(i64 *out, i64 *cand);
 int hhx_dense_layout(i32 n_rows, i32 n_cols, i64 nnz_b);
 namespace hhx { i64 pool_cached_bytes(); }
 
@@ -351,6 +353,8 @@ static int mcl_impl(const hhx_csr *m, int pre_expanded, int expansion, double in
     *converged = 0;
     hhx_csr *cur = nullptr;                  // matrix at the end of the previous iteration (== last_matrix)
     int rc = 0;
+    i64 demand_out = 0, demand_cand = 0;     // candidate / survivor pool demand of the previous fused iteration
+    bool have_demand = false;
     for (int it = first_it; it < max_iter && !rc; ++it) {
         const hhx_csr *src = cur ? cur : m;  // operand of this iteration's expansion
         const bool expand = (it > 0 || !pre_expanded) && expansion > 1;
@@ -376,8 +380,14 @@ static int mcl_impl(const hhx_csr *m, int pre_expanded, int expansion, double in
                 i64 f = 0;
                 if (it == 0 && nl && run == src)   // iteration 0, expansion 2: both operands are the link matrix itself
                     rc = expand_links_iteration0(src, *nl, inflation, pruning, &p, &f, &st_c);
-                else
+                else {
+                    // the pools of this iteration from the demand of the one before (first iteration of a resumed loop: the operand is what an
+                    // iteration left, its survivors ARE the entries of `src`; the candidates of the low inflations run to ~2.5 x the survivors)
+                    if (have_demand) hhx_expand_set_hint(demand_out, demand_cand);
+                    else if (first_it > 0) hhx_expand_set_hint(src->nnz, 3 * src->nnz);
                     rc = hhx_expand_inflate_prune(run, src, HHX_MCL_FX_SHIFT, inflation, pruning, &p, &f, &st_c);   // :2030-2042
+                    if (!rc) { hhx_expand_last_demand(&demand_out, &demand_cand); have_demand = true; }
+                }
                 st_f += f;
             }
             if (run != src && run) hhx_csr_free(const_cast<hhx_csr *>(run));

@@ -1,4 +1,6 @@
 // Runtime plumbing: error state, stream, caching allocator, device scans, matrix handles.
+#include <chrono>
+
 #include "hhx_common.h"
 
 namespace hhx {
@@ -51,16 +53,24 @@ void *pool_alloc(size_t bytes) {
         }
     }
     void *p = nullptr;
+    const bool timed = prof_enabled() && !arena;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, c);
     if (e != hipSuccess) {
         (void)hipGetLastError();                 // the failed attempt must not surface at the next launch check
         pool_trim();
+        if (timed) prof_count("pool_trims_on_failure", 1);
         e = hipMalloc(&p, c);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             fail("hipMalloc(%zu bytes) failed: %s", c, hipGetErrorString(e));
             return nullptr;
         }
+    }
+    if (timed) {                                 // what fresh device memory costs the caller's thread (~30 ms per GB)
+        prof_count("pool_fresh_bytes", (i64)c);
+        prof_count("pool_fresh_calls", 1);
+        prof_count("pool_fresh_us", (i64)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
     }
     std::lock_guard<std::mutex> lk(g_pool_mu);
     g_live[p] = Live{c, arena};
