@@ -194,6 +194,8 @@ def main():
         step()
     _lib.profile_reset()
     _lib.profile_enable(True)
+    if sharded_path:
+        sharded.STAGES = {}            # per-stage clocks of the row-block MCL (raw all-gather, iteration 0, every exchange, the replicated tail): a few stream syncs per iteration
     barrier()
     t0 = time.perf_counter()
     t_ing = t_mcl = t_pre = 0.0
@@ -206,6 +208,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.profile_enable(False)
+    mcl_stages = None
+    if sharded_path:
+        mcl_stages, sharded.STAGES = sharded.STAGES, None
     tm = torch.tensor([elapsed, t_ing, t_mcl, t_pre], dtype=torch.float64, device=dev)
     if sharded_path:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -303,6 +308,8 @@ def main():
             out['ingest']['text'] = text_leg(args, gen, id1, p1, id2, p2, dev)
         if sharded_path:
             out['ingest']['sharded_build_ms_last_step'] = state.get('shard_ms')
+            # rank 0's clocks per step, to lay next to DESIGN.md 5.2: [ms, bytes received by this rank, calls]
+            out['mcl']['sharded_stage_ms_bytes_calls_per_step'] = {k_: [v[0] / K, v[1] / K, v[2] / K] for k_, v in (mcl_stages or {}).items()}
         if state.get('matrix') is not None and args.sweep > 1:
             try:
                 out['sweep'] = sweep_leg(args, state['matrix'], t_mcl / K)
@@ -354,10 +361,12 @@ def main():
         try:
             full = sharded.allgather_rows(eng, state.pop('block'), state['shape'], dist)
             barrier()
+            sharded.STAGES = {}
             ts = time.perf_counter()
             res_sw = sharded.sweep_sharded(eng, full, infl, 200, 1e-4, dist)
             barrier()
-            sweep_sh = {'seconds': time.perf_counter() - ts, 'inflations': infl, 'iterations': [r[4] for r in res_sw], 'converged': [bool(r[5]) for r in res_sw],
+            sweep_stages, sharded.STAGES = sharded.STAGES, None
+            sweep_sh = {'seconds': time.perf_counter() - ts, 'stage_ms_bytes_calls': {k_: [round(v[0], 3), v[1], v[2]] for k_, v in sweep_stages.items()}, 'inflations': infl, 'iterations': [r[4] for r in res_sw], 'converged': [bool(r[5]) for r in res_sw],
                         'clusters': [int(len(r[0])) for r in res_sw], 'ranks': world,
                         'what': 'sharded.sweep_sharded: one expansion shared by the ranks (each holds its rows of M^2), dense epilogue + exchange per '
                                 'inflation, heavy iterations row-sharded (>= %.0e products), light remainders dealt by predicted cost' % sharded.SWEEP_SHARD_PRODUCTS}

@@ -18,6 +18,7 @@ The collective logic is written against a small `engine` interface so that tests
 CPU (gloo, world_size 2) with an oracle-backed engine; the product engine is HipEngine (no fallback).
 """
 import os
+import time
 
 import numpy as np
 
@@ -175,6 +176,8 @@ class HipEngine:
 
     def sync(self):
         _lib.check(_lib.load().hhx_synchronize())
+        if self.device.type == 'cuda':
+            self.torch.cuda.current_stream(self.device).synchronize()       # the collectives run on torch's stream
 
     # ---- sharded link-matrix build (hhx_shard_*): `src` is this rank's finalized _lib.Ingest
     def shard_open(self, src, in_set):
@@ -235,9 +238,47 @@ class HipEngine:
 
 
 # ------------------------------------------------------------------ collectives on variable-size blocks
+CHECK_EXCHANGES = os.environ.get('HAPHIC_CHECK_EXCHANGES', '1') != '0'      # checksum every all-to-all(v) round (first runs on real xGMI: keep it on)
 MAX_MESSAGE_BYTES = 1 << 30     # one collective call never moves more than this per peer: all_to_all_single of this stack (RCCL 2.26.6 /
                                 # torch 2.10) silently delivers only the first half of any per-peer message above 2^30 bytes
                                 # (tools/rccl_probe.py -> profiles/r03_rccl_probe.jsonl; all-gather and all-reduce are intact to 8.7 GB)
+
+
+# Per-stage wall clocks of the multi-rank paths, for bench.py --gpus N: STAGES = {} switches the recording on (None: off, no
+# extra synchronisation).  Every entry: [milliseconds, bytes received by this rank, calls].  The clock of a stage is read after a device
+# synchronisation, so a recorded run has a handful of stream syncs more than an unrecorded one.
+STAGES = None
+
+
+class _stage:
+    def __init__(self, engine, name, nbytes=0):
+        self.engine, self.name, self.nbytes = engine, name, nbytes
+
+    def __enter__(self):
+        if STAGES is not None:
+            self.engine.sync()
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if STAGES is not None and exc[0] is None:
+            self.engine.sync()
+            rec = STAGES.setdefault(self.name, [0.0, 0, 0])
+            rec[0] += (time.perf_counter() - self.t0) * 1e3
+            rec[1] += int(self.nbytes)
+            rec[2] += 1
+        return False
+
+
+def _bits_sum(x, torch):
+    """a wrapping int64 checksum of a tensor's bytes"""
+    if x.numel() == 0:
+        return 0
+    v = x.contiguous().view(torch.uint8)
+    pad = (-v.numel()) % 8
+    if pad:
+        v = torch.cat([v, torch.zeros(pad, dtype=torch.uint8, device=v.device)])
+    return int(v.view(torch.int64).sum().item())
 
 
 def _all_gather_var(t, dist, torch):
@@ -279,17 +320,33 @@ def _all_to_all_var(t, send_counts, dist, torch):
     out = torch.empty(int(sum(recv_counts)), dtype=t.dtype, device=t.device)
     s_off = np.concatenate([[0], np.cumsum(send_counts)]).tolist()
     r_off = np.concatenate([[0], np.cumsum(recv_counts)]).tolist()
+    broken = None
     for lo in range(0, max(int(longest.item()), 1), step):
         s_k = [max(0, min(step, c - lo)) for c in send_counts]
         r_k = [max(0, min(step, c - lo)) for c in recv_counts]
-        piece = torch.cat([t[s_off[p] + lo:s_off[p] + lo + s_k[p]] for p in range(world)]) if sum(s_k) else t[:0]
+        pieces = [t[s_off[p] + lo:s_off[p] + lo + s_k[p]] for p in range(world)]
+        piece = torch.cat(pieces) if sum(s_k) else t[:0]
         got = torch.empty(int(sum(r_k)), dtype=t.dtype, device=t.device)
         dist.all_to_all_single(got, piece.contiguous(), output_split_sizes=r_k, input_split_sizes=s_k)
+        if CHECK_EXCHANGES:
+            # all_to_all_single of this stack has been seen to deliver a message SHORT without an error (profiles/r03_rccl_probe.jsonl: beyond
+            # 2^30 B per peer); the slices above stay below that, and this makes sure: what arrived from every peer must have the checksum the
+            # peer computed over what it sent (one more exchange of `world` integers per round)
+            sent = torch.tensor([_bits_sum(x, torch) for x in pieces], dtype=torch.int64, device=t.device)
+            want = torch.empty(world, dtype=torch.int64, device=t.device)
+            dist.all_to_all_single(want, sent)
+            want = want.tolist()
         at = 0
         for p in range(world):
             if r_k[p]:
-                out[r_off[p] + lo:r_off[p] + lo + r_k[p]] = got[at:at + r_k[p]]
+                part = got[at:at + r_k[p]]
+                if CHECK_EXCHANGES and broken is None and _bits_sum(part, torch) != want[p]:
+                    broken = 'all-to-all: the %d elements rank %d sent to rank %d in one round did not arrive intact (%d expected in all)' % (
+                        r_k[p], p, dist.get_rank(), recv_counts[p])
+                out[r_off[p] + lo:r_off[p] + lo + r_k[p]] = part
                 at += r_k[p]
+    if broken is not None:                    # raised after the last round: every rank has run the same sequence of collectives
+        raise RuntimeError(broken)
     return out, recv_counts
 
 
@@ -322,7 +379,7 @@ def balanced_ranges(cost, world):
 HEADER = 6     # doubles per rank: rows, entries, convergence statistic, nnz of the expanded rows, survivors, products
 
 
-def exchange_rows(engine, local, n_cols, dist, stat=0.0, counts=(0, 0, 0)):
+def exchange_rows(engine, local, n_cols, dist, stat=0.0, counts=(0, 0, 0), stage='exchange_rows'):
     """The exchange of the row-block MCL — all-gather(v) of the row blocks, all-reduce(max) of the convergence statistic
     (:2044-2050) and the sums of the per-iteration counts — in TWO collectives:
       1. all-gather of a 6-double header per rank: the sizes of the variable-length blocks, the convergence statistic (a
@@ -346,21 +403,23 @@ def exchange_rows(engine, local, n_cols, dist, stat=0.0, counts=(0, 0, 0)):
     msg = engine.pack_block(local, stride)
     out = scratch('gathered', world * stride, torch.int32)       # persistent: consumed by unpack_blocks before the next exchange
     step = max(1, MAX_MESSAGE_BYTES // 4)
-    if stride <= step:
-        dist.all_gather_into_tensor(out, msg)
-    else:
-        out2 = out.view(world, stride)
-        for lo in range(0, stride, step):
-            hi = min(stride, lo + step)
-            piece = scratch('piece', world * (hi - lo), torch.int32)
-            dist.all_gather_into_tensor(piece, msg[lo:hi].contiguous())
-            out2[:, lo:hi] = piece.view(world, hi - lo)
-    return engine.unpack_blocks(rows, nnzs, out, stride, n_cols), heads
+    with _stage(engine, stage, world * stride * 4):
+        if stride <= step:
+            dist.all_gather_into_tensor(out, msg)
+        else:
+            out2 = out.view(world, stride)
+            for lo in range(0, stride, step):
+                hi = min(stride, lo + step)
+                piece = scratch('piece', world * (hi - lo), torch.int32)
+                dist.all_gather_into_tensor(piece, msg[lo:hi].contiguous())
+                out2[:, lo:hi] = piece.view(world, hi - lo)
+        full = engine.unpack_blocks(rows, nnzs, out, stride, n_cols)     # fails if the row lengths of a message do not add up to its header
+    return full, heads
 
 
-def allgather_rows(engine, local, n_cols, dist):
+def allgather_rows(engine, local, n_cols, dist, stage='allgather_rows'):
     """all-gather(v) of row blocks -> the full matrix on every rank (rows in rank order)"""
-    return exchange_rows(engine, local, n_cols, dist)[0]
+    return exchange_rows(engine, local, n_cols, dist, stage=stage)[0]
 
 
 # Iteration 0 on the symmetric half across ranks trades 0.4 F / N products per rank (187 / N ms at C3) for an exchange of
@@ -456,13 +515,15 @@ def _agree(ok, engine, dist):
     return bool(int(t.item()))
 
 
-def sharded_iteration(engine, cur_full, it, expansion, inflation, pruning, dist):
+def sharded_iteration(engine, cur_full, it, expansion, inflation, pruning, dist, stage='mcl_sharded_iteration'):
     """Iteration `it` >= 1 of mcl() (:2030-2050) with T sharded by row block: the blocks are cut anew at equal PRODUCT counts of
     THIS iteration (every rank holds cur_full, so re-cutting costs no communication — a row's weight changes from one iteration to
     the next as clusters form), every rank expands / inflates / prunes its rows against the whole matrix, then the two-collective
     exchange.  Returns (the new full matrix, largest convergence statistic over the ranks, [nnz_A, nnz_C, survivors, products])."""
     world, rank = dist.get_world_size(), dist.get_rank()
     n = engine.shape(cur_full)[0]
+    compute = _stage(engine, stage + '_compute')
+    compute.__enter__()
     b = balanced_ranges(engine.row_products(cur_full, cur_full), world)
     a = engine.row_block(cur_full, b[rank], b[rank + 1])
     st_f = 0
@@ -485,7 +546,8 @@ def sharded_iteration(engine, cur_full, it, expansion, inflation, pruning, dist)
         engine.free(run)
     stat = engine.convergence_stat(p, a) if it > 1 else 0.0
     engine.free(a)
-    full, heads = exchange_rows(engine, p, n, dist, stat=stat, counts=(st_c, engine.shape(p)[2], st_f))
+    compute.__exit__(None, None, None)
+    full, heads = exchange_rows(engine, p, n, dist, stat=stat, counts=(st_c, engine.shape(p)[2], st_f), stage=stage + '_exchange')
     engine.free(p)
     return full, np.float32(heads[:, 2].max()), [engine.shape(cur_full)[2]] + [int(v) for v in heads[:, 3:].sum(axis=0)]
 
@@ -509,7 +571,7 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
     links_full = None
     own_full = False
     if local_links is not None:
-        links_full = allgather_rows(engine, local_links, n, dist)       # exchange: the raw link matrix, once
+        links_full = allgather_rows(engine, local_links, n, dist, stage='mcl_raw_allgather')       # exchange: the raw link matrix, once
         if expansion != 2:
             # mkl_matrix_power :2017-2023 recurses for any e: T^(e-1) rows need the normalised matrix as a plain operand, so the
             # raw blocks are normalised (:2144, row-local) and the general path below runs
@@ -536,15 +598,16 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
         symmetric = (SYMMETRIC_MIN_WORLD is not None and world >= SYMMETRIC_MIN_WORLD and SYMMETRIC_HALF and hasattr(engine, 'dense_upper')
                      and engine.links_integer_ok(links_full))
         p = None
-        if symmetric:
-            b = balanced_ranges(upper_cost(products, symmetric_window(engine, n)), world)
-            p, f, st_c = expand_links_symmetric(engine, links_full, b, inflation, pruning, dist)   # None: some rank could not hold its block
-        if p is None:
-            b = balanced_ranges(products, world)
-            p, f, st_c = engine.expand_links(links_full, b[rank], b[rank + 1], inflation, pruning)       # iteration 0, class stream
+        with _stage(engine, 'mcl_iteration0_compute'):
+            if symmetric:
+                b = balanced_ranges(upper_cost(products, symmetric_window(engine, n)), world)
+                p, f, st_c = expand_links_symmetric(engine, links_full, b, inflation, pruning, dist)   # None: some rank could not hold its block
+            if p is None:
+                b = balanced_ranges(products, world)
+                p, f, st_c = engine.expand_links(links_full, b[rank], b[rank + 1], inflation, pruning)       # iteration 0, class stream
         st_a = engine.shape(links_full)[2]
         engine.free(links_full)
-        cur_full, heads = exchange_rows(engine, p, n, dist, counts=(st_c, engine.shape(p)[2], f))
+        cur_full, heads = exchange_rows(engine, p, n, dist, counts=(st_c, engine.shape(p)[2], f), stage='mcl_iteration0_exchange')
         engine.free(p)
         stats.append([st_a] + [int(v) for v in heads[:, 3:].sum(axis=0)])
         own_full = True
@@ -554,7 +617,8 @@ def mcl_sharded_engine(engine, full_norm, expansion, inflation, iters, pruning, 
         n = engine.shape(cur_full)[0]
     for it in range(n_iter, iters):
         if world > 1 and it >= 1 and engine.shape(cur_full)[2] <= replicate_nnz and hasattr(engine, 'mcl_resume'):
-            res, n_iter, converged, tail = engine.mcl_resume(cur_full, it, expansion, inflation, iters, pruning)
+            with _stage(engine, 'mcl_replicated_tail'):
+                res, n_iter, converged, tail = engine.mcl_resume(cur_full, it, expansion, inflation, iters, pruning)
             stats.extend(np.asarray(tail, np.int64).tolist())
             if own_full:
                 engine.free(cur_full)
@@ -604,7 +668,8 @@ def sweep_sharded(engine, links_full, inflations, iters, pruning, dist, shard_pr
     # the fused iteration 0 (hhx_expand_links: no dense block) — same accumulators, same bits, one expansion per inflation.
     d, f_local, c_local = None, 0, 0
     try:
-        d, f_local, c_local = engine.dense_rows(links_full, b[rank], b[rank + 1])
+        with _stage(engine, 'sweep_expansion'):
+            d, f_local, c_local = engine.dense_rows(links_full, b[rank], b[rank + 1])
     except (RuntimeError, MemoryError):
         d = None
     if not _agree(d is not None, engine, dist):
@@ -617,15 +682,16 @@ def sweep_sharded(engine, links_full, inflations, iters, pruning, dist, shard_pr
     try:
         for k, infl in enumerate(inflations):
             infl = float(infl)
-            if d is not None:
-                p = engine.dense_first(d, infl, pruning)
-            else:
-                p, f_local, c_local = engine.expand_links(links_full, b[rank], b[rank + 1], infl, pruning)
-            cur, _heads = exchange_rows(engine, p, n, dist, counts=(c_local, engine.shape(p)[2], f_local))
+            with _stage(engine, 'sweep_iteration0_compute'):
+                if d is not None:
+                    p = engine.dense_first(d, infl, pruning)
+                else:
+                    p, f_local, c_local = engine.expand_links(links_full, b[rank], b[rank + 1], infl, pruning)
+            cur, _heads = exchange_rows(engine, p, n, dist, counts=(c_local, engine.shape(p)[2], f_local), stage='sweep_iteration0_exchange')
             engine.free(p)
             it, converged, finished = 1, False, iters <= 1
             while not finished and world > 1 and float(engine.shape(cur)[2]) ** 2 / max(n, 1) >= shard_products:
-                full, mx, _st = sharded_iteration(engine, cur, it, 2, infl, pruning, dist)
+                full, mx, _st = sharded_iteration(engine, cur, it, 2, infl, pruning, dist, stage='sweep_sharded_iteration')
                 engine.free(cur)
                 cur = full
                 it += 1
@@ -657,12 +723,14 @@ def sweep_sharded(engine, links_full, inflations, iters, pruning, dist, shard_pr
             results.append((k,) + tuple(engine.interpret(cur)) + (n, it, converged))
         engine.free(cur)
     for k, cur, it in mine:
-        res, n_iter, converged, _tail = engine.mcl_resume(cur, it, 2, float(inflations[k]), iters, pruning)
+        with _stage(engine, 'sweep_light_tails_on_this_rank'):
+            res, n_iter, converged, _tail = engine.mcl_resume(cur, it, 2, float(inflations[k]), iters, pruning)
         engine.free(cur)
         results.append((k,) + tuple(engine.interpret(res)) + (n, n_iter, converged))
         engine.free(res)
     gathered = [None] * world
-    dist.all_gather_object(gathered, results)
+    with _stage(engine, 'sweep_gather_results'):
+        dist.all_gather_object(gathered, results)
     out = [None] * len(inflations)
     for part in gathered:
         for r in part:

@@ -229,9 +229,34 @@ def _worker(rank, world, port, q):
         assert torch.equal(got, torch.cat([piece(s_, rank) for s_ in range(world)])) and rc == [piece(s_, rank).numel() for s_ in range(world)]
         parts = sharded._all_gather_var(send, dist, torch)
         assert all(torch.equal(parts[r], torch.cat([piece(r, d) for d in range(world)])) for r in range(world))
+        # a transport that delivers a message SHORT without an error (what all_to_all_single of the RCCL stack did beyond 2^30 B per peer,
+        # profiles/r03_rccl_probe.jsonl): every round is checksummed, the receiver raises
+        real = dist.all_to_all_single
+
+        def lossy(out, inp, output_split_sizes=None, input_split_sizes=None):
+            real(out, inp, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes)
+            if output_split_sizes is not None and out.numel() > 8 and out.dtype == torch.int64 and out.numel() != world:
+                out[-3:] = 0                        # the tail of the last piece never arrived
+        dist.all_to_all_single = lossy
+        try:
+            failed = False
+            try:
+                sharded._all_to_all_var(send, [piece(rank, d).numel() for d in range(world)], dist, torch)
+            except RuntimeError as e:
+                failed = 'did not arrive intact' in str(e)
+            # (a rank whose received data fit in 8 elements is not touched by `lossy`: it must come through clean; the others must raise,
+            # and only after the last round — every rank runs the same sequence of collectives)
+            assert failed == (sum(piece(s_, rank).numel() for s_ in range(world)) > 8), 'a truncated all-to-all went unnoticed'
+        finally:
+            dist.all_to_all_single = real
+        dist.barrier()
         # ---- MCL row-block shard
         T = stochastic(400, 6, 5)
+        sharded.STAGES = {}                                   # per-stage clocks for bench.py --gpus N: every stage of the path must report
         res, n_iter, conv, stats = sharded.mcl_sharded_engine(eng, T, 2, 2.0, 100, 1e-4, dist, replicate_nnz=0)     # every iteration sharded
+        st_rec, sharded.STAGES = sharded.STAGES, None
+        assert set(st_rec) == {'mcl_sharded_iteration_compute', 'mcl_sharded_iteration_exchange'}, st_rec
+        assert st_rec['mcl_sharded_iteration_exchange'][2] == n_iter and st_rec['mcl_sharded_iteration_exchange'][1] > 0 and st_rec['mcl_sharded_iteration_compute'][0] > 0
         # replicated tail: the row-block iterations until the matrix is small, then every rank finishes alone — same everything
         thr = int(stats[2][0])                                # entries of the matrix that enters iteration 2
         res_r, n_iter_r, conv_r, stats_r = sharded.mcl_sharded_engine(eng, T, 2, 2.0, 100, 1e-4, dist, replicate_nnz=thr)
