@@ -23,6 +23,9 @@ from itertools import repeat
 import numpy as np
 
 
+THAW_LOG = []          # (kind, keys, seconds) of every thaw of this process: what the reference's own Python costs when it touches a table
+
+
 class Thawed(defaultdict):
     """A LinkTable / PairLists after its entries became real dict entries: a defaultdict in all but the class name."""
 
@@ -64,7 +67,10 @@ class _Frozen(defaultdict):
         if type(self) is Thawed:
             return
         import gc
+        import time
+        t0 = time.perf_counter()
         session = self._session
+        kind = self._kind
         collect = gc.isenabled()
         gc.disable()                      # millions of fresh tuples: the generational collector would walk them again and again
         try:
@@ -78,6 +84,7 @@ class _Frozen(defaultdict):
         self.__dict__.clear()
         self.__class__ = Thawed
         session.note_thawed()
+        THAW_LOG.append((kind, dict.__len__(self), time.perf_counter() - t0))
 
     # answered from the arrays
     def __len__(self):

@@ -662,6 +662,8 @@ def test_c4_40k_cluster_files_against_the_reference(tmp_path):
         full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(cluster.IdArrays(names, id1, p1, id2, p2), fa_dict, A(),
                                                                                  frag_len_dict, set(names), 'int32', 'int32')
     del HT, clm, id1, p1, id2, p2
+    from haphic_amd import containers
+    del containers.THAW_LOG[:]
     assert (len(full), len(flank), sum(full.values())) == (int(g['n_full']), int(g['n_flank']), int(g['full_total']))
     for k, v in c4_40k.coord_digest(coord, cid).items():
         assert str(v) == str(g[k]), 'ctg_coord_dict differs from the reference\'s: ' + k
@@ -672,6 +674,11 @@ def test_c4_40k_cluster_files_against_the_reference(tmp_path):
         for k in [k for k, x in zip(d, gone) if x]:
             del d[k]
     remaining = {n_ for n_, r in zip(names, g['remaining']) if r}
+    # what the reference's own Python (remove_allelic_HiC_links :474-689) costs once it touches the tables: every container it walks thaws
+    thawed = {kind: (keys, round(sec, 2)) for kind, keys, sec in containers.THAW_LOG}
+    assert set(thawed) == {'full', 'flank', 'crd'} and thawed['full'][0] == int(g['n_full']) and thawed['flank'][0] == int(g['n_flank'])
+    with tick('c4 40k: thawing %s' % ', '.join('%s %d keys %.2f s' % (k, v[0], v[1]) for k, v in sorted(thawed.items()))):
+        pass
     mat, fidx = cluster.dict_to_matrix(flank, remaining, dense_matrix=False, add_self_loops=True, _device=True)
     del full, flank
     assert np.array_equal(np.array([fidx.get(n_, -1) for n_ in names], np.int32), g['frag_index']), 'index map'
