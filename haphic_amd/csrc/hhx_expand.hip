@@ -1709,8 +1709,11 @@ __global__ __launch_bounds__(EX_T_CMP) void k_expand_compact(ExParams P, const i
 constexpr int HASH_T = 512, HASH_C = 4096, HASH_LIMIT = 3072, HASH_STAGE = 256, HASH_PER = HASH_C / HASH_T, HASH_PROBES = 128;
 constexpr int HASH_U = 4;           // 16-byte lane loads (two entries each) per B row and step: 4 x 128 = 512 entries
 constexpr u32 HASH_EMPTY = 0xffffffffu;
+#ifdef HHX_HASH_STATS
+__device__ unsigned long long g_hash_stats[4];
+#endif
 __host__ __device__ inline size_t hash_lds_bytes(i32 W) {
-    return (size_t)HASH_C * (8 + 4) + (size_t)HASH_STAGE * (8 + 4 + 4) + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + (8 + 4) + 16 + (size_t)W * 8;
+    return (size_t)(HASH_C + HHX_WAVE) * 8 + (size_t)HASH_C * 4 + (size_t)HASH_STAGE * (8 + 4 + 4) + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + (8 + 4) + 16 + (size_t)W * 8;
 }
 __device__ __forceinline__ u32 hash_slot(u32 col) { return (col * 0x9e3779b1u) >> 20; }      // 12 bits = HASH_C slots
 // Inserting the 2 * HASH_U entries a lane holds of one B row.  A column's home is a two-slot bucket (an even slot and its
@@ -1734,39 +1737,48 @@ __device__ __forceinline__ bool hash_try(u64 *acc, u32 *keys, i32 *ctr, u32 slot
     atomicAdd((unsigned long long *)&acc[slot], (unsigned long long)g);
     return true;
 }
-__device__ __forceinline__ void hash_consume(u64 *acc, u32 *keys, i32 *ctr, const int4 (&t)[HASH_U], i32 q_first, i32 qb, i32 qe, double da) {
+// Round 6: the fast round is branch-free — the sum of an entry whose column is not in its home bucket (and of the slots a lane holds beyond the row's
+// end) goes to the lane's own scratch accumulator behind the table, like the masked entries of the window kernel, instead of two exec-mask regions per
+// product (the ISA spent ~30 instructions per product there, 16 now) — and the slow loop reads its entry back from memory (an L1 hit: the wave has just
+// loaded it) instead of selecting it out of the lane's eight with a chain of v_cndmask (16 per leftover).
+__device__ __forceinline__ void hash_consume(u64 *acc, u32 *keys, i32 *ctr, const int2 *__restrict__ Bjx, const int4 (&t)[HASH_U], i32 q_first, i32 qb, i32 qe,
+                                             double da) {
     constexpr int K = 2 * HASH_U;
-    u32 pend = 0;
-#pragma unroll
-    for (int u = 0; u < HASH_U; ++u) {
-        const i32 q = q_first + u * 2 * HHX_WAVE;
-        if (q >= qb && q < qe) pend |= 1u << (2 * u);
-        if (q + 1 < qe) pend |= 1u << (2 * u + 1);
-    }
     uint2 cur[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const u32 col = (u32)((k & 1) ? t[k >> 1].z : t[k >> 1].x);
         cur[k] = *reinterpret_cast<const uint2 *>(&keys[hash_slot(col) & (HASH_C - 2)]);
     }
+    const u32 scratch = HASH_C + (u32)lane_id();
+    u32 pend = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
+        const i32 q = q_first + (k >> 1) * 2 * HHX_WAVE + (k & 1);
+        const bool valid = (k & 1) ? q < qe : (q >= qb && q < qe);       // a row starts at any parity: the slot before an odd start is not its entry
         const u32 col = (u32)((k & 1) ? t[k >> 1].z : t[k >> 1].x);
         const bool m0 = cur[k].x == col, m1 = cur[k].y == col;
-        if (((pend >> k) & 1u) && (m0 || m1)) {
-            const u64 g = fx_bits(da * (double)__int_as_float((k & 1) ? t[k >> 1].w : t[k >> 1].y));
-            atomicAdd((unsigned long long *)&acc[(hash_slot(col) & (HASH_C - 2)) + (m0 ? 0u : 1u)], (unsigned long long)g);
-            pend &= ~(1u << k);
-        }
+        const bool hit = valid && (m0 || m1);
+        const u64 g = fx_bits(da * (double)__int_as_float((k & 1) ? t[k >> 1].w : t[k >> 1].y));
+        atomicAdd((unsigned long long *)&acc[hit ? (hash_slot(col) & (HASH_C - 2)) + (m0 ? 0u : 1u) : scratch], (unsigned long long)g);
+        pend |= (valid && !hit) ? 1u << k : 0u;
     }
-    while (pend) {                                           // per lane: its leftovers, one after the other
+#ifdef HHX_HASH_STATS                                        // measurement build only: leftovers per wave step (sum over lanes, maximum over lanes)
+    {
+        const i32 c = __popc(pend);
+        i32 mx = c;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_down(mx, o, HHX_WAVE));
+        const i32 sm = wave_sum_i32(c);
+        if (lane_id() == 0) { atomicAdd(&g_hash_stats[0], 1ull); atomicAdd(&g_hash_stats[1], (unsigned long long)sm); atomicAdd(&g_hash_stats[2], (unsigned long long)mx); }
+    }
+#endif
+    while (pend) {                                           // per lane: its leftovers (first touches, columns pushed out of their home bucket)
         const int k = __ffs((int)pend) - 1;
         pend &= pend - 1;
-        u32 col = 0, xb = 0;
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk)
-            if (kk == k) { col = (u32)((kk & 1) ? t[kk >> 1].z : t[kk >> 1].x); xb = (u32)((kk & 1) ? t[kk >> 1].w : t[kk >> 1].y); }
-        const u64 g = fx_bits(da * (double)__uint_as_float(xb));
+        const int2 e = Bjx[q_first + (k >> 1) * 2 * HHX_WAVE + (k & 1)];
+        const u32 col = (u32)e.x;
+        const u64 g = fx_bits(da * (double)__int_as_float(e.y));
         u32 slot = hash_slot(col) & (HASH_C - 2);
         for (int probes = 0;; ++probes) {
             const uint2 c2 = *reinterpret_cast<const uint2 *>(&keys[slot]);
@@ -1785,7 +1797,7 @@ __global__ __launch_bounds__(HASH_T, 4) void k_expand_hash(ExParams P, const i32
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ExLds l;
     unsigned char *p = smem;
-    l.acc = (u64 *)p; p += (size_t)HASH_C * 8;
+    l.acc = (u64 *)p; p += (size_t)(HASH_C + HHX_WAVE) * 8;        // + one scratch accumulator per lane (hash_consume)
     l.st_da = (double *)p; p += HASH_STAGE * 8;
     l.red_d = (double *)p; p += EX_WAVES_MAX * 8;
     l.bcast = (i64 *)p; p += 8;
@@ -1825,19 +1837,20 @@ __global__ __launch_bounds__(HASH_T, 4) void k_expand_hash(ExParams P, const i32
                 const i32 span = max(qe0 - s0, qe1 - s1);
                 for (i32 off = 0; off < span; off += HASH_U * 2 * HHX_WAVE) {
                     int4 t0[HASH_U], t1[HASH_U];
+                    // unconditional loads: a lane beyond its row's end reads the (even) slot before the end instead — hash_consume masks by position
 #pragma unroll
                     for (int u = 0; u < HASH_U; ++u) {
                         const i32 q = s0 + off + u * 2 * HHX_WAVE + 2 * lane;
-                        t0[u] = q < qe0 ? *reinterpret_cast<const int4 *>(P.Bjx + q) : make_int4(0, 0, 0, 0);
+                        t0[u] = *reinterpret_cast<const int4 *>(P.Bjx + (q < qe0 ? q : s0));
                     }
 #pragma unroll
                     for (int u = 0; u < HASH_U; ++u) {
                         const i32 q = s1 + off + u * 2 * HHX_WAVE + 2 * lane;
-                        t1[u] = q < qe1 ? *reinterpret_cast<const int4 *>(P.Bjx + q) : make_int4(0, 0, 0, 0);
+                        t1[u] = *reinterpret_cast<const int4 *>(P.Bjx + (q < qe1 ? q : s1));
                     }
                     if (__hip_atomic_load(&l.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                    hash_consume(l.acc, keys, l.ctr, t0, s0 + off + 2 * lane, qb0, qe0, da0);
-                    hash_consume(l.acc, keys, l.ctr, t1, s1 + off + 2 * lane, qb1, qe1, da1);
+                    hash_consume(l.acc, keys, l.ctr, P.Bjx, t0, s0 + off + 2 * lane, qb0, qe0, da0);
+                    hash_consume(l.acc, keys, l.ctr, P.Bjx, t1, s1 + off + 2 * lane, qb1, qe1, da1);
                 }
                 if (__hip_atomic_load(&l.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
             }
@@ -2361,6 +2374,17 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 const unsigned per_cu = lds_hash > 80 * 1024 ? 1 : 2;
                 k_expand_hash<<<std::min<unsigned>(hc[3], 256 * per_cu * 4), HASH_T, lds_hash, g_stream>>>(P, list_h.p, (i32)hc[3], W, row_f.p, window_min,
                                                                                                       list_w.p, list_c.p, counts.p);
+#ifdef HHX_HASH_STATS
+                {
+                    unsigned long long hs[4] = {0, 0, 0, 0};
+                    (void)hipStreamSynchronize(g_stream);
+                    (void)hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_hash_stats), sizeof hs);
+                    fprintf(stderr, "[hash stats] rows %u: consumes %llu, leftovers %llu (%.2f per consume of 512), sum of per-consume maxima %llu (%.2f per consume)\n", hc[3], hs[0], hs[1],
+                            hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[0] ? (double)hs[2] / hs[0] : 0.0);
+                    unsigned long long z[4] = {0, 0, 0, 0};
+                    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hash_stats), z, sizeof z);
+                }
+#endif
             }
             HHX_LAUNCH_CHECK();
             HHX_HIP(hipMemcpyAsync(hc, counts.p, sizeof hc, hipMemcpyDeviceToHost, g_stream));
