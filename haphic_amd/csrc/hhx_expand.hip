@@ -1713,9 +1713,11 @@ constexpr u32 HASH_EMPTY = 0xffffffffu;
 __device__ unsigned long long g_hash_stats[4];
 #endif
 __host__ __device__ inline size_t hash_lds_bytes(i32 W) {
-    return (size_t)(HASH_C + HHX_WAVE) * 8 + (size_t)HASH_C * 4 + (size_t)HASH_STAGE * (8 + 4 + 4) + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + (8 + 4) + 16 + (size_t)W * 8;
+    const size_t tail = (size_t)W * 8 > (size_t)(HASH_T / HHX_WAVE) * HHX_WAVE * 8 ? (size_t)W * 8 : (size_t)(HASH_T / HHX_WAVE) * HHX_WAVE * 8;      // bitmap + prefix; while the products are walked: the waves' leftover queues
+    return (size_t)(HASH_C + HHX_WAVE) * 8 + (size_t)HASH_C * 4 + (size_t)HASH_STAGE * (8 + 4 + 4) + (size_t)EX_WAVES_MAX * (8 + 4 + 4) + 8 + (8 + 4) + 16 + tail;
 }
-__device__ __forceinline__ u32 hash_slot(u32 col) { return (col * 0x9e3779b1u) >> 20; }      // 12 bits = HASH_C slots
+// 12 bits = HASH_C slots.  A 24-bit multiply (v_mul_u32_u24: full rate; v_mul_lo_u32 issues at a quarter of it): columns are matrix indices, far below 2^24
+__device__ __forceinline__ u32 hash_slot(u32 col) { return __umul24(col, 0x9e3779u) >> 20; }
 // Inserting the 2 * HASH_U entries a lane holds of one B row.  A column's home is a two-slot bucket (an even slot and its
 // neighbour, one 8-byte LDS read); keys are never removed, so a column sits before the first empty slot of its probe
 // sequence and a stale read can only make a lane try a compare-and-swap it loses.
@@ -1739,10 +1741,38 @@ __device__ __forceinline__ bool hash_try(u64 *acc, u32 *keys, i32 *ctr, u32 slot
 }
 // Round 6: the fast round is branch-free — the sum of an entry whose column is not in its home bucket (and of the slots a lane holds beyond the row's
 // end) goes to the lane's own scratch accumulator behind the table, like the masked entries of the window kernel, instead of two exec-mask regions per
-// product (the ISA spent ~30 instructions per product there, 16 now) — and the slow loop reads its entry back from memory (an L1 hit: the wave has just
-// loaded it) instead of selecting it out of the lane's eight with a chain of v_cndmask (16 per leftover).
-__device__ __forceinline__ void hash_consume(u64 *acc, u32 *keys, i32 *ctr, const int2 *__restrict__ Bjx, const int4 (&t)[HASH_U], i32 q_first, i32 qb, i32 qe,
-                                             double da) {
+// product — and the leftovers (first touches, columns pushed out of their home bucket: 3.3 % of the products of iteration 1 at C3, but some in EVERY wave
+// step of 512) no longer stop the wave: their positions are appended to a per-wave queue in LDS (a DPP prefix sum of the lanes' counts: no LDS round trip)
+// and inserted in bulk, sixty-four at a time with every lane busy, when the queue fills or the wave has finished its staged entries.  The slow insert is a
+// chain of dependent LDS round trips (bucket read, compare-and-swap, counter): run per wave step it was ~1.5 such chains per 8 products of a lane.
+__device__ __forceinline__ i32 wave_incl_scan_dpp(i32 v) {      // inclusive prefix sum over the 64 lanes, VALU only (row_shr 1/2/4/8, row_bcast 15/31)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ void hash_insert(u64 *acc, u32 *keys, i32 *ctr, u32 col, u64 g) {
+    u32 slot = hash_slot(col) & (HASH_C - 2);
+    for (int probes = 0;; ++probes) {
+        const uint2 c2 = *reinterpret_cast<const uint2 *>(&keys[slot]);
+        if (hash_try(acc, keys, ctr, slot, c2.x, col, g) || hash_try(acc, keys, ctr, slot + 1, c2.y, col, g)) break;
+        if (probes >= HASH_PROBES) { ctr[1] = 1; break; }        // a cluster this long means the table is filling up
+        slot = (slot + 2) & (HASH_C - 2);
+    }
+}
+// the queued leftovers of this wave: entry = position in Bjx | staged A entry << 32
+__device__ __forceinline__ void hash_drain(u64 *acc, u32 *keys, i32 *ctr, const int2 *__restrict__ Bjx, const double *st_da, const u64 *wq, i32 n) {
+    for (i32 i = lane_id(); i < n; i += HHX_WAVE) {
+        const u64 w = wq[i];
+        const int2 e = Bjx[(i32)(u32)w];
+        hash_insert(acc, keys, ctr, (u32)e.x, fx_bits(st_da[(i32)(w >> 32)] * (double)__int_as_float(e.y)));
+    }
+}
+__device__ __forceinline__ void hash_consume(u64 *acc, u32 *keys, i32 *ctr, const int2 *__restrict__ Bjx, const double *st_da, u64 *wq, i32 wq_cap, i32 &wq_n,
+                                             const int4 (&t)[HASH_U], i32 q_first, i32 qb, i32 qe, double da, i32 e_staged) {
     constexpr int K = 2 * HASH_U;
     uint2 cur[K];
 #pragma unroll
@@ -1773,20 +1803,30 @@ __device__ __forceinline__ void hash_consume(u64 *acc, u32 *keys, i32 *ctr, cons
         if (lane_id() == 0) { atomicAdd(&g_hash_stats[0], 1ull); atomicAdd(&g_hash_stats[1], (unsigned long long)sm); atomicAdd(&g_hash_stats[2], (unsigned long long)mx); }
     }
 #endif
-    while (pend) {                                           // per lane: its leftovers (first touches, columns pushed out of their home bucket)
-        const int k = __ffs((int)pend) - 1;
-        pend &= pend - 1;
-        const int2 e = Bjx[q_first + (k >> 1) * 2 * HHX_WAVE + (k & 1)];
-        const u32 col = (u32)e.x;
-        const u64 g = fx_bits(da * (double)__int_as_float(e.y));
-        u32 slot = hash_slot(col) & (HASH_C - 2);
-        for (int probes = 0;; ++probes) {
-            const uint2 c2 = *reinterpret_cast<const uint2 *>(&keys[slot]);
-            if (hash_try(acc, keys, ctr, slot, c2.x, col, g) || hash_try(acc, keys, ctr, slot + 1, c2.y, col, g)) break;
-            if (probes >= HASH_PROBES) { ctr[1] = 1; break; }    // a cluster this long means the table is filling up
-            slot = (slot + 2) & (HASH_C - 2);
+    const i32 c = __popc(pend);
+    const i32 incl = wave_incl_scan_dpp(c);
+    const i32 total = __builtin_amdgcn_readlane(incl, HHX_WAVE - 1);
+    if (total == 0) return;                                  // wave-uniform
+    if (wq_n + total > wq_cap) {                             // no room: what is queued goes in first; a step with more leftovers than the queue holds
+        hash_drain(acc, keys, ctr, Bjx, st_da, wq, wq_n);    // (the first steps of a row, when the table is empty) is inserted lane by lane as before
+        wq_n = 0;
+        if (total > wq_cap) {
+            while (pend) {
+                const int k = __ffs((int)pend) - 1;
+                pend &= pend - 1;
+                const int2 e = Bjx[q_first + (k >> 1) * 2 * HHX_WAVE + (k & 1)];
+                hash_insert(acc, keys, ctr, (u32)e.x, fx_bits(da * (double)__int_as_float(e.y)));
+            }
+            return;
         }
     }
+    i32 at = wq_n + incl - c;
+    while (pend) {                                           // writes only: nothing to wait for
+        const int k = __ffs((int)pend) - 1;
+        pend &= pend - 1;
+        wq[at++] = (u64)(u32)(q_first + (k >> 1) * 2 * HHX_WAVE + (k & 1)) | ((u64)(u32)e_staged << 32);
+    }
+    wq_n += total;
 }
 __global__ __launch_bounds__(256) void k_pack_jx(i64 n, const i32 *__restrict__ j, const float *__restrict__ x, int2 *__restrict__ out) {
     for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) out[k] = make_int2(j[k], __float_as_int(x[k]));
@@ -1812,15 +1852,19 @@ __global__ __launch_bounds__(HASH_T, 4) void k_expand_hash(ExParams P, const i32
     l.bitmap = (u32 *)p; p += (size_t)W * 4;
     l.prefix = (u32 *)p;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / HHX_WAVE;
+    // per-wave leftover queue in the bitmap + prefix region (idle until the table is read out): 8-byte entries, a multiple of 64 per wave
+    const i32 region = max(2 * W, (HASH_T / HHX_WAVE) * HHX_WAVE * 2);             // in 4-byte words
+    const i32 wq_cap = ((region / 2) / (HASH_T / HHX_WAVE)) & ~(HHX_WAVE - 1);
+    u64 *const wq = reinterpret_cast<u64 *>(l.bitmap) + (size_t)wave * wq_cap;
     i64 nnzc = 0;
     for (i32 li = blockIdx.x; li < n_list; li += gridDim.x) {
         const i32 row = rows[li];
         const i32 a_b = P.Ap[row], a_e = P.Ap[row + 1];
         for (i32 t = tid; t < HASH_C; t += HASH_T) { keys[t] = HASH_EMPTY; l.acc[t] = 0; }
-        for (i32 w = tid; w < W; w += HASH_T) l.bitmap[w] = 0;
         if (tid == 0) { l.ctr[0] = 0; l.ctr[1] = 0; }
         __syncthreads();
         bool fits = true;
+        i32 wq_n = 0;                                        // this wave's queued leftovers (wave-uniform)
         for (i32 a0 = a_b; a0 < a_e && fits; a0 += HASH_STAGE) {
             const i32 len = min(HASH_STAGE, a_e - a0);
             stage_chunk(P, l, a0, len);
@@ -1849,11 +1893,13 @@ __global__ __launch_bounds__(HASH_T, 4) void k_expand_hash(ExParams P, const i32
                         t1[u] = *reinterpret_cast<const int4 *>(P.Bjx + (q < qe1 ? q : s1));
                     }
                     if (__hip_atomic_load(&l.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                    hash_consume(l.acc, keys, l.ctr, P.Bjx, t0, s0 + off + 2 * lane, qb0, qe0, da0);
-                    hash_consume(l.acc, keys, l.ctr, P.Bjx, t1, s1 + off + 2 * lane, qb1, qe1, da1);
+                    hash_consume(l.acc, keys, l.ctr, P.Bjx, l.st_da, wq, wq_cap, wq_n, t0, s0 + off + 2 * lane, qb0, qe0, da0, e);
+                    hash_consume(l.acc, keys, l.ctr, P.Bjx, l.st_da, wq, wq_cap, wq_n, t1, s1 + off + 2 * lane, qb1, qe1, da1, e + 1);
                 }
                 if (__hip_atomic_load(&l.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
             }
+            hash_drain(l.acc, keys, l.ctr, P.Bjx, l.st_da, wq, wq_n);      // before the staged entries they refer to are replaced
+            wq_n = 0;
             __syncthreads();
             fits = l.ctr[1] == 0;
             __syncthreads();
@@ -1870,6 +1916,8 @@ __global__ __launch_bounds__(HASH_T, 4) void k_expand_hash(ExParams P, const i32
             continue;
         }
         // the table's keys -> bitmap; (key, sum) pairs wait in registers while the accumulator array changes its meaning
+        for (i32 w = tid; w < W; w += HASH_T) l.bitmap[w] = 0;      // (the region held the leftover queues until here)
+        __syncthreads();
         u32 kk[HASH_PER];
         u64 aa[HASH_PER];
 #pragma unroll
