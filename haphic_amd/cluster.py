@@ -943,7 +943,7 @@ class PairsText:
     device arrays straight into the ingest; iterating it yields the reference's (ref, mref, pos, mpos) tuples for
     any other consumer.  alignments.bed is written in the working directory as the reference does (:1549)."""
 
-    def __init__(self, pairs, aln_format, inter_only, chunk_bytes=256 << 20, bed_path='alignments.bed', bed_writers=8):
+    def __init__(self, pairs, aln_format, inter_only, chunk_bytes=int(os.environ.get('HAPHIC_TEXT_CHUNK_MB', '256')) << 20, bed_path='alignments.bed', bed_writers=8):
         assert aln_format in ('pairs', 'bgzipped_pairs')
         self.path, self.aln_format, self.inter_only = pairs, aln_format, inter_only
         self.chunk_bytes, self.bed_path, self.bed_writers = chunk_bytes, bed_path, bed_writers
@@ -1009,7 +1009,7 @@ class PairsText:
             # the native front end: the file read ahead into pinned memory by threads of the library (hhx_text_reader), alignments.bed deferred
             size = os.path.getsize(self.path)
             sink = _lib.ByteSink(self.bed_path, expected_bytes=int(1.45 * size)) if self.bed_path else None       # two BED records ~ 1.35 x the line
-            reader = _lib.TextReader(self.path, self.chunk_bytes, threads=8)
+            reader = _lib.TextReader(self.path, self.chunk_bytes, threads=int(os.environ.get('HAPHIC_READ_THREADS', '8')))
             try:
                 if sink is not None:
                     parser.set_bed_sink(sink)

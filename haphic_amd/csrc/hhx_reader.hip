@@ -96,6 +96,7 @@ extern "C" int hhx_text_reader_open(const char *path, int64_t chunk_bytes, int n
     r->size = (i64)st.st_size;
     r->chunk = (size_t)chunk_bytes;
     r->cap = 2 * (size_t)chunk_bytes + 4096;                           // a carried tail is shorter than a chunk (or the file has a line longer than one)
+    if ((size_t)r->size + 4096 < r->cap) r->cap = (size_t)r->size + 4096;      // a small file: no more pinned memory than it has bytes (pinning costs ~0.5 ms per MB)
     r->n_threads = n_threads > 0 ? std::min(n_threads, 16) : 4;
     for (int k = 0; k < 2; ++k)
         if (hipHostMalloc((void **)&r->buf[k], r->cap, hipHostMallocDefault) != hipSuccess) {
