@@ -271,14 +271,11 @@ class _stage:
 
 
 def _bits_sum(x, torch):
-    """a wrapping int64 checksum of a tensor's bytes"""
+    """a wrapping int64 checksum of a tensor's bit patterns (the elements re-read as integers of their own size: legal at any storage offset)"""
     if x.numel() == 0:
         return 0
-    v = x.contiguous().view(torch.uint8)
-    pad = (-v.numel()) % 8
-    if pad:
-        v = torch.cat([v, torch.zeros(pad, dtype=torch.uint8, device=v.device)])
-    return int(v.view(torch.int64).sum().item())
+    as_int = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[x.element_size()]
+    return int(x.contiguous().view(as_int).sum(dtype=torch.int64).item())
 
 
 def _all_gather_var(t, dist, torch):
