@@ -1520,6 +1520,22 @@ def recommend_inflation(result_stat, nchrs, len_ratio):
     return True
 
 
+def _write_inflation_dir(outdir, inflation, result_clusters, group_lines, fa_dict, timing_row):
+    """inflation_X/mcl_inflation_X.clusters.txt and the group files (:2200-2218); group_lines: the body of every group file when it was cut from arrays"""
+    t0 = time.perf_counter()
+    os.makedirs(outdir, exist_ok=True)
+    with open(os.path.join(outdir, 'mcl_inflation_{}.clusters.txt'.format(inflation)), 'w') as fout:
+        fout.write('#Group\tnContigs\tContigs\n')
+        fout.write(''.join('group{}_{}bp\t{}\t{}\n'.format(k, group_len, len(ctgs), ' '.join(ctgs)) for k, (ctgs, group_len) in enumerate(result_clusters, 1)))
+    for k, (ctgs, group_len) in enumerate(result_clusters, 1):
+        with open(os.path.join(outdir, 'group{}_{}bp.txt'.format(k, group_len)), 'w') as fout:
+            if group_lines is not None:
+                fout.write('#Contig\tRECounts\tLength\n' + group_lines[k - 1])
+            else:
+                fout.write('#Contig\tRECounts\tLength\n' + ''.join('{}\t{}\t{}\n'.format(ctg, fa_dict[ctg][2], fa_dict[ctg][1]) for ctg in ctgs))
+    timing_row.append(time.perf_counter() - t0)          # [.., seconds the helper thread spent on this directory]
+
+
 SWEEP_TIMING = []      # of the last run_mcl_clustering: [inflation, seconds of mcl() + interpret_result, seconds of its cluster / group files] (measurement only)
 
 
@@ -1615,6 +1631,7 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
         write_files = True
     timing = SWEEP_TIMING
     del timing[:]
+    file_writer, file_jobs = None, []
     # the per-contig half of :2172-2218 on arrays when no fragment is a bin (the loops below otherwise): names, lengths and the group-file line of
     # every matrix index, gathered once; per inflation the clusters are cut out of them with numpy instead of one Python statement per contig
     by_index = None
@@ -1661,18 +1678,21 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
         if not write_files:
             result_clusters_list.append((inflation, result_clusters))
             continue
-        os.makedirs(outdir, exist_ok=True)
-        with open(os.path.join(outdir, 'mcl_inflation_{}.clusters.txt'.format(inflation)), 'w') as fout:
-            fout.write('#Group\tnContigs\tContigs\n')
-            fout.write(''.join('group{}_{}bp\t{}\t{}\n'.format(k, group_len, len(ctgs), ' '.join(ctgs)) for k, (ctgs, group_len) in enumerate(result_clusters, 1)))
-        for k, (ctgs, group_len) in enumerate(result_clusters, 1):
-            with open(os.path.join(outdir, 'group{}_{}bp.txt'.format(k, group_len)), 'w') as fout:
-                if group_lines is not None:
-                    fout.write('#Contig\tRECounts\tLength\n' + group_lines[k - 1])
-                else:
-                    fout.write('#Contig\tRECounts\tLength\n' + ''.join('{}\t{}\t{}\n'.format(ctg, fa_dict[ctg][2], fa_dict[ctg][1]) for ctg in ctgs))
+        # the directory of this inflation is written by a helper thread while the next inflation's mcl() waits for the device (the library calls
+        # release the GIL): ~0.1-0.7 s of Python and small-file system calls per inflation that the sweep no longer waits for one after the other.
+        # Joined (failures re-raised) before this function returns: the files exist when the reference's would.
+        if file_writer is None:
+            from concurrent.futures import ThreadPoolExecutor
+            file_writer = ThreadPoolExecutor(1)
+        file_jobs.append(file_writer.submit(_write_inflation_dir, outdir, inflation, result_clusters, group_lines, fa_dict, timing[-1]))
         result_clusters_list.append((inflation, result_clusters))
         timing[-1][2] = time.perf_counter() - t_start
+    try:
+        for job in file_jobs:
+            job.result()
+    finally:
+        if file_writer is not None:
+            file_writer.shutdown(wait=True)
     if pre is not None and pre is not m:
         pre.free()
     if sweep is not None:

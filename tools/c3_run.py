@@ -188,7 +188,7 @@ def run_sequence(pairs_path, gen, nchrs, workdir, sweep=True, log=None):
             t['run_mcl_clustering_s'] = time.perf_counter() - t_matrix
             out['mcl_rounds'] = rounds
             out['inflations_with_a_valid_partition'] = len(res)
-            out['per_inflation_mcl_s_files_s'] = [[a, round(b, 3), round(c, 3)] for a, b, c in cluster.SWEEP_TIMING]
+            out['per_inflation_mcl_s_files_s'] = [[r[0]] + [round(x, 3) for x in r[1:]] for r in cluster.SWEEP_TIMING]     # inflation, mcl() + interpret, cluster lists on the caller's thread, the directory on the helper thread
         pend_at_end = _lib.files_pending()[0]
         tj = time.perf_counter()
         _lib.files_join()
