@@ -614,6 +614,7 @@ def sweep_leg(args, m, one_mcl_s):
     firsts, errors = [], {}
     ta = time.perf_counter()
     if len(sw.bounds) == 2:                                          # M^2 fits as one resident block (n = 100k: 40 GB)
+        warm = sw._prewarm(min(cluster.DenseSweep.GROUP, len(inflations)))      # as DenseSweep.first_iterations does: the first group's pools, allocated while the expansion runs
         blk = _lib.DenseRows(m, 0, n)                                # the expansion, once
         sw.n_products = blk.n_products
         sync()
@@ -636,8 +637,12 @@ def sweep_leg(args, m, one_mcl_s):
                         errors[str(infl)] = str(e1)[:200]
             sync()
             ep[' '.join(str(x) for x in grp)] = (time.perf_counter() - te) * 1e3
+        if warm is not None:
+            warm.join()                                              # (it has long finished: ~0.4 s of allocations started with the expansion)
         firsts = firsts[::-1]
         out['epilogue_group_ms'] = ep
+        out['pools_prewarmed_during_the_expansion'] = warm is not None
+        out['fresh_pool_GB_during_the_epilogues'] = _lib.profile_counter('pool_fresh_bytes') / 1e9
         sync()
         tc = time.perf_counter()
         _lib.profile_enable(False)

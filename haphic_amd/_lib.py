@@ -37,6 +37,7 @@ SIGNATURES = {
     'hhx_set_stream': (C.c_int, [C.c_void_p]),
     'hhx_synchronize': (C.c_int, []),
     'hhx_pool_trim': (C.c_int, []),
+    'hhx_pool_prewarm': (C.c_int, [C.c_int32, c_i64p]),
     'hhx_tune': (C.c_int, [C.c_char_p, C.c_int64]),
     'hhx_profile_enable': (C.c_int, [C.c_int]),
     'hhx_profile_reset': (C.c_int, []),
@@ -352,6 +353,12 @@ def mem_info():
     f, t = C.c_int64(0), C.c_int64(0)
     check(load().hhx_mem_info(C.byref(f), C.byref(t)))
     return f.value, t.value
+
+
+def pool_prewarm(sizes):
+    """hhx_pool_prewarm: blocks of these byte sizes from the driver into the pool's cache (call it from a helper thread while a long kernel runs)"""
+    a = np.ascontiguousarray(sizes, np.int64)
+    check(load().hhx_pool_prewarm(len(a), a.ctypes.data_as(c_i64p)))
 
 
 def pool_cached_bytes():

@@ -634,17 +634,22 @@ class DenseSweep:
 
     def _first_iterations(self, inflations):
         inflations = [float(x) for x in inflations]
+        warm = None
         if len(self.bounds) == 2 and self.resident is None:
+            warm = self._prewarm(min(self.GROUP, len(inflations)))
             try:
                 self.resident = _lib.DenseRows(self.links, 0, self.n)
                 self.n_products = self.resident.n_products
             except RuntimeError:
+                if warm is not None:
+                    warm.join()
                 # the one block did not fit after all (free memory moved since the plan, or the library chose the square where the
                 # triangle was planned): back to row blocks within the budget
                 if not self._budget_rows or self._budget_rows >= self.n:
                     raise
                 _lib.load().hhx_pool_trim()
                 self.bounds = list(range(0, self.n, int(self._budget_rows))) + [self.n]
+        self._warm = warm if len(self.bounds) == 2 and self.resident is not None else None
         if len(self.bounds) == 2:
             # GROUP inflations at a time in one pass over the block (hhx_dense_inflate_prune_multi: the division and the log2 of
             # x^r = exp2(r log2 x) once per entry, the 4 n^2 bytes read once per group); the matrices of a group wait their turn
@@ -674,7 +679,27 @@ class DenseSweep:
                 for p in pieces[k]:
                     p.free()
 
+    def _prewarm(self, group):
+        """the candidate / survivor pools and the packed outputs of the first group of inflations, taken from the driver by a helper thread WHILE the
+        expansion runs (0.3 s at 100k contigs; fresh device memory costs 12-30 ms per GB): sizes as the library's own first guess
+        (hhx_expand_dense_impl: 0.6 survivors and 1.0 candidates per entry of the link matrix).  Only when the device has room to spare."""
+        import threading
+        nnz, n = self.links.nnz, self.n
+        out_b, cand_b = int(4 * (0.6 * nnz + n)), int(4 * (1.0 * nnz + n))
+        # the first group's pools, its packed outputs, then the (smaller) outputs of the groups after it: the thread keeps going while the first
+        # passes over the block run, and is joined when the sweep's first iterations are done
+        sizes = ([out_b, out_b, cand_b, cand_b] * group) + [out_b, out_b] * group + [out_b // 2] * (2 * group) + [out_b // 4] * (4 * group)
+        free_bytes, _total = _lib.mem_info()
+        if group < 2 or (free_bytes + _lib.pool_cached_bytes()) < 2 * (sum(sizes) + 4 * n * n):
+            return None
+        t = threading.Thread(target=_lib.pool_prewarm, args=(sizes,), daemon=True)
+        t.start()
+        return t
+
     def close(self):
+        warm, self._warm = getattr(self, '_warm', None), None
+        if warm is not None:
+            warm.join()
         if self._gen is not None:                            # a suspended generator holds the matrices of its group: release them now
             self._gen.close()
             self._gen = None

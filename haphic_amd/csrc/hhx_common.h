@@ -56,6 +56,7 @@ inline int fail(const char *fmt, ...) {
 void *pool_alloc(size_t bytes);   // nullptr on failure (g_err set)
 void pool_free(void *p);
 void pool_trim();
+i64 pool_cached_bytes();
 // a private free list for a library thread that launches on its own stream (hhx_jobs.hip); nullptr = the callers' list
 struct Arena { std::multimap<size_t, void *> free; };
 extern thread_local Arena *g_arena;

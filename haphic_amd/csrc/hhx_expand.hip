@@ -2724,6 +2724,16 @@ int hhx_expand_dense_impl(const hhx_csr *a, const hhx_csr *b, const hhx_links_op
     if (rc) { delete d; return rc; }
     d->cap_win = plan[0]; d->n_win = plan[1];
     if (tri && (plan[0] != plan_cap || plan[1] != plan_win)) { delete d; return fail("hhx_expand_dense_impl: the window plan changed under the triangle"); }
+    // A first guess of what the lowest inflation of a sweep keeps of these rows — 0.6 survivors and 1.0 candidates per entry of the operand's share of
+    // the link matrix (measured at 100k contigs / inflation 1.1: 0.52 and 0.80) — so that the FIRST pass over the block can already take a group of
+    // inflations with pools of the right order (without it the lowest inflation ran alone, twice: once to learn its demand).  Marked as
+    // coming from below every inflation (last_inflation = 1): a wrong guess costs the retry of the inflations whose pools overflowed, as any hint does.
+    if (tune_get("dense_seed_hint", 1) && b->n_rows > 0) {
+        const double share = (double)a->n_rows / (double)b->n_rows;
+        d->last_out = std::max<i64>((i64)(0.6 * share * (double)b->nnz), (i64)a->n_rows * 8);
+        d->last_cand = std::max<i64>((i64)(1.0 * share * (double)b->nnz), (i64)a->n_rows * 16);
+        d->last_inflation = 1.0;
+    }
     *out = d;
     return 0;
 }
@@ -2847,18 +2857,21 @@ static int dense_inflate_prune_multi_impl(const hhx_dense *d, int K, const doubl
     bool single = (cap + EX_T_WIN - 1) / EX_T_WIN > DE_PER || K == 1;
     for (int k = 0; k < K; ++k) single = single || inflations[k] == 2.0;
     if (single) {
+        // the group pass FIRST: its hint (the demand of its lowest inflation) then covers the inflations that go alone — the other way round the lone
+        // 2.0 left a hint that every lower inflation of the group overflowed (a retry of the pass: 70 ms of the 259 ms of the 1.6-2.0 group until round 6)
         int rc1 = 0;
         std::vector<double> rest;
-        std::vector<int> at;
-        for (int k = 0; k < K && !rc1; ++k) {
-            if (inflations[k] == 2.0 || K == 1 || (cap + EX_T_WIN - 1) / EX_T_WIN > DE_PER) rc1 = hhx_dense_inflate_prune(d, inflations[k], pruning, &outs[k]);
+        std::vector<int> at, alone;
+        for (int k = 0; k < K; ++k) {
+            if (inflations[k] == 2.0 || K == 1 || (cap + EX_T_WIN - 1) / EX_T_WIN > DE_PER) alone.push_back(k);
             else { rest.push_back(inflations[k]); at.push_back(k); }
         }
-        if (!rc1 && !rest.empty()) {
+        if (!rest.empty()) {
             std::vector<hhx_csr *> o2(rest.size(), nullptr);
             rc1 = hhx_dense_inflate_prune_multi(d, (int)rest.size(), rest.data(), pruning, o2.data());
             for (size_t t = 0; t < at.size(); ++t) outs[at[t]] = o2[t];
         }
+        for (size_t t = 0; t < alone.size() && !rc1; ++t) rc1 = hhx_dense_inflate_prune(d, inflations[alone[t]], pruning, &outs[alone[t]]);
         if (rc1) for (int k = 0; k < K; ++k) if (outs[k]) { hhx_csr_free(outs[k]); outs[k] = nullptr; }
         return rc1;
     }
@@ -2870,7 +2883,11 @@ static int dense_inflate_prune_multi_impl(const hhx_dense *d, int K, const doubl
         for (int k = 1; k < K; ++k) if (inflations[k] < inflations[lowest]) lowest = k;
         i64 per_infl = d->last_out ? 8 * (d->last_out + d->last_cand) : 0;
         if (d->last_out && inflations[lowest] < d->last_inflation) per_infl *= 2;
-        const int fit = !d->last_out ? 0 : (int)std::max<i64>(1, std::min<i64>(MULTI_MAX, ((i64)6 << 30) / std::max<i64>(per_infl, 1)));
+        // pools of a pass: 6 GB when the device is tight, up to 32 GB when a quarter of what is free (driver + the pool's cache) allows it
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        const i64 pass_bytes = std::min<i64>((i64)32 << 30, std::max<i64>((i64)6 << 30, ((i64)free_b + pool_cached_bytes()) / 4));
+        const int fit = !d->last_out ? 0 : (int)std::max<i64>(1, std::min<i64>(MULTI_MAX, pass_bytes / std::max<i64>(per_infl, 1)));
         if (!d->last_out || fit < K) {
             // split: [lowest alone | the rest] without a hint; [the first `fit` | the rest] with one — recursion ends at K == 1 or fit >= K
             std::vector<int> first, rest;

@@ -1,10 +1,11 @@
-// The library's file-writer thread: the three files run() writes between its seams — HT_links.pkl :2879,
-// paired_links.clm :2888, full_links.pkl :2929 (output_pickle :710-715, output_clm :376-392) — are read by nothing later in run(), yet their
-// encoding (7.3 s at 100k contigs / 500 M pairs) sat between parse_alignments* and filter_fragments / dict_to_matrix / the inflation sweep.
-// The *_async entry points validate and open the file on the caller's thread, queue the work and return; ONE host thread owned by the
-// library runs the queue in submission order on a non-blocking stream of its own with a pool arena of its own (hhx_runtime.hip: a free list
-// belongs to one stream), so the device half of a job (grouping / sorting / formatting the CLM text, ordering the HT items) overlaps the
-// caller's kernels.  hhx_files_join waits for the queue and returns the first failure; hhx_ingest_destroy waits for the jobs of its handle.
+// The library's file-writer threads: the files run() writes between its seams — alignments.bed inside the generators :1549-1557,
+// HT_links.pkl :2879, paired_links.clm :2888, full_links.pkl :2929 (output_pickle :710-715, output_clm :376-392) — are read by nothing later in run(),
+// yet writing them (98 GB at 100k contigs / 500 M pairs: 20+ s on a RAM disk that takes ~4.3 GB/s per file) sat between parse_alignments* and
+// filter_fragments / dict_to_matrix / the inflation sweep.  The *_async entry points validate and open the file on the caller's thread, queue the work
+// and return; a LANE is a host thread owned by the library that runs its queue in submission order on a low-priority non-blocking stream of its own with a
+// pool arena of its own (hhx_runtime.hip: a free list belongs to one stream), so the device half of a job (grouping / sorting / formatting the CLM
+// text, ordering the HT items, copying the BED slabs out) overlaps the caller's kernels.  Two lanes, because several files scale where one does not.
+// hhx_files_join waits for both queues and returns the first failure; hhx_ingest_destroy waits for the jobs of its handle.
 #include <fcntl.h>
 #include <unistd.h>
 

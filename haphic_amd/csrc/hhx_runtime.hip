@@ -352,6 +352,21 @@ extern "C" int hhx_synchronize(void) {
     HHX_HIP(hipStreamSynchronize(g_stream));
     return 0;
 }
+// Blocks of the given sizes are taken from the driver NOW and left in the pool's cache: called from a helper thread of the caller while a long kernel runs on
+// the caller's stream (the expansion of the inflation sweep, 300 ms), it hides what the next step's pools would cost in fresh device memory
+// (12-30 ms per GB).  Nothing has touched the blocks: any stream may take them.
+extern "C" int hhx_pool_prewarm(int32_t n, const int64_t *bytes) {
+    if (n < 0 || (n && !bytes)) return fail("hhx_pool_prewarm: bad argument");
+    for (i32 k = 0; k < n; ++k) {                        // in the order given (what is needed first comes first); every block is in the cache as soon as it exists
+        if (bytes[k] <= 0) continue;
+        void *p = nullptr;
+        if (hipMalloc(&p, size_class((size_t)bytes[k])) != hipSuccess) { (void)hipGetLastError(); break; }     // no room: what is there is enough of a head start
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_free.emplace(size_class((size_t)bytes[k]), p);
+    }
+    return 0;
+}
+
 extern "C" int hhx_pool_trim(void) {
     pool_trim();
     return 0;

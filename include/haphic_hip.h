@@ -41,6 +41,9 @@ int hhx_set_device(int device);
 int hhx_set_stream(void *hip_stream);          /* hipStream_t; NULL = null stream (thread-local) */
 int hhx_synchronize(void);
 int hhx_pool_trim(void);                       /* release cached device memory */
+/* take blocks of these sizes from the driver now and leave them in the pool's cache (thread-safe; meant for a helper thread of the caller while a long
+ * kernel runs: the next step's pools then cost no fresh device memory).  Stops quietly when the device has no room. */
+int hhx_pool_prewarm(int32_t n, const int64_t *bytes);
 /* per-kernel device timing with HIP events on the launch stream (bench.py's roofline leg):
  * names: "ingest" (map + partition + aggregate of one push), "aggregate", "ingest_merge", "link_matrix",
  * "spgemm_symbolic", "spgemm_numeric", "expand_window", "expand_window_short", "expand_hash", "expand_compact",
