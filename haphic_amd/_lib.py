@@ -149,6 +149,7 @@ SIGNATURES = {
     'hhx_byte_sink_close': (C.c_int, [C.c_void_p, c_i64p]),
     'hhx_pairs_parser_set_bed_sink': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hhx_text_reader_open': (C.c_int, [C.c_char_p, C.c_int64, C.c_int, c_vpp]),
+    'hhx_text_reader_open_bgzf': (C.c_int, [C.c_char_p, C.c_int64, C.c_int, c_vpp]),
     'hhx_text_reader_next': (C.c_int, [C.c_void_p, c_vpp, c_i64p]),
     'hhx_text_reader_close': (C.c_int, [C.c_void_p]),
     'hhx_files_pending': (C.c_int, [c_i64p, c_i64p]),
@@ -567,9 +568,11 @@ class ByteSink:
 class TextReader:
     """hhx_text_reader: a text file as chunks of whole lines in pinned host memory, read ahead by threads of the library"""
 
-    def __init__(self, path, chunk_bytes=256 << 20, threads=4):
+    def __init__(self, path, chunk_bytes=256 << 20, threads=4, bgzf=False):
+        """bgzf: the file is bgzipped (BGZF blocks inflated by the threads); RuntimeError('... is not a BGZF file ...') for anything else"""
         self.h = C.c_void_p()
-        check(load().hhx_text_reader_open(os.fsencode(path), int(chunk_bytes), int(threads), C.byref(self.h)))
+        fn = load().hhx_text_reader_open_bgzf if bgzf else load().hhx_text_reader_open
+        check(fn(os.fsencode(path), int(chunk_bytes), int(threads), C.byref(self.h)))
 
     def __iter__(self):
         """(host pointer, bytes) per chunk; a pointer is valid until the next one is asked for"""

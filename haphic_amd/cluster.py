@@ -1030,11 +1030,19 @@ class PairsText:
         parser = _lib.PairsParser(names)
         if wide:
             parser.set_wide(True)
-        if _lib.files_async() and self.aln_format == 'pairs':
-            # the native front end: the file read ahead into pinned memory by threads of the library (hhx_text_reader), alignments.bed deferred
-            size = os.path.getsize(self.path)
+        reader = None
+        if _lib.files_async():
+            # the native front end: the file read ahead into pinned memory by threads of the library (hhx_text_reader), alignments.bed deferred.
+            # bgzipped .pairs: the BGZF blocks are inflated by those threads; a plain gzip stream (no block boundaries) keeps Python's gzip below
+            threads = int(os.environ.get('HAPHIC_READ_THREADS', '8'))
+            try:
+                reader = _lib.TextReader(self.path, self.chunk_bytes, threads=threads, bgzf=self.aln_format != 'pairs')
+            except RuntimeError as e:
+                if self.aln_format == 'pairs' or 'not a BGZF file' not in str(e):
+                    raise
+        if reader is not None:
+            size = os.path.getsize(self.path) * (1 if self.aln_format == 'pairs' else 4)                          # (text deflates ~4 x)
             sink = _lib.ByteSink(self.bed_path, expected_bytes=int(1.45 * size)) if self.bed_path else None       # two BED records ~ 1.35 x the line
-            reader = _lib.TextReader(self.path, self.chunk_bytes, threads=int(os.environ.get('HAPHIC_READ_THREADS', '8')))
             try:
                 if sink is not None:
                     parser.set_bed_sink(sink)
@@ -1059,6 +1067,7 @@ class PairsText:
                 parser.destroy()
             return
         from concurrent.futures import ThreadPoolExecutor, wait
+        st['bed'] = 'in place'
         fd = os.open(self.bed_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644) if self.bed_path else None
         pool = ThreadPoolExecutor(self.bed_writers) if fd is not None else None
         pending = []                                             # [futures of chunk k - 1, futures of chunk k]

@@ -15,12 +15,7 @@
 //          id -2), so stream order — which decides dict insertion order downstream — is preserved.
 // BAM layout (SAM spec §4.2), little endian, offsets from the record's block_size field: refID 4, pos 8, flag 18,
 // next_refID 24, next_pos 28.
-#include <zlib.h>
-
-#include <atomic>
-#include <thread>
-
-#include "hhx_common.h"
+#include "hhx_bgzf.h"
 
 using namespace hhx;
 
@@ -49,67 +44,6 @@ struct hhx_bam {
 };
 
 namespace {
-
-struct Block { size_t cdata, clen, isize, out; };
-
-inline u32 rd32(const unsigned char *p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
-
-// Splits b->comp into whole BGZF blocks (at most max_inflated bytes of output).  Returns the number of compressed bytes
-// covered; blocks[] get offsets into b->comp.  rc != 0 on a malformed header.
-int scan_blocks(const std::vector<unsigned char> &comp, size_t max_inflated, std::vector<Block> &blocks, size_t &used, size_t &inflated) {
-    used = 0; inflated = 0;
-    const size_t n = comp.size();
-    while (used + 18 <= n) {
-        const unsigned char *p = comp.data() + used;
-        if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return fail("BAM: not a BGZF block at compressed offset (+%zu)", used);
-        const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8);
-        if (used + 12 + xlen > n) break;
-        size_t bsize = 0;
-        for (size_t x = 0; x + 4 <= xlen;) {                     // extra subfields: SI1 SI2 SLEN(2) data
-            const unsigned char *s = p + 12 + x;
-            const size_t slen = (size_t)s[2] | ((size_t)s[3] << 8);
-            if (s[0] == 'B' && s[1] == 'C' && slen == 2) bsize = ((size_t)s[4] | ((size_t)s[5] << 8)) + 1;
-            x += 4 + slen;
-        }
-        if (!bsize || bsize < 12 + xlen + 8) return fail("BAM: BGZF block without a BC subfield");
-        if (used + bsize > n) break;
-        const size_t isize = rd32(p + bsize - 4);
-        if (inflated + isize > max_inflated && !blocks.empty()) break;
-        blocks.push_back({used + 12 + xlen, bsize - 12 - xlen - 8, isize, inflated});
-        inflated += isize;
-        used += bsize;
-    }
-    return 0;
-}
-
-int inflate_blocks(const unsigned char *comp, const std::vector<Block> &blocks, unsigned char *out, int threads) {
-    std::atomic<size_t> next(0);
-    std::atomic<int> bad(0);
-    auto work = [&]() {
-        z_stream zs;
-        for (;;) {
-            const size_t k = next.fetch_add(1);
-            if (k >= blocks.size()) return;
-            const Block &b = blocks[k];
-            if (b.isize == 0) continue;                          // the empty EOF marker block
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
-            zs.next_in = const_cast<unsigned char *>(comp + b.cdata);
-            zs.avail_in = (uInt)b.clen;
-            zs.next_out = out + b.out;
-            zs.avail_out = (uInt)b.isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
-            inflateEnd(&zs);
-        }
-    };
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, blocks.size()));
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
-    return bad ? fail("BAM: a BGZF block failed to inflate") : 0;
-}
 
 int refill(hhx_bam *b, size_t want) {
     while (!b->eof && b->comp.size() < want) {
@@ -177,22 +111,22 @@ extern "C" int hhx_bam_open(const char *path, int threads, hhx_bam **out) {
     if (!rc && memcmp(b->carry.data(), "BAM\1", 4) != 0) rc = fail("BAM: bad magic (not a BAM file)");
     size_t at = 0;
     if (!rc) {
-        const size_t l_text = rd32(b->carry.data() + 4);
+        const size_t l_text = bgzf_rd32(b->carry.data() + 4);
         rc = need(12 + l_text);
         if (!rc) {
             b->header_text.assign((const char *)b->carry.data() + 8, l_text);
             while (!b->header_text.empty() && b->header_text.back() == '\0') b->header_text.pop_back();
-            const size_t n_ref = rd32(b->carry.data() + 8 + l_text);
+            const size_t n_ref = bgzf_rd32(b->carry.data() + 8 + l_text);
             at = 12 + l_text;
             b->name_off.push_back(0);
             for (size_t r = 0; r < n_ref && !rc; ++r) {
                 rc = need(at + 4);
                 if (rc) break;
-                const size_t l_name = rd32(b->carry.data() + at);
+                const size_t l_name = bgzf_rd32(b->carry.data() + at);
                 rc = need(at + 4 + l_name + 4);
                 if (rc) break;
                 std::string nm((const char *)b->carry.data() + at + 4, l_name ? l_name - 1 : 0);
-                b->ref_len.push_back((i32)rd32(b->carry.data() + at + 4 + l_name));
+                b->ref_len.push_back((i32)bgzf_rd32(b->carry.data() + at + 4 + l_name));
                 b->names_cat += nm;
                 b->name_off.push_back((i64)b->names_cat.size());
                 b->ref_names.push_back(std::move(nm));
@@ -254,7 +188,7 @@ extern "C" int hhx_bam_next(hhx_bam *b, int need_flags, int drop_same_ref, i32 n
         off.reserve(total / 200 + 16);
         size_t at = 0;
         while (at + 4 <= total) {
-            const size_t len = rd32(b->pin + at);
+            const size_t len = bgzf_rd32(b->pin + at);
             if (len < 32) return fail("BAM: record of %zu bytes (corrupt stream)", len);
             if (at + 4 + len > total) break;
             off.push_back((i64)at);

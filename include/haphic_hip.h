@@ -370,6 +370,9 @@ int hhx_pairs_parser_destroy(hhx_pairs_parser *p);
  * takes such a chunk to the device at PCIe rate. */
 typedef struct hhx_text_reader hhx_text_reader;
 int hhx_text_reader_open(const char *path, int64_t chunk_bytes, int n_threads, hhx_text_reader **out);
+/* the same over a bgzipped file (`bgzipped_pairs`: gzip.open in the reference :1541 / :1564): BGZF blocks inflated by n_threads threads straight into the
+ * pinned buffer.  A file that is not BGZF (a plain gzip stream has no block boundaries to inflate in parallel) is refused: the caller keeps its gzip reader. */
+int hhx_text_reader_open_bgzf(const char *path, int64_t chunk_bytes, int n_threads, hhx_text_reader **out);
 int hhx_text_reader_next(hhx_text_reader *r, const uint8_t **host, int64_t *n_bytes);
 int hhx_text_reader_close(hhx_text_reader *r);
 /* measurement only — the writer counterpart of hhx_pairs_parse for synthetic read pairs ("pairs written as .pairs text"): line k =

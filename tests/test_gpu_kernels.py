@@ -361,6 +361,8 @@ def test_pairs_text_through_ingest(tmp_path, monkeypatch):
     (tmp_path / 'in.pairs').write_bytes(raw)
     with gzip.open(tmp_path / 'in.pairs.gz', 'wb') as f:
         f.write(raw)
+    from tests import bam_fixture as bf
+    (tmp_path / 'in.pairs.bgz').write_bytes(b''.join(bf.bgzf_block(raw[a:a + 3001]) for a in range(0, len(raw), 3001)) + bf.EOF_BLOCK)      # bgzip's container
     monkeypatch.chdir(tmp_path)
     rng = np.random.default_rng(5)
     lens = rng.integers(3_000_000, 6_000_000, len(names))
@@ -380,7 +382,8 @@ def test_pairs_text_through_ingest(tmp_path, monkeypatch):
         remove_concentrated_links = False
         max_read_pairs = 200
         nwindows = 50
-    for fname, fmt, chunk in (('in.pairs', 'pairs', 256 << 20), ('in.pairs', 'pairs', 3000), ('in.pairs.gz', 'bgzipped_pairs', 10000)):
+    for fname, fmt, chunk in (('in.pairs', 'pairs', 256 << 20), ('in.pairs', 'pairs', 3000), ('in.pairs.gz', 'bgzipped_pairs', 10000),
+                              ('in.pairs.bgz', 'bgzipped_pairs', 256 << 20), ('in.pairs.bgz', 'bgzipped_pairs', 70_000)):
         aln = cluster.pairs_generator_inter_ctgs(fname, fmt)
         aln.chunk_bytes = chunk
         full, flank, HT, clm, frag_link, coord = cluster.parse_alignments_for_ctgs(aln, fa_dict, A(), frag_len_dict, set(names),
@@ -414,6 +417,41 @@ def test_text_reader_chunks_are_the_file(tmp_path):
         assert b''.join(got) == text, case
         assert all(p[-1:] in (b'\n', b'\r') for p in got[:-1]) and all(len(p) <= 2 * chunk + 4096 for p in got), case
         assert len(got) >= len(text) // (2 * chunk + 4096), case
+    # bgzipped text (BGZF: SAM specification 4.1): blocks of any payload size up to 64 KiB, empty blocks, the EOF marker; inflated by the reader's threads
+    from tests import bam_fixture as bf
+    import gzip
+    for case, (n_lines, chunk, payload_max, eof_block) in enumerate([(0, 4096, 100, True), (3, 4096, 7, False), (20_000, 100_000, 65_000, True), (150_000, 1 << 20, 30_000, True),
+                                                                      (40_000, 50_000, 500, False)]):
+        lines = [b'r%d\tctg%d\t%d\tctg%d\t%d\t+\t-' % (k, rng.integers(0, 1000), rng.integers(1, 10**7), rng.integers(0, 1000), rng.integers(1, 10**7)) for k in range(n_lines)]
+        text = b'\n'.join(lines) + (b'\n' if lines else b'')
+        blocks, at = [], 0
+        while at < len(text):
+            n = int(rng.integers(1, payload_max + 1))
+            blocks.append(bf.bgzf_block(text[at:at + n]))
+            if rng.random() < 0.02:
+                blocks.append(bf.bgzf_block(b''))
+            at += n
+        data = b''.join(blocks) + (bf.EOF_BLOCK if eof_block else b'')
+        path = tmp_path / ('z%d.txt.gz' % case)
+        path.write_bytes(data)
+        assert gzip.decompress(data) == text if data else True
+        if not data:
+            continue
+        reader = _lib.TextReader(str(path), chunk, threads=5, bgzf=True)
+        got = [ctypes.string_at(host, n) for host, n in reader]
+        reader.close()
+        assert b''.join(got) == text, ('bgzf', case)
+        assert all(p[-1:] == b'\n' for p in got[:-1]), ('bgzf', case)
+    plain = tmp_path / 'plain.gz'
+    plain.write_bytes(gzip.compress(b'r1\tctg1\t5\tctg2\t9\t+\t-\n' * 100))
+    with pytest.raises(RuntimeError, match='not a BGZF file'):
+        _lib.TextReader(str(plain), 4096, bgzf=True)
+    cut = tmp_path / 'cut.gz'
+    cut.write_bytes(data[:len(data) // 2])                             # a file that ends inside a block
+    reader = _lib.TextReader(str(cut), 1 << 20, bgzf=True)
+    with pytest.raises(RuntimeError, match='BGZF'):
+        list(reader)
+    reader.close()
     with pytest.raises(RuntimeError, match='cannot open'):
         _lib.TextReader(str(tmp_path / 'absent.txt'))
     path = tmp_path / 'long.txt'
