@@ -108,3 +108,38 @@ def test_dict_to_matrix_folds_reversed_keys_like_the_reference(monkeypatch):
     assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices) and np.array_equal(got.data, want.data)
     with pytest.raises(ValueError, match='links a fragment with itself'):
         cluster.dict_to_matrix({(names[0], names[0]): 3}, frag_set, dense_matrix=False)
+
+
+def test_run_is_rebound_to_join_the_file_writers(monkeypatch, tmp_path):
+    """round 6: output_pickle / output_clm / the .pairs front end only QUEUE their files (csrc/hhx_jobs.hip), so patch_reference re-binds run() :2738 itself:
+    the writers are joined — and a writer's failure raised — before run() returns to main() :2967 / HapHiC_pipeline.py:358; a failure of run() itself
+    is the one that is raised, after the queue has been drained.  (A stand-in module: the re-binding needs no reference checkout.)"""
+    import numpy as np
+    from haphic_amd import _lib, patch
+    _lib.load()
+    calls = []
+    H = types.ModuleType('HapHiC_cluster_stand_in')
+
+    def run(args, log_file=None):
+        """the reference's run()"""
+        calls.append(('run', args, log_file))
+        if args == 'boom':
+            raise ValueError('the run failed')
+        # what a seam of the real run() does: queue a file on the library's writer lanes
+        i = np.arange(5, dtype=np.int32)
+        _lib.write_link_pickle_async(str(tmp_path / 'x.pkl') if args != 'full' else '/dev/full', i, i[::-1].copy(), np.arange(5), ['c%d' % k for k in range(5)])
+        return 'done'
+    H.run = run
+    saved = patch.patch_reference(H, ingest=True, matrix_build=True)
+    try:
+        assert H.run.__wrapped__ is run and H.run.__doc__ == run.__doc__ and saved['run'] is run
+        assert H.run('args', log_file='l') == 'done' and calls[-1] == ('run', 'args', 'l')
+        assert _lib.files_pending()[0] == 0 and (tmp_path / 'x.pkl').stat().st_size > 0       # complete when run() returns
+        with pytest.raises(RuntimeError, match='/dev/full'):                                   # a writer's failure surfaces from run()
+            H.run('full')
+        with pytest.raises(ValueError, match='the run failed'):                                # run()'s own failure wins; nothing is left queued
+            H.run('boom')
+        assert _lib.files_pending()[0] == 0
+    finally:
+        patch.unpatch_reference(H, saved)
+    assert H.run is run
