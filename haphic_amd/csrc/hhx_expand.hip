@@ -861,6 +861,23 @@ __global__ __launch_bounds__(256) void k_row_attractor(i32 n_list, const i32 *__
         if (lane == 0) { key[li] = (u64)(u32)bc; val[li] = (u64)(u32)row; }
     }
 }
+// min-hash of a row's column pattern: two rows share it with the probability of the Jaccard index of their patterns, so the rows of one cluster — of one chromosome,
+// before the clusters have formed — sort next to each other (hhx_expand_impl: order_rows)
+__global__ __launch_bounds__(256) void k_row_minhash(i32 n_list, const i32 *__restrict__ rows, const i32 *__restrict__ Ap, const i32 *__restrict__ Aj,
+                                                     u64 *__restrict__ key, u64 *__restrict__ val) {
+    const int lane = lane_id();
+    for (i32 li = blockIdx.x * 4 + threadIdx.x / HHX_WAVE; li < n_list; li += gridDim.x * 4) {
+        const i32 row = rows[li];
+        u32 h = 0xffffffffu;
+        for (i32 p = Ap[row] + lane; p < Ap[row + 1]; p += HHX_WAVE) h = min(h, (u32)Aj[p] * 0x9e3779b1u);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) h = min(h, (u32)__shfl_down((int)h, o, HHX_WAVE));
+        if (lane == 0) { key[li] = (u64)h; val[li] = (u64)(u32)row; }
+    }
+}
+__global__ __launch_bounds__(256) void k_rows_from_sorted(i32 n, const u64 *__restrict__ sorted_rows, i32 *__restrict__ list) {
+    for (i32 li = blockIdx.x * blockDim.x + threadIdx.x; li < n; li += gridDim.x * blockDim.x) list[li] = (i32)sorted_rows[li];
+}
 // union pattern of a group: bitmap in LDS (dynamic: W words of bits + W words of prefix + scan scratch)
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_group_union(i32 n_groups, i32 R, const i32 *__restrict__ grp_rows, const i32 *__restrict__ Ap,
@@ -2337,6 +2354,25 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     DevBuf<float> Gx;
     i32 n_groups = 0;
     i64 group_entries = 0;              // entries of the union rows
+    // Rows of the window class in the order of (min-hash of the pattern, row) — tune "row_order", 1 unless switched off.  The rows a launch has in flight together (one per
+    // workgroup, 256 at a time) then walk largely the SAME rows of B, which they find in the Infinity Cache instead of HBM: the heavy iterations of a low-inflation tail
+    // run at 1.31-1.37e12 products/s instead of 1.15-1.18e12 (C3, inflation 1.1: 7.39 -> 6.74 s).  The order of the rows changes no bit of the result.
+    auto order_rows = [&](DevBuf<i32> &list, i64 nl) -> int {
+        if (dense || coded.raw || a != b || !tune_get("row_order", 1)) return 0;
+        KTimer kt("row_order");
+        DevBuf<u64> key, val, skey, sval;
+        if (key.alloc((size_t)nl) || val.alloc((size_t)nl) || skey.alloc((size_t)nl) || sval.alloc((size_t)nl)) return 1;
+        k_row_minhash<<<(unsigned)std::min<i64>((nl + 3) / 4, 4096), 256, 0, g_stream>>>((i32)nl, list.p, a->indptr.p, a->indices.p, key.p, val.p);
+        HHX_LAUNCH_CHECK();
+        int rbits = 1;
+        while (rbits < 31 && (n_rows >> rbits)) ++rbits;
+        HHX_TRY(stable_sort_pairs_u64(val.p, sval.p, key.p, skey.p, nl, rbits));              // by row ...
+        HHX_TRY(stable_sort_pairs_u64(skey.p, key.p, sval.p, val.p, nl, 32));                 // ... then, stably, by min-hash: the order does not depend on the list's
+        k_rows_from_sorted<<<(unsigned)std::min<i64>((nl + 255) / 256, 4096), 256, 0, g_stream>>>((i32)nl, val.p, list.p);
+        HHX_LAUNCH_CHECK();
+        HHX_HIP(hipStreamSynchronize(g_stream));                                              // the sort buffers die with this scope
+        return 0;
+    };
     int group_mode = -1;                // -1: not decided yet (first attempt), 0: one row per workgroup, 1: groups
     DevBuf<int4> rec;                   // window kernel: records + stream of the right operand, built once per call
     DevBuf<unsigned short> c16;
@@ -2506,6 +2542,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 }
             }
         }
+        if (group_mode == 0 && attempt == 0 && hc[0] >= 1024) HHX_TRY(order_rows(list_w, (i64)hc[0]));
         const i32 cap_use = group_mode == 1 ? cap_g : cap_win;
         const i32 n_win_use = group_mode == 1 ? n_win_g : n_win;
         P.n_win = n_win_use;

@@ -492,6 +492,25 @@ def test_low_inflation_whole_tails_against_oracle():
                     'k_expand_group: the tail at 1.2 differs from the one-row-per-walk kernel'
                 plain[0].free()
                 grouped[0].free()
+            if r == 1.3:
+                # the rows of the window class are taken in min-hash order (hhx_expand_impl: order_rows; hhx_tune("row_order", 0) switches it off): the same tail, bit for
+                # bit, and the ordering pass did run
+                _lib.profile_reset()
+                _lib.profile_enable(True)
+                try:
+                    ordered = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4)
+                finally:
+                    _lib.profile_enable(False)
+                assert _lib.profile_get('row_order')[1] > 0, 'no iteration of the tail at 1.3 ordered its window-class rows'
+                _lib.tune('row_order', 0)
+                try:
+                    as_listed = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4)
+                finally:
+                    _lib.tune('row_order', None)
+                assert ordered[1:] == as_listed[1:] and all(np.array_equal(u, v) for u, v in zip(ordered[0].to_arrays(), as_listed[0].to_arrays())), \
+                    'the order of the window-class rows changed the tail at 1.3'
+                ordered[0].free()
+                as_listed[0].free()
             n_iter, stats, window_products = _whole_tail_against_oracle(first, r, '3.4k contigs, inflation %r' % r, '3.4k whole tail at %r' % r)
             through_window += window_products
             assert n_iter > 10

@@ -1,6 +1,7 @@
 """Does a narrower column window — a slice of the operand stream that fits the 256 MB Infinity Cache — pay in the heavy iterations of a low-inflation tail?  The tail at
 inflation 1.1 (C3) under hhx_tune("cache_slice_mb", v): v = 0 (the default plan: 5 windows), then slices that force 6, 8 and 10 windows; every variant must give the same bits.
-    python tools/tail_window_probe.py [inflation]"""
+    python tools/tail_window_probe.py [inflation] [knob] [v1,v2,...]
+With a knob named (any hhx_tune switch, e.g. row_order 0,1,2,0) the same tail is timed under each of its values instead."""
 import hashlib
 import json
 import os
@@ -36,8 +37,11 @@ def main():
     blk.free()
     out = {'inflation': infl, 'n': int(n), 'first_iteration_nnz': int(first.nnz)}
     ref = None
-    for slice_mb in (0, 280, 230, 180, 130, 0):
-        _lib.tune('cache_slice_mb', slice_mb if slice_mb else None)
+    knob = sys.argv[2] if len(sys.argv) > 2 else 'cache_slice_mb'
+    values = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else (0, 280, 230, 180, 130, 0)
+    out['knob'] = knob
+    for slice_mb in values:
+        _lib.tune(knob, slice_mb if slice_mb or knob != 'cache_slice_mb' else None)
         f = first.copy()
         sync()
         _lib.profile_reset()
@@ -49,12 +53,14 @@ def main():
         _lib.profile_enable(False)
         digest = hashlib.sha256(b''.join(np.ascontiguousarray(a).tobytes() for a in res.to_arrays())).hexdigest()[:16]
         ref = ref or digest
-        key = 'slice_mb_%d%s' % (slice_mb, '_again' if slice_mb == 0 and 'slice_mb_0' in out else '')
+        key = '%s_%d' % (knob if knob != 'cache_slice_mb' else 'slice_mb', slice_mb)
+        while key in out:
+            key += '_again'
         out[key] = {'seconds': dt, 'iterations': n_iter, 'window_kernel_ms': _lib.profile_get('expand_window')[0] + _lib.profile_get('expand_window_short')[0],
-                    'window_launches': _lib.profile_get('expand_window')[1] + _lib.profile_get('expand_window_short')[1], 'same_bits': digest == ref}
+                    'window_launches': _lib.profile_get('expand_window')[1] + _lib.profile_get('expand_window_short')[1], 'hash_kernel_ms': _lib.profile_get('expand_hash')[0], 'order_ms': _lib.profile_get('row_order')[0], 'same_bits': digest == ref}
         f.free()
         res.free()
-    _lib.tune('cache_slice_mb', None)
+    _lib.tune(knob, None)
     first.free()
     m.free()
     print(json.dumps(out))
