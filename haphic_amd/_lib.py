@@ -37,6 +37,7 @@ SIGNATURES = {
     'hhx_set_stream': (C.c_int, [C.c_void_p]),
     'hhx_synchronize': (C.c_int, []),
     'hhx_pool_trim': (C.c_int, []),
+    'hhx_pool_trim_keep': (C.c_int, [C.c_int64]),
     'hhx_pool_prewarm': (C.c_int, [C.c_int32, c_i64p]),
     'hhx_tune': (C.c_int, [C.c_char_p, C.c_int64]),
     'hhx_profile_enable': (C.c_int, [C.c_int]),

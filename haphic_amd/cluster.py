@@ -596,6 +596,28 @@ def _log_mcl(n_iter, converged, expansion, inflation, iters, pruning):
                         n_iter, expansion, inflation, iters, pruning))
 
 
+_DENSE_WARM = None     # the helper thread that takes the sweep's dense block from the driver while the alignments are read (_prewarm_dense_block)
+
+
+def _prewarm_dense_block(n):
+    """The inflation sweep keeps M^2 as ONE float32 block of n x n (hhx_dense_layout: while that is at most a quarter of the device) and a first
+    allocation of that size costs the caller's thread 1-3 s (25-75 ms per GB while the file-writer threads are busy with the driver: measured inside the
+    whole C3 run, where it was the difference between the 6.7 s of the tail at inflation 1.1 and the 9-11 s of the first round of the sweep).  n is known when
+    the alignments start to flow (the fragment table), the block is needed when the link matrix is ready: a helper thread takes it from the driver in between
+    (hhx_pool_prewarm: it waits in the pool's cache, survives the trim after the ingest, and goes like any cached block when memory runs out).
+    DenseSweep joins the thread before it asks for its block."""
+    global _DENSE_WARM
+    import threading
+    if _DENSE_WARM is not None and _DENSE_WARM.is_alive():
+        return
+    free_bytes, total = _lib.mem_info()
+    need = 4 * n * ((n + 31) // 32 * 32)
+    if n < 20000 or need > total // 4 or free_bytes + _lib.pool_cached_bytes() < 0.75 * total:
+        return                                   # small enough to cost nothing / the library would store the triangle or row blocks / the device is in use
+    _DENSE_WARM = threading.Thread(target=_lib.pool_prewarm, args=([need],), daemon=True)
+    _DENSE_WARM.start()
+
+
 class DenseSweep:
     """The inflation sweep of run_mcl_clustering :2155-2158 with ONE expansion.  Every inflation restarts mcl() from the matrix
     pre-expanded at :2146-2147; M^2 of a link matrix is nearly dense, so its rows are kept in HBM as float32 row blocks
@@ -623,6 +645,7 @@ class DenseSweep:
             if block_rows < n and _lib.links_plan(links)[1] == 2:
                 block_rows = n                               # all rows in one block after all: the library stores it as the upper block triangle (half the bytes)
         self.bounds = list(range(0, n, int(block_rows))) + [n]
+        self.stage_s = {}                                    # measurement: seconds the caller spent in the sweep's own steps (SWEEP_STAGES)
         self.resident = None                                 # the only block when the whole M^2 fits: kept for the whole sweep
         self.n_products = 0
         self._gen = None
@@ -636,9 +659,15 @@ class DenseSweep:
         inflations = [float(x) for x in inflations]
         warm = None
         if len(self.bounds) == 2 and self.resident is None:
+            t_0 = time.perf_counter()
+            if _DENSE_WARM is not None:
+                _DENSE_WARM.join()                # the block it took is in the pool's cache now
+            self.stage_s['wait_for_the_block_taken_ahead'] = time.perf_counter() - t_0
             warm = self._prewarm(min(self.GROUP, len(inflations)))
             try:
+                t_0 = time.perf_counter()
                 self.resident = _lib.DenseRows(self.links, 0, self.n)
+                self.stage_s['expansion_call'] = time.perf_counter() - t_0
                 self.n_products = self.resident.n_products
             except RuntimeError:
                 if warm is not None:
@@ -654,7 +683,9 @@ class DenseSweep:
             # GROUP inflations at a time in one pass over the block (hhx_dense_inflate_prune_multi: the division and the log2 of
             # x^r = exp2(r log2 x) once per entry, the 4 n^2 bytes read once per group); the matrices of a group wait their turn
             for lo in range(0, len(inflations), self.GROUP):
+                t_0 = time.perf_counter()
                 ready = self.resident.inflate_prune_multi(inflations[lo:lo + self.GROUP], self.pruning)
+                self.stage_s.setdefault('epilogue_calls', []).append(time.perf_counter() - t_0)
                 try:
                     while ready:
                         yield ready.pop(0)
@@ -688,7 +719,10 @@ class DenseSweep:
         out_b, cand_b = int(4 * (0.6 * nnz + n)), int(4 * (1.0 * nnz + n))
         # the first group's pools, its packed outputs, then the (smaller) outputs of the groups after it: the thread keeps going while the first
         # passes over the block run, and is joined when the sweep's first iterations are done
-        sizes = ([out_b, out_b, cand_b, cand_b] * group) + [out_b, out_b] * group + [out_b // 2] * (2 * group) + [out_b // 4] * (4 * group)
+        # ... and the candidate pools of the first tail's first iteration (hhx_mcl_resume: 3 candidates per entry of T1, + 50 %; T1 at the lowest inflation holds
+        # ~0.55 of the link matrix's entries): two blocks of ~3 GB at C3 that cost the caller 0.1-0.6 s when it has to take them itself while the file writers free theirs
+        tail_cand = int(4 * 1.5 * 3 * 0.55 * nnz)
+        sizes = ([out_b, out_b, cand_b, cand_b] * group) + [tail_cand, tail_cand] + [out_b, out_b] * group + [out_b // 2] * (2 * group) + [out_b // 4] * (4 * group)
         free_bytes, _total = _lib.mem_info()
         if group < 2 or (free_bytes + _lib.pool_cached_bytes()) < 2 * (sum(sizes) + 4 * n * n):
             return None
@@ -1247,7 +1281,7 @@ def _ids_from_alignments(alignments, cid, chunk, wide=False):
         yield b1[:k], p1[:k], b2[:k], p2[:k], k
 
 
-def _ingest_handle(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False, want_frag_pairs=False):
+def _ingest_handle(alignments, table, flank, bins, chunk=1 << 22, want_pairs=False, want_frag_pairs=False, sweep_follows=False):
     """Feed an alignment iterator (name tuples, as the reference's generators :1539-1593 yield them, or the device-side front
     ends of this package) through the device ingest; returns the finalized handle (_lib.Ingest), tables resident in HBM."""
     text = isinstance(alignments, PairsText)
@@ -1258,6 +1292,8 @@ def _ingest_handle(alignments, table, flank, bins, chunk=1 << 22, want_pairs=Fal
             ing.keep_pairs()
         if want_frag_pairs:
             ing.keep_frag_pairs()
+        if sweep_follows and (text or bam) and not bins:
+            _prewarm_dense_block(table.n_frag)   # run() goes on to run_mcl_clustering: its dense block is taken from the driver while the file is read
         if text:                             # a1 on the device: text chunk -> id arrays -> ingest, nothing returns to the host
             for parser, k in alignments.batches(table.ctg_names, wide=table.wide):
                 if k:
@@ -1286,7 +1322,9 @@ def _ingest_handle(alignments, table, flank, bins, chunk=1 << 22, want_pairs=Fal
             # the front end's transient blocks (chunk buffers, partition scratch: ~90 GB at 5e8 pairs) sit in the pool's cache, where nothing
             # that follows is of their sizes (lending them to the file-writer thread was tried: its sorts want 4 GB blocks, these are smaller, and
             # it ended up holding both); the device is idle here: back to the driver, before the sweep and the file-writer threads want the room
-            _lib.check(_lib.load().hhx_pool_trim())
+            # ... except, when the sweep follows, 24 GB of its mid-size blocks: the operand stream and the first pools of the sweep take them instead of fresh ones,
+            # which cost the caller 1-1.5 s while the file-writer threads are releasing their own memory (tools/c3_run.py: sweep_stages_s)
+            _lib.check(_lib.load().hhx_pool_trim_keep(24 << 30) if sweep_follows else _lib.load().hhx_pool_trim())
         if hasattr(alignments, 'stats'):
             _lib.check(_lib.load().hhx_synchronize())
             alignments.stats['finalize_s'] = time.perf_counter() - t_fin
@@ -1463,7 +1501,8 @@ class IngestSession:
 def ingest_session(alignments, table, fa_dict, args, bins, pos_int_type, dist_int_type, chunk=1 << 22, want_frag_pairs=False):
     """Alignments (the reference's generators :1539-1593, or this package's PairsText / BamRecords / IdArrays) through the device
     ingest; the handle stays alive inside the returned IngestSession."""
-    ing = _ingest_handle(alignments, table, int(args.flank * 1000), bins, chunk, want_pairs=True, want_frag_pairs=want_frag_pairs)
+    ing = _ingest_handle(alignments, table, int(args.flank * 1000), bins, chunk, want_pairs=True, want_frag_pairs=want_frag_pairs,
+                         sweep_follows=not getattr(args, 'skip_clustering', False))
     return IngestSession(ing, table, fa_dict, args, pos_int_type, dist_int_type)
 
 
@@ -1570,6 +1609,7 @@ def _write_inflation_dir(outdir, inflation, result_clusters, group_lines, fa_dic
     timing_row.append(time.perf_counter() - t0)          # [.., seconds the helper thread spent on this directory]
 
 
+SWEEP_STAGES = {}      # of the last run_mcl_clustering with a DenseSweep: seconds of its steps on the caller's thread (measurement only)
 SWEEP_TIMING = []      # of the last run_mcl_clustering: [inflation, seconds of mcl() + interpret_result, seconds of its cluster / group files] (measurement only)
 
 
@@ -1635,7 +1675,10 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
 
     def run_one(inflation):
         if sweep is not None:
-            res = mcl_resume_device(next(firsts), expansion, float(inflation), max_iter, pruning)
+            first = next(firsts)
+            t_0 = time.perf_counter()
+            res = mcl_resume_device(first, expansion, float(inflation), max_iter, pruning)
+            sweep.stage_s.setdefault('tails', []).append(time.perf_counter() - t_0)
         elif pre is not None:
             res = mcl_device(pre, expansion, float(inflation), max_iter, pruning)
         else:
@@ -1730,6 +1773,8 @@ def run_mcl_clustering(link_matrix, bin_set, frag_len_dict, frag_index_dict, exp
     if pre is not None and pre is not m:
         pre.free()
     if sweep is not None:
+        SWEEP_STAGES.clear()
+        SWEEP_STAGES.update(sweep.stage_s)
         sweep.close()
     m.free()
     max_nclusters = max([len(rc) for _, rc in result_clusters_list])

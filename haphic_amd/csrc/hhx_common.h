@@ -55,7 +55,7 @@ inline int fail(const char *fmt, ...) {
 // hipFree synchronises the device, so blocks are recycled by power-of-two size class.
 void *pool_alloc(size_t bytes);   // nullptr on failure (g_err set)
 void pool_free(void *p);
-void pool_trim();
+void pool_trim(bool everything = true, i64 keep_bytes = 0);   // false: a block taken ahead of its use (hhx_pool_prewarm) stays cached, once; keep_bytes: hhx_pool_trim_keep
 i64 pool_cached_bytes();
 // a private free list for a library thread that launches on its own stream (hhx_jobs.hip); nullptr = the callers' list
 struct Arena { std::multimap<size_t, void *> free; };

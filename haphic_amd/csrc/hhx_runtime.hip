@@ -21,6 +21,7 @@ std::multimap<size_t, void *> g_free;           // size class -> block (the call
 struct Live { size_t size; Arena *owner; };
 std::map<void *, Live> g_live;                  // block -> size class, arena it was taken from
 std::vector<void *> g_quarantine;               // freed on another thread than the owner's: no stream order to rely on, released by pool_trim
+std::map<void *, int> g_prewarmed;              // taken ahead of their use (hhx_pool_prewarm) and not handed out yet -> the hhx_pool_trim calls it has survived (one, at most)
 
 size_t size_class(size_t bytes) {
     size_t c = 256;
@@ -49,6 +50,7 @@ void *pool_alloc(size_t bytes) {
             void *p = it->second;
             g_live[p] = Live{it->first, arena};
             fl.erase(it);
+            g_prewarmed.erase(p);
             return p;
         }
     }
@@ -58,7 +60,7 @@ void *pool_alloc(size_t bytes) {
     hipError_t e = hipMalloc(&p, c);
     if (e != hipSuccess) {
         (void)hipGetLastError();                 // the failed attempt must not surface at the next launch check
-        pool_trim();
+        pool_trim(true);
         if (timed) prof_count("pool_trims_on_failure", 1);
         e = hipMalloc(&p, c);
         if (e != hipSuccess) {
@@ -67,6 +69,9 @@ void *pool_alloc(size_t bytes) {
             return nullptr;
         }
     }
+    static const bool pool_log = getenv("HHX_POOL_LOG") != nullptr;       // measurement: every fresh block of the callers' threads, with what the driver took
+    if (pool_log && !arena)
+        fprintf(stderr, "[hhx pool] fresh %.3f GB in %.1f ms\n", (double)c / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (timed) {                                 // what fresh device memory costs the caller's thread (~30 ms per GB)
         prof_count("pool_fresh_bytes", (i64)c);
         prof_count("pool_fresh_calls", 1);
@@ -125,16 +130,29 @@ i64 pool_cached_bytes() {
     return b;
 }
 
-void pool_trim() {
+// everything: out of device memory (pool_alloc).  Otherwise (hhx_pool_trim: "what the last step cached is of no use to the next") a block that was
+// taken ahead for a later step stays — once: the second trim that finds it unused releases it
+void pool_trim(bool everything, i64 keep_bytes) {
     std::vector<void *> blocks;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         // only the list of the calling thread's stream and the quarantine: another thread's arena is in use by that thread
         std::multimap<size_t, void *> &fl = g_arena ? g_arena->free : g_free;
-        for (auto &kv : fl) blocks.push_back(kv.second);
-        fl.clear();
+        std::multimap<size_t, void *> kept;
+        i64 kept_mid = 0;
+        for (auto it = fl.rbegin(); it != fl.rend(); ++it) {             // largest first
+            auto pw = everything ? g_prewarmed.end() : g_prewarmed.find(it->second);
+            const bool small = it->first <= (size_t(64) << 20), mid = !small && it->first <= (size_t(8) << 30);
+            if (pw != g_prewarmed.end() && pw->second++ == 0) kept.emplace(it->first, it->second);
+            else if (!everything && keep_bytes > 0 && (small || (mid && kept_mid + (i64)it->first <= keep_bytes))) {
+                kept.emplace(it->first, it->second);                     // hhx_pool_trim_keep: what the next step can use whatever its sizes are
+                if (mid) kept_mid += (i64)it->first;
+            } else blocks.push_back(it->second);
+        }
+        fl.swap(kept);
         if (g_arena)                             // out of memory on the arena's thread: the callers' cache goes too
             { for (auto &kv : g_free) blocks.push_back(kv.second); g_free.clear(); }
+        for (void *p : blocks) g_prewarmed.erase(p);
         blocks.insert(blocks.end(), g_quarantine.begin(), g_quarantine.end());
         g_quarantine.clear();
     }
@@ -363,12 +381,18 @@ extern "C" int hhx_pool_prewarm(int32_t n, const int64_t *bytes) {
         if (hipMalloc(&p, size_class((size_t)bytes[k])) != hipSuccess) { (void)hipGetLastError(); break; }     // no room: what is there is enough of a head start
         std::lock_guard<std::mutex> lk(g_pool_mu);
         g_free.emplace(size_class((size_t)bytes[k]), p);
+        g_prewarmed[p] = 0;
     }
     return 0;
 }
 
 extern "C" int hhx_pool_trim(void) {
-    pool_trim();
+    pool_trim(false);
+    return 0;
+}
+extern "C" int hhx_pool_trim_keep(int64_t keep_bytes) {
+    if (keep_bytes < 0) return fail("hhx_pool_trim_keep: bad argument");
+    pool_trim(false, keep_bytes);
     return 0;
 }
 // The knobs the kernels read (tune_get): which kernel class / arithmetic / layout a call takes.  Every setting of every knob gives

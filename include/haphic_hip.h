@@ -40,9 +40,14 @@ int hhx_device_count(int *count);
 int hhx_set_device(int device);
 int hhx_set_stream(void *hip_stream);          /* hipStream_t; NULL = null stream (thread-local) */
 int hhx_synchronize(void);
-int hhx_pool_trim(void);                       /* release cached device memory */
+int hhx_pool_trim(void);                       /* release cached device memory (a block of hhx_pool_prewarm nobody has used yet survives ONE such call) */
+/* the same, but the blocks of at most 64 MiB and, largest first, up to keep_bytes of the blocks of at most 8 GiB stay cached: between two steps of one job the
+ * transient blocks of the first (tens of GB at C3) go back to the driver while the second still finds blocks for its own mid-size buffers — a fresh block costs
+ * 12-30 ms per GB, and 0.1-0.6 s a call while another thread of the process is releasing memory (measured inside the whole C3 run: DESIGN.md 1.2) */
+int hhx_pool_trim_keep(int64_t keep_bytes);
 /* take blocks of these sizes from the driver now and leave them in the pool's cache (thread-safe; meant for a helper thread of the caller while a long
- * kernel runs: the next step's pools then cost no fresh device memory).  Stops quietly when the device has no room. */
+ * kernel runs: the next step's pools then cost no fresh device memory).  Stops quietly when the device has no room.  Such a block survives the next
+ * hhx_pool_trim (not the one after) unless it has been handed out in between; when the device runs out of memory it is released like every other cached block. */
 int hhx_pool_prewarm(int32_t n, const int64_t *bytes);
 /* per-kernel device timing with HIP events on the launch stream (bench.py's roofline leg):
  * names: "ingest" (map + partition + aggregate of one push), "aggregate", "ingest_merge", "link_matrix",

@@ -60,6 +60,9 @@ class _Raw:
     def hhx_pool_trim(self):
         return 0
 
+    def hhx_pool_trim_keep(self, keep_bytes):
+        return 0
+
     def hhx_synchronize(self):
         return 0
 

@@ -1110,3 +1110,31 @@ def test_link_matrix_packed_and_wide_entries():
     k = np.flatnonzero((out['flank_i'] == a) & (out['flank_j'] == b))
     assert len(k) == 1 and out['flank_cnt'][k[0]] > (1 << 24)
     ing.destroy()
+
+
+def test_pool_blocks_taken_ahead_and_the_trim_that_keeps():
+    """hhx_pool_prewarm / hhx_pool_trim / hhx_pool_trim_keep (include/haphic_hip.h): a block taken ahead of its use survives ONE trim; the keeping trim leaves the
+    small blocks and, largest first, up to keep_bytes of the mid-size ones.  (Sizes are 64 MiB granules above 64 MiB: the cached byte counts are exact.)"""
+    L = _lib.load()
+    _lib.check(L.hhx_pool_trim())
+    _lib.check(L.hhx_pool_trim())                 # twice: whatever an earlier test took ahead is gone too
+    base = _lib.pool_cached_bytes()
+    MiB = 1 << 20
+    _lib.pool_prewarm([640 * MiB])
+    assert _lib.pool_cached_bytes() == base + 640 * MiB
+    _lib.check(L.hhx_pool_trim())
+    assert _lib.pool_cached_bytes() == base + 640 * MiB, 'the block taken ahead did not survive the first trim'
+    _lib.check(L.hhx_pool_trim())
+    assert _lib.pool_cached_bytes() == base, 'an unused block taken ahead survived two trims'
+    # the keeping trim: 3 mid-size blocks of 128 / 256 / 512 MiB and a small one; keep_bytes = 800 MiB keeps 512 + 256
+    _lib.check(L.hhx_pool_trim())
+    _lib.check(L.hhx_pool_trim())
+    base = _lib.pool_cached_bytes()
+    _lib.pool_prewarm([128 * MiB, 256 * MiB, 512 * MiB, 1 * MiB])
+    _lib.check(L.hhx_pool_trim())                 # spends their one exemption: plain cached blocks from here on
+    assert _lib.pool_cached_bytes() == base + 897 * MiB
+    _lib.check(L.hhx_pool_trim_keep(800 * MiB))
+    assert _lib.pool_cached_bytes() == base + (512 + 256 + 1) * MiB
+    _lib.check(L.hhx_pool_trim_keep(0))           # keep_bytes 0 = hhx_pool_trim
+    assert _lib.pool_cached_bytes() == base
+    assert L.hhx_pool_trim_keep(-1) != 0

@@ -124,7 +124,7 @@ def run_sequence(pairs_path, gen, nchrs, workdir, sweep=True, log=None):
     sync = lambda: _lib.check(_lib.load().hhx_synchronize())            # noqa: E731
     names = list(gen.names)
     fa_dict = {nm: [None, int(ln), int(ln) // 256 + 1] for nm, ln in zip(names, gen.length.tolist())}      # parse_fasta's shape (:111); GATC density of uniform ACGT
-    a = types.SimpleNamespace(flank=500, remove_allelic_links=0, remove_concentrated_links=False, max_read_pairs=200, nwindows=50)
+    a = types.SimpleNamespace(flank=500, remove_allelic_links=0, remove_concentrated_links=False, max_read_pairs=200, nwindows=50, skip_clustering=not sweep)
     cwd = os.getcwd()
     os.chdir(workdir)
     t = {}
@@ -182,10 +182,21 @@ def run_sequence(pairs_path, gen, nchrs, workdir, sweep=True, log=None):
                     break
         sampler = threading.Thread(target=sample, daemon=True)
         sampler.start()
+        profile = bool(os.environ.get('C3_RUN_PROFILE'))     # measurement: the library's kernel clocks and pool counters over the sweep
+        if sweep and profile:
+            _lib.profile_reset()
+            _lib.profile_enable(True)
         if sweep:
             res, rounds = cluster.run_mcl_clustering(m, bin_set, frag_len_dict, fidx, 2, 1.1, 3.0, 0.1, 200, 1e-4, fa_dict, nchrs, False)
             sync()
             t['run_mcl_clustering_s'] = time.perf_counter() - t_matrix
+            if profile:
+                _lib.profile_enable(False)
+                out['sweep_kernel_ms_launches'] = {k: [round(_lib.profile_get(k)[0], 1), _lib.profile_get(k)[1]] for k in (
+                    'expand_window', 'expand_window_short', 'expand_hash', 'expand_finalize', 'expand_compact', 'expand_tiny', 'class_layout', 'row_order', 'convergence',
+                    'inflate_stats', 'prune_write', 'dense_epilogue', 'dense_transpose') if _lib.profile_get(k)[1]}
+                out['sweep_pool'] = {k: _lib.profile_counter(k) for k in ('pool_fresh_bytes', 'pool_fresh_calls', 'pool_fresh_us', 'pool_trims_on_failure', 'expand_pool_retries')}
+            out['sweep_stages_s'] = {k: ([round(x, 3) for x in v] if isinstance(v, list) else round(v, 3)) for k, v in cluster.SWEEP_STAGES.items()}
             out['mcl_rounds'] = rounds
             out['inflations_with_a_valid_partition'] = len(res)
             out['per_inflation_mcl_s_files_s'] = [[r[0]] + [round(x, 3) for x in r[1:]] for r in cluster.SWEEP_TIMING]     # inflation, mcl() + interpret, cluster lists on the caller's thread, the directory on the helper thread
