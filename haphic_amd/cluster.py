@@ -17,6 +17,7 @@ reference's observable ordering depends on CPython for: the set-of-tuples in int
 """
 import logging
 import os
+import sys
 import time
 from array import array
 from collections import defaultdict
@@ -609,6 +610,9 @@ def _prewarm_dense_block(n):
     global _DENSE_WARM
     import threading
     if _DENSE_WARM is not None and _DENSE_WARM.is_alive():
+        return
+    torch = sys.modules.get('torch')             # several ranks: the sweep is shared out (sharded.sweep_sharded), no rank keeps the whole block — and ranks may share a device
+    if torch is not None and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         return
     free_bytes, total = _lib.mem_info()
     need = 4 * n * ((n + 31) // 32 * 32)
