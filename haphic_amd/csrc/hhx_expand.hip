@@ -390,17 +390,22 @@ __device__ __forceinline__ void xtile_fetch(const ExParams &P, const BatchRegs &
     t.n = t.valid ? c.qe - c.q : 0;
     t.da_lo = c.da_lo; t.da_hi = c.da_hi;
     const i32 base = t.valid ? c.q : 0;
+    // scalar base + 32-bit lane offset + immediate (global_load ... v_off, s[base] offset:u * 128): a load costs a compare, a select and (for the values) a shift instead of
+    // an add, a compare, a select, a sign extension and two 64-bit address adds.  A position past the end of the segment reads the first entry of its block (one address
+    // for all such lanes, inside the arrays: they end with a tile of slack) and is masked where it is consumed.
+    const char *const bc = reinterpret_cast<const char *>(P.Sc16 + base), *const bx = reinterpret_cast<const char *>(P.Sx + base);
+    u32 lane2 = (u32)lane_id() * 2u;
+    asm volatile("" : "+v"(lane2));                               // opaque here: u * 128 stays an immediate of the load instead of a hoisted register per block
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
-        const i32 pos = lane_id() + u * HHX_WAVE;
-        const i32 qs = pos < t.n ? base + pos : 0;
+        const u32 off2 = lane_id() + u * HHX_WAVE < t.n ? lane2 : 0u;
         if (FX) {
-            const u32 w = __float_as_uint(P.Sx[qs]);
+            const u32 w = *reinterpret_cast<const u32 *>(bx + (size_t)(off2 * 2u) + u * 256);
             t.j[u] = w & 0xffffu;
             t.v[u] = w >> 16;
         } else {
-            t.j[u] = (u32)P.Sc16[qs];
-            t.v[u] = __float_as_uint(P.Sx[qs]);
+            t.j[u] = (u32)*reinterpret_cast<const unsigned short *>(bc + (size_t)off2 + u * 128);
+            t.v[u] = *reinterpret_cast<const u32 *>(bx + (size_t)(off2 * 2u) + u * 256);
         }
     }
     c.q += UX * HHX_WAVE;
@@ -412,7 +417,7 @@ __device__ __forceinline__ void xtile_consume(const ExLds &l, const XTile<UX> &t
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
         const bool ok = lane_id() + u * HHX_WAVE < t.n;
-        const u64 g = FX ? ga * (u64)t.v[u] : fx_bits(da * (double)__uint_as_float(t.v[u]));     // FX: the slot holds the link count c_kj
+        const u64 g = FX ? ga * (u64)t.v[u] : fx_bits_prod(da, (double)__uint_as_float(t.v[u]));     // FX: the slot holds the link count c_kj
         if (PROBE == 1) sink += ok ? g + t.j[u] : 0;
         else atomicAdd((unsigned long long *)&l.acc[ok ? (i32)t.j[u] : dummy], (unsigned long long)g);
     }
@@ -1785,7 +1790,7 @@ __device__ __forceinline__ void hash_drain(u64 *acc, u32 *keys, i32 *ctr, const 
     for (i32 i = lane_id(); i < n; i += HHX_WAVE) {
         const u64 w = wq[i];
         const int2 e = Bjx[(i32)(u32)w];
-        hash_insert(acc, keys, ctr, (u32)e.x, fx_bits(st_da[(i32)(w >> 32)] * (double)__int_as_float(e.y)));
+        hash_insert(acc, keys, ctr, (u32)e.x, fx_bits_prod(st_da[(i32)(w >> 32)], (double)__int_as_float(e.y)));
     }
 }
 __device__ __forceinline__ void hash_consume(u64 *acc, u32 *keys, i32 *ctr, const int2 *__restrict__ Bjx, const double *st_da, u64 *wq, i32 wq_cap, i32 &wq_n,
@@ -1806,7 +1811,7 @@ __device__ __forceinline__ void hash_consume(u64 *acc, u32 *keys, i32 *ctr, cons
         const u32 col = (u32)((k & 1) ? t[k >> 1].z : t[k >> 1].x);
         const bool m0 = cur[k].x == col, m1 = cur[k].y == col;
         const bool hit = valid && (m0 || m1);
-        const u64 g = fx_bits(da * (double)__int_as_float((k & 1) ? t[k >> 1].w : t[k >> 1].y));
+        const u64 g = fx_bits_prod(da, (double)__int_as_float((k & 1) ? t[k >> 1].w : t[k >> 1].y));
         atomicAdd((unsigned long long *)&acc[hit ? (hash_slot(col) & (HASH_C - 2)) + (m0 ? 0u : 1u) : scratch], (unsigned long long)g);
         pend |= (valid && !hit) ? 1u << k : 0u;
     }
@@ -1832,7 +1837,7 @@ __device__ __forceinline__ void hash_consume(u64 *acc, u32 *keys, i32 *ctr, cons
                 const int k = __ffs((int)pend) - 1;
                 pend &= pend - 1;
                 const int2 e = Bjx[q_first + (k >> 1) * 2 * HHX_WAVE + (k & 1)];
-                hash_insert(acc, keys, ctr, (u32)e.x, fx_bits(da * (double)__int_as_float(e.y)));
+                hash_insert(acc, keys, ctr, (u32)e.x, fx_bits_prod(da, (double)__int_as_float(e.y)));
             }
             return;
         }
@@ -2575,7 +2580,8 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 explicit_frac = b->nnz ? 1.0 - (double)h / (double)b->nnz : 1.0;
                 // slack: a wide tile reads up to 8 entries past a sub-segment end, an exhausted cursor entry 0
                 if (slots + STREAM_PREFIX > (i64)INT32_MAX - 4096) return fail("expand: the padded operand stream needs %lld slots (int32 cursors)", (long long)slots);
-                if (c16.alloc((size_t)slots + STREAM_PREFIX + 64) || cls_x.alloc((size_t)slots + STREAM_PREFIX + 64)) return 1;
+                // + a tile of slack: a masked lane of an explicit tile reads the first entry of its block, whatever lies there (xtile_fetch)
+                if (c16.alloc((size_t)slots + STREAM_PREFIX + 8 * HHX_WAVE + 64) || cls_x.alloc((size_t)slots + STREAM_PREFIX + 8 * HHX_WAVE + 64)) return 1;
                 if (use_cls && tune_get("cls_balance", 1))
                     k_layout_write<true><<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win_use, cap_use, n_classes, b->indptr.p, b->indices.p, b->data.p, coded.n16,
                                                                       coded.row_sum, cnt4.p, offs.p, c16.p, cls_x.p, rec.p, fx ? 1 : 0);
