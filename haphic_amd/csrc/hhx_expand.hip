@@ -390,20 +390,26 @@ __device__ __forceinline__ void xtile_fetch(const ExParams &P, const BatchRegs &
     t.n = t.valid ? c.qe - c.q : 0;
     t.da_lo = c.da_lo; t.da_hi = c.da_hi;
     const i32 base = t.valid ? c.q : 0;
-    // scalar base + 32-bit lane offset + immediate (global_load ... v_off, s[base] offset:u * 128): a load costs a compare, a select and (for the values) a shift instead of
-    // an add, a compare, a select, a sign extension and two 64-bit address adds.  A position past the end of the segment reads the first entry of its block (one address
-    // for all such lanes, inside the arrays: they end with a tile of slack) and is masked where it is consumed.
-    const char *const bc = reinterpret_cast<const char *>(P.Sc16 + base), *const bx = reinterpret_cast<const char *>(P.Sx + base);
-    u32 lane2 = (u32)lane_id() * 2u;
-    asm volatile("" : "+v"(lane2));                               // opaque here: u * 128 stays an immediate of the load instead of a hoisted register per block
+    if constexpr (FX) {                                            // iteration 0: one 32-bit word per entry; a masked position reads entry 0 of the array (one cached line)
 #pragma unroll
-    for (int u = 0; u < UX; ++u) {
-        const u32 off2 = lane_id() + u * HHX_WAVE < t.n ? lane2 : 0u;
-        if (FX) {
-            const u32 w = *reinterpret_cast<const u32 *>(bx + (size_t)(off2 * 2u) + u * 256);
+        for (int u = 0; u < UX; ++u) {
+            const i32 pos = lane_id() + u * HHX_WAVE;
+            const u32 w = __float_as_uint(P.Sx[pos < t.n ? base + pos : 0]);
             t.j[u] = w & 0xffffu;
             t.v[u] = w >> 16;
-        } else {
+        }
+    } else {
+        // the generic stream of the iterations >= 1: scalar base + 32-bit lane offset + immediate (global_load ... v_off, s[base] offset:u * 128) — a load costs a compare,
+        // a select and (for the values) a shift instead of an add, a compare, a select, a sign extension and two 64-bit address adds.  A position past the end of the
+        // segment reads the first entry of its block (one address for all such lanes, inside the arrays: they end with a tile of slack) and is masked where it is consumed.
+        // (Not for iteration 0: there the blocks past the end pull lines of the next segment through a fabric that is the limit, + 5 % of its bytes; and choosing the base
+        // per block with a scalar select serialises the loads of a tile: measured, 5.8 -> 7.3 s over the tail at 1.1.)
+        const char *const bc = reinterpret_cast<const char *>(P.Sc16 + base), *const bx = reinterpret_cast<const char *>(P.Sx + base);
+        u32 lane2 = (u32)lane_id() * 2u;
+        asm volatile("" : "+v"(lane2));                           // opaque here: u * 128 stays an immediate of the load instead of a hoisted register per block
+#pragma unroll
+        for (int u = 0; u < UX; ++u) {
+            const u32 off2 = lane_id() + u * HHX_WAVE < t.n ? lane2 : 0u;
             t.j[u] = (u32)*reinterpret_cast<const unsigned short *>(bc + (size_t)off2 + u * 128);
             t.v[u] = *reinterpret_cast<const u32 *>(bx + (size_t)(off2 * 2u) + u * 256);
         }
