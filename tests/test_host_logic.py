@@ -227,3 +227,40 @@ def test_cluster_files_array_path_equals_the_loops():
             ctgs.sort(key=lambda c: length[c], reverse=True)
         assert result == [list(g) for g in ref] and all(type(t) is int for _c, t in result)
         assert bodies == [''.join('%s\t%d\t%d\n' % (c, length[c] // 256 + 1, length[c]) for c in ctgs) for ctgs, _t in ref]
+
+
+def test_dense_block_is_taken_ahead_only_when_the_sweep_will_use_it(monkeypatch):
+    """cluster._prewarm_dense_block: the sweep's n x n float32 block is taken from the driver while the alignment file is read — only for orders whose block the library
+    keeps whole (at most a quarter of the device), on a device that is otherwise empty, in a single-process run; the size is that of the n x roundup32(n) block"""
+    import threading
+    import types
+    from haphic_amd import cluster
+    GiB = 1 << 30
+    asked = []
+    state = {'free': 280 * GiB, 'total': 288 * GiB, 'cached': 0}
+    fake = types.SimpleNamespace(mem_info=lambda: (state['free'], state['total']), pool_cached_bytes=lambda: state['cached'],
+                                 pool_prewarm=lambda sizes: asked.append(list(sizes)))
+    monkeypatch.setattr(cluster, '_lib', fake)
+    monkeypatch.setattr(cluster, '_DENSE_WARM', None)
+
+    def run(n):
+        monkeypatch.setattr(cluster, '_DENSE_WARM', None)
+        del asked[:]
+        cluster._prewarm_dense_block(n)
+        t = cluster._DENSE_WARM
+        if t is not None:
+            assert isinstance(t, threading.Thread)
+            t.join()
+        return list(asked)
+
+    assert run(99878) == [[4 * 99878 * 99904]]                       # BASELINE configs[2]: 39.9 GB
+    assert run(19999) == []                                          # small: a fresh block of that size costs nothing
+    assert run(140000) == []                                         # 78 GB > a quarter of 288 GB: the library stores the upper block triangle, row block by row block
+    state['free'] = 150 * GiB
+    assert run(99878) == []                                          # somebody else is using the device
+    state['cached'] = 100 * GiB
+    assert run(99878) == [[4 * 99878 * 99904]]                       # ... unless it is this library's own cache
+    # several ranks: the sweep is shared out, no rank keeps the whole block
+    dist = types.SimpleNamespace(is_available=lambda: True, is_initialized=lambda: True, get_world_size=lambda: 8)
+    monkeypatch.setitem(__import__('sys').modules, 'torch', types.SimpleNamespace(distributed=dist))
+    assert run(99878) == []
