@@ -440,6 +440,92 @@ __device__ __forceinline__ void pass_explicit(const ExParams &P, const ExLds &l,
     }
 }
 
+// block tiles (the generic stream of the iterations >= 1; hhx_tune("block_tiles")) ------------------------------------------------
+// An explicit tile above belongs to ONE (B row, window) segment: a segment of ~400 entries fills 6.3 of the 8 blocks of its tile, and over a low-inflation tail a third of
+// all issued slots — loads, fixed-point products, LDS atomics — are masked positions (profiles/r06_tail_pmc.json).  Here the unit is the 64-entry BLOCK: the segments of
+// the stream start on multiples of 64 slots and their last block is padded with (scratch column, 0.0f) entries (k_layout_write), so a block needs no range test, and a tile
+// is any UX consecutive blocks of the batch's block list, whatever segments they belong to — the multiplier double(a_ik * scale) is taken per block (a scalar), not per tile.
+// The block list of a batch (<= 32 segments, one per lane): an inclusive scan of the segments' block counts; then, CH blocks at a time, lane j finds the segment of block
+// c0 + j by bisection over the scan (6 ds_bpermute) and keeps the block's descriptor (stream position, multiplier); the tiles read descriptors f .. f + UX - 1 with
+// v_readlane.  Blocks past the end of the list are the EMPTY block: position 0 (the stream prefix: scratch columns), multiplier 0.  Every load of a group is issued
+// unconditionally (exact wait counts), nothing between a tile's loads and its atomics depends on a lane.
+template <int UX>
+struct BTile { u32 j[UX], v[UX]; };
+// tile = the blocks of descriptors f .. f + UX - 1 (wave-uniform f): scalar base per block + one 32-bit lane offset (global_load ... v_off, s[base:base+1])
+template <int UX, int AM>
+__device__ __forceinline__ void btile_fetch(const ExParams &P, i32 d_pos, i32 f, u32 lane2, BTile<UX> &t) {
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+        const i32 pos = __builtin_amdgcn_readlane(d_pos, f + u);
+        if constexpr (AM == 1) {                                      // one 32-bit offset from the start of the arrays (the host: the stream has fewer than 2^30 slots)
+            const u32 o2 = lane2 + (u32)pos * 2u;
+            t.j[u] = (u32)*reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(P.Sc16) + (size_t)o2);
+            t.v[u] = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(P.Sx) + (size_t)(o2 * 2u));
+            continue;
+        }
+        const char *const bc = reinterpret_cast<const char *>(P.Sc16 + pos), *const bx = reinterpret_cast<const char *>(P.Sx + pos);
+        u32 off = lane2;
+        asm volatile("" : "+v"(off));                                 // opaque per block: or (Sc16 + lane offset) is hoisted as a 64-bit VGPR pair and every load pays a 64-bit VALU add
+        t.j[u] = (u32)*reinterpret_cast<const unsigned short *>(bc + (size_t)off);
+        t.v[u] = *reinterpret_cast<const u32 *>(bx + (size_t)(off * 2u));
+    }
+}
+template <int PROBE, int UX>
+__device__ __forceinline__ void btile_consume(const ExLds &l, u32 d_lo, u32 d_hi, i32 f, const BTile<UX> &t, u64 &sink) {
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+        const u64 ga = ((u64)(u32)__builtin_amdgcn_readlane((int)d_hi, f + u) << 32) | (u32)__builtin_amdgcn_readlane((int)d_lo, f + u);
+        const u64 g = fx_bits_prod(__longlong_as_double((long long)ga), (double)__uint_as_float(t.v[u]));
+        if (PROBE == 1) sink += g + t.j[u];
+        else atomicAdd((unsigned long long *)&l.acc[t.j[u]], (unsigned long long)g);
+    }
+}
+template <int PROBE, int UX, int G, int AM>
+__device__ __forceinline__ void pass_blocks(const ExParams &P, const ExLds &l, const BatchRegs &r, i32 cnt, u64 &sink) {
+    constexpr int CH = 64 / (UX * G) * (UX * G);                       // blocks described at a time: whole groups of tiles
+    const i32 lane = lane_id();
+    const i32 qb = ceil64(r.b3);
+    const i32 nblk = lane < cnt && r.b4 > qb ? (r.b4 - qb + 63) >> 6 : 0;
+    i32 incl = nblk;
+#pragma unroll
+    for (int o = 1; o < HHX_WAVE; o <<= 1) {
+        const i32 t = __shfl_up(incl, o, HHX_WAVE);
+        if (lane >= o) incl += t;
+    }
+    const i32 excl = incl - nblk;
+    const i32 total = __builtin_amdgcn_readlane(incl, HHX_WAVE - 1);
+    u32 lane2 = (u32)lane * 2u;
+    asm volatile("" : "+v"(lane2));                                   // opaque: one offset register for every load of the pass
+    for (i32 c0 = 0; c0 < total; c0 += CH) {
+        const i32 B = c0 + lane;
+        i32 sg = 0;                                                   // the first segment whose inclusive count exceeds B (exists while B < total)
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1)
+            if (__shfl(incl, sg + step - 1, HHX_WAVE) <= B) sg += step;
+        const bool real = B < total;
+        const i32 p_real = __shfl(qb, sg, HHX_WAVE) + ((B - __shfl(excl, sg, HHX_WAVE)) << 6);
+        const u32 s_lo = (u32)__shfl((int)r.da_lo, sg, HHX_WAVE), s_hi = (u32)__shfl((int)r.da_hi, sg, HHX_WAVE);
+        const i32 d_pos = real ? p_real : 0;                          // past the list: the empty block
+        const u32 d_lo = real ? s_lo : 0u, d_hi = real ? s_hi : 0u;
+        const i32 nb = min(CH, total - c0);
+        i32 f = 0;
+        // whole groups: the loads of G tiles back to back, then the tiles in order — one basic block, no test of any kind between a load and its atomic
+        for (; f + UX * G <= nb; f += UX * G) {
+            BTile<UX> t[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) btile_fetch<UX, AM>(P, d_pos, f + k * UX, lane2, t[k]);
+#pragma unroll
+            for (int k = 0; k < G; ++k) btile_consume<PROBE, UX>(l, d_lo, d_hi, f + k * UX, t[k], sink);
+        }
+        // what is left of the list (fewer than G tiles, once per batch): a tile at a time; its blocks past the list are the empty block
+        for (; f < nb; f += UX) {
+            BTile<UX> t;
+            btile_fetch<UX, AM>(P, d_pos, f, lane2, t);
+            btile_consume<PROBE, UX>(l, d_lo, d_hi, f, t, sink);
+        }
+    }
+}
+
 // narrow uniform tiles: the count-2 and count-3 sub-segments (a few dozen entries each) ------------------------------
 // 16-bit columns only, UN entries per lane; the value of the sub-segment is wave-uniform, its product is formed in the fetch
 template <int UN>
@@ -755,7 +841,7 @@ struct DenseSrc {
 // UX / RX: entries per lane of an explicit tile and explicit tiles per group; RW: wide tiles per group.  Measured at
 // n = 100k, iteration 0 (tools/expand_probe.py): groups of 3 wide / 8 explicit tiles 590 ms, 3 / 5 597, 2 / 3 636; 512-thread
 // workgroups with twice the group sizes 806 ms — the sixteen waves per CU, not the depth of a wave's group, hide the latency.
-template <int PROBE, int UX, int RX, int RW, bool FX = false, int T = EX_T_WIN>
+template <int PROBE, int UX, int RX, int RW, bool FX = false, int T = EX_T_WIN, bool BLK = false>
 __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__restrict__ rows, i32 n_list, i32 cap, i32 wv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ExLds l = win_carve(smem, cap);
@@ -789,9 +875,12 @@ __global__ __launch_bounds__(T) void k_expand_window(ExParams P, const i32 *__re
             n_uni += cur.b3 - cur.b0;
             n_prod += (cur.b3 - cur.b0) + max(0, cur.b4 - ceil64(cur.b3));
             n_a += lane_id() == 0 ? cnt : 0;
+            if constexpr (BLK) pass_blocks<PROBE, UX, RX, RW>(P, l, cur, cnt, sink);              // a general operand (narrow_classes == -1) in 64-entry blocks
+            else {
             if (P.narrow_classes >= 0) pass_wide<PROBE, RW>(P, l, cur, cnt, dummy, sink);      // -1: a general operand, every segment is explicit
             if (!FX && P.narrow_classes > 0) pass_narrow<PROBE, 2, 8>(P, l, cur, cnt, dummy, sink);
             pass_explicit<PROBE, UX, RX, FX>(P, l, cur, cnt, dummy, sink);
+            }
             batch = nb;
         }
         __syncthreads();
@@ -1249,9 +1338,12 @@ __global__ __launch_bounds__(256) void k_layout_write(i32 n_rows, i32 n_win, i32
         if (BALANCE && fill) layout_flush_unit(L, fill, oc + base[0]);
         // the slots between the end of the count-1 sub-segment and the next multiple of 8 belong to the last lane that reads it
         if (n16 && nc == 1 && (c4.x & 7) && lane < 8 - (c4.x & 7)) oc[s0 + c4.x + lane] = (unsigned short)(cap + ((c4.x >> 3) & 63));
+        // float stream: the slots between the end of the explicit part and the next multiple of 64 hold (a scratch column, 0.0f) — the block tiles
+        // (pass_blocks) consume whole 64-entry blocks without a range test: a padding entry adds an exact 0 to a scratch accumulator
+        if (!fx && lane < ((-c4.w) & 63)) { oc[base[3] + lane] = (unsigned short)(cap + lane); ox[base[3] + lane] = 0.0f; }
     }
-    if (blockIdx.x == 0 && threadIdx.x < HHX_WAVE)           // the stream prefix: eight copies of lane l's scratch column
-        for (int j = 0; j < 8; ++j) oc[threadIdx.x * 8 + j] = (unsigned short)(cap + threadIdx.x);
+    if (blockIdx.x == 0 && threadIdx.x < HHX_WAVE)           // the stream prefix: eight copies of lane l's scratch column (values: 0 — block 0 of the stream is the block tiles' empty block)
+        for (int j = 0; j < 8; ++j) { oc[threadIdx.x * 8 + j] = (unsigned short)(cap + threadIdx.x); if (!fx) ox[threadIdx.x * 8 + j] = 0.0f; }
 }
 
 __global__ __launch_bounds__(EX_T_CMP) void k_expand_window_finalize(ExParams P, const i32 *__restrict__ rows, i32 n_list) {
@@ -2219,20 +2311,20 @@ static void window_plan(i32 n_cols, i64 nnz_b, i32 *cap_win_out, i32 *n_win_out)
     *n_win_out = (n_cols + cap_win - 1) / cap_win;
 }
 
-template <int PROBE, int UX, int RX, int RW, bool FX, int T = EX_T_WIN>
+template <int PROBE, int UX, int RX, int RW, bool FX, int T = EX_T_WIN, bool BLK = false>
 static int launch_window_fx(const ExParams &P, const i32 *rows, i32 n_list, i32 cap, size_t lds, unsigned grid) {
     static int attr_dev = -1;           // the attribute is per device: keyed on the current ordinal
     int dev = 0;
     HHX_HIP(hipGetDevice(&dev));
     if (attr_dev != dev) {
-        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window<PROBE, UX, RX, RW, FX, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HHX_HIP(hipFuncSetAttribute((const void *)k_expand_window<PROBE, UX, RX, RW, FX, T, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_dev = dev;
     }
     for (i32 wv = 0; wv < P.n_win; ++wv) {
         // symmetric mode: the rows are in identity order and launch wv takes the row blocks I <= wv (blocks J >= I of S)
         const i32 n_w = P.sym ? (i32)std::max<i64>(0, std::min<i64>(n_list, (i64)(wv + 1) * cap - P.sym_row0)) : n_list;
         if (n_w == 0) continue;
-        k_expand_window<PROBE, UX, RX, RW, FX, T><<<std::min<unsigned>(grid, (unsigned)std::max(n_w, 1)), T, lds, g_stream>>>(P, P.sym ? nullptr : rows, n_w, cap, wv);
+        k_expand_window<PROBE, UX, RX, RW, FX, T, BLK><<<std::min<unsigned>(grid, (unsigned)std::max(n_w, 1)), T, lds, g_stream>>>(P, P.sym ? nullptr : rows, n_w, cap, wv);
     }
     return 0;
 }
@@ -2389,6 +2481,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
     DevBuf<unsigned short> c16;
     DevBuf<float> cls_x;
     double explicit_frac = 1.0;         // share of B's entries outside the value-uniform sub-segments
+    i64 stream_slots = 0;               // slots of the operand stream (prefix included)
     if (cap_win + N_DUMMY > 65536) return fail("expand: column window wider than 16 bits");
     // candidate pool: early windows test against a partial row sum and admit more than finally survive
     i64 pool_cap = dense ? 64 : std::max<i64>(4 * a->nnz + 16 * (i64)n_rows, (i64)1 << 22);
@@ -2588,6 +2681,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 if (slots + STREAM_PREFIX > (i64)INT32_MAX - 4096) return fail("expand: the padded operand stream needs %lld slots (int32 cursors)", (long long)slots);
                 // + a tile of slack: a masked lane of an explicit tile reads the first entry of its block, whatever lies there (xtile_fetch)
                 if (c16.alloc((size_t)slots + STREAM_PREFIX + 8 * HHX_WAVE + 64) || cls_x.alloc((size_t)slots + STREAM_PREFIX + 8 * HHX_WAVE + 64)) return 1;
+                stream_slots = slots + STREAM_PREFIX;
                 if (use_cls && tune_get("cls_balance", 1))
                     k_layout_write<true><<<lgrid, 256, 0, g_stream>>>(b->n_rows, n_win_use, cap_use, n_classes, b->indptr.p, b->indices.p, b->data.p, coded.n16,
                                                                       coded.row_sum, cnt4.p, offs.p, c16.p, cls_x.p, rec.p, fx ? 1 : 0);
@@ -2606,6 +2700,9 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             if (P.wb < 1 || P.wb > WB_MAX) P.wb = WB_MAX;
             // explicit tiles: UX x 64 entries, sized to the mean explicit sub-segment (a tile costs its 2 UX loads and UX
             // LDS atomics per lane whether filled or not); tune "tile_u" overrides
+            // block tiles (pass_blocks): the general operand only — no uniform sub-segments, float values, the padding written by k_layout_write
+            int block_tiles = (!use_cls && !fx && P.narrow_classes == -1 && group_mode != 1) ? (int)tune_get("block_tiles", 15) : 0;
+            if (block_tiles >= 10 && stream_slots >= ((i64)1 << 30) - 4096) block_tiles -= 10;      // 32-bit byte offsets of the float32 values
             const double xlen = seg_len * explicit_frac;
             const int ux = tile_env ? tile_env : (xlen > 288.0 ? 8 : (xlen > 200.0 ? 4 : (xlen > 136.0 ? 3 : (xlen > 68.0 ? 2 : 1))));
             tile_u = ux;
@@ -2630,7 +2727,16 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 else if (probe == 1) HHX_TRY((launch_window<1, 3, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else
 #endif
-                if (ux >= 8) HHX_TRY((launch_window<0, 8, 3, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
+#define HHX_BLK(UXV, GV, AMV) HHX_TRY((launch_window_fx<0, UXV, GV, AMV, false, EX_T_WIN, true>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)))
+                if (block_tiles && prof_enabled()) prof_count("expand_block_tile_launches", n_win);
+                if (block_tiles == 15) HHX_BLK(4, 5, 1);          // groups of 20 blocks, one 32-bit offset per block
+                else if (block_tiles == 5) HHX_BLK(4, 5, 0);      // ... a scalar base per block (streams of 2^30 slots and more)
+                else if (block_tiles == 11) HHX_BLK(4, 4, 1);     // measured beside them (C3 tail at 1.1: 5.06 / 5.15 / 5.23 s against 5.01 / 5.17 s; tiles per segment: 5.81 s)
+                else if (block_tiles == 1) HHX_BLK(4, 4, 0);
+                else if (block_tiles == 2) HHX_BLK(8, 3, 0);
+                else if (block_tiles) return fail("expand: block_tiles %d is not a shape", block_tiles);
+#undef HHX_BLK
+                else if (ux >= 8) HHX_TRY((launch_window<0, 8, 3, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else if (ux == 4) HHX_TRY((launch_window<0, 4, 4, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else if (ux == 3) HHX_TRY((launch_window<0, 3, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));
                 else if (ux == 2) HHX_TRY((launch_window<0, 2, 8, 3>(P, list_w.p, (i32)hc[0], cap_win, lds_win, grid)));

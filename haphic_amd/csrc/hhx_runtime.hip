@@ -398,7 +398,7 @@ extern "C" int hhx_pool_trim_keep(int64_t keep_bytes) {
 // The knobs the kernels read (tune_get): which kernel class / arithmetic / layout a call takes.  Every setting of every knob gives
 // the same results (the verification tests switch classes with them and compare bits); an unknown name is refused.
 static const char *const k_tune_names[] = {"cls", "cls_nc", "cls_balance", "links_integer", "links_sym", "hash_max", "tile_u", "win_batch",
-                                           "cache_slice_mb", "dense_tri", "reuse", "row_order", "dense_seed_hint",
+                                           "cache_slice_mb", "dense_tri", "reuse", "row_order", "dense_seed_hint", "block_tiles",
 #ifdef HHX_PROBE_BUILD
                                            "probe",          // measurement build only: the LDS atomics switched off, results are garbage
 #endif

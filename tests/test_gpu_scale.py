@@ -492,6 +492,26 @@ def test_low_inflation_whole_tails_against_oracle():
                     'k_expand_group: the tail at 1.2 differs from the one-row-per-walk kernel'
                 plain[0].free()
                 grouped[0].free()
+            if r == 1.1:
+                # the generic stream is walked in 64-entry BLOCKS, a tile = consecutive blocks of the batch whatever segments they belong to (pass_blocks; the default),
+                # or in tiles of one segment each (hhx_tune("block_tiles", 0)): the same tail, bit for bit, under both and under the other block shapes / addressings
+                _lib.profile_reset()
+                _lib.profile_enable(True)
+                try:
+                    blocks = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4)
+                finally:
+                    _lib.profile_enable(False)
+                assert _lib.profile_counter('expand_block_tile_launches') > 0, 'no launch of the tail at 1.1 took the block tiles'
+                for shape in (0, 5, 11, 1, 2):
+                    _lib.tune('block_tiles', shape)
+                    try:
+                        other = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4)
+                    finally:
+                        _lib.tune('block_tiles', None)
+                    assert blocks[1:] == other[1:] and all(np.array_equal(u, v) for u, v in zip(blocks[0].to_arrays(), other[0].to_arrays())), \
+                        'hhx_tune("block_tiles", %d) changed the tail at 1.1' % shape
+                    other[0].free()
+                blocks[0].free()
             if r == 1.3:
                 # the rows of the window class are taken in min-hash order (hhx_expand_impl: order_rows; hhx_tune("row_order", 0) switches it off): the same tail, bit for
                 # bit, and the ordering pass did run
