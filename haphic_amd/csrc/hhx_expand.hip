@@ -453,7 +453,7 @@ template <int UX>
 struct BTile { u32 j[UX], v[UX]; };
 // tile = the blocks of descriptors f .. f + UX - 1 (wave-uniform f): scalar base per block + one 32-bit lane offset (global_load ... v_off, s[base:base+1])
 template <int UX, int AM>
-__device__ __forceinline__ void btile_fetch(const ExParams &P, i32 d_pos, i32 f, u32 lane2, BTile<UX> &t) {
+__device__ __forceinline__ void btile_fetch(const ExParams &P, i32 d_pos, i32 f, u32 lane2, u32 lane4, BTile<UX> &t) {
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
         const i32 pos = __builtin_amdgcn_readlane(d_pos, f + u);
@@ -463,6 +463,14 @@ __device__ __forceinline__ void btile_fetch(const ExParams &P, i32 d_pos, i32 f,
             t.v[u] = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(P.Sx) + (size_t)(o2 * 2u));
             continue;
         }
+        if constexpr (AM == 3) {                                      // the loads written by hand: scalar base per block, the two lane offsets of the pass as they are —
+            // no VALU instruction for an address.  The compiler does not know these are loads: the consumer waits itself (btile_wait), and the values are first
+            // touched THROUGH that wait.
+            const char *const sc = reinterpret_cast<const char *>(P.Sc16) + ((size_t)(u32)pos << 1), *const sx = reinterpret_cast<const char *>(P.Sx) + ((size_t)(u32)pos << 2);
+            asm volatile("global_load_ushort %0, %1, %2" : "=v"(t.j[u]) : "v"(lane2), "s"(sc));
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(t.v[u]) : "v"(lane4), "s"(sx));
+            continue;
+        }
         const char *const bc = reinterpret_cast<const char *>(P.Sc16 + pos), *const bx = reinterpret_cast<const char *>(P.Sx + pos);
         u32 off = lane2;
         asm volatile("" : "+v"(off));                                 // opaque per block: or (Sc16 + lane offset) is hoisted as a 64-bit VGPR pair and every load pays a 64-bit VALU add
@@ -470,14 +478,23 @@ __device__ __forceinline__ void btile_fetch(const ExParams &P, i32 d_pos, i32 f,
         t.v[u] = *reinterpret_cast<const u32 *>(bx + (size_t)(off * 2u));
     }
 }
-template <int PROBE, int UX>
-__device__ __forceinline__ void btile_consume(const ExLds &l, u32 d_lo, u32 d_hi, i32 f, const BTile<UX> &t, u64 &sink) {
+// AFTER >= 0 (hand-written loads): the number of loads issued behind this tile's last one; block u is touched when at most AFTER + 2 (UX - 1 - u) loads are outstanding
+template <int PROBE, int UX, int AFTER>
+__device__ __forceinline__ void btile_consume(const ExLds &l, u32 d_lo, u32 d_hi, i32 f, BTile<UX> &t, u64 &sink) {
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
+        if constexpr (AFTER >= 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(t.j[u]), "+v"(t.v[u]) : "n"(AFTER + 2 * (UX - 1 - u)));
         const u64 ga = ((u64)(u32)__builtin_amdgcn_readlane((int)d_hi, f + u) << 32) | (u32)__builtin_amdgcn_readlane((int)d_lo, f + u);
         const u64 g = fx_bits_prod(__longlong_as_double((long long)ga), (double)__uint_as_float(t.v[u]));
         if (PROBE == 1) sink += g + t.j[u];
         else atomicAdd((unsigned long long *)&l.acc[t.j[u]], (unsigned long long)g);
+    }
+}
+template <int K, int G, int PROBE, int UX, int AM>
+__device__ __forceinline__ void group_consume_blocks(const ExLds &l, u32 d_lo, u32 d_hi, i32 f, BTile<UX> (&t)[G], u64 &sink) {
+    if constexpr (K < G) {
+        btile_consume<PROBE, UX, AM == 3 ? 2 * UX * (G - 1 - K) : -1>(l, d_lo, d_hi, f + K * UX, t[K], sink);
+        group_consume_blocks<K + 1, G, PROBE, UX, AM>(l, d_lo, d_hi, f, t, sink);
     }
 }
 template <int PROBE, int UX, int G, int AM>
@@ -496,6 +513,7 @@ __device__ __forceinline__ void pass_blocks(const ExParams &P, const ExLds &l, c
     const i32 total = __builtin_amdgcn_readlane(incl, HHX_WAVE - 1);
     u32 lane2 = (u32)lane * 2u;
     asm volatile("" : "+v"(lane2));                                   // opaque: one offset register for every load of the pass
+    const u32 lane4 = lane2 * 2u;
     for (i32 c0 = 0; c0 < total; c0 += CH) {
         const i32 B = c0 + lane;
         i32 sg = 0;                                                   // the first segment whose inclusive count exceeds B (exists while B < total)
@@ -513,15 +531,14 @@ __device__ __forceinline__ void pass_blocks(const ExParams &P, const ExLds &l, c
         for (; f + UX * G <= nb; f += UX * G) {
             BTile<UX> t[G];
 #pragma unroll
-            for (int k = 0; k < G; ++k) btile_fetch<UX, AM>(P, d_pos, f + k * UX, lane2, t[k]);
-#pragma unroll
-            for (int k = 0; k < G; ++k) btile_consume<PROBE, UX>(l, d_lo, d_hi, f + k * UX, t[k], sink);
+            for (int k = 0; k < G; ++k) btile_fetch<UX, AM>(P, d_pos, f + k * UX, lane2, lane4, t[k]);
+            group_consume_blocks<0, G, PROBE, UX, AM>(l, d_lo, d_hi, f, t, sink);
         }
         // what is left of the list (fewer than G tiles, once per batch): a tile at a time; its blocks past the list are the empty block
         for (; f < nb; f += UX) {
             BTile<UX> t;
-            btile_fetch<UX, AM>(P, d_pos, f, lane2, t);
-            btile_consume<PROBE, UX>(l, d_lo, d_hi, f, t, sink);
+            btile_fetch<UX, AM>(P, d_pos, f, lane2, lane4, t);
+            btile_consume<PROBE, UX, AM == 3 ? 0 : -1>(l, d_lo, d_hi, f, t, sink);
         }
     }
 }
@@ -2702,7 +2719,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
             // LDS atomics per lane whether filled or not); tune "tile_u" overrides
             // block tiles (pass_blocks): the general operand only — no uniform sub-segments, float values, the padding written by k_layout_write
             int block_tiles = (!use_cls && !fx && P.narrow_classes == -1 && group_mode != 1) ? (int)tune_get("block_tiles", 15) : 0;
-            if (block_tiles >= 10 && stream_slots >= ((i64)1 << 30) - 4096) block_tiles -= 10;      // 32-bit byte offsets of the float32 values
+            if (block_tiles >= 10 && block_tiles < 20 && stream_slots >= ((i64)1 << 30) - 4096) block_tiles -= 10;      // 32-bit byte offsets of the float32 values
             const double xlen = seg_len * explicit_frac;
             const int ux = tile_env ? tile_env : (xlen > 288.0 ? 8 : (xlen > 200.0 ? 4 : (xlen > 136.0 ? 3 : (xlen > 68.0 ? 2 : 1))));
             tile_u = ux;
@@ -2733,6 +2750,7 @@ int hhx_expand_impl(const hhx_csr *a, const hhx_csr *b, const CodedOperand &code
                 else if (block_tiles == 5) HHX_BLK(4, 5, 0);      // ... a scalar base per block (streams of 2^30 slots and more)
                 else if (block_tiles == 11) HHX_BLK(4, 4, 1);     // measured beside them (C3 tail at 1.1: 5.06 / 5.15 / 5.23 s against 5.01 / 5.17 s; tiles per segment: 5.81 s)
                 else if (block_tiles == 1) HHX_BLK(4, 4, 0);
+                else if (block_tiles == 31) HHX_BLK(4, 4, 3);     // the loads written by hand (no VALU instruction for an address): 4.92 s — 1.7 % for loads the compiler cannot see: not the default
                 else if (block_tiles == 2) HHX_BLK(8, 3, 0);
                 else if (block_tiles) return fail("expand: block_tiles %d is not a shape", block_tiles);
 #undef HHX_BLK

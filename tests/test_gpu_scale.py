@@ -502,7 +502,7 @@ def test_low_inflation_whole_tails_against_oracle():
                 finally:
                     _lib.profile_enable(False)
                 assert _lib.profile_counter('expand_block_tile_launches') > 0, 'no launch of the tail at 1.1 took the block tiles'
-                for shape in (0, 5, 11, 1, 2):
+                for shape in (0, 5, 11, 1, 2, 31):
                     _lib.tune('block_tiles', shape)
                     try:
                         other = _lib.mcl_resume(first, 1, 2, r, 200, 1e-4)
