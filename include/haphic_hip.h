@@ -61,7 +61,10 @@ int hhx_pool_prewarm(int32_t n, const int64_t *bytes);
  * round-off, not the same bits: the other specification of DESIGN.md 2); "links_sym" 0 = every row walks all its products;
  * "dense_tri" 1 / 0 = force / forbid the upper-block-triangle storage of the dense block; "hash_max" = largest product count of a
  * row that tries the LDS hash table first (0: window / compact classes only); "tile_u", "win_batch", "cache_slice_mb" (tile
- * shapes and window count of the window kernel).  value INT64_MIN: back to the default.  Unset knobs fall back to the
+ * shapes and window count of the window kernel); "block_tiles" 0 = iterations >= 1 of the window class walk the stream in tiles
+ * of one (B row, window) segment each instead of 64-entry blocks (default 15; 1, 2, 5, 11, 31: other block-tile shapes /
+ * addressings); "row_order" 0 = the window-class rows as listed instead of in min-hash order; "reuse" 4 / 2 = the grouped kernel;
+ * "dense_seed_hint" (the sweep's first pool sizes).  value INT64_MIN: back to the default.  Unset knobs fall back to the
  * environment variable HHX_<NAME>. */
 int hhx_tune(const char *name, int64_t value);
 int hhx_profile_enable(int on);
