@@ -356,9 +356,13 @@ struct Payload {            // MODE 1 only
     const u32 *ht = nullptr, *fl = nullptr;
 };
 
-// bucket bits of the group-by of n_items records (attempt: after an LDS overflow, more buckets) and the radix bits per level
-inline i64 ingest_per_bucket() { static const i64 v = getenv("HHX_ING_BUCKET") ? atoll(getenv("HHX_ING_BUCKET")) : 1024; return v; }
-inline int ingest_level_bits() { static const int v = getenv("HHX_ING_LBITS") ? atoi(getenv("HHX_ING_LBITS")) : 7; return v; }
+// bucket bits of the group-by of n_items records (attempt: after an LDS overflow, more buckets) and the radix bits per level.
+// Up to 2048 records a bucket (k_aggregate takes such a bucket in two sub-passes over the L2-resident records) and up to 9 bits a level: 500 M
+// pairs are 2^18 buckets = TWO radix levels of 9 bits instead of 2^19 = three of 6 + 6 + 7 — one pass of the 6 GB of records through HBM less.
+// Measured at C3 (tools/ingest_probe.py, profiles/r06_ingest_levels_probe.json): 1024 / 7 (rounds 1-6) 39.5 ms, 2048 / 9 37.1 ms, 4096 / 9 38.5 ms
+// (four sub-passes: the aggregation 7.6 -> 9.1 ms), 1024 / 9 40.1 ms (still three levels).
+inline i64 ingest_per_bucket() { static const i64 v = getenv("HHX_ING_BUCKET") ? atoll(getenv("HHX_ING_BUCKET")) : 2048; return v; }
+inline int ingest_level_bits() { static const int v = getenv("HHX_ING_LBITS") ? atoi(getenv("HHX_ING_LBITS")) : 9; return v; }
 inline int ingest_total_bits(i64 n_items, int attempt) {
     int total_bits = 0;
     while ((n_items >> total_bits) > ingest_per_bucket() && total_bits < 24) ++total_bits;
