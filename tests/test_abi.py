@@ -56,3 +56,28 @@ def test_new_bindings_marshal_and_reject_null_handles():
     assert L.hhx_dense_inflate_prune(None, 2.0, 1e-4, _lib.C.byref(o)) != 0 and L.hhx_dense_free(None) == 0
     assert L.hhx_csr_pack_block(None, None, 0) != 0
     assert L.hhx_tune(b'cls', 1) == 0
+
+
+def test_tune_knobs_documented_and_refused_when_unknown():
+    """every knob hhx_tune accepts (k_tune_names in csrc/hhx_runtime.hip) is named in the header's description of hhx_tune, every knob a kernel
+    reads (tune_get in csrc/) is one hhx_tune accepts, and an unknown name is refused (hhx_tune does not touch the GPU)"""
+    rt = open(os.path.join(ROOT, 'haphic_amd', 'csrc', 'hhx_runtime.hip')).read()
+    block = re.search(r'k_tune_names\[\]\s*=\s*\{(.*?)nullptr\};', rt, flags=re.S).group(1)
+    block = re.sub(r'#ifdef HHX_PROBE_BUILD.*?#endif', '', block, flags=re.S)            # the measurement build's own knob
+    names = re.findall(r'"([a-z0-9_]+)"', block)
+    assert len(names) >= 10 and 'block_tiles' in names
+    header = open(os.path.join(ROOT, 'include', 'haphic_hip.h')).read()
+    for n in names:
+        assert '"%s"' % n in header, 'hhx_tune knob %r is not described in include/haphic_hip.h' % n
+    read = set()
+    for f in os.listdir(os.path.join(ROOT, 'haphic_amd', 'csrc')):
+        if f.endswith(('.hip', '.h')):
+            read |= set(re.findall(r'tune_get\("([a-z0-9_]+)"', open(os.path.join(ROOT, 'haphic_amd', 'csrc', f)).read()))
+    # resources of the host side, read once through the same helper and settable by their environment variable alone (HHX_FILE_LANES: writer threads,
+    # HHX_BED_HBM_GB: the size of the alignments.bed ring in HBM) — not kernel classes, hence not hhx_tune names
+    env_only = {'file_lanes', 'bed_hbm_gb'}
+    assert read - {'probe'} - env_only <= set(names), 'read by a kernel, refused by hhx_tune: %s' % sorted(read - {'probe'} - env_only - set(names))
+    lib = _lib.load()
+    assert lib.hhx_tune(b'no_such_knob', 1) != 0
+    assert b'unknown knob' in lib.hhx_last_error()
+    assert lib.hhx_tune(b'block_tiles', 0) == 0 and lib.hhx_tune(b'block_tiles', -2 ** 63) == 0
